@@ -1,0 +1,184 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: 2-D DT-CWT forward + inverse, 4096x4096 float32, nlevels=4,
+near_sym_a / qshift_a (BASELINE.json metric, configs[1]) on N MI355X GPUs of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one forward + one inverse of one image per GPU, input and pyramid resident in
+HBM.  N > 1 is weak scaling over independent images (the path shards by image, no
+data-path collective; the only collective is one RCCL broadcast of the filter taps at
+set-up).  Rank 0 prints ONE JSON line.  The roofline object is for the dominant kernel
+(the slower of the two level-1 kernels), its duration measured with hipEvent pairs on the
+library's stream; cpu_baseline times the NumPy oracle (a port of the reference's
+algorithm) on one image on the host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ROWS = COLS = 4096
+NLEVELS = 4
+BIORT, QSHIFT = 'near_sym_a', 'qshift_a'
+HBM_PEAK = 8.0e12             # B/s, MI355X spec (MI355X_MICROARCH.md)
+FWD_BYTES_PER_PX = 20.0       # read X, write Yl + all Yh
+STEP_BYTES_PER_PX = 40.0      # forward + inverse
+L1_BYTES_PER_PX = 20.0        # level-1 kernel: X 4 + LoLo 4 + Yh[0] 12 (inverse: mirrored)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--rows', type=int, default=ROWS)
+    ap.add_argument('--cols', type=int, default=COLS)
+    ap.add_argument('--batch', type=int, default=1, help='images per GPU per step')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    dist = None
+    torch = None
+    try:
+        import torch                                   # plumbing: barrier, device sync, RCCL
+    except Exception:
+        torch = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    import dtcwt_amd
+    from dtcwt_amd.coeffs import biort, qshift
+    from dtcwt_amd.hip import Context, DeviceArray, _lib
+
+    if not _lib.have_hip():
+        raise _lib.NoHIPPresentError('bench.py needs a GPU and dtcwt_amd/libdtcwt_hip.so')
+    ctx = Context(local_rank % max(_lib.device_count(), 1))
+
+    # filter taps: rank 0 owns the table, one RCCL broadcast over xGMI hands it to the others
+    bt = [np.asarray(h, np.float64).reshape(-1) for h in biort(BIORT)]
+    qt = [np.asarray(h, np.float64).reshape(-1) for h in qshift(QSHIFT)]
+    if world > 1:
+        flat = np.concatenate(bt + qt)
+        buf = torch.from_numpy(flat if rank == 0 else np.zeros_like(flat)).cuda()
+        dist.broadcast(buf, src=0)
+        flat = buf.cpu().numpy()
+        sizes = [len(h) for h in bt + qt]
+        parts, off = [], 0
+        for n in sizes:
+            parts.append(flat[off:off + n].copy()); off += n
+        bt, qt = parts[:4], parts[4:]
+
+    B, R, C = args.batch, args.rows, args.cols
+    t2 = dtcwt_amd.hip.Transform2d(tuple(bt), tuple(qt), ctx=ctx)
+    plan = t2.plan(B, R, C, NLEVELS)
+    rs = np.random.RandomState(1000 * rank)             # random, not zero: DVFS
+    X = ctx.to_device(rs.standard_normal((B, R, C)).astype(np.float32))
+    Yl = DeviceArray(ctx, (B,) + plan.low, np.float32)
+    Yh = [DeviceArray(ctx, (B,) + plan.high[l] + (6,), np.complex64) for l in range(NLEVELS)]
+    Z = DeviceArray(ctx, (B,) + plan.ext, np.float32)
+
+    def step():
+        plan.forward_into(X, Yl, Yh)
+        plan.inverse_into(Yl, Yh, None, Z)
+
+    def fence():
+        ctx.sync()
+        if world > 1:
+            dist.barrier()
+        if torch is not None and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        ctx.sync()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # sanity of the timed work: reconstruction equals the input
+    err = float(np.abs(Z.get()[0, :64, :64] - X.get()[0, :64, :64]).max())
+
+    # ---- roofline of the dominant kernel: hipEvent pair around every level kernel -------
+    plan.set_profiling(True)
+    kf = np.zeros(NLEVELS); ki = np.zeros(NLEVELS)
+    nprof = max(5, min(args.steps, 50))
+    for _ in range(nprof):
+        step()
+        f, i = plan.kernel_ms()
+        kf += f; ki += i
+    plan.set_profiling(False)
+    kf /= nprof; ki /= nprof
+    px = float(B) * R * C
+    cand = [('k_fwd1 (level-1 forward)', kf[0]), ('k_inv1 (level-1 inverse)', ki[0])]
+    name, ms = max(cand, key=lambda c: c[1])
+    achieved = L1_BYTES_PER_PX * px / (ms * 1e-3) / 1e9       # GB/s
+    roofline = {'bound': 'hbm', 'kernel': name, 'achieved': round(achieved, 1), 'peak': HBM_PEAK / 1e9,
+                'unit': 'GB/s', 'frac': round(achieved * 1e9 / HBM_PEAK, 4), 'traffic': None,
+                'kernel_ms': round(float(ms), 5), 'algorithmic_bytes_per_launch': L1_BYTES_PER_PX * px,
+                'fwd_kernel_ms': [round(float(x), 5) for x in kf],
+                'inv_kernel_ms': [round(float(x), 5) for x in ki],
+                'step_frac': round(STEP_BYTES_PER_PX * px / (dt / args.steps) / HBM_PEAK, 4)}
+    tr = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if os.path.exists(tr):
+        try:
+            roofline['traffic'] = json.load(open(tr)).get(name.split(' ')[0])
+        except Exception:
+            pass
+
+    value = world * px * args.steps / dt / 1e6
+    out = {
+        'metric': 'Mpixels/s 2D DT-CWT fwd+inv, 4096^2 f32 nlevels=4',
+        'value': round(value, 1), 'unit': 'Mpixels/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 5), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': '2D forward+inverse %dx%d f32, nlevels=%d, %s/%s, %d image(s) per GPU per step'
+                               % (R, C, NLEVELS, BIORT, QSHIFT, B),
+                   'sharding': 'independent images per GPU, no data-path collective'},
+        'roofline': roofline, 'recon_max_abs_err': err,
+    }
+
+    # ---- CPU baseline: the oracle (a NumPy port of the reference's algorithm), rank 0 ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import dtcwt_oracle as o
+        Xh = X.get()[0]
+        to = o.Transform2d(biort(BIORT), qshift(QSHIFT))
+        c0 = time.perf_counter()
+        p = to.forward(Xh, nlevels=NLEVELS)
+        zc = to.inverse(p)
+        cdt = time.perf_counter() - c0
+        out['cpu_baseline'] = {'value': round(R * C / cdt / 1e6, 3), 'unit': 'Mpixels/s', 'cores': 1,
+                               'kind': 'port', 'host_cpus': os.cpu_count(), 'numpy': np.__version__,
+                               'sample': '1 image %dx%d f32 fwd+inv nlevels=%d (%.1f s)' % (R, C, NLEVELS, cdt)}
+        # the timed GPU output against the CPU port on the same input
+        out['gpu_vs_cpu_recon_max_abs_diff'] = float(np.abs(Z.get()[0] - zc).max())
+    elif rank == 0:
+        out['cpu_baseline'] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

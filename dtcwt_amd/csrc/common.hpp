@@ -1,0 +1,56 @@
+// Shared declarations of libdtcwt_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "dtcwt_hip.h"
+
+struct dtcwt_hip_ctx {
+    int device;
+    hipStream_t stream;
+    bool owns_stream;
+    int cus;
+};
+
+struct dtcwt_hip_event {
+    hipEvent_t ev;
+};
+
+// thread-local error text returned by dtcwt_hip_last_error()
+int dtcwt_set_error(int code, const char *fmt, ...);
+
+#define DT_CHECK_HIP(expr)                                                               \
+    do {                                                                                 \
+        hipError_t e__ = (expr);                                                         \
+        if (e__ != hipSuccess)                                                           \
+            return dtcwt_set_error(-2, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                                   __FILE__, __LINE__);                                  \
+    } while (0)
+
+#define DT_REQUIRE(cond, ...)                                                            \
+    do {                                                                                 \
+        if (!(cond)) return dtcwt_set_error(-1, __VA_ARGS__);                            \
+    } while (0)
+
+// Half-sample symmetric reflection of an integer index into [0, n): ... 1 0 | 0 1 ...
+// n-1 | n-1 n-2 ...  (what dtcwt/utils.py:136-153 `reflect(x, -0.5, n-0.5)` computes for
+// integer x).  Multi-bounce safe.
+__host__ __device__ inline int64_t dt_reflect(int64_t u, int64_t n) {
+    int64_t p = 2 * n;
+    int64_t j = u % p;
+    if (j < 0) j += p;
+    return j < n ? j : p - 1 - j;
+}
+
+// Cheap variant for |overshoot| < n (single bounce), used by the fused tiles.
+__device__ inline int dt_reflect1(int u, int n) {
+    u = u < 0 ? -1 - u : u;
+    return u >= n ? 2 * n - 1 - u : u;
+}
+
+__host__ __device__ inline int64_t dt_clamp(int64_t u, int64_t lo, int64_t hi) {
+    return u < lo ? lo : (u > hi ? hi : u);
+}

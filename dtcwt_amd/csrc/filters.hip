@@ -1,0 +1,502 @@
+// Generic (any length, any axis, f32/f64) column filters and the quad/cube <-> complex
+// packings of the DT-CWT.  These are the building blocks behind the public low-level
+// functions (colfilter / coldfilt / colifilt), the 1-D and 3-D transforms and the
+// band-pass ("_bp") 2-D wavelets; the float32 2-D level loop has fused kernels of its own
+// (fused2d.hip).
+//
+// One thread produces one output *group* along the filter axis: 1 sample (colfilter),
+// the (A, B) pair 2i, 2i+1 (coldfilt) or the four phases 4j..4j+3 (colifilt).  Lanes run
+// along whichever of the two other view dimensions is contiguous, so global loads of a
+// wavefront are coalesced rows; tap re-reads are served by L1/L2.
+//
+// Index algebra: SURVEY.md Appendix A (verified against the reference by the oracle).
+#include "common.hpp"
+
+namespace {
+
+template <typename T>
+struct Taps {
+    T a[DTCWT_HIP_MAX_TAPS];
+    T b[DTCWT_HIP_MAX_TAPS];
+};
+
+struct Geo {
+    int64_t outer, n, inner;
+    int64_t xso, xsn, xsi;
+    int64_t yso, ysn, ysi;
+    int64_t L;        // logical input length n + pad_lo + pad_hi
+    int64_t nout;     // logical output length
+    int64_t ngroups;  // thread groups along the filter axis
+    int32_t pad_lo, crop_lo;
+    int64_t nwrite;   // nout - crop_lo - crop_hi
+    int32_t inner_fast;
+    int32_t accumulate;
+};
+
+__device__ inline bool decode(const Geo &g, int64_t &o, int64_t &grp, int64_t &i) {
+    int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = g.outer * g.ngroups * g.inner;
+    if (id >= total) return false;
+    if (g.inner_fast) {
+        i = id % g.inner;
+        int64_t t = id / g.inner;
+        grp = t % g.ngroups;
+        o = t / g.ngroups;
+    } else {
+        grp = id % g.ngroups;
+        int64_t t = id / g.ngroups;
+        i = t % g.inner;
+        o = t / g.inner;
+    }
+    return true;
+}
+
+// logical sample u (any integer) -> real input sample
+__device__ inline int64_t src_index(const Geo &g, int64_t u) {
+    int64_t r = dt_reflect(u, g.L) - g.pad_lo;
+    return dt_clamp(r, 0, g.n - 1);
+}
+
+template <typename T>
+__device__ inline void put(const Geo &g, T *Yb, int64_t lo, T v) {
+    int64_t w = lo - g.crop_lo;
+    if (w < 0 || w >= g.nwrite) return;
+    T *p = Yb + w * g.ysn;
+    *p = g.accumulate ? (*p + v) : v;
+}
+
+// Y[i] = sum_k h[k] X[rho(i + m-1-k - m/2)]          (dtcwt/numpy/lowlevel.py:47-80)
+template <typename T>
+__global__ void __launch_bounds__(256) k_colfilter(const T *__restrict__ X, T *__restrict__ Y,
+                                                   Geo g, Taps<T> taps, int m) {
+    int64_t o, i, grp;
+    if (!decode(g, o, grp, i)) return;
+    const T *Xb = X + o * g.xso + i * g.xsi;
+    T *Yb = Y + o * g.yso + i * g.ysi;
+    int64_t lo = grp + g.crop_lo;     // only the written range is launched
+    int64_t base = lo + (m - 1) - (m / 2);
+    T acc = 0;
+    for (int k = 0; k < m; ++k) acc += taps.a[k] * Xb[src_index(g, base - k) * g.xsn];
+    put(g, Yb, lo, acc);
+}
+
+// coldfilt (dtcwt/numpy/lowlevel.py:82-154): with p = m/2, b_k = 4(i+p-1-k) - m
+//   A[i] = sum_k ha[2k] X[rho(b_k+4)] + ha[2k+1] X[rho(b_k+2)]
+//   B[i] = sum_k hb[2k] X[rho(b_k+5)] + hb[2k+1] X[rho(b_k+3)]
+// (Y[2i], Y[2i+1]) = (A, B) if sum(ha*hb) > 0 else (B, A).
+template <typename T>
+__global__ void __launch_bounds__(256) k_coldfilt(const T *__restrict__ X, T *__restrict__ Y,
+                                                  Geo g, Taps<T> taps, int m, int a_first) {
+    int64_t o, i, grp;
+    if (!decode(g, o, grp, i)) return;
+    const T *Xb = X + o * g.xso + i * g.xsi;
+    T *Yb = Y + o * g.yso + i * g.ysi;
+    int p = m / 2;
+    T A = 0, B = 0;
+    for (int k = 0; k < p; ++k) {
+        int64_t b = 4 * (grp + p - 1 - k) - m;
+        A += taps.a[2 * k] * Xb[src_index(g, b + 4) * g.xsn];
+        A += taps.a[2 * k + 1] * Xb[src_index(g, b + 2) * g.xsn];
+        B += taps.b[2 * k] * Xb[src_index(g, b + 5) * g.xsn];
+        B += taps.b[2 * k + 1] * Xb[src_index(g, b + 3) * g.xsn];
+    }
+    put(g, Yb, 2 * grp, a_first ? A : B);
+    put(g, Yb, 2 * grp + 1, a_first ? B : A);
+}
+
+// colifilt (dtcwt/numpy/lowlevel.py:156-260), n = m/2 taps per polyphase branch,
+// jj = j+n-1-k:
+//   m/2 even: t = 3+2jj, (ta,tb) = pos ? (t,t-1) : (t-1,t)
+//      Y[4j]   += hae[k] X[rho(tb-2-m2)]   Y[4j+1] += hbe[k] X[rho(ta-2-m2)]
+//      Y[4j+2] += hao[k] X[rho(tb-m2)]     Y[4j+3] += hbo[k] X[rho(ta-m2)]
+//   m/2 odd:  t = 2+2jj
+//      Y[4j]   += hao[k] X[rho(tb-m2)]     Y[4j+1] += hbo[k] X[rho(ta-m2)]
+//      Y[4j+2] += hae[k] X[rho(tb-m2)]     Y[4j+3] += hbe[k] X[rho(ta-m2)]
+template <typename T>
+__global__ void __launch_bounds__(256) k_colifilt(const T *__restrict__ X, T *__restrict__ Y,
+                                                  Geo g, Taps<T> taps, int m, int pos) {
+    int64_t o, i, grp;
+    if (!decode(g, o, grp, i)) return;
+    const T *Xb = X + o * g.xso + i * g.xsi;
+    T *Yb = Y + o * g.yso + i * g.ysi;
+    int m2 = m / 2, n = m2;
+    T y0 = 0, y1 = 0, y2 = 0, y3 = 0;
+    if ((m2 & 1) == 0) {
+        for (int k = 0; k < n; ++k) {
+            int64_t t = 3 + 2 * (grp + n - 1 - k);
+            int64_t ta = pos ? t : t - 1, tb = pos ? t - 1 : t;
+            T hao = taps.a[2 * k], hae = taps.a[2 * k + 1];
+            T hbo = taps.b[2 * k], hbe = taps.b[2 * k + 1];
+            y0 += hae * Xb[src_index(g, tb - 2 - m2) * g.xsn];
+            y1 += hbe * Xb[src_index(g, ta - 2 - m2) * g.xsn];
+            y2 += hao * Xb[src_index(g, tb - m2) * g.xsn];
+            y3 += hbo * Xb[src_index(g, ta - m2) * g.xsn];
+        }
+    } else {
+        for (int k = 0; k < n; ++k) {
+            int64_t t = 2 + 2 * (grp + n - 1 - k);
+            int64_t ta = pos ? t : t - 1, tb = pos ? t - 1 : t;
+            T xb = Xb[src_index(g, tb - m2) * g.xsn];
+            T xa = Xb[src_index(g, ta - m2) * g.xsn];
+            y0 += taps.a[2 * k] * xb;
+            y1 += taps.b[2 * k] * xa;
+            y2 += taps.a[2 * k + 1] * xb;
+            y3 += taps.b[2 * k + 1] * xa;
+        }
+    }
+    put(g, Yb, 4 * grp, y0);
+    put(g, Yb, 4 * grp + 1, y1);
+    put(g, Yb, 4 * grp + 2, y2);
+    put(g, Yb, 4 * grp + 3, y3);
+}
+
+// q2c (dtcwt/numpy/transform2d.py:301-322): quad (a b / c d):
+//   z0 = s((a-d) + j(b+c)),  z1 = s((a+d) + j(b-c)),  s = sqrt(1/2)
+template <typename T>
+__global__ void __launch_bounds__(256) k_q2c(const T *__restrict__ y, int64_t batch, int64_t R2,
+                                             int64_t C2, int64_t sb, int64_t sr,
+                                             T *__restrict__ Yh, int slot0, int slot1) {
+    int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= batch * R2 * C2) return;
+    int64_t v = id % C2, u = (id / C2) % R2, b = id / (C2 * R2);
+    const T *q = y + b * sb + (2 * u) * sr + 2 * v;
+    T a = q[0], bb = q[1], c = q[sr], d = q[sr + 1];
+    const T s = (T)0.70710678118654752440;
+    T *rec = Yh + id * 12;
+    rec[2 * slot0] = s * (a - d);
+    rec[2 * slot0 + 1] = s * (bb + c);
+    rec[2 * slot1] = s * (a + d);
+    rec[2 * slot1 + 1] = s * (bb - c);
+}
+
+// c2q (dtcwt/numpy/transform2d.py:324-350): P = s(g0 w0 + g1 w1), Q = s(g0 w0 - g1 w1);
+//   a = Re P, b = Im P, c = Im Q, d = -Re Q.
+template <typename T>
+__global__ void __launch_bounds__(256) k_c2q(const T *__restrict__ Yh, int64_t batch, int64_t R,
+                                             int64_t C, int slot0, int slot1, T g0, T g1,
+                                             T *__restrict__ x, int64_t sb, int64_t sr) {
+    int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= batch * R * C) return;
+    int64_t v = id % C, u = (id / C) % R, b = id / (C * R);
+    const T *rec = Yh + id * 12;
+    T w0r = rec[2 * slot0] * g0, w0i = rec[2 * slot0 + 1] * g0;
+    T w1r = rec[2 * slot1] * g1, w1i = rec[2 * slot1 + 1] * g1;
+    T *q = x + b * sb + (2 * u) * sr + 2 * v;
+    q[0] = w0r + w1r;
+    q[1] = w0i + w1i;
+    q[sr] = w0i - w1i;
+    q[sr + 1] = -(w0r - w1r);
+}
+
+// cube2c (dtcwt/numpy/transform3d.py:532-579)
+template <typename T>
+__global__ void __launch_bounds__(256) k_cube2c(const T *__restrict__ y, int64_t e0, int64_t e1,
+                                                int64_t e2, int64_t s0, int64_t s1,
+                                                T *__restrict__ Yh, int octant) {
+    int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= e0 * e1 * e2) return;
+    int64_t w = id % e2, v = (id / e2) % e1, u = id / (e2 * e1);
+    const T *q = y + (2 * u) * s0 + (2 * v) * s1 + 2 * w;
+    T A = q[0], B = q[s1], C = q[s0], D = q[s0 + s1];
+    T E = q[1], F = q[s1 + 1], G = q[s0 + 1], H = q[s0 + s1 + 1];
+    const T h = (T)0.5;
+    T *rec = Yh + id * 56 + octant * 8;
+    rec[0] = (A - G - D - F) * h;  rec[1] = (B - H + C + E) * h;
+    rec[2] = (A - G + D + F) * h;  rec[3] = (-B + H + C + E) * h;
+    rec[4] = (A + G + D - F) * h;  rec[5] = (B + H - C + E) * h;
+    rec[6] = (A + G - D + F) * h;  rec[7] = (-B - H - C + E) * h;
+}
+
+// c2cube (dtcwt/numpy/transform3d.py:581-619)
+template <typename T>
+__global__ void __launch_bounds__(256) k_c2cube(const T *__restrict__ Yh, int64_t e0, int64_t e1,
+                                                int64_t e2, int octant, T *__restrict__ y,
+                                                int64_t s0, int64_t s1) {
+    int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= e0 * e1 * e2) return;
+    int64_t w = id % e2, v = (id / e2) % e1, u = id / (e2 * e1);
+    const T *rec = Yh + id * 56 + octant * 8;
+    T pr = rec[0], pi = rec[1], qr = rec[2], qi = rec[3];
+    T rr = rec[4], ri = rec[5], sr = rec[6], si = rec[7];
+    const T h = (T)0.5;
+    T *q = y + (2 * u) * s0 + (2 * v) * s1 + 2 * w;
+    q[0] = (pr + qr + rr + sr) * h;               // A  (0,0,0)
+    q[s0 + 1] = (-pr - qr + rr + sr) * h;         // G  (1,0,1)
+    q[s0 + s1] = (-pr + qr + rr - sr) * h;        // D  (1,1,0)
+    q[s1 + 1] = (-pr + qr - rr + sr) * h;         // F  (0,1,1)
+    q[s1] = (pi - qi + ri - si) * h;              // B  (0,1,0)
+    q[s0 + s1 + 1] = (-pi + qi + ri - si) * h;    // H  (1,1,1)
+    q[s0] = (pi + qi - ri - si) * h;              // C  (1,0,0)
+    q[1] = (pi + qi + ri + si) * h;               // E  (0,0,1)
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_scale(T *x, int64_t n, T g) {
+    int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id < n) x[id] *= g;
+}
+
+// 1-D packing: Yh[j] = Hi[2j] + i Hi[2j+1]   (dtcwt/numpy/transform1d.py:88,100)
+template <typename T>
+__global__ void __launch_bounds__(256) k_pack1d(const T *__restrict__ hi, int64_t J, int64_t k,
+                                                T *__restrict__ Yh) {
+    int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= J * k) return;
+    int64_t c = id % k, j = id / k;
+    Yh[2 * id] = hi[(2 * j) * k + c];
+    Yh[2 * id + 1] = hi[(2 * j + 1) * k + c];
+}
+
+// c2q1d with gain: Hi[2j] = g Re Yh[j], Hi[2j+1] = g Im Yh[j]   (transform1d.py:153,171,186-196)
+template <typename T>
+__global__ void __launch_bounds__(256) k_unpack1d(const T *__restrict__ Yh, int64_t J, int64_t k,
+                                                  T g, T *__restrict__ hi) {
+    int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= J * k) return;
+    int64_t c = id % k, j = id / k;
+    hi[(2 * j) * k + c] = g * Yh[2 * id];
+    hi[(2 * j + 1) * k + c] = g * Yh[2 * id + 1];
+}
+
+int make_geo(const dtcwt_hip_view *v, int64_t nout_of_L(int64_t, int), int m, int group,
+             int flags, Geo &g) {
+    DT_REQUIRE(v, "view is NULL");
+    DT_REQUIRE(v->outer >= 0 && v->n >= 1 && v->inner >= 0, "bad view extents");
+    DT_REQUIRE(v->pad_lo >= 0 && v->pad_hi >= 0 && v->crop_lo >= 0 && v->crop_hi >= 0,
+               "negative pad/crop");
+    g.outer = v->outer; g.n = v->n; g.inner = v->inner;
+    g.xso = v->xso; g.xsn = v->xsn; g.xsi = v->xsi;
+    g.yso = v->yso; g.ysn = v->ysn; g.ysi = v->ysi;
+    g.L = v->n + v->pad_lo + v->pad_hi;
+    g.nout = nout_of_L(g.L, m);
+    g.pad_lo = v->pad_lo;
+    g.crop_lo = v->crop_lo;
+    g.nwrite = g.nout - v->crop_lo - v->crop_hi;
+    DT_REQUIRE(g.nwrite >= 0, "crop exceeds output length");
+    g.ngroups = group == 1 ? g.nwrite : g.nout / group;
+    g.inner_fast = (v->xsi == 1 && v->ysi == 1) || v->inner == 1 ? 1 : 0;
+    if (v->inner > 1 && v->xsn == 1 && v->ysn == 1) g.inner_fast = 0;
+    g.accumulate = (flags & DTCWT_HIP_ACCUMULATE) ? 1 : 0;
+    return 0;
+}
+
+template <typename T>
+void load_taps(Taps<T> &t, const double *a, const double *b, int m) {
+    for (int k = 0; k < DTCWT_HIP_MAX_TAPS; ++k) {
+        t.a[k] = (a && k < m) ? (T)a[k] : (T)0;
+        t.b[k] = (b && k < m) ? (T)b[k] : (T)0;
+    }
+}
+
+inline unsigned blocks_for(int64_t total) { return (unsigned)((total + 255) / 256); }
+
+int64_t nout_colfilter(int64_t L, int m) { return (m & 1) ? L : L + 1; }
+int64_t nout_coldfilt(int64_t L, int) { return L / 2; }
+int64_t nout_colifilt(int64_t L, int) { return 2 * L; }
+
+double dot(const double *a, const double *b, int m) {
+    double s = 0;
+    for (int k = 0; k < m; ++k) s += a[k] * b[k];
+    return s;
+}
+
+}  // namespace
+
+#define DT_LAUNCH_CHECK() DT_CHECK_HIP(hipGetLastError())
+
+extern "C" {
+
+int dtcwt_hip_colfilter(dtcwt_hip_ctx *ctx, int dtype, const void *X, void *Y,
+                        const dtcwt_hip_view *v, const double *h, int m, int flags) {
+    DT_REQUIRE(ctx && X && Y && h, "NULL argument");
+    DT_REQUIRE(m >= 1 && m <= DTCWT_HIP_MAX_TAPS, "filter length %d not in [1, %d]", m,
+               DTCWT_HIP_MAX_TAPS);
+    DT_REQUIRE(dtype == DTCWT_HIP_F32 || dtype == DTCWT_HIP_F64, "bad dtype %d", dtype);
+    Geo g;
+    int rc = make_geo(v, nout_colfilter, m, 1, flags, g);
+    if (rc) return rc;
+    int64_t total = g.outer * g.ngroups * g.inner;
+    if (total == 0) return 0;
+    DT_REQUIRE(total < ((int64_t)1 << 39), "problem too large");
+    DT_CHECK_HIP(hipSetDevice(ctx->device));
+    if (dtype == DTCWT_HIP_F32) {
+        Taps<float> t; load_taps(t, h, nullptr, m);
+        k_colfilter<float><<<blocks_for(total), 256, 0, ctx->stream>>>((const float *)X, (float *)Y, g, t, m);
+    } else {
+        Taps<double> t; load_taps(t, h, nullptr, m);
+        k_colfilter<double><<<blocks_for(total), 256, 0, ctx->stream>>>((const double *)X, (double *)Y, g, t, m);
+    }
+    DT_LAUNCH_CHECK();
+    return 0;
+}
+
+int dtcwt_hip_coldfilt(dtcwt_hip_ctx *ctx, int dtype, const void *X, void *Y,
+                       const dtcwt_hip_view *v, const double *ha, const double *hb, int m,
+                       int flags) {
+    DT_REQUIRE(ctx && X && Y && ha && hb, "NULL argument");
+    DT_REQUIRE(m >= 2 && m <= DTCWT_HIP_MAX_TAPS && (m % 2) == 0,
+               "Lengths of ha and hb must be even (and <= %d)", DTCWT_HIP_MAX_TAPS);
+    DT_REQUIRE(dtype == DTCWT_HIP_F32 || dtype == DTCWT_HIP_F64, "bad dtype %d", dtype);
+    Geo g;
+    int rc = make_geo(v, nout_coldfilt, m, 2, flags, g);
+    if (rc) return rc;
+    DT_REQUIRE(g.L % 4 == 0, "No. of rows in X must be a multiple of 4");
+    int64_t total = g.outer * g.ngroups * g.inner;
+    if (total == 0) return 0;
+    DT_REQUIRE(total < ((int64_t)1 << 39), "problem too large");
+    int a_first = dot(ha, hb, m) > 0 ? 1 : 0;
+    DT_CHECK_HIP(hipSetDevice(ctx->device));
+    if (dtype == DTCWT_HIP_F32) {
+        Taps<float> t; load_taps(t, ha, hb, m);
+        k_coldfilt<float><<<blocks_for(total), 256, 0, ctx->stream>>>((const float *)X, (float *)Y, g, t, m, a_first);
+    } else {
+        Taps<double> t; load_taps(t, ha, hb, m);
+        k_coldfilt<double><<<blocks_for(total), 256, 0, ctx->stream>>>((const double *)X, (double *)Y, g, t, m, a_first);
+    }
+    DT_LAUNCH_CHECK();
+    return 0;
+}
+
+int dtcwt_hip_colifilt(dtcwt_hip_ctx *ctx, int dtype, const void *X, void *Y,
+                       const dtcwt_hip_view *v, const double *ha, const double *hb, int m,
+                       int flags) {
+    DT_REQUIRE(ctx && X && Y && ha && hb, "NULL argument");
+    DT_REQUIRE(m >= 2 && m <= DTCWT_HIP_MAX_TAPS && (m % 2) == 0,
+               "Lengths of ha and hb must be even (and <= %d)", DTCWT_HIP_MAX_TAPS);
+    DT_REQUIRE(dtype == DTCWT_HIP_F32 || dtype == DTCWT_HIP_F64, "bad dtype %d", dtype);
+    Geo g;
+    int rc = make_geo(v, nout_colifilt, m, 4, flags, g);
+    if (rc) return rc;
+    DT_REQUIRE(g.L % 2 == 0, "No. of rows in X must be a multiple of 2");
+    int64_t total = g.outer * g.ngroups * g.inner;
+    if (total == 0) return 0;
+    DT_REQUIRE(total < ((int64_t)1 << 39), "problem too large");
+    int pos = dot(ha, hb, m) > 0 ? 1 : 0;
+    DT_CHECK_HIP(hipSetDevice(ctx->device));
+    if (dtype == DTCWT_HIP_F32) {
+        Taps<float> t; load_taps(t, ha, hb, m);
+        k_colifilt<float><<<blocks_for(total), 256, 0, ctx->stream>>>((const float *)X, (float *)Y, g, t, m, pos);
+    } else {
+        Taps<double> t; load_taps(t, ha, hb, m);
+        k_colifilt<double><<<blocks_for(total), 256, 0, ctx->stream>>>((const double *)X, (double *)Y, g, t, m, pos);
+    }
+    DT_LAUNCH_CHECK();
+    return 0;
+}
+
+int dtcwt_hip_q2c(dtcwt_hip_ctx *ctx, int dtype, const void *y, int64_t batch, int64_t rows,
+                  int64_t cols, int64_t y_sb, int64_t y_sr, void *Yh, int slot0, int slot1) {
+    DT_REQUIRE(ctx && y && Yh, "NULL argument");
+    DT_REQUIRE(rows % 2 == 0 && cols % 2 == 0, "q2c needs even rows/cols");
+    DT_REQUIRE(slot0 >= 0 && slot0 < 6 && slot1 >= 0 && slot1 < 6, "bad subband slot");
+    int64_t total = batch * (rows / 2) * (cols / 2);
+    if (total == 0) return 0;
+    DT_CHECK_HIP(hipSetDevice(ctx->device));
+    if (dtype == DTCWT_HIP_F32)
+        k_q2c<float><<<blocks_for(total), 256, 0, ctx->stream>>>((const float *)y, batch, rows / 2, cols / 2, y_sb, y_sr, (float *)Yh, slot0, slot1);
+    else if (dtype == DTCWT_HIP_F64)
+        k_q2c<double><<<blocks_for(total), 256, 0, ctx->stream>>>((const double *)y, batch, rows / 2, cols / 2, y_sb, y_sr, (double *)Yh, slot0, slot1);
+    else
+        return dtcwt_set_error(-1, "bad dtype %d", dtype);
+    DT_LAUNCH_CHECK();
+    return 0;
+}
+
+int dtcwt_hip_c2q(dtcwt_hip_ctx *ctx, int dtype, const void *Yh, int64_t batch, int64_t rows,
+                  int64_t cols, int slot0, int slot1, double gain0, double gain1, void *x,
+                  int64_t x_sb, int64_t x_sr) {
+    DT_REQUIRE(ctx && x && Yh, "NULL argument");
+    DT_REQUIRE(slot0 >= 0 && slot0 < 6 && slot1 >= 0 && slot1 < 6, "bad subband slot");
+    int64_t total = batch * rows * cols;
+    if (total == 0) return 0;
+    const double s = 0.70710678118654752440;
+    DT_CHECK_HIP(hipSetDevice(ctx->device));
+    if (dtype == DTCWT_HIP_F32)
+        k_c2q<float><<<blocks_for(total), 256, 0, ctx->stream>>>((const float *)Yh, batch, rows, cols, slot0, slot1, (float)(s * gain0), (float)(s * gain1), (float *)x, x_sb, x_sr);
+    else if (dtype == DTCWT_HIP_F64)
+        k_c2q<double><<<blocks_for(total), 256, 0, ctx->stream>>>((const double *)Yh, batch, rows, cols, slot0, slot1, s * gain0, s * gain1, (double *)x, x_sb, x_sr);
+    else
+        return dtcwt_set_error(-1, "bad dtype %d", dtype);
+    DT_LAUNCH_CHECK();
+    return 0;
+}
+
+int dtcwt_hip_cube2c(dtcwt_hip_ctx *ctx, int dtype, const void *y, int64_t d0, int64_t d1,
+                     int64_t d2, int64_t s0, int64_t s1, void *Yh, int octant) {
+    DT_REQUIRE(ctx && y && Yh, "NULL argument");
+    DT_REQUIRE(d0 % 2 == 0 && d1 % 2 == 0 && d2 % 2 == 0, "cube2c needs even extents");
+    DT_REQUIRE(octant >= 0 && octant < 7, "bad octant");
+    int64_t total = (d0 / 2) * (d1 / 2) * (d2 / 2);
+    if (total == 0) return 0;
+    DT_CHECK_HIP(hipSetDevice(ctx->device));
+    if (dtype == DTCWT_HIP_F32)
+        k_cube2c<float><<<blocks_for(total), 256, 0, ctx->stream>>>((const float *)y, d0 / 2, d1 / 2, d2 / 2, s0, s1, (float *)Yh, octant);
+    else if (dtype == DTCWT_HIP_F64)
+        k_cube2c<double><<<blocks_for(total), 256, 0, ctx->stream>>>((const double *)y, d0 / 2, d1 / 2, d2 / 2, s0, s1, (double *)Yh, octant);
+    else
+        return dtcwt_set_error(-1, "bad dtype %d", dtype);
+    DT_LAUNCH_CHECK();
+    return 0;
+}
+
+int dtcwt_hip_c2cube(dtcwt_hip_ctx *ctx, int dtype, const void *Yh, int64_t e0, int64_t e1,
+                     int64_t e2, int octant, void *y, int64_t s0, int64_t s1) {
+    DT_REQUIRE(ctx && y && Yh, "NULL argument");
+    DT_REQUIRE(octant >= 0 && octant < 7, "bad octant");
+    int64_t total = e0 * e1 * e2;
+    if (total == 0) return 0;
+    DT_CHECK_HIP(hipSetDevice(ctx->device));
+    if (dtype == DTCWT_HIP_F32)
+        k_c2cube<float><<<blocks_for(total), 256, 0, ctx->stream>>>((const float *)Yh, e0, e1, e2, octant, (float *)y, s0, s1);
+    else if (dtype == DTCWT_HIP_F64)
+        k_c2cube<double><<<blocks_for(total), 256, 0, ctx->stream>>>((const double *)Yh, e0, e1, e2, octant, (double *)y, s0, s1);
+    else
+        return dtcwt_set_error(-1, "bad dtype %d", dtype);
+    DT_LAUNCH_CHECK();
+    return 0;
+}
+
+int dtcwt_hip_pack1d(dtcwt_hip_ctx *ctx, int dtype, const void *hi, int64_t J, int64_t k, void *Yh) {
+    DT_REQUIRE(ctx && hi && Yh, "NULL argument");
+    if (J * k == 0) return 0;
+    DT_CHECK_HIP(hipSetDevice(ctx->device));
+    if (dtype == DTCWT_HIP_F32)
+        k_pack1d<float><<<blocks_for(J * k), 256, 0, ctx->stream>>>((const float *)hi, J, k, (float *)Yh);
+    else if (dtype == DTCWT_HIP_F64)
+        k_pack1d<double><<<blocks_for(J * k), 256, 0, ctx->stream>>>((const double *)hi, J, k, (double *)Yh);
+    else
+        return dtcwt_set_error(-1, "bad dtype %d", dtype);
+    DT_LAUNCH_CHECK();
+    return 0;
+}
+
+int dtcwt_hip_unpack1d(dtcwt_hip_ctx *ctx, int dtype, const void *Yh, int64_t J, int64_t k, double gain,
+                       void *hi) {
+    DT_REQUIRE(ctx && hi && Yh, "NULL argument");
+    if (J * k == 0) return 0;
+    DT_CHECK_HIP(hipSetDevice(ctx->device));
+    if (dtype == DTCWT_HIP_F32)
+        k_unpack1d<float><<<blocks_for(J * k), 256, 0, ctx->stream>>>((const float *)Yh, J, k, (float)gain, (float *)hi);
+    else if (dtype == DTCWT_HIP_F64)
+        k_unpack1d<double><<<blocks_for(J * k), 256, 0, ctx->stream>>>((const double *)Yh, J, k, gain, (double *)hi);
+    else
+        return dtcwt_set_error(-1, "bad dtype %d", dtype);
+    DT_LAUNCH_CHECK();
+    return 0;
+}
+
+int dtcwt_hip_scale(dtcwt_hip_ctx *ctx, int dtype, void *x, int64_t count, double gain) {
+    DT_REQUIRE(ctx && x, "NULL argument");
+    if (count == 0) return 0;
+    DT_CHECK_HIP(hipSetDevice(ctx->device));
+    if (dtype == DTCWT_HIP_F32)
+        k_scale<float><<<blocks_for(count), 256, 0, ctx->stream>>>((float *)x, count, (float)gain);
+    else if (dtype == DTCWT_HIP_F64)
+        k_scale<double><<<blocks_for(count), 256, 0, ctx->stream>>>((double *)x, count, gain);
+    else
+        return dtcwt_set_error(-1, "bad dtype %d", dtype);
+    DT_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

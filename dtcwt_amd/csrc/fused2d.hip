@@ -1,0 +1,343 @@
+// Device-resident 2-D DT-CWT level loop: __global__ wrappers of the tile programs in
+// fused2d_tiles.hpp and the plan object behind dtcwt_hip_plan2d_* (include/dtcwt_hip.h).
+//
+// Replaces Transform2d.forward / .inverse of dtcwt/numpy/transform2d.py:40-295 for
+// float32 batches: one kernel launch per level and direction, all intermediates of a
+// level in LDS, LoLo of each level in HBM (it is the next level's input and the
+// `scales` output), Yh written/read as whole 48-byte 6-subband records.
+#include <vector>
+
+#include "common.hpp"
+#include "fused2d_tiles.hpp"
+#include "fused2d_table.hpp"
+
+using namespace dt2d;
+
+namespace {
+
+// -------------------------------------------------------------------------- kernels
+template <class C>
+__global__ void __launch_bounds__(DT_NT) k_fwd1(Fwd1Params p) {
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
+    const int ntile = p.tilesR * p.tilesC * p.B;
+    int t = xcd_tile(blockIdx.x, ntile);
+    if (t >= ntile) return;
+    int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    float *sx = smem, *sLo = smem + C::SX, *sHi = sLo + C::SL;
+    int r0 = tr * C::TR, c0 = tc * C::TC;
+    fwd1_load<C>(p, sx, threadIdx.x, b, r0, c0);
+    __syncthreads();
+    fwd1_cols<C>(p, sx, sLo, sHi, threadIdx.x);
+    __syncthreads();
+    fwd1_rows<C>(p, sLo, sHi, threadIdx.x, b, r0, c0);
+}
+
+template <class C>
+__global__ void __launch_bounds__(DT_NT) k_fwd2(Fwd2Params p) {
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
+    const int ntile = p.tilesR * p.tilesC * p.B;
+    int t = xcd_tile(blockIdx.x, ntile);
+    if (t >= ntile) return;
+    int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    float *sx = smem, *sLo = smem + C::SX, *sHi = sLo + C::SL;
+    int r0 = tr * C::TR, c0 = tc * C::TC;
+    fwd2_load<C>(p, sx, threadIdx.x, b, r0, c0);
+    __syncthreads();
+    fwd2_cols<C>(p, sx, sLo, sHi, threadIdx.x);
+    __syncthreads();
+    fwd2_rows<C>(p, sLo, sHi, threadIdx.x, b, r0, c0);
+}
+
+template <class C>
+__global__ void __launch_bounds__(DT_NT) k_inv1(Inv1Params p) {
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
+    const int ntile = p.tilesR * p.tilesC * p.B;
+    int t = xcd_tile(blockIdx.x, ntile);
+    if (t >= ntile) return;
+    int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    float *s0 = smem, *s1 = s0 + C::SP, *s2 = s1 + C::SP, *s3 = s2 + C::SP;
+    float *y1 = s3 + C::SP, *y2 = y1 + C::SY;
+    int r0 = tr * C::TR, c0 = tc * C::TC;
+    inv1_load<C>(p, s0, s1, s2, s3, threadIdx.x, b, r0, c0);
+    __syncthreads();
+    inv1_cols<C>(p, s0, s1, s2, s3, y1, y2, threadIdx.x);
+    __syncthreads();
+    inv1_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0);
+}
+
+template <class C>
+__global__ void __launch_bounds__(DT_NT) k_inv2(Inv2Params p) {
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
+    const int ntile = p.tilesR * p.tilesC * p.B;
+    int t = xcd_tile(blockIdx.x, ntile);
+    if (t >= ntile) return;
+    int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    float *s0 = smem, *s1 = s0 + C::SP, *s2 = s1 + C::SP, *s3 = s2 + C::SP;
+    float *y1 = s3 + C::SP, *y2 = y1 + C::SY;
+    int r0 = tr * C::TR, c0 = tc * C::TC;
+    inv2_load<C>(p, s0, s1, s2, s3, threadIdx.x, b, r0, c0);
+    __syncthreads();
+    inv2_cols<C>(p, s0, s1, s2, s3, y1, y2, threadIdx.x);
+    __syncthreads();
+    inv2_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0);
+}
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline unsigned grid_for(int ntile) { return (unsigned)(cdiv(ntile, 8) * 8); }
+
+// ------------------------------------------------------------------ launch dispatch
+template <class C>
+int launch_fwd1(Fwd1Params &p, hipStream_t s) {
+    p.tilesR = cdiv(p.LR, C::TR); p.tilesC = cdiv(p.LC, C::TC);
+    k_fwd1<C><<<grid_for(p.tilesR * p.tilesC * p.B), DT_NT, 0, s>>>(p);
+    return 0;
+}
+template <class C>
+int launch_fwd2(Fwd2Params &p, hipStream_t s) {
+    p.tilesR = cdiv(p.LR / 2, C::TR); p.tilesC = cdiv(p.LC / 2, C::TC);
+    k_fwd2<C><<<grid_for(p.tilesR * p.tilesC * p.B), DT_NT, 0, s>>>(p);
+    return 0;
+}
+template <class C>
+int launch_inv1(Inv1Params &p, hipStream_t s) {
+    p.tilesR = cdiv(p.R, C::TR); p.tilesC = cdiv(p.C, C::TC);
+    k_inv1<C><<<grid_for(p.tilesR * p.tilesC * p.B), DT_NT, 0, s>>>(p);
+    return 0;
+}
+template <class C>
+int launch_inv2(Inv2Params &p, hipStream_t s) {
+    p.tilesR = cdiv(p.zr, C::TR); p.tilesC = cdiv(p.zc, C::TC);
+    k_inv2<C><<<grid_for(p.tilesR * p.tilesC * p.B), DT_NT, 0, s>>>(p);
+    return 0;
+}
+
+// Tile shapes and supported tap lengths live in fused2d_table.hpp (shared with the
+// test-only host emulator so both step through identical configurations).
+#define DT_CASE_FWD1(TR, TC, A, B) if (m0 == A && m1 == B) return launch_fwd1<Fwd1Cfg<TR, TC, A, B>>(p, s);
+#define DT_CASE_INV1(TR, TC, A, B) if (m0 == A && m1 == B) return launch_inv1<Inv1Cfg<TR, TC, A, B>>(p, s);
+#define DT_CASE_FWD2(TR, TC, M) if (m == M) return launch_fwd2<Fwd2Cfg<TR, TC, M>>(p, s);
+#define DT_CASE_INV2(TR, TC, M) if (m == M) return launch_inv2<Inv2Cfg<TR, TC, M>>(p, s);
+int dispatch_fwd1(int m0, int m1, Fwd1Params &p, hipStream_t s) { DT_FWD1_TABLE(DT_CASE_FWD1) return -3; }
+int dispatch_inv1(int m0, int m1, Inv1Params &p, hipStream_t s) { DT_INV1_TABLE(DT_CASE_INV1) return -3; }
+int dispatch_fwd2(int m, Fwd2Params &p, hipStream_t s) { DT_FWD2_TABLE(DT_CASE_FWD2) return -3; }
+int dispatch_inv2(int m, Inv2Params &p, hipStream_t s) { DT_INV2_TABLE(DT_CASE_INV2) return -3; }
+
+#define DT_HAS2(TR, TC, A, B) if (m0 == A && m1 == B) return true;
+#define DT_HAS1(TR, TC, M) if (m == M) return true;
+bool fwd1_supported(int m0, int m1) { DT_FWD1_TABLE(DT_HAS2) return false; }
+bool inv1_supported(int m0, int m1) { DT_INV1_TABLE(DT_HAS2) return false; }
+bool q_supported(int m) { DT_FWD2_TABLE(DT_HAS1) return false; }
+
+double dotd(const std::vector<double> &a, const std::vector<double> &b) {
+    double s = 0;
+    for (size_t k = 0; k < a.size(); ++k) s += a[k] * b[k];
+    return s;
+}
+void put_taps(float *dst, const std::vector<double> &src) {
+    for (int k = 0; k < DT_MAXT; ++k) dst[k] = k < (int)src.size() ? (float)src[k] : 0.f;
+}
+
+struct Level {
+    int inR, inC;       // forward input (real) size
+    int padR, padC;     // level >= 2 only
+    int LR, LC;         // logical input size
+    int loR, loC;       // LoLo output size
+    int hR, hC;         // Yh size
+};
+
+}  // namespace
+
+struct dtcwt_hip_plan2d {
+    dtcwt_hip_ctx *ctx;
+    int batch, rows, cols, nlevels;
+    int extR, extC;
+    std::vector<Level> lv;
+    std::vector<double> biort[4];     // h0o g0o h1o g1o
+    std::vector<double> qshift[8];    // h0a h0b g0a g0b h1a h1b g1a g1b
+    std::vector<float *> work;        // LoLo / Z per level (level nlevels-1 unused on fwd)
+    bool profiling = false;           // record an event pair around every level kernel
+    std::vector<hipEvent_t> ev;       // [fwd: 2 per level][inv: 2 per level]
+};
+
+extern "C" {
+
+int dtcwt_hip_plan2d_create(dtcwt_hip_ctx *ctx, int batch, int rows, int cols, int nlevels,
+                            const double *const *biort_host, const int *biort_len,
+                            const double *const *qshift_host, const int *qshift_len,
+                            dtcwt_hip_plan2d **out) {
+    DT_REQUIRE(ctx && out && biort_host && biort_len && qshift_host && qshift_len, "NULL argument");
+    DT_REQUIRE(batch >= 1 && rows >= 1 && cols >= 1 && nlevels >= 1, "bad plan extents");
+    for (int i = 0; i < 4; ++i)
+        DT_REQUIRE(biort_len[i] >= 1 && biort_len[i] <= DT_MAXT, "biort length out of range");
+    for (int i = 0; i < 8; ++i)
+        DT_REQUIRE(qshift_len[i] == qshift_len[0] && qshift_len[i] <= DT_MAXT, "qshift lengths differ");
+    if (!fwd1_supported(biort_len[0], biort_len[2]) || !inv1_supported(biort_len[1], biort_len[3]) ||
+        (nlevels >= 2 && !q_supported(qshift_len[0])))
+        return dtcwt_set_error(-3, "no fused kernel for tap lengths biort (%d,%d,%d,%d) qshift %d",
+                               biort_len[0], biort_len[1], biort_len[2], biort_len[3], qshift_len[0]);
+    dtcwt_hip_plan2d *p = new dtcwt_hip_plan2d();
+    p->ctx = ctx; p->batch = batch; p->rows = rows; p->cols = cols; p->nlevels = nlevels;
+    for (int i = 0; i < 4; ++i) p->biort[i].assign(biort_host[i], biort_host[i] + biort_len[i]);
+    for (int i = 0; i < 8; ++i) p->qshift[i].assign(qshift_host[i], qshift_host[i] + qshift_len[i]);
+    p->extR = rows + (rows & 1);
+    p->extC = cols + (cols & 1);
+    Level l0{rows, cols, 0, 0, p->extR, p->extC, p->extR, p->extC, p->extR / 2, p->extC / 2};
+    p->lv.push_back(l0);
+    for (int l = 1; l < nlevels; ++l) {
+        const Level &pr = p->lv.back();
+        Level L;
+        L.inR = pr.loR; L.inC = pr.loC;
+        L.padR = (L.inR % 4) ? 1 : 0; L.padC = (L.inC % 4) ? 1 : 0;
+        L.LR = L.inR + 2 * L.padR; L.LC = L.inC + 2 * L.padC;
+        L.loR = L.LR / 2; L.loC = L.LC / 2;
+        L.hR = L.LR / 4; L.hC = L.LC / 4;
+        p->lv.push_back(L);
+    }
+    p->work.assign(nlevels, nullptr);
+    for (int l = 0; l < nlevels; ++l) {
+        size_t bytes = (size_t)batch * p->lv[l].loR * p->lv[l].loC * sizeof(float);
+        void *d = nullptr;
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e == hipSuccess) e = hipMalloc(&d, bytes ? bytes : 16);
+        if (e != hipSuccess) {
+            for (float *w : p->work) if (w) (void)hipFree(w);
+            delete p;
+            return dtcwt_set_error(-2, "hipMalloc of plan workspace failed: %s", hipGetErrorString(e));
+        }
+        p->work[l] = (float *)d;
+    }
+    *out = p;
+    return 0;
+}
+
+int dtcwt_hip_plan2d_destroy(dtcwt_hip_plan2d *p) {
+    if (!p) return 0;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    for (float *w : p->work) if (w) (void)hipFree(w);
+    for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
+    delete p;
+    return 0;
+}
+
+int dtcwt_hip_plan2d_set_profiling(dtcwt_hip_plan2d *p, int enable) {
+    DT_REQUIRE(p, "NULL plan");
+    if (enable && p->ev.empty()) {
+        DT_CHECK_HIP(hipSetDevice(p->ctx->device));
+        p->ev.resize(4 * p->nlevels);
+        for (auto &e : p->ev) DT_CHECK_HIP(hipEventCreate(&e));
+    }
+    p->profiling = enable != 0;
+    return 0;
+}
+
+int dtcwt_hip_plan2d_kernel_ms(dtcwt_hip_plan2d *p, float *fwd_ms, float *inv_ms) {
+    DT_REQUIRE(p && p->profiling && !p->ev.empty(), "profiling is not enabled on this plan");
+    DT_CHECK_HIP(hipStreamSynchronize(p->ctx->stream));
+    const int nl = p->nlevels;
+    for (int l = 0; l < nl; ++l) {
+        if (fwd_ms) DT_CHECK_HIP(hipEventElapsedTime(&fwd_ms[l], p->ev[2 * l], p->ev[2 * l + 1]));
+        if (inv_ms) DT_CHECK_HIP(hipEventElapsedTime(&inv_ms[l], p->ev[2 * (nl + l)], p->ev[2 * (nl + l) + 1]));
+    }
+    return 0;
+}
+
+int dtcwt_hip_plan2d_shapes(const dtcwt_hip_plan2d *p, int *s) {
+    DT_REQUIRE(p && s, "NULL argument");
+    s[0] = p->extR; s[1] = p->extC;
+    s[2] = p->lv.back().loR; s[3] = p->lv.back().loC;
+    for (int l = 0; l < p->nlevels; ++l) {
+        s[4 + 4 * l] = p->lv[l].hR; s[5 + 4 * l] = p->lv[l].hC;
+        s[6 + 4 * l] = p->lv[l].loR; s[7 + 4 * l] = p->lv[l].loC;
+    }
+    return 0;
+}
+
+int dtcwt_hip_plan2d_forward(dtcwt_hip_plan2d *p, const float *X, float *Yl, void *const *Yh,
+                             float *const *Ys) {
+    DT_REQUIRE(p && X && Yl && Yh, "NULL argument");
+    DT_CHECK_HIP(hipSetDevice(p->ctx->device));
+    hipStream_t s = p->ctx->stream;
+    const int nl = p->nlevels;
+    const float *in = X;
+    for (int l = 0; l < nl; ++l) {
+        const Level &L = p->lv[l];
+        float *lo = (l == nl - 1 && !Ys) ? Yl : (Ys ? Ys[l] : p->work[l]);
+        DT_REQUIRE(lo && Yh[l], "NULL output buffer at level %d", l);
+        int rc;
+        if (p->profiling) DT_CHECK_HIP(hipEventRecord(p->ev[2 * l], s));
+        if (l == 0) {
+            Fwd1Params q{};
+            q.X = in; q.LoLo = lo; q.Yh = (float *)Yh[l];
+            q.B = p->batch; q.inR = L.inR; q.inC = L.inC; q.LR = L.LR; q.LC = L.LC;
+            put_taps(q.h0, p->biort[0]); put_taps(q.h1, p->biort[2]);
+            rc = dispatch_fwd1((int)p->biort[0].size(), (int)p->biort[2].size(), q, s);
+        } else {
+            Fwd2Params q{};
+            q.X = in; q.LoLo = lo; q.Yh = (float *)Yh[l];
+            q.B = p->batch; q.inR = L.inR; q.inC = L.inC; q.padR = L.padR; q.padC = L.padC;
+            q.LR = L.LR; q.LC = L.LC;
+            // coldfilt(X, h0b, h0a) / coldfilt(X, h1b, h1a)   (transform2d.py:143-157)
+            put_taps(q.l_a, p->qshift[1]); put_taps(q.l_b, p->qshift[0]);
+            put_taps(q.h_a, p->qshift[5]); put_taps(q.h_b, p->qshift[4]);
+            q.lo_a_first = dotd(p->qshift[1], p->qshift[0]) > 0;
+            q.hi_a_first = dotd(p->qshift[5], p->qshift[4]) > 0;
+            rc = dispatch_fwd2((int)p->qshift[0].size(), q, s);
+        }
+        if (rc) return dtcwt_set_error(rc, "no fused forward kernel at level %d", l);
+        DT_CHECK_HIP(hipGetLastError());
+        if (p->profiling) DT_CHECK_HIP(hipEventRecord(p->ev[2 * l + 1], s));
+        in = lo;
+    }
+    if (Ys) {   // Yl is a separate buffer from the last scale
+        const Level &L = p->lv[nl - 1];
+        DT_CHECK_HIP(hipMemcpyAsync(Yl, Ys[nl - 1], (size_t)p->batch * L.loR * L.loC * sizeof(float),
+                                    hipMemcpyDeviceToDevice, s));
+    }
+    return 0;
+}
+
+int dtcwt_hip_plan2d_inverse(dtcwt_hip_plan2d *p, const float *Yl, const void *const *Yh,
+                             const double *gain, float *Z) {
+    DT_REQUIRE(p && Yl && Yh && Z, "NULL argument");
+    DT_CHECK_HIP(hipSetDevice(p->ctx->device));
+    hipStream_t s = p->ctx->stream;
+    const int nl = p->nlevels;
+    const double rs = 0.70710678118654752440;
+    const float *in = Yl;
+    for (int l = nl - 1; l >= 0; --l) {
+        const Level &L = p->lv[l];
+        DT_REQUIRE(Yh[l], "NULL Yh at level %d", l);
+        float g[6];
+        for (int d = 0; d < 6; ++d) g[d] = (float)(rs * (gain ? gain[d * nl + l] : 1.0));
+        int rc;
+        if (p->profiling) DT_CHECK_HIP(hipEventRecord(p->ev[2 * (nl + l)], s));
+        if (l == 0) {
+            Inv1Params q{};
+            q.Z = in; q.Yh = (const float *)Yh[0]; q.X = Z;
+            q.B = p->batch; q.R = L.LR; q.C = L.LC;
+            for (int d = 0; d < 6; ++d) q.g[d] = g[d];
+            put_taps(q.g0, p->biort[1]); put_taps(q.g1, p->biort[3]);
+            rc = dispatch_inv1((int)p->biort[1].size(), (int)p->biort[3].size(), q, s);
+        } else {
+            Inv2Params q{};
+            float *out = p->work[l - 1];          // size of LoLo_{l-1} = this level's input
+            q.Z = in; q.Yh = (const float *)Yh[l]; q.Out = out;
+            q.B = p->batch; q.zr = L.loR; q.zc = L.loC; q.cropR = L.padR; q.cropC = L.padC;
+            for (int d = 0; d < 6; ++d) q.g[d] = g[d];
+            // colifilt(X, g0b, g0a) / colifilt(X, g1b, g1a)   (transform2d.py:248-260)
+            put_taps(q.l_a, p->qshift[3]); put_taps(q.l_b, p->qshift[2]);
+            put_taps(q.h_a, p->qshift[7]); put_taps(q.h_b, p->qshift[6]);
+            q.lo_pos = dotd(p->qshift[3], p->qshift[2]) > 0;
+            q.hi_pos = dotd(p->qshift[7], p->qshift[6]) > 0;
+            rc = dispatch_inv2((int)p->qshift[0].size(), q, s);
+            in = out;
+        }
+        if (rc) return dtcwt_set_error(rc, "no fused inverse kernel at level %d", l);
+        DT_CHECK_HIP(hipGetLastError());
+        if (p->profiling) DT_CHECK_HIP(hipEventRecord(p->ev[2 * (nl + l) + 1], s));
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,173 @@
+// Runtime part of the C ABI: contexts, device buffers, events (include/dtcwt_hip.h).
+#include <cstring>
+
+#include "common.hpp"
+
+static thread_local char g_err[512] = "";
+
+int dtcwt_set_error(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" {
+
+int dtcwt_hip_abi_version(void) { return DTCWT_HIP_ABI_VERSION; }
+
+const char *dtcwt_hip_last_error(void) { return g_err; }
+
+int dtcwt_hip_device_count(int *count) {
+    DT_REQUIRE(count, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return dtcwt_set_error(-2, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return 0;
+}
+
+int dtcwt_hip_device_info(int device, char *name, int *cus, size_t *mem_bytes) {
+    hipDeviceProp_t p;
+    DT_CHECK_HIP(hipGetDeviceProperties(&p, device));
+    if (name) {
+        snprintf(name, 256, "%s (%s)", p.name, p.gcnArchName);
+    }
+    if (cus) *cus = p.multiProcessorCount;
+    if (mem_bytes) *mem_bytes = p.totalGlobalMem;
+    return 0;
+}
+
+int dtcwt_hip_ctx_create(int device, void *stream, dtcwt_hip_ctx **out) {
+    DT_REQUIRE(out, "ctx out pointer is NULL");
+    int n = 0;
+    DT_CHECK_HIP(hipGetDeviceCount(&n));
+    DT_REQUIRE(device >= 0 && device < n, "device %d out of range (%d devices)", device, n);
+    DT_CHECK_HIP(hipSetDevice(device));
+    dtcwt_hip_ctx *c = new dtcwt_hip_ctx();
+    c->device = device;
+    c->owns_stream = (stream == nullptr);
+    if (stream) {
+        c->stream = reinterpret_cast<hipStream_t>(stream);
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete c;
+            return dtcwt_set_error(-2, "hipStreamCreate failed: %s", hipGetErrorString(e));
+        }
+    }
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) == hipSuccess) c->cus = p.multiProcessorCount;
+    else c->cus = 256;
+    *out = c;
+    return 0;
+}
+
+int dtcwt_hip_ctx_destroy(dtcwt_hip_ctx *c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->owns_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+int dtcwt_hip_sync(dtcwt_hip_ctx *c) {
+    DT_REQUIRE(c, "ctx is NULL");
+    DT_CHECK_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+void *dtcwt_hip_ctx_stream(dtcwt_hip_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int dtcwt_hip_malloc(dtcwt_hip_ctx *c, size_t bytes, void **dptr) {
+    DT_REQUIRE(c && dptr, "NULL argument");
+    DT_CHECK_HIP(hipSetDevice(c->device));
+    *dptr = nullptr;
+    if (bytes == 0) bytes = 16;
+    DT_CHECK_HIP(hipMalloc(dptr, bytes));
+    return 0;
+}
+
+int dtcwt_hip_free(dtcwt_hip_ctx *c, void *dptr) {
+    DT_REQUIRE(c, "ctx is NULL");
+    if (!dptr) return 0;
+    DT_CHECK_HIP(hipSetDevice(c->device));
+    DT_CHECK_HIP(hipStreamSynchronize(c->stream));
+    DT_CHECK_HIP(hipFree(dptr));
+    return 0;
+}
+
+int dtcwt_hip_memcpy_h2d(dtcwt_hip_ctx *c, void *dst, const void *src, size_t bytes) {
+    DT_REQUIRE(c, "ctx is NULL");
+    if (!bytes) return 0;
+    DT_CHECK_HIP(hipSetDevice(c->device));
+    DT_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    // pageable host memory: make the call safe to follow by a host-side free/reuse
+    DT_CHECK_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int dtcwt_hip_memcpy_d2h(dtcwt_hip_ctx *c, void *dst, const void *src, size_t bytes) {
+    DT_REQUIRE(c, "ctx is NULL");
+    if (!bytes) return 0;
+    DT_CHECK_HIP(hipSetDevice(c->device));
+    DT_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    DT_CHECK_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int dtcwt_hip_memcpy_d2d(dtcwt_hip_ctx *c, void *dst, const void *src, size_t bytes) {
+    DT_REQUIRE(c, "ctx is NULL");
+    if (!bytes) return 0;
+    DT_CHECK_HIP(hipSetDevice(c->device));
+    DT_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+int dtcwt_hip_memset(dtcwt_hip_ctx *c, void *dst, int value, size_t bytes) {
+    DT_REQUIRE(c, "ctx is NULL");
+    if (!bytes) return 0;
+    DT_CHECK_HIP(hipSetDevice(c->device));
+    DT_CHECK_HIP(hipMemsetAsync(dst, value, bytes, c->stream));
+    return 0;
+}
+
+int dtcwt_hip_event_create(dtcwt_hip_ctx *c, dtcwt_hip_event **ev) {
+    DT_REQUIRE(c && ev, "NULL argument");
+    DT_CHECK_HIP(hipSetDevice(c->device));
+    dtcwt_hip_event *e = new dtcwt_hip_event();
+    hipError_t r = hipEventCreate(&e->ev);
+    if (r != hipSuccess) {
+        delete e;
+        return dtcwt_set_error(-2, "hipEventCreate failed: %s", hipGetErrorString(r));
+    }
+    *ev = e;
+    return 0;
+}
+
+int dtcwt_hip_event_record(dtcwt_hip_ctx *c, dtcwt_hip_event *ev) {
+    DT_REQUIRE(c && ev, "NULL argument");
+    DT_CHECK_HIP(hipEventRecord(ev->ev, c->stream));
+    return 0;
+}
+
+int dtcwt_hip_event_elapsed_ms(dtcwt_hip_event *a, dtcwt_hip_event *b, float *ms) {
+    DT_REQUIRE(a && b && ms, "NULL argument");
+    DT_CHECK_HIP(hipEventSynchronize(b->ev));
+    DT_CHECK_HIP(hipEventElapsedTime(ms, a->ev, b->ev));
+    return 0;
+}
+
+int dtcwt_hip_event_destroy(dtcwt_hip_event *ev) {
+    if (!ev) return 0;
+    (void)hipEventDestroy(ev->ev);
+    delete ev;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,355 @@
+"""ctypes binding of libdtcwt_hip.so (the C ABI declared in include/dtcwt_hip.h).
+
+Plays the role dtcwt/opencl/lowlevel.py:1-21,150-181 plays for PyOpenCL in the reference:
+import never fails; the first *use* without a usable runtime raises
+:class:`NoHIPPresentError` (a ``RuntimeError``), never a silent CPU fallback.
+"""
+import ctypes
+import importlib.util
+import os
+import threading
+
+import numpy as np
+
+__all__ = ['NoHIPPresentError', 'HipError', 'lib', 'have_hip', 'Context', 'DeviceArray',
+           'default_context', 'View', 'F32', 'F64', 'ACCUMULATE', 'LIB_PATH']
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                        'libdtcwt_hip.so')
+
+F32, F64 = 0, 1
+ACCUMULATE = 1
+MAX_TAPS = 40
+
+
+class NoHIPPresentError(RuntimeError):
+    """libdtcwt_hip.so is missing/unloadable or no HIP device is present."""
+
+
+class HipError(RuntimeError):
+    """A call into libdtcwt_hip.so failed."""
+
+
+class View(ctypes.Structure):
+    """struct dtcwt_hip_view"""
+    _fields_ = [('outer', ctypes.c_int64), ('n', ctypes.c_int64), ('inner', ctypes.c_int64),
+                ('xso', ctypes.c_int64), ('xsn', ctypes.c_int64), ('xsi', ctypes.c_int64),
+                ('yso', ctypes.c_int64), ('ysn', ctypes.c_int64), ('ysi', ctypes.c_int64),
+                ('pad_lo', ctypes.c_int32), ('pad_hi', ctypes.c_int32),
+                ('crop_lo', ctypes.c_int32), ('crop_hi', ctypes.c_int32)]
+
+
+_lib = None
+_lib_error = None
+_lock = threading.Lock()
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_i64 = ctypes.c_int64
+_sz = ctypes.c_size_t
+_dbl = ctypes.c_double
+_pd = ctypes.POINTER(ctypes.c_double)
+
+# name -> (restype, argtypes); every symbol include/dtcwt_hip.h declares
+SIGNATURES = {
+    'dtcwt_hip_abi_version': (_i, []),
+    'dtcwt_hip_last_error': (ctypes.c_char_p, []),
+    'dtcwt_hip_device_count': (_i, [ctypes.POINTER(_i)]),
+    'dtcwt_hip_device_info': (_i, [_i, ctypes.c_char_p, ctypes.POINTER(_i), ctypes.POINTER(_sz)]),
+    'dtcwt_hip_ctx_create': (_i, [_i, _vp, ctypes.POINTER(_vp)]),
+    'dtcwt_hip_ctx_destroy': (_i, [_vp]),
+    'dtcwt_hip_sync': (_i, [_vp]),
+    'dtcwt_hip_ctx_stream': (_vp, [_vp]),
+    'dtcwt_hip_malloc': (_i, [_vp, _sz, ctypes.POINTER(_vp)]),
+    'dtcwt_hip_free': (_i, [_vp, _vp]),
+    'dtcwt_hip_memcpy_h2d': (_i, [_vp, _vp, _vp, _sz]),
+    'dtcwt_hip_memcpy_d2h': (_i, [_vp, _vp, _vp, _sz]),
+    'dtcwt_hip_memcpy_d2d': (_i, [_vp, _vp, _vp, _sz]),
+    'dtcwt_hip_memset': (_i, [_vp, _vp, _i, _sz]),
+    'dtcwt_hip_event_create': (_i, [_vp, ctypes.POINTER(_vp)]),
+    'dtcwt_hip_event_record': (_i, [_vp, _vp]),
+    'dtcwt_hip_event_elapsed_ms': (_i, [_vp, _vp, ctypes.POINTER(ctypes.c_float)]),
+    'dtcwt_hip_event_destroy': (_i, [_vp]),
+    'dtcwt_hip_colfilter': (_i, [_vp, _i, _vp, _vp, ctypes.POINTER(View), _pd, _i, _i]),
+    'dtcwt_hip_coldfilt': (_i, [_vp, _i, _vp, _vp, ctypes.POINTER(View), _pd, _pd, _i, _i]),
+    'dtcwt_hip_colifilt': (_i, [_vp, _i, _vp, _vp, ctypes.POINTER(View), _pd, _pd, _i, _i]),
+    'dtcwt_hip_q2c': (_i, [_vp, _i, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i, _i]),
+    'dtcwt_hip_c2q': (_i, [_vp, _i, _vp, _i64, _i64, _i64, _i, _i, _dbl, _dbl, _vp, _i64, _i64]),
+    'dtcwt_hip_cube2c': (_i, [_vp, _i, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i]),
+    'dtcwt_hip_c2cube': (_i, [_vp, _i, _vp, _i64, _i64, _i64, _i, _vp, _i64, _i64]),
+    'dtcwt_hip_pack1d': (_i, [_vp, _i, _vp, _i64, _i64, _vp]),
+    'dtcwt_hip_unpack1d': (_i, [_vp, _i, _vp, _i64, _i64, _dbl, _vp]),
+    'dtcwt_hip_scale': (_i, [_vp, _i, _vp, _i64, _dbl]),
+    'dtcwt_hip_plan2d_create': (_i, [_vp, _i, _i, _i, _i, ctypes.POINTER(_pd), ctypes.POINTER(_i),
+                                     ctypes.POINTER(_pd), ctypes.POINTER(_i), ctypes.POINTER(_vp)]),
+    'dtcwt_hip_plan2d_destroy': (_i, [_vp]),
+    'dtcwt_hip_plan2d_shapes': (_i, [_vp, ctypes.POINTER(_i)]),
+    'dtcwt_hip_plan2d_forward': (_i, [_vp, _vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
+    'dtcwt_hip_plan2d_inverse': (_i, [_vp, _vp, ctypes.POINTER(_vp), _pd, _vp]),
+    'dtcwt_hip_plan2d_set_profiling': (_i, [_vp, _i]),
+    'dtcwt_hip_plan2d_kernel_ms': (_i, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
+}
+
+
+def _preload_runtime():
+    """If PyTorch-ROCm is installed it ships its own libamdhip64.so; a process that uses
+    both torch and this library must share ONE HIP runtime.  Loading torch's copy first
+    (same SONAME as the system one) makes the dynamic linker bind both to it, whichever
+    is imported first.  Set DTCWT_HIP_RUNTIME=system to skip."""
+    if os.environ.get('DTCWT_HIP_RUNTIME', '') == 'system':
+        return
+    try:
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), 'lib', 'libamdhip64.so')
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
+def load_library(path=None):
+    """Load (once) and return the ctypes handle; raises NoHIPPresentError."""
+    global _lib, _lib_error
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if _lib_error is not None:
+            raise NoHIPPresentError(_lib_error)
+        path = path or os.environ.get('DTCWT_HIP_LIBRARY', LIB_PATH)
+        if not os.path.exists(path):
+            _lib_error = ('%s not found: build it with `make -C dtcwt_amd/csrc` (or '
+                          '`python -c "import __graft_entry__ as g; g.build()"`)' % path)
+            raise NoHIPPresentError(_lib_error)
+        _preload_runtime()
+        try:
+            handle = ctypes.CDLL(path)
+        except OSError as e:
+            _lib_error = 'cannot load %s: %s' % (path, e)
+            raise NoHIPPresentError(_lib_error)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+        return _lib
+
+
+def lib():
+    return load_library()
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().dtcwt_hip_last_error()
+        raise HipError('libdtcwt_hip: %s (code %d)' % (msg.decode('utf-8', 'replace') if msg else '?', rc))
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    try:
+        rc = lib().dtcwt_hip_device_count(ctypes.byref(n))
+    except NoHIPPresentError:
+        return 0
+    return n.value if rc == 0 else 0
+
+
+def have_hip():
+    """True when the library loads and at least one HIP device is visible."""
+    return device_count() > 0
+
+
+def dtype_code(dt):
+    dt = np.dtype(dt)
+    if dt == np.float32 or dt == np.complex64:
+        return F32
+    if dt == np.float64 or dt == np.complex128:
+        return F64
+    raise TypeError('unsupported dtype %s' % dt)
+
+
+def taps_arg(h):
+    """(keep-alive array, double*, length) for a filter vector."""
+    a = np.ascontiguousarray(np.asarray(h, dtype=np.float64).reshape(-1))
+    if a.shape[0] > MAX_TAPS:
+        raise ValueError('filters longer than %d taps are not supported by the hip backend' % MAX_TAPS)
+    return a, a.ctypes.data_as(_pd), int(a.shape[0])
+
+
+class Context(object):
+    """A device + stream (``dtcwt_hip_ctx``).  ``stream`` may be a raw ``hipStream_t``
+    value (e.g. ``torch.cuda.current_stream().cuda_stream``) to run on a caller's stream;
+    the analogue of the OpenCL backend's ``queue`` (dtcwt/opencl/lowlevel.py:154-167)."""
+
+    def __init__(self, device=0, stream=None):
+        L = lib()
+        if device_count() < 1:
+            raise NoHIPPresentError('no HIP device visible to libdtcwt_hip.so')
+        h = _vp()
+        check(L.dtcwt_hip_ctx_create(int(device), _vp(stream) if stream else None, ctypes.byref(h)))
+        self._h = h
+        self.device = int(device)
+        self._lib = L
+
+    @property
+    def handle(self):
+        return self._h
+
+    def sync(self):
+        check(self._lib.dtcwt_hip_sync(self._h))
+
+    def empty(self, shape, dtype):
+        return DeviceArray(self, shape, dtype)
+
+    def zeros(self, shape, dtype):
+        a = DeviceArray(self, shape, dtype)
+        check(self._lib.dtcwt_hip_memset(self._h, a.ptr, 0, a.nbytes))
+        return a
+
+    def to_device(self, X, dtype=None):
+        X = np.ascontiguousarray(X, dtype=dtype)
+        a = DeviceArray(self, X.shape, X.dtype)
+        check(self._lib.dtcwt_hip_memcpy_h2d(self._h, a.ptr, X.ctypes.data_as(_vp), X.nbytes))
+        return a
+
+    def event(self):
+        return Event(self)
+
+    def __del__(self):
+        try:
+            if getattr(self, '_h', None):
+                self._lib.dtcwt_hip_ctx_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class Event(object):
+    def __init__(self, ctx):
+        self.ctx = ctx
+        h = _vp()
+        check(ctx._lib.dtcwt_hip_event_create(ctx.handle, ctypes.byref(h)))
+        self._h = h
+
+    def record(self):
+        check(self.ctx._lib.dtcwt_hip_event_record(self.ctx.handle, self._h))
+        return self
+
+    def elapsed_ms(self, later):
+        ms = ctypes.c_float(0)
+        check(self.ctx._lib.dtcwt_hip_event_elapsed_ms(self._h, later._h, ctypes.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            if getattr(self, '_h', None):
+                self.ctx._lib.dtcwt_hip_event_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class DeviceArray(object):
+    """A C-contiguous array in HBM: pointer + shape + dtype.  Owns its memory unless
+    wrapping a foreign pointer (``DeviceArray.wrap``)."""
+
+    def __init__(self, ctx, shape, dtype, ptr=None, owner=None):
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.size = int(np.prod(self.shape, dtype=np.int64)) if self.shape else 1
+        self.nbytes = self.size * self.dtype.itemsize
+        self._owner = owner
+        if ptr is None:
+            p = _vp()
+            check(ctx._lib.dtcwt_hip_malloc(ctx.handle, self.nbytes, ctypes.byref(p)))
+            self.ptr = p.value
+            self._owned = True
+        else:
+            self.ptr = int(ptr)
+            self._owned = False
+
+    @classmethod
+    def wrap(cls, ctx, obj):
+        """Zero-copy view of an on-device tensor (anything with ``data_ptr()``, ``shape``
+        and ``dtype`` such as a contiguous torch CUDA/ROCm tensor), by analogy with the
+        OpenCL backend accepting pyopencl arrays (dtcwt/opencl/transform2d.py:133-135)."""
+        if hasattr(obj, 'is_contiguous') and not obj.is_contiguous():
+            raise ValueError('device tensors must be contiguous')
+        dt = str(obj.dtype).replace('torch.', '')
+        return cls(ctx, tuple(obj.shape), np.dtype(dt), ptr=obj.data_ptr(), owner=obj)
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    @property
+    def __cuda_array_interface__(self):
+        return {'shape': self.shape, 'typestr': self.dtype.str, 'data': (self.ptr, False),
+                'version': 2, 'strides': None}
+
+    def reshape(self, *shape):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
+            shape = tuple(shape[0])
+        assert int(np.prod(shape, dtype=np.int64)) == self.size
+        return DeviceArray(self.ctx, shape, self.dtype, ptr=self.ptr, owner=self)
+
+    def view(self, dtype):
+        dtype = np.dtype(dtype)
+        shape = list(self.shape)
+        shape[-1] = shape[-1] * self.dtype.itemsize // dtype.itemsize
+        return DeviceArray(self.ctx, shape, dtype, ptr=self.ptr, owner=self)
+
+    def get(self):
+        """Copy to a NumPy array (synchronises the stream)."""
+        out = np.empty(self.shape, dtype=self.dtype)
+        check(self.ctx._lib.dtcwt_hip_memcpy_d2h(self.ctx.handle, out.ctypes.data_as(_vp), self.ptr,
+                                                 self.nbytes))
+        return out
+
+    def set(self, X):
+        X = np.ascontiguousarray(X, dtype=self.dtype)
+        assert X.shape == self.shape
+        check(self.ctx._lib.dtcwt_hip_memcpy_h2d(self.ctx.handle, self.ptr, X.ctypes.data_as(_vp), X.nbytes))
+        return self
+
+    def copy(self):
+        out = DeviceArray(self.ctx, self.shape, self.dtype)
+        check(self.ctx._lib.dtcwt_hip_memcpy_d2d(self.ctx.handle, out.ptr, self.ptr, self.nbytes))
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, '_owned', False) and self.ptr:
+                self.ctx._lib.dtcwt_hip_free(self.ctx.handle, self.ptr)
+                self.ptr = 0
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device=None):
+    """Memoised context on ``device`` (default: env DTCWT_HIP_DEVICE, LOCAL_RANK or 0)."""
+    if device is None:
+        device = int(os.environ.get('DTCWT_HIP_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+        n = device_count()
+        if n:
+            device %= n
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+def is_device_array(X):
+    return isinstance(X, DeviceArray)
+
+
+def is_foreign_device_tensor(X):
+    """torch-like tensor living on a GPU."""
+    return hasattr(X, 'data_ptr') and getattr(X, 'is_cuda', False)

@@ -1,0 +1,78 @@
+"""Pyramid container of the ``hip`` backend.
+
+Interface of dtcwt/numpy/common.py:5-32 (``lowpass``, ``highpasses``, ``scales``) with the
+device-resident behaviour of the reference's OpenCL pyramid
+(dtcwt/opencl/transform2d.py:30-84): the subband buffers stay in HBM
+(``hip_lowpass`` / ``hip_highpasses`` / ``hip_scales``, :class:`DeviceArray` instances) and
+the NumPy attributes are filled by ONE device-to-host copy on first access and memoised.
+Constructed from NumPy arrays it behaves like the NumPy pyramid and uploads lazily when
+an inverse transform needs device buffers.
+"""
+import numpy as np
+
+from dtcwt_amd.utils import asfarray
+from dtcwt_amd.hip._lib import DeviceArray
+
+__all__ = ['Pyramid']
+
+
+def _is_dev(x):
+    return isinstance(x, DeviceArray)
+
+
+class Pyramid(object):
+    def __init__(self, lowpass, highpasses, scales=None):
+        self._low = lowpass if _is_dev(lowpass) else asfarray(lowpass)
+        self._high = tuple(x if (x is None or _is_dev(x)) else asfarray(x) for x in highpasses)
+        self._scales = None if scales is None else tuple(x if _is_dev(x) else asfarray(x) for x in scales)
+        self._host = {}
+
+    # ---- raw device handles (None where the entry was given as a host array) ----
+    @property
+    def hip_lowpass(self):
+        return self._low if _is_dev(self._low) else None
+
+    @property
+    def hip_highpasses(self):
+        return tuple(x if _is_dev(x) else None for x in self._high)
+
+    @property
+    def hip_scales(self):
+        if self._scales is None:
+            return None
+        return tuple(x if _is_dev(x) else None for x in self._scales)
+
+    # ---- NumPy-compatible attributes, memoised --------------------------------
+    def _get(self, key, x):
+        if x is None or not _is_dev(x):
+            return x
+        if key not in self._host:
+            self._host[key] = x.get()
+        return self._host[key]
+
+    @property
+    def lowpass(self):
+        return self._get('l', self._low)
+
+    @property
+    def highpasses(self):
+        return tuple(self._get(('h', i), x) for i, x in enumerate(self._high))
+
+    @property
+    def scales(self):
+        if self._scales is None:
+            return None
+        return tuple(self._get(('s', i), x) for i, x in enumerate(self._scales))
+
+    # ---- used by the inverse transforms ---------------------------------------
+    def device_parts(self, ctx, real_dtype=None):
+        """(lowpass, highpasses) as DeviceArrays on *ctx* (uploading host arrays);
+        highpass entries may be None."""
+        def up(x, cplx):
+            if x is None or _is_dev(x):
+                return x
+            if real_dtype is not None:
+                dt = (np.complex64 if real_dtype == np.float32 else np.complex128) if cplx else real_dtype
+                return ctx.to_device(x, dtype=dt)
+            return ctx.to_device(x)
+        return up(self._low, False), tuple(up(x, True) for x in self._high)

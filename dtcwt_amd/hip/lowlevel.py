@@ -1,0 +1,187 @@
+"""Low-level column filters of the ``hip`` backend: ``colfilter``, ``coldfilt``,
+``colifilt`` with the signatures, shape rules and ``ValueError`` behaviour of
+dtcwt/numpy/lowlevel.py:47-260, executed by the gfx950 kernels of libdtcwt_hip.so.
+
+NumPy in -> NumPy out (like dtcwt/opencl/lowlevel.py:24-148, which returns host arrays);
+:class:`DeviceArray` in -> :class:`DeviceArray` out (stays in HBM).  float32 and float64
+are preserved, anything else is promoted to float64 (dtcwt/utils.py:98-105).
+
+The ``axis_*`` functions are the device-side building blocks used by the transforms:
+they filter along any axis of a C-contiguous device array, with the logical edge
+replication / output cropping the level loops need done by index arithmetic.
+"""
+import ctypes
+
+import numpy as np
+
+from dtcwt_amd.utils import asfarray
+from dtcwt_amd.hip import _lib
+from dtcwt_amd.hip._lib import DeviceArray, View, check, dtype_code, taps_arg
+
+__all__ = ['colfilter', 'coldfilt', 'colifilt', 'axis_colfilter', 'axis_coldfilt',
+           'axis_colifilt', 'q2c', 'c2q']
+
+
+def _prod(t):
+    r = 1
+    for s in t:
+        r *= int(s)
+    return r
+
+
+def _view(X, axis, nwrite, pad, crop):
+    shape = X.shape
+    outer, n, inner = _prod(shape[:axis]), int(shape[axis]), _prod(shape[axis + 1:])
+    v = View()
+    v.outer, v.n, v.inner = outer, n, inner
+    v.xso, v.xsn, v.xsi = n * inner, inner, 1
+    v.yso, v.ysn, v.ysi = nwrite * inner, inner, 1
+    v.pad_lo, v.pad_hi = int(pad[0]), int(pad[1])
+    v.crop_lo, v.crop_hi = int(crop[0]), int(crop[1])
+    return v
+
+
+def _out(X, axis, nwrite, out, accumulate):
+    shape = X.shape[:axis] + (nwrite,) + X.shape[axis + 1:]
+    if out is None:
+        if accumulate:
+            raise ValueError('accumulate needs an output array')
+        return DeviceArray(X.ctx, shape, X.dtype)
+    if out.shape != shape or out.dtype != X.dtype:
+        raise ValueError('output array has shape %s dtype %s, need %s %s' % (out.shape, out.dtype, shape, X.dtype))
+    return out
+
+
+def axis_colfilter(X, h, axis=0, out=None, accumulate=False, pad=(0, 0), crop=(0, 0)):
+    """Device colfilter along *axis* (dtcwt/numpy/lowlevel.py:47-80)."""
+    axis = axis % X.ndim
+    keep, hp, m = taps_arg(h)
+    L = X.shape[axis] + pad[0] + pad[1]
+    nout = L if m % 2 else L + 1
+    nwrite = nout - crop[0] - crop[1]
+    Y = _out(X, axis, nwrite, out, accumulate)
+    v = _view(X, axis, nwrite, pad, crop)
+    check(_lib.lib().dtcwt_hip_colfilter(X.ctx.handle, dtype_code(X.dtype), X.ptr, Y.ptr, ctypes.byref(v),
+                                         hp, m, _lib.ACCUMULATE if accumulate else 0))
+    return Y
+
+
+def _pair_args(ha, hb):
+    ka, pa, ma = taps_arg(ha)
+    kb, pb, mb = taps_arg(hb)
+    if np.shape(ha) != np.shape(hb) and ma != mb:
+        raise ValueError('Shapes of ha and hb must be the same')
+    if ma != mb:
+        raise ValueError('Shapes of ha and hb must be the same')
+    if ma % 2 != 0:
+        raise ValueError('Lengths of ha and hb must be even')
+    return (ka, kb), pa, pb, ma
+
+
+def axis_coldfilt(X, ha, hb, axis=0, out=None, accumulate=False, pad=(0, 0), crop=(0, 0)):
+    """Device coldfilt along *axis* (dtcwt/numpy/lowlevel.py:82-154)."""
+    axis = axis % X.ndim
+    keep, pa, pb, m = _pair_args(ha, hb)
+    L = X.shape[axis] + pad[0] + pad[1]
+    if L % 4 != 0:
+        raise ValueError('No. of rows in X must be a multiple of 4')
+    nwrite = L // 2 - crop[0] - crop[1]
+    Y = _out(X, axis, nwrite, out, accumulate)
+    v = _view(X, axis, nwrite, pad, crop)
+    check(_lib.lib().dtcwt_hip_coldfilt(X.ctx.handle, dtype_code(X.dtype), X.ptr, Y.ptr, ctypes.byref(v),
+                                        pa, pb, m, _lib.ACCUMULATE if accumulate else 0))
+    return Y
+
+
+def axis_colifilt(X, ha, hb, axis=0, out=None, accumulate=False, pad=(0, 0), crop=(0, 0)):
+    """Device colifilt along *axis* (dtcwt/numpy/lowlevel.py:156-260)."""
+    axis = axis % X.ndim
+    keep, pa, pb, m = _pair_args(ha, hb)
+    L = X.shape[axis] + pad[0] + pad[1]
+    if L % 2 != 0:
+        raise ValueError('No. of rows in X must be a multiple of 2')
+    nwrite = 2 * L - crop[0] - crop[1]
+    Y = _out(X, axis, nwrite, out, accumulate)
+    v = _view(X, axis, nwrite, pad, crop)
+    check(_lib.lib().dtcwt_hip_colifilt(X.ctx.handle, dtype_code(X.dtype), X.ptr, Y.ptr, ctypes.byref(v),
+                                        pa, pb, m, _lib.ACCUMULATE if accumulate else 0))
+    return Y
+
+
+def q2c(y, Yh, slot0, slot1):
+    """Device q2c of plane(s) y [..., R, C] into subbands slot0/slot1 of Yh [..., R/2,
+    C/2, 6] (dtcwt/numpy/transform2d.py:301-322 + the slice-assign of :122-127)."""
+    R, C = y.shape[-2:]
+    batch = _prod(y.shape[:-2])
+    check(_lib.lib().dtcwt_hip_q2c(y.ctx.handle, dtype_code(y.dtype), y.ptr, batch, R, C, R * C, C,
+                                   Yh.ptr, slot0, slot1))
+    return Yh
+
+
+def c2q(Yh, slot0, slot1, gain0, gain1, out=None):
+    """Device c2q of subbands slot0/slot1 of Yh [..., R, C, 6] -> real plane [..., 2R, 2C]
+    (dtcwt/numpy/transform2d.py:324-350)."""
+    R, C = Yh.shape[-3:-1]
+    batch = _prod(Yh.shape[:-3])
+    rdt = np.float32 if Yh.dtype == np.complex64 else np.float64
+    if out is None:
+        out = DeviceArray(Yh.ctx, Yh.shape[:-3] + (2 * R, 2 * C), rdt)
+    check(_lib.lib().dtcwt_hip_c2q(Yh.ctx.handle, dtype_code(Yh.dtype), Yh.ptr, batch, R, C, slot0, slot1,
+                                   float(gain0), float(gain1), out.ptr, 4 * R * C, 2 * C))
+    return out
+
+
+# ------------------------------------------------------------------ public functions
+def _to_dev(X, ctx):
+    """-> (DeviceArray 2-D, was_host)"""
+    if isinstance(X, DeviceArray):
+        if X.ndim != 2:
+            raise ValueError('device input must be two-dimensional')
+        return X, False
+    X = asfarray(X)
+    if X.ndim != 2:
+        raise ValueError('X must be a two-dimensional array')
+    ctx = ctx or _lib.default_context()
+    return ctx.to_device(X), True
+
+
+def colfilter(X, h, ctx=None):
+    """Filter the columns of image *X* with *h*, no decimation, symmetric extension.
+    Output has the rows of X (odd-length h) or one more (even-length h)."""
+    Xd, host = _to_dev(X, ctx)
+    Y = axis_colfilter(Xd, h, axis=0)
+    return Y.get() if host else Y
+
+
+def coldfilt(X, ha, hb, ctx=None):
+    """Dual-tree decimating column filter: rows % 4 == 0, even-length ha/hb of equal
+    shape (``ValueError`` otherwise); output has half the rows."""
+    if not isinstance(X, DeviceArray):
+        X = asfarray(X)
+    r = X.shape[0]
+    if r % 4 != 0:
+        raise ValueError('No. of rows in X must be a multiple of 4')
+    if np.shape(ha) != np.shape(hb):
+        raise ValueError('Shapes of ha and hb must be the same')
+    if np.asarray(ha).reshape(-1).shape[0] % 2 != 0:
+        raise ValueError('Lengths of ha and hb must be even')
+    Xd, host = _to_dev(X, ctx)
+    Y = axis_coldfilt(Xd, ha, hb, axis=0)
+    return Y.get() if host else Y
+
+
+def colifilt(X, ha, hb, ctx=None):
+    """Dual-tree interpolating column filter: rows % 2 == 0, even-length ha/hb of equal
+    shape (``ValueError`` otherwise); output has twice the rows."""
+    if not isinstance(X, DeviceArray):
+        X = asfarray(X)
+    r = X.shape[0]
+    if r % 2 != 0:
+        raise ValueError('No. of rows in X must be a multiple of 2')
+    if np.shape(ha) != np.shape(hb):
+        raise ValueError('Shapes of ha and hb must be the same')
+    if np.asarray(ha).reshape(-1).shape[0] % 2 != 0:
+        raise ValueError('Lengths of ha and hb must be even')
+    Xd, host = _to_dev(X, ctx)
+    Y = axis_colifilt(Xd, ha, hb, axis=0)
+    return Y.get() if host else Y

@@ -1,0 +1,522 @@
+"""2-D DT-CWT on MI355X: ``Transform2d`` of the ``hip`` backend.
+
+Same constructor, ``forward`` / ``inverse`` signatures, shapes, dtypes, exceptions and
+log messages as dtcwt/numpy/transform2d.py:18-295.  The level loop runs on the device:
+
+* float32 images with the shipped 4-vector biort / 8-vector q-shift sets go through the
+  fused plan (``dtcwt_hip_plan2d_*``): one gfx950 kernel per level and direction;
+* everything else (float64, the band-pass ``_bp`` sets, unusual tap lengths) goes through
+  the generic device filters (``dtcwt_hip_colfilter/coldfilt/colifilt/q2c/c2q``).
+
+There is no host fallback: without the library or a GPU the first use raises
+``NoHIPPresentError``.  Batches of equally-sized images are transformed in one go by
+``forward_channels`` / ``inverse_channels`` (interface of the reference's TensorFlow
+backend, dtcwt/tf/transform2d.py:179-336, :422-588).
+"""
+import ctypes
+import logging
+
+import numpy as np
+
+from dtcwt_amd.coeffs import biort as _biort, qshift as _qshift
+from dtcwt_amd.defaults import DEFAULT_BIORT, DEFAULT_QSHIFT
+from dtcwt_amd.utils import asfarray, flat_taps
+from dtcwt_amd.hip import _lib
+from dtcwt_amd.hip._lib import DeviceArray, check
+from dtcwt_amd.hip.common import Pyramid
+from dtcwt_amd.hip import lowlevel as ll
+
+__all__ = ['Transform2d', 'dtwavexfm2', 'dtwaveifm2']
+
+_vp = ctypes.c_void_p
+_pd = ctypes.POINTER(ctypes.c_double)
+
+
+class _Plan2d(object):
+    """RAII wrapper of dtcwt_hip_plan2d."""
+
+    def __init__(self, ctx, batch, rows, cols, nlevels, biort, qshift):
+        L = _lib.lib()
+        self.ctx = ctx
+        self._keep = [flat_taps(h) for h in biort[:4]] + [flat_taps(h) for h in qshift[:8]]
+        bp = (_pd * 4)(*[a.ctypes.data_as(_pd) for a in self._keep[:4]])
+        bl = (ctypes.c_int * 4)(*[a.shape[0] for a in self._keep[:4]])
+        qp = (_pd * 8)(*[a.ctypes.data_as(_pd) for a in self._keep[4:]])
+        ql = (ctypes.c_int * 8)(*[a.shape[0] for a in self._keep[4:]])
+        h = _vp()
+        rc = L.dtcwt_hip_plan2d_create(ctx.handle, batch, rows, cols, nlevels, bp, bl, qp, ql, ctypes.byref(h))
+        if rc == -3:
+            raise NotImplementedError(L.dtcwt_hip_last_error().decode())
+        check(rc)
+        self._h = h
+        self._lib = L
+        self.batch, self.rows, self.cols, self.nlevels = batch, rows, cols, nlevels
+        s = (ctypes.c_int * (4 + 4 * nlevels))()
+        check(L.dtcwt_hip_plan2d_shapes(h, s))
+        self.ext = (s[0], s[1])
+        self.low = (s[2], s[3])
+        self.high = [(s[4 + 4 * l], s[5 + 4 * l]) for l in range(nlevels)]
+        self.scale = [(s[6 + 4 * l], s[7 + 4 * l]) for l in range(nlevels)]
+
+    def forward(self, Xd, include_scale):
+        ctx, B, nl = self.ctx, self.batch, self.nlevels
+        Yl = DeviceArray(ctx, (B,) + self.low, np.float32)
+        Yh = [DeviceArray(ctx, (B,) + self.high[l] + (6,), np.complex64) for l in range(nl)]
+        Ys = [DeviceArray(ctx, (B,) + self.scale[l], np.float32) for l in range(nl)] if include_scale else None
+        yh_p = (_vp * nl)(*[a.ptr for a in Yh])
+        ys_p = (_vp * nl)(*[a.ptr for a in Ys]) if Ys else None
+        check(self._lib.dtcwt_hip_plan2d_forward(self._h, Xd.ptr, Yl.ptr, yh_p, ys_p))
+        return Yl, Yh, Ys
+
+    def forward_into(self, Xd, Yl, Yh, Ys=None):
+        """Launch into caller-provided buffers (no allocation: benchmark inner loop)."""
+        nl = self.nlevels
+        yh_p = (_vp * nl)(*[a.ptr for a in Yh])
+        ys_p = (_vp * nl)(*[a.ptr for a in Ys]) if Ys else None
+        check(self._lib.dtcwt_hip_plan2d_forward(self._h, Xd.ptr, Yl.ptr, yh_p, ys_p))
+
+    def inverse_into(self, Yl, Yh, gain_mask, Z):
+        nl = self.nlevels
+        yh_p = (_vp * nl)(*[a.ptr for a in Yh])
+        if gain_mask is None:
+            gp = None
+        else:
+            g = np.ascontiguousarray(np.asarray(gain_mask, dtype=np.float64).reshape(6, nl))
+            gp = g.ctypes.data_as(_pd)
+        check(self._lib.dtcwt_hip_plan2d_inverse(self._h, Yl.ptr, yh_p, gp, Z.ptr))
+
+    def inverse(self, Yl, Yh, gain_mask):
+        Z = DeviceArray(self.ctx, (self.batch,) + self.ext, np.float32)
+        self.inverse_into(Yl, Yh, gain_mask, Z)
+        return Z
+
+    def set_profiling(self, enable=True):
+        check(self._lib.dtcwt_hip_plan2d_set_profiling(self._h, 1 if enable else 0))
+
+    def kernel_ms(self):
+        """(forward ms per level, inverse ms per level) of the last calls (profiling on)."""
+        f = (ctypes.c_float * self.nlevels)()
+        i = (ctypes.c_float * self.nlevels)()
+        check(self._lib.dtcwt_hip_plan2d_kernel_ms(self._h, f, i))
+        return list(f), list(i)
+
+    def __del__(self):
+        try:
+            if getattr(self, '_h', None):
+                self._lib.dtcwt_hip_plan2d_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def _level_geometry(rows, cols, nlevels):
+    """Shapes of every level exactly as dtcwt/numpy/transform2d.py:86-160 produces them."""
+    R, C = rows + (rows & 1), cols + (cols & 1)
+    lv = [dict(inR=rows, inC=cols, padR=rows & 1, padC=cols & 1, loR=R, loC=C)]
+    for _ in range(1, nlevels):
+        r, c = lv[-1]['loR'], lv[-1]['loC']
+        pr, pc = int(r % 4 != 0), int(c % 4 != 0)
+        lv.append(dict(inR=r, inC=c, padR=pr, padC=pc, loR=(r + 2 * pr) // 2, loC=(c + 2 * pc) // 2))
+    return (R, C), lv
+
+
+class Transform2d(object):
+    """An implementation of the 2D DT-CWT on AMD Instinct GPUs via HIP.  *biort* and
+    *qshift* are wavelet names (:py:func:`dtcwt_amd.coeffs.biort`/``qshift``) or tuples of
+    tap vectors: (h0o, g0o, h1o, g1o[, h2o, g2o]) and (h0a, h0b, g0a, g0b, h1a, h1b, g1a,
+    g1b[, h2a, h2b, g2a, g2b]) -- dtcwt/numpy/transform2d.py:18-38.
+
+    *ctx* (optional) is a :class:`dtcwt_amd.hip.Context` (device + stream), the analogue of
+    the OpenCL backend's ``queue`` argument (dtcwt/opencl/transform2d.py:108-110)."""
+
+    def __init__(self, biort=DEFAULT_BIORT, qshift=DEFAULT_QSHIFT, ctx=None):
+        try:
+            self.biort = _biort(biort)
+        except TypeError:
+            self.biort = biort
+        try:
+            self.qshift = _qshift(qshift)
+        except TypeError:
+            self.qshift = qshift
+        self._ctx = ctx
+        self._plans = {}
+
+    # ------------------------------------------------------------------ helpers
+    @property
+    def ctx(self):
+        if self._ctx is None:
+            self._ctx = _lib.default_context()
+        return self._ctx
+
+    def _taps(self):
+        if len(self.biort) not in (4, 6):
+            raise ValueError('Biort wavelet must have 6 or 4 components.')
+        if len(self.qshift) not in (8, 12):
+            raise ValueError('Qshift wavelet must have 12 or 8 components.')
+        return self.biort, self.qshift
+
+    def _plan(self, batch, rows, cols, nlevels):
+        """Fused plan or None when the wavelets have no fused kernels."""
+        if len(self.biort) != 4 or len(self.qshift) != 8:
+            return None
+        key = (batch, rows, cols, nlevels)
+        if key not in self._plans:
+            try:
+                self._plans[key] = _Plan2d(self.ctx, batch, rows, cols, nlevels, self.biort, self.qshift)
+            except NotImplementedError:
+                self._plans[key] = None
+        return self._plans[key]
+
+    def plan(self, batch, rows, cols, nlevels):
+        """The fused plan for a batch shape (benchmark / advanced use); raises
+        NotImplementedError when these wavelets only have the generic path."""
+        p = self._plan(batch, rows, cols, nlevels)
+        if p is None:
+            raise NotImplementedError('no fused plan for these wavelets')
+        return p
+
+    # ------------------------------------------------------------------ forward
+    def _forward_device(self, Xd, nlevels, include_scale):
+        """Xd: DeviceArray [B, r, c] float32/float64.  Returns (Yl, [Yh], [Ys]|None) with
+        a leading batch axis."""
+        B, r, c = Xd.shape
+        if Xd.dtype == np.float32:
+            plan = self._plan(B, r, c, nlevels)
+            if plan is not None:
+                return plan.forward(Xd, include_scale)
+        return self._forward_generic(Xd, nlevels, include_scale)
+
+    def _forward_generic(self, Xd, nlevels, include_scale):
+        biort, qshift = self._taps()
+        h0o, g0o, h1o, g1o = biort[:4]
+        h0a, h0b, g0a, g0b, h1a, h1b, g1a, g1b = qshift[:8]
+        bp1, bp2 = len(biort) >= 6, len(qshift) >= 12
+        B, r, c = Xd.shape
+        cdt = np.complex64 if Xd.dtype == np.float32 else np.complex128
+        (R, C), lv = _level_geometry(r, c, nlevels)
+        Yh, Ys = [], []
+        # level 1 (transform2d.py:112-130); odd sizes extended by index math (:86-94)
+        pr, pc = (0, lv[0]['padR']), (0, lv[0]['padC'])
+        Lo = ll.axis_colfilter(Xd, h0o, axis=1, pad=pr)
+        Hi = ll.axis_colfilter(Xd, h1o, axis=1, pad=pr)
+        LoLo = ll.axis_colfilter(Lo, h0o, axis=2, pad=pc)
+        y = DeviceArray(Xd.ctx, (B, LoLo.shape[1] >> 1, LoLo.shape[2] >> 1, 6), cdt)
+        ll.q2c(ll.axis_colfilter(Hi, h0o, axis=2, pad=pc), y, 0, 5)
+        ll.q2c(ll.axis_colfilter(Lo, h1o, axis=2, pad=pc), y, 2, 3)
+        if bp1:
+            Ba = ll.axis_colfilter(Xd, biort[4], axis=1, pad=pr)
+            ll.q2c(ll.axis_colfilter(Ba, biort[4], axis=2, pad=pc), y, 1, 4)
+        else:
+            ll.q2c(ll.axis_colfilter(Hi, h1o, axis=2, pad=pc), y, 1, 4)
+        Yh.append(y)
+        Ys.append(LoLo)
+        for level in range(1, nlevels):                      # :132-160
+            g = lv[level]
+            pr, pc = (g['padR'],) * 2, (g['padC'],) * 2
+            Lo = ll.axis_coldfilt(LoLo, h0b, h0a, axis=1, pad=pr)
+            Hi = ll.axis_coldfilt(LoLo, h1b, h1a, axis=1, pad=pr)
+            if bp2:
+                Ba = ll.axis_coldfilt(LoLo, qshift[9], qshift[8], axis=1, pad=pr)
+            LoLo = ll.axis_coldfilt(Lo, h0b, h0a, axis=2, pad=pc)
+            y = DeviceArray(Xd.ctx, (B, LoLo.shape[1] >> 1, LoLo.shape[2] >> 1, 6), cdt)
+            ll.q2c(ll.axis_coldfilt(Hi, h0b, h0a, axis=2, pad=pc), y, 0, 5)
+            ll.q2c(ll.axis_coldfilt(Lo, h1b, h1a, axis=2, pad=pc), y, 2, 3)
+            if bp2:
+                ll.q2c(ll.axis_coldfilt(Ba, qshift[9], qshift[8], axis=2, pad=pc), y, 1, 4)
+            else:
+                ll.q2c(ll.axis_coldfilt(Hi, h1b, h1a, axis=2, pad=pc), y, 1, 4)
+            Yh.append(y)
+            Ys.append(LoLo)
+        return LoLo, Yh, (Ys if include_scale else None)
+
+    @staticmethod
+    def _log_extension(original, extended):
+        """The warnings of dtcwt/numpy/transform2d.py:164-183."""
+        er, ec = extended[0] != original[0], extended[1] != original[1]
+        if not (er or ec):
+            return
+        logging.warning('The image entered is now a {0} NOT a {1}.'.format(
+            'x'.join(str(s) for s in extended), 'x'.join(str(s) for s in original)))
+        if er and ec:
+            logging.warning('The bottom row and rightmost column have been duplicated, prior to decomposition.')
+        elif er:
+            logging.warning('The bottom row has been duplicated, prior to decomposition.')
+        else:
+            logging.warning('The rightmost column has been duplicated, prior to decomposition.')
+
+    def forward(self, X, nlevels=3, include_scale=False):
+        """Perform a *n*-level DTCWT-2D decomposition on a 2D matrix *X*.
+
+        :param X: 2D real array (NumPy-compatible), or a 2-D :class:`DeviceArray` / torch
+            GPU tensor already in HBM (cf. dtcwt/opencl/transform2d.py:133-135)
+        :param nlevels: Number of levels of wavelet decomposition
+        :returns: A :py:class:`Pyramid` whose buffers live on the device.
+        """
+        self._taps()
+        if _lib.is_foreign_device_tensor(X):
+            X = DeviceArray.wrap(self.ctx, X)
+        if isinstance(X, DeviceArray):
+            if X.ndim != 2:
+                raise ValueError('Input array must be two-dimensional')
+            Xd = X
+        else:
+            X = np.atleast_2d(asfarray(X))
+            if X.ndim >= 3:
+                raise ValueError('The entered image is {0}, which is invalid '.format(
+                    'x'.join(str(s) for s in X.shape)) + 'for the 2D transform in a hip backend. ' +
+                    'Please enter each image slice separately.')
+            Xd = self.ctx.to_device(X)
+        r, c = Xd.shape
+        R, C = r + (r & 1), c + (c & 1)
+        if nlevels == 0:
+            # :98-102 returns the (edge-extended) input
+            Xe = Xd.get()
+            if R != r:
+                Xe = np.vstack((Xe, Xe[[-1], :]))
+            if C != c:
+                Xe = np.hstack((Xe, Xe[:, [-1]]))
+            return Pyramid(Xe, (), ()) if include_scale else Pyramid(Xe, ())
+        Yl, Yh, Ys = self._forward_device(Xd.reshape(1, r, c), nlevels, include_scale)
+        self._log_extension((r, c), (R, C))
+        drop = lambda a: a.reshape(a.shape[1:])
+        if include_scale:
+            return Pyramid(drop(Yl), tuple(drop(y) for y in Yh), tuple(drop(s) for s in Ys))
+        return Pyramid(drop(Yl), tuple(drop(y) for y in Yh))
+
+    # ------------------------------------------------------------------ inverse
+    @staticmethod
+    def _check_shapes(low_shape, high_shapes):
+        """Validate pyramid geometry the way the reference's loop would discover it
+        (dtcwt/numpy/transform2d.py:263-271); returns per-level crop flags."""
+        nl = len(high_shapes)
+        crops = [(0, 0)] * nl
+        z = tuple(low_shape)
+        for level in range(nl - 1, -1, -1):
+            h = tuple(high_shapes[level][:2])
+            if len(high_shapes[level]) != 3 or high_shapes[level][2] != 6 or z != (2 * h[0], 2 * h[1]):
+                raise ValueError('Sizes of highpasses are not valid for DTWAVEIFM2')
+            if level >= 1:
+                S = (2 * high_shapes[level - 1][0], 2 * high_shapes[level - 1][1])
+                z2 = [2 * z[0], 2 * z[1]]
+                cr = [0, 0]
+                for a in (0, 1):
+                    if z2[a] != S[a]:
+                        z2[a] -= 2
+                        cr[a] = 1
+                if tuple(z2) != S:
+                    raise ValueError('Sizes of highpasses are not valid for DTWAVEIFM2')
+                crops[level] = tuple(cr)
+                z = tuple(z2)
+        return crops
+
+    def _inverse_device(self, Yl, Yh, gain_mask):
+        """Yl [B, r, c], Yh[l] [B, h, w, 6] DeviceArrays -> Z [B, R, C]."""
+        nl = len(Yh)
+        B = Yl.shape[0]
+        crops = self._check_shapes(Yl.shape[1:], [y.shape[1:] for y in Yh])
+        R, C = 2 * Yh[0].shape[1], 2 * Yh[0].shape[2]
+        if Yl.dtype == np.float32:
+            plan = self._plan(B, R, C, nl)
+            if plan is not None:
+                if plan.low != tuple(Yl.shape[1:]) or any(plan.high[l] != tuple(Yh[l].shape[1:3]) for l in range(nl)):
+                    raise ValueError('Sizes of highpasses are not valid for DTWAVEIFM2')
+                return plan.inverse(Yl, Yh, gain_mask)
+        return self._inverse_generic(Yl, Yh, gain_mask, crops)
+
+    def _inverse_generic(self, Z, Yh, gain_mask, crops):
+        biort, qshift = self._taps()
+        h0o, g0o, h1o, g1o = biort[:4]
+        h0a, h0b, g0a, g0b, h1a, h1b, g1a, g1b = qshift[:8]
+        bp1, bp2 = len(biort) >= 6, len(qshift) >= 12
+        nl = len(Yh)
+        gm = np.ones((6, nl)) if gain_mask is None else np.array(gain_mask, dtype=np.float64)
+        level = nl
+        while level >= 2:                                    # transform2d.py:242-273
+            w, g = Yh[level - 1], gm[:, level - 1]
+            cr, cc = crops[level - 1]
+            lh = ll.c2q(w, 0, 5, g[0], g[5])
+            hl = ll.c2q(w, 2, 3, g[2], g[3])
+            hh = ll.c2q(w, 1, 4, g[1], g[4])
+            y1 = ll.axis_colifilt(Z, g0b, g0a, axis=1, crop=(cr, cr))
+            ll.axis_colifilt(lh, g1b, g1a, axis=1, crop=(cr, cr), out=y1, accumulate=True)
+            y2 = ll.axis_colifilt(hl, g0b, g0a, axis=1, crop=(cr, cr))
+            if bp2:
+                y2bp = ll.axis_colifilt(hh, qshift[11], qshift[10], axis=1, crop=(cr, cr))
+            else:
+                ll.axis_colifilt(hh, g1b, g1a, axis=1, crop=(cr, cr), out=y2, accumulate=True)
+            Z = ll.axis_colifilt(y1, g0b, g0a, axis=2, crop=(cc, cc))
+            ll.axis_colifilt(y2, g1b, g1a, axis=2, crop=(cc, cc), out=Z, accumulate=True)
+            if bp2:
+                ll.axis_colifilt(y2bp, qshift[11], qshift[10], axis=2, crop=(cc, cc), out=Z, accumulate=True)
+            level -= 1
+        if level == 1:                                       # :275-293
+            w, g = Yh[0], gm[:, 0]
+            lh = ll.c2q(w, 0, 5, g[0], g[5])
+            hl = ll.c2q(w, 2, 3, g[2], g[3])
+            hh = ll.c2q(w, 1, 4, g[1], g[4])
+            y1 = ll.axis_colfilter(Z, g0o, axis=1)
+            ll.axis_colfilter(lh, g1o, axis=1, out=y1, accumulate=True)
+            y2 = ll.axis_colfilter(hl, g0o, axis=1)
+            if bp1:
+                y2bp = ll.axis_colfilter(hh, biort[5], axis=1)
+            else:
+                ll.axis_colfilter(hh, g1o, axis=1, out=y2, accumulate=True)
+            Z = ll.axis_colfilter(y1, g0o, axis=2)
+            ll.axis_colfilter(y2, g1o, axis=2, out=Z, accumulate=True)
+            if bp1:
+                ll.axis_colfilter(y2bp, biort[5], axis=2, out=Z, accumulate=True)
+        return Z
+
+    def inverse(self, pyramid, gain_mask=None, device_output=False):
+        """Perform an *n*-level dual-tree complex wavelet (DTCWT) 2D reconstruction.
+
+        :param pyramid: A :py:class:`Pyramid`-like object (device or NumPy buffers).
+        :param gain_mask: (6, nlevels) gains per subband/level, default ones
+            (dtcwt/numpy/transform2d.py:190-217).
+        :param device_output: return the :class:`DeviceArray` instead of a NumPy array.
+        :returns: the reconstruction, shape of the (even-extended) input.
+        """
+        self._taps()
+        nl = len(pyramid.highpasses)
+        if nl == 0:
+            return pyramid.lowpass
+        if gain_mask is not None:
+            gain_mask = np.array(gain_mask, dtype=np.float64)
+            if gain_mask.shape != (6, nl):
+                raise ValueError('gain_mask must have shape (6, %d)' % nl)
+        if hasattr(pyramid, 'device_parts'):
+            probe = pyramid.hip_lowpass if pyramid.hip_lowpass is not None else pyramid.lowpass
+            rdt = np.float32 if probe.dtype in (np.float32, np.complex64) else np.float64
+            Yl, Yh = pyramid.device_parts(self.ctx, rdt)
+        else:
+            low = asfarray(pyramid.lowpass)
+            rdt = np.float32 if low.dtype == np.float32 else np.float64
+            cdt = np.complex64 if rdt == np.float32 else np.complex128
+            Yl = self.ctx.to_device(low, dtype=rdt)
+            Yh = tuple(self.ctx.to_device(np.asarray(y), dtype=cdt) for y in pyramid.highpasses)
+        if Yl.ndim != 2 or any(y.ndim != 3 for y in Yh):
+            raise ValueError('Sizes of highpasses are not valid for DTWAVEIFM2')
+        Z = self._inverse_device(Yl.reshape((1,) + Yl.shape), [y.reshape((1,) + y.shape) for y in Yh], gain_mask)
+        Z = Z.reshape(Z.shape[1:])
+        return Z if device_output else Z.get()
+
+    # ------------------------------------------------------------------ batched API
+    _FORMATS = ('nhw', 'chw', 'hwn', 'hwc', 'nchw', 'nhwc')
+
+    @staticmethod
+    def _to_nhw(X, data_format):
+        """Host array in *data_format* -> ([N, h, w] contiguous, restore-info)."""
+        if data_format in ('nhw', 'chw'):
+            if X.ndim != 3:
+                raise ValueError('%s input must be three-dimensional' % data_format)
+            return X, None
+        if data_format in ('hwn', 'hwc'):
+            if X.ndim != 3:
+                raise ValueError('%s input must be three-dimensional' % data_format)
+            return np.ascontiguousarray(np.moveaxis(X, 2, 0)), None
+        if X.ndim != 4:
+            raise ValueError('%s input must be four-dimensional' % data_format)
+        if data_format == 'nchw':
+            n, ch, h, w = X.shape
+            return X.reshape(n * ch, h, w), (n, ch)
+        n, h, w, ch = X.shape                                  # nhwc
+        return np.ascontiguousarray(np.moveaxis(X, 3, 1)).reshape(n * ch, h, w), (n, ch)
+
+    @staticmethod
+    def _from_nhw(A, data_format, info):
+        """[N, h, w(, 6)] host array back to *data_format* (subband axis stays last)."""
+        if data_format in ('nhw', 'chw'):
+            return A
+        if data_format in ('hwn', 'hwc'):
+            return np.moveaxis(A, 0, 2)
+        n, ch = info
+        A = A.reshape((n, ch) + A.shape[1:])
+        if data_format == 'nchw':
+            return A
+        return np.moveaxis(A, 1, 3)                            # nhwc
+
+    def forward_channels(self, X, data_format='nhw', nlevels=3, include_scale=False):
+        """Transform a batch of equally sized images at once.
+
+        ``data_format``: "nhw"/"chw" (native, zero-copy for device arrays), "hwn"/"hwc",
+        "nchw", "nhwc".  Returns a Pyramid whose ``lowpass`` has the batch layout of the
+        input and whose ``highpasses[l]`` have one extra trailing axis of size 6, as the
+        reference's TF backend does (dtcwt/tf/transform2d.py:179-336)."""
+        self._taps()
+        data_format = data_format.lower()
+        if data_format not in self._FORMATS:
+            raise ValueError('The data format must be one of: {}'.format(self._FORMATS))
+        if _lib.is_foreign_device_tensor(X):
+            X = DeviceArray.wrap(self.ctx, X)
+        native = data_format in ('nhw', 'chw')
+        if isinstance(X, DeviceArray):
+            if not native or X.ndim != 3:
+                raise ValueError('device inputs must be in nhw/chw layout')
+            Xd, info = X, None
+        else:
+            Xh, info = self._to_nhw(asfarray(X), data_format)
+            Xd = self.ctx.to_device(Xh)
+        B, r, c = Xd.shape
+        if nlevels == 0:
+            Xe = Xd.get()
+            if r & 1:
+                Xe = np.concatenate((Xe, Xe[:, -1:, :]), axis=1)
+            if c & 1:
+                Xe = np.concatenate((Xe, Xe[:, :, -1:]), axis=2)
+            Xe = self._from_nhw(Xe, data_format, info)
+            return Pyramid(Xe, (), ()) if include_scale else Pyramid(Xe, ())
+        Yl, Yh, Ys = self._forward_device(Xd, nlevels, include_scale)
+        self._log_extension((r, c), (r + (r & 1), c + (c & 1)))
+        if native:
+            return Pyramid(Yl, tuple(Yh), tuple(Ys) if include_scale else None)
+        f = lambda a: self._from_nhw(a.get(), data_format, info)
+        return Pyramid(f(Yl), tuple(f(y) for y in Yh), tuple(f(s) for s in Ys) if include_scale else None)
+
+    def inverse_channels(self, pyramid, data_format='nhw', gain_mask=None, device_output=False):
+        """Inverse of :meth:`forward_channels` (dtcwt/tf/transform2d.py:422-588)."""
+        self._taps()
+        data_format = data_format.lower()
+        if data_format not in self._FORMATS:
+            raise ValueError('The data format must be one of: {}'.format(self._FORMATS))
+        nl = len(pyramid.highpasses)
+        native = data_format in ('nhw', 'chw')
+        if nl == 0:
+            return pyramid.lowpass
+        if native and hasattr(pyramid, 'device_parts'):
+            probe = pyramid.hip_lowpass if pyramid.hip_lowpass is not None else pyramid.lowpass
+            rdt = np.float32 if probe.dtype in (np.float32, np.complex64) else np.float64
+            Yl, Yh = pyramid.device_parts(self.ctx, rdt)
+            info = None
+        else:
+            low = asfarray(pyramid.lowpass)
+            rdt = np.float32 if low.dtype == np.float32 else np.float64
+            cdt = np.complex64 if rdt == np.float32 else np.complex128
+            lowb, info = self._to_nhw(low, data_format)
+            Yl = self.ctx.to_device(lowb, dtype=rdt)
+            Yh = []
+            for y in pyramid.highpasses:
+                y = np.asarray(y)
+                # move the subband axis out of the way: treat (..., 6) as 6 more channels
+                parts = [self._to_nhw(np.ascontiguousarray(y[..., d]), data_format)[0] for d in range(6)]
+                Yh.append(self.ctx.to_device(np.stack(parts, axis=-1), dtype=cdt))
+        if Yl.ndim != 3 or any(y.ndim != 4 for y in Yh):
+            raise ValueError('Sizes of highpasses are not valid for DTWAVEIFM2')
+        Z = self._inverse_device(Yl, list(Yh), gain_mask)
+        if device_output and native:
+            return Z
+        return self._from_nhw(Z.get(), data_format, info)
+
+
+def dtwavexfm2(X, nlevels=3, biort=DEFAULT_BIORT, qshift=DEFAULT_QSHIFT, include_scale=False, ctx=None):
+    """Function-style forward (cf. dtcwt/opencl/transform2d.py:22-28, dtcwt/compat.py:107)."""
+    t = Transform2d(biort=biort, qshift=qshift, ctx=ctx)
+    r = t.forward(X, nlevels=nlevels, include_scale=include_scale)
+    if include_scale:
+        return r.lowpass, r.highpasses, r.scales
+    return r.lowpass, r.highpasses
+
+
+def dtwaveifm2(Yl, Yh, biort=DEFAULT_BIORT, qshift=DEFAULT_QSHIFT, gain_mask=None, ctx=None):
+    """Function-style inverse (dtcwt/compat.py:145-184)."""
+    t = Transform2d(biort=biort, qshift=qshift, ctx=ctx)
+    return t.inverse(Pyramid(Yl, Yh), gain_mask=gain_mask)

@@ -1,0 +1,205 @@
+"""3-D DT-CWT on the device: ``Transform3d`` of the ``hip`` backend.
+
+Interface, shapes, dtypes and exceptions of dtcwt/numpy/transform3d.py:14-619.  The
+reference filters slice by slice inside Python loops; here each level filters the whole
+volume along axis 2, then 1, then 0 with the generic device filters (the axis-wise order
+SURVEY.md section 3.3 shows to be identical) and packs the seven highpass octants with
+the ``cube2c`` kernel into the reference's ``[d0/2, d1/2, d2/2, 28]`` complex layout.
+Edge padding (``ext_mode`` 4: one plane, 8: two planes per side, :322-335) and the
+inverse's cropping (:505-524) are index arithmetic inside the filters, never copies.
+
+One deliberate difference: the reference's highpass-free level-1 inverse
+(``_level1_ifm_no_highpass``, :442-458) forgets a transpose, so it swaps axes 0 and 2 of
+cubic volumes and raises on non-cubic ones; this backend returns the intended result.
+"""
+import numpy as np
+
+from dtcwt_amd.coeffs import biort as _biort, qshift as _qshift
+from dtcwt_amd.defaults import DEFAULT_BIORT, DEFAULT_QSHIFT
+from dtcwt_amd.utils import asfarray, flat_taps
+from dtcwt_amd.hip import _lib
+from dtcwt_amd.hip._lib import DeviceArray, check, dtype_code
+from dtcwt_amd.hip.common import Pyramid
+from dtcwt_amd.hip import lowlevel as ll
+
+__all__ = ['Transform3d']
+
+# (hi on axis 0, hi on axis 1, hi on axis 2) of the highpass octants in the order the
+# reference concatenates them (transform3d.py:278-289, :372-383)
+_OCTANTS = ((0, 1, 0), (1, 0, 0), (1, 1, 0), (0, 0, 1), (0, 1, 1), (1, 0, 1), (1, 1, 1))
+
+
+def _cube2c(vol, sub, Yh, octant):
+    """cube2c of the leading ``sub`` block of device volume *vol* into Yh[..., 4o:4o+4]."""
+    d0, d1, d2 = sub
+    s0, s1 = vol.shape[1] * vol.shape[2], vol.shape[2]
+    check(_lib.lib().dtcwt_hip_cube2c(vol.ctx.handle, dtype_code(vol.dtype), vol.ptr, d0, d1, d2, s0, s1,
+                                      Yh.ptr, octant))
+
+
+def _c2cube(Yh, octant):
+    e0, e1, e2 = Yh.shape[:3]
+    rdt = np.float32 if Yh.dtype == np.complex64 else np.float64
+    out = DeviceArray(Yh.ctx, (2 * e0, 2 * e1, 2 * e2), rdt)
+    check(_lib.lib().dtcwt_hip_c2cube(Yh.ctx.handle, dtype_code(Yh.dtype), Yh.ptr, e0, e1, e2, octant, out.ptr,
+                                      4 * e1 * e2, 2 * e2))
+    return out
+
+
+class Transform3d(object):
+    """An implementation of the 3D DT-CWT on AMD GPUs via HIP.  *biort*/*qshift* as for
+    :class:`Transform2d`; *ext_mode* 4 or 8 as in dtcwt/numpy/transform3d.py:22-35,:86-99."""
+
+    def __init__(self, biort=DEFAULT_BIORT, qshift=DEFAULT_QSHIFT, ext_mode=4, ctx=None):
+        try:
+            self.biort = _biort(biort)
+        except TypeError:
+            self.biort = biort
+        try:
+            self.qshift = _qshift(qshift)
+        except TypeError:
+            self.qshift = qshift
+        self.ext_mode = ext_mode
+        self._ctx = ctx
+
+    @property
+    def ctx(self):
+        if self._ctx is None:
+            self._ctx = _lib.default_context()
+        return self._ctx
+
+    def _taps(self):
+        if len(self.biort) not in (4, 6):
+            raise ValueError('Biort wavelet must have 6 or 4 components.')
+        if len(self.qshift) not in (8, 12):
+            raise ValueError('Qshift wavelet must have 12 or 8 components.')
+        if self.ext_mode != 4 and self.ext_mode != 8:
+            raise ValueError('ext_mode must be one of 4 or 8')
+        return self.biort[:4], self.qshift[:8]
+
+    # ------------------------------------------------------------------ forward
+    @staticmethod
+    def _split(V, fn, lo, hi, pads):
+        """volume -> {(a0, a1, a2): octant}; axis order 2, 1, 0."""
+        parts = {(): V}
+        for axis in (2, 1, 0):
+            nxt = {}
+            for key, vol in parts.items():
+                nxt[(0,) + key] = fn(vol, *lo, axis=axis, pad=pads[axis])
+                nxt[(1,) + key] = fn(vol, *hi, axis=axis, pad=pads[axis])
+            parts = nxt
+        return parts
+
+    def _pack(self, parts, sub, cdt):
+        Yh = DeviceArray(parts[(0, 0, 0)].ctx, (sub[0] // 2, sub[1] // 2, sub[2] // 2, 28), cdt)
+        for n, o in enumerate(_OCTANTS):
+            _cube2c(parts[o], sub, Yh, n)
+        return Yh
+
+    def forward(self, X, nlevels=3, include_scale=False, discard_level_1=False):
+        """Perform a *n*-level DTCWT-3D decomposition on a 3D matrix *X*; each element of
+        ``highpasses`` is a 4-D complex array whose last axis has size 28
+        (dtcwt/numpy/transform3d.py:37-131)."""
+        (h0o, g0o, h1o, g1o), (h0a, h0b, g0a, g0b, h1a, h1b, g1a, g1b) = self._taps()
+        if isinstance(X, DeviceArray):
+            Xd = X
+            if Xd.ndim != 3:
+                raise ValueError('device input must be three-dimensional')
+        else:
+            Xd = self.ctx.to_device(np.atleast_3d(asfarray(X)))
+        cdt = np.complex64 if Xd.dtype == np.float32 else np.complex128
+        Yl = Xd
+        Yh = [None] * nlevels
+        Ys = [None] * nlevels
+        nopad = ((0, 0),) * 3
+        for level in range(nlevels):
+            if level == 0:
+                mult = 2 if self.ext_mode == 4 else 4
+                if any(s % mult for s in Yl.shape):            # :214-217
+                    raise ValueError('Input shape should be a multiple of %d in each direction when '
+                                     'self.ext_mode == %d' % (mult, self.ext_mode))
+                if discard_level_1:                            # :291-315
+                    for axis in (2, 1, 0):
+                        Yl = ll.axis_colfilter(Yl, h0o, axis=axis)
+                else:
+                    sub = Yl.shape      # even-length taps: octants are (N+1)^3, packed from [:N]
+                    parts = self._split(Yl, ll.axis_colfilter, (h0o,), (h1o,), nopad)
+                    Yl = parts[(0, 0, 0)]
+                    Yh[0] = self._pack(parts, sub, cdt)
+            else:                                              # :317-383
+                mult, npad = (4, 1) if self.ext_mode == 4 else (8, 2)
+                pads = tuple((npad, npad) if Yl.shape[a] % mult else (0, 0) for a in range(3))
+                parts = self._split(Yl, ll.axis_coldfilt, (h0b, h0a), (h1b, h1a), pads)
+                Yl = parts[(0, 0, 0)]
+                Yh[level] = self._pack(parts, Yl.shape, cdt)
+            Ys[level] = Yl
+        if include_scale:
+            return Pyramid(Yl, tuple(Yh), tuple(Ys))
+        return Pyramid(Yl, tuple(Yh))
+
+    # ------------------------------------------------------------------ inverse
+    @staticmethod
+    def _merge(Yl, Yh, fn, lo, hi, crops):
+        """8 octants -> one volume; axis order 1, 0, 2 (transform3d.py:425-435, :485-495)."""
+        parts = {(0, 0, 0): Yl}
+        for n, o in enumerate(_OCTANTS):
+            parts[o] = _c2cube(Yh, n)
+        p1 = {}
+        for a0 in (0, 1):
+            for a2 in (0, 1):
+                y = fn(parts[(a0, 0, a2)], *lo, axis=1, crop=crops[1])
+                fn(parts[(a0, 1, a2)], *hi, axis=1, crop=crops[1], out=y, accumulate=True)
+                p1[(a0, a2)] = y
+        p0 = {}
+        for a2 in (0, 1):
+            y = fn(p1[(0, a2)], *lo, axis=0, crop=crops[0])
+            fn(p1[(1, a2)], *hi, axis=0, crop=crops[0], out=y, accumulate=True)
+            p0[a2] = y
+        y = fn(p0[0], *lo, axis=2, crop=crops[2])
+        fn(p0[1], *hi, axis=2, crop=crops[2], out=y, accumulate=True)
+        return y
+
+    def inverse(self, pyramid, device_output=False):
+        """Perform an *n*-level dual-tree complex wavelet (DTCWT) 3D reconstruction
+        (dtcwt/numpy/transform3d.py:133-206); ``highpasses[0]`` may be ``None``."""
+        (h0o, g0o, h1o, g1o), (h0a, h0b, g0a, g0b, h1a, h1b, g1a, g1b) = self._taps()
+        nlevels = len(pyramid.highpasses)
+        if hasattr(pyramid, 'device_parts'):
+            probe = pyramid.hip_lowpass if pyramid.hip_lowpass is not None else pyramid.lowpass
+            rdt = np.float32 if probe.dtype in (np.float32, np.complex64) else np.float64
+            Yl, Yh = pyramid.device_parts(self.ctx, rdt)
+        else:
+            low = asfarray(pyramid.lowpass)
+            rdt = np.float32 if low.dtype == np.float32 else np.float64
+            cdt = np.complex64 if rdt == np.float32 else np.complex128
+            Yl = self.ctx.to_device(low, dtype=rdt)
+            Yh = tuple(None if y is None else self.ctx.to_device(np.asarray(y), dtype=cdt)
+                       for y in pyramid.highpasses)
+        if nlevels == 0:
+            return Yl if device_output else Yl.get()
+        nocrop = ((0, 0),) * 3
+        for level in range(nlevels):
+            cur = Yh[-level - 1]
+            if level == nlevels - 1:                           # level 1
+                if cur is None:                                # :442-458 (see module docstring)
+                    for axis in (1, 0, 2):
+                        Yl = ll.axis_colfilter(Yl, g0o, axis=axis)
+                elif flat_taps(g0o).shape[0] % 2 == 0:
+                    # even-length taps (:394-398, :437-438): first N samples of the lowpass
+                    # block, N -> N+1 per axis, then drop sample 0 of every axis.
+                    n0, n1, n2 = (2 * s for s in cur.shape[:3])
+                    low = self.ctx.to_device(np.ascontiguousarray(Yl.get()[:n0, :n1, :n2]))
+                    Yl = self._merge(low, cur, ll.axis_colfilter, (g0o,), (g1o,), ((1, 0),) * 3)
+                else:
+                    if tuple(Yl.shape) != tuple(2 * s for s in cur.shape[:3]):
+                        raise ValueError('Sizes of highpasses are not valid for the 3D inverse')
+                    Yl = self._merge(Yl, cur, ll.axis_colfilter, (g0o,), (g1o,), nocrop)
+            else:                                              # :460-526
+                if tuple(Yl.shape) != tuple(2 * s for s in cur.shape[:3]):
+                    raise ValueError('Sizes of highpasses are not valid for the 3D inverse')
+                nxt = Yh[-level - 2]
+                prev = tuple(nxt.shape[:3]) if nxt is not None else tuple(2 * s for s in cur.shape[:3])
+                c = 1 if self.ext_mode == 4 else 2
+                crops = tuple((c, c) if cur.shape[a] * 2 != prev[a] else (0, 0) for a in range(3))
+                Yl = self._merge(Yl, cur, ll.axis_colifilt, (g0b, g0a), (g1b, g1a), crops)
+        return Yl if device_output else Yl.get()

@@ -1,0 +1,183 @@
+/* dtcwt_hip.h -- C ABI of libdtcwt_hip.so, the MI355X (gfx950) DT-CWT filter bank.
+ *
+ * This is the drop-in boundary of the `hip` backend.  The reference (rjw57/dtcwt) is
+ * pure Python and has no FFI; each entry point below states which reference function it
+ * replaces (paths relative to the reference root).  Host code (dtcwt_amd/hip/, via
+ * ctypes) does shape/argument checking and raises the reference's exceptions *before*
+ * calling in; the library itself never throws across the boundary.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; dtcwt_hip_last_error() returns a
+ *     thread-local message for the last failing call of the calling thread;
+ *   - pointers named X/Y/Yl/Yh/... are DEVICE pointers unless the name says host;
+ *     filter taps are HOST pointers to double (cast to the signal dtype inside, as
+ *     dtcwt/numpy/lowlevel.py:33 does);
+ *   - dtype: DTCWT_HIP_F32 or DTCWT_HIP_F64 for the generic filters; the fused 2-D plan
+ *     is float32 (the precision the OpenCL/TF backends of the reference also use);
+ *   - calls are asynchronous on the context's stream; dtcwt_hip_sync() waits;
+ *   - a context (and everything created from it) is single-threaded; different contexts
+ *     may be driven from different host threads;
+ *   - the caller owns every device buffer it passes; plans own their workspaces.
+ */
+#ifndef DTCWT_HIP_H
+#define DTCWT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DTCWT_HIP_ABI_VERSION 1
+
+#define DTCWT_HIP_F32 0
+#define DTCWT_HIP_F64 1
+
+#define DTCWT_HIP_MAX_TAPS 40          /* longest shipped filter is qshift_32 (32 taps) */
+
+/* flags for the generic filters */
+#define DTCWT_HIP_ACCUMULATE 1         /* Y += result instead of Y = result */
+
+typedef struct dtcwt_hip_ctx dtcwt_hip_ctx;
+typedef struct dtcwt_hip_plan2d dtcwt_hip_plan2d;
+typedef struct dtcwt_hip_event dtcwt_hip_event;
+
+/* ---------------------------------------------------------------- runtime ---------- */
+int dtcwt_hip_abi_version(void);
+const char *dtcwt_hip_last_error(void);
+int dtcwt_hip_device_count(int *count);
+/* name: buffer of >= 256 bytes; cus: compute units; mem_bytes: total HBM */
+int dtcwt_hip_device_info(int device, char *name, int *cus, size_t *mem_bytes);
+
+/* Context = device + stream.  `stream` NULL: the context creates and owns a stream;
+ * otherwise it is a hipStream_t owned by the caller (e.g. torch's current stream).
+ * Analogue of the `queue=` argument of the reference's OpenCL backend
+ * (dtcwt/opencl/transform2d.py:108-110, dtcwt/opencl/lowlevel.py:154-167). */
+int dtcwt_hip_ctx_create(int device, void *stream, dtcwt_hip_ctx **ctx);
+int dtcwt_hip_ctx_destroy(dtcwt_hip_ctx *ctx);
+int dtcwt_hip_sync(dtcwt_hip_ctx *ctx);
+void *dtcwt_hip_ctx_stream(dtcwt_hip_ctx *ctx);
+
+/* Device buffers: replace to_device/to_array/empty of dtcwt/opencl/lowlevel.py:169-181. */
+int dtcwt_hip_malloc(dtcwt_hip_ctx *ctx, size_t bytes, void **dptr);
+int dtcwt_hip_free(dtcwt_hip_ctx *ctx, void *dptr);
+int dtcwt_hip_memcpy_h2d(dtcwt_hip_ctx *ctx, void *dst, const void *src_host, size_t bytes);
+int dtcwt_hip_memcpy_d2h(dtcwt_hip_ctx *ctx, void *dst_host, const void *src, size_t bytes);
+int dtcwt_hip_memcpy_d2d(dtcwt_hip_ctx *ctx, void *dst, const void *src, size_t bytes);
+int dtcwt_hip_memset(dtcwt_hip_ctx *ctx, void *dst, int value, size_t bytes);
+
+/* HIP events on the context's stream (timing of the benchmark harness). */
+int dtcwt_hip_event_create(dtcwt_hip_ctx *ctx, dtcwt_hip_event **ev);
+int dtcwt_hip_event_record(dtcwt_hip_ctx *ctx, dtcwt_hip_event *ev);
+int dtcwt_hip_event_elapsed_ms(dtcwt_hip_event *start, dtcwt_hip_event *stop, float *ms);
+int dtcwt_hip_event_destroy(dtcwt_hip_event *ev);
+
+/* ---------------------------------------------------------------- generic filters --- */
+/* A strided 3-D view  A[o][j][i]  (o < outer, j < n, i < inner) addresses element
+ * base + o*so + j*sn + i*si  (strides in ELEMENTS).  All three filters act along j.
+ * A 2-D column filter is outer=batch, n=rows, inner=cols, si=1; a row filter swaps the
+ * roles (sn=1, si=row stride); 3-D volumes use the same view per axis.
+ *
+ * Logical extension of the input before filtering (what the transform drivers do with
+ * vstack/hstack/concatenate): the filtered signal has logical length
+ * n + pad_lo + pad_hi where logical sample u is input sample clamp(u-pad_lo, 0, n-1)
+ * (edge replication: dtcwt/numpy/transform2d.py:86-94, :134-140; transform3d.py:322-335).
+ * Output cropping (the inverse's Z[1:-1], transform2d.py:263-268): the first crop_lo
+ * and last crop_hi logical output samples are not written.
+ */
+typedef struct dtcwt_hip_view {
+    int64_t outer, n, inner;       /* input extents (n = real input samples along j) */
+    int64_t xso, xsn, xsi;         /* input strides */
+    int64_t yso, ysn, ysi;         /* output strides */
+    int32_t pad_lo, pad_hi;        /* logical edge replication of the input */
+    int32_t crop_lo, crop_hi;      /* logical output samples dropped */
+} dtcwt_hip_view;
+
+/* colfilter: replaces dtcwt/numpy/lowlevel.py:47-80.  Logical output length is
+ * L (m odd) or L+1 (m even), L = n+pad_lo+pad_hi. */
+int dtcwt_hip_colfilter(dtcwt_hip_ctx *ctx, int dtype, const void *X, void *Y,
+                        const dtcwt_hip_view *v, const double *h_host, int m, int flags);
+/* coldfilt: replaces dtcwt/numpy/lowlevel.py:82-154.  L % 4 == 0, m even; output L/2. */
+int dtcwt_hip_coldfilt(dtcwt_hip_ctx *ctx, int dtype, const void *X, void *Y,
+                       const dtcwt_hip_view *v, const double *ha_host, const double *hb_host,
+                       int m, int flags);
+/* colifilt: replaces dtcwt/numpy/lowlevel.py:156-260.  L % 2 == 0, m even; output 2L. */
+int dtcwt_hip_colifilt(dtcwt_hip_ctx *ctx, int dtype, const void *X, void *Y,
+                       const dtcwt_hip_view *v, const double *ha_host, const double *hb_host,
+                       int m, int flags);
+
+/* q2c: replaces dtcwt/numpy/transform2d.py:301-322 plus the slice-assign into Yh
+ * (:122-127).  y: [batch][rows][cols] real plane (strides in elements), rows, cols even;
+ * Yh: [batch][rows/2][cols/2][6] interleaved complex; the pair goes to subbands
+ * slot0 (p-q) and slot1 (p+q). */
+int dtcwt_hip_q2c(dtcwt_hip_ctx *ctx, int dtype, const void *y, int64_t batch, int64_t rows,
+                  int64_t cols, int64_t y_sb, int64_t y_sr, void *Yh, int slot0, int slot1);
+/* c2q: replaces dtcwt/numpy/transform2d.py:324-350.  Yh: [batch][rows][cols][6];
+ * x: [batch][2 rows][2 cols]. */
+int dtcwt_hip_c2q(dtcwt_hip_ctx *ctx, int dtype, const void *Yh, int64_t batch, int64_t rows,
+                  int64_t cols, int slot0, int slot1, double gain0, double gain1, void *x,
+                  int64_t x_sb, int64_t x_sr);
+/* cube2c: replaces dtcwt/numpy/transform3d.py:532-579 for one octant.
+ * y: real volume view [d0][d1][d2] with element strides (s0, s1, 1), d* even;
+ * Yh: [d0/2][d1/2][d2/2][28] complex; writes components 4*octant .. 4*octant+3. */
+int dtcwt_hip_cube2c(dtcwt_hip_ctx *ctx, int dtype, const void *y, int64_t d0, int64_t d1,
+                     int64_t d2, int64_t s0, int64_t s1, void *Yh, int octant);
+/* c2cube: replaces dtcwt/numpy/transform3d.py:581-619 for one octant.
+ * Yh: [e0][e1][e2][28]; y: [2e0][2e1][2e2] view with strides (s0, s1, 1). */
+int dtcwt_hip_c2cube(dtcwt_hip_ctx *ctx, int dtype, const void *Yh, int64_t e0, int64_t e1,
+                     int64_t e2, int octant, void *y, int64_t s0, int64_t s1);
+/* interleave / de-interleave of the 1-D transform: hi is [2J][k] real, Yh is [J][k]
+ * complex.  pack1d: Yh[j] = Hi[2j] + i Hi[2j+1] (dtcwt/numpy/transform1d.py:88,100);
+ * unpack1d: c2q1d of gain*Yh (:153,171,186-196). */
+int dtcwt_hip_pack1d(dtcwt_hip_ctx *ctx, int dtype, const void *hi, int64_t J, int64_t k, void *Yh);
+int dtcwt_hip_unpack1d(dtcwt_hip_ctx *ctx, int dtype, const void *Yh, int64_t J, int64_t k,
+                       double gain, void *hi);
+/* x[i] *= gain */
+int dtcwt_hip_scale(dtcwt_hip_ctx *ctx, int dtype, void *x, int64_t count, double gain);
+
+/* ---------------------------------------------------------------- fused 2-D plan ---- */
+/* The device-resident level loop of Transform2d.forward / .inverse
+ * (dtcwt/numpy/transform2d.py:40-188, :190-295) for a batch of equally sized float32
+ * images: one fused kernel per level (column pass, row pass and q2c/c2q inside one LDS
+ * tile), pyramid buffers in HBM in the reference's layout:
+ *     X      [batch][rows][cols]              float32 (rows/cols as given, may be odd)
+ *     Yl     [batch][lr][lc]                  float32
+ *     Yh[l]  [batch][hr_l][hc_l][6]           complex64 (interleaved re, im)
+ *     Ys[l]  [batch][sr_l][sc_l]              float32 (include_scale)
+ * Shapes follow the reference exactly, including the bottom/right replication of odd
+ * inputs (:86-94) and the edge padding of levels whose size is not a multiple of 4
+ * (:134-140) -- done by index arithmetic, never by copying.
+ *
+ * biort_host:  4 vectors h0o, g0o, h1o, g1o          (odd lengths, <= DTCWT_HIP_MAX_TAPS)
+ * qshift_host: 8 vectors h0a, h0b, g0a, g0b, h1a, h1b, g1a, g1b (one even length)
+ * given as arrays of pointers + lengths.  The band-pass ("_bp", 6/12 vector) wavelets
+ * are handled by the host through the generic filters.
+ */
+int dtcwt_hip_plan2d_create(dtcwt_hip_ctx *ctx, int batch, int rows, int cols, int nlevels,
+                            const double *const *biort_host, const int *biort_len,
+                            const double *const *qshift_host, const int *qshift_len,
+                            dtcwt_hip_plan2d **plan);
+int dtcwt_hip_plan2d_destroy(dtcwt_hip_plan2d *plan);
+/* shapes[0..1] = extended input rows, cols; shapes[2..3] = Yl rows, cols; then for each
+ * level l: Yh rows, cols, scale rows, cols  (4 ints per level). */
+int dtcwt_hip_plan2d_shapes(const dtcwt_hip_plan2d *plan, int *shapes);
+/* Ys may be NULL (no include_scale); otherwise nlevels device pointers. */
+int dtcwt_hip_plan2d_forward(dtcwt_hip_plan2d *plan, const float *X, float *Yl,
+                             void *const *Yh, float *const *Ys);
+/* gain_mask_host: 6*nlevels doubles, gain_mask[d*nlevels + l] (the reference's (6,
+ * nlevels) array, C order) or NULL for all ones.  Z: [batch][ext rows][ext cols]. */
+int dtcwt_hip_plan2d_inverse(dtcwt_hip_plan2d *plan, const float *Yl, const void *const *Yh,
+                             const double *gain_mask_host, float *Z);
+
+/* Per-kernel timing for the benchmark's roofline report: when enabled, every level kernel
+ * of forward/inverse is bracketed by a hipEvent pair on the plan's stream;
+ * kernel_ms() synchronises and returns the durations of the LAST forward (fwd_ms[l]) and
+ * inverse (inv_ms[l]) call, l = 0 .. nlevels-1.  Either pointer may be NULL. */
+int dtcwt_hip_plan2d_set_profiling(dtcwt_hip_plan2d *plan, int enable);
+int dtcwt_hip_plan2d_kernel_ms(dtcwt_hip_plan2d *plan, float *fwd_ms, float *inv_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DTCWT_HIP_H */

@@ -494,14 +494,14 @@ class Transform1d(object):
         if level < 0:
             return Lo
         while level >= 1:
-            Hi = c2q1d(Yh[level] * gain_mask[level])
+            Hi = c2q1d(Yh[level] * Yh[level].real.dtype.type(gain_mask[level]))
             Lo = colifilt(Lo, g0b, g0a) + colifilt(Hi, g1b, g1a)
             if Lo.shape[0] != 2 * Yh[level - 1].shape[0]:
                 Lo = Lo[1:-1]
             if Lo.shape[0] != 2 * Yh[level - 1].shape[0] or Lo.shape[1] != Yh[level - 1].shape[1]:
                 raise ValueError('Yh sizes are not valid for DTWAVEIFM')
             level -= 1
-        Hi = c2q1d(Yh[0] * gain_mask[0])
+        Hi = c2q1d(Yh[0] * Yh[0].real.dtype.type(gain_mask[0]))
         Z = colfilter(Lo, g0o) + colfilter(Hi, g1o)
         return Z.flatten() if Z.shape[1] == 1 else Z
 

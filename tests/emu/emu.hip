@@ -1,0 +1,153 @@
+// TEST-ONLY host emulator of the fused 2-D tile programs.
+//
+// Steps through the very same __host__ __device__ phase functions the gfx950 kernels call
+// (dtcwt_amd/csrc/fused2d_tiles.hpp, same tile configurations from fused2d_table.hpp), one
+// workgroup at a time, thread by thread, phase by phase, on the CPU, with plain arrays in
+// place of LDS.  It exists so the index algebra of the kernels can be checked against the
+// oracle in the CPU test-suite (no GPU in the build container).  It is not linked into
+// libdtcwt_hip.so, not declared in include/dtcwt_hip.h and never loaded by dtcwt_amd.
+#include <cstring>
+#include <vector>
+
+#include "fused2d_tiles.hpp"
+#include "fused2d_table.hpp"
+
+using namespace dt2d;
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static void put_taps(float *dst, const double *src, int m) {
+    for (int k = 0; k < DT_MAXT; ++k) dst[k] = k < m ? (float)src[k] : 0.f;
+}
+static double dotd(const double *a, const double *b, int m) {
+    double s = 0;
+    for (int k = 0; k < m; ++k) s += a[k] * b[k];
+    return s;
+}
+
+template <class C>
+static int run_fwd1(Fwd1Params p) {
+    p.tilesR = cdiv(p.LR, C::TR); p.tilesC = cdiv(p.LC, C::TC);
+    std::vector<float> smem(C::LDS_FLOATS + 4);
+    float *base = smem.data();
+    while (((uintptr_t)base) & 15) ++base;
+    float *sx = base, *sLo = sx + C::SX, *sHi = sLo + C::SL;
+    for (int b = 0; b < p.B; ++b)
+        for (int tr = 0; tr < p.tilesR; ++tr)
+            for (int tc = 0; tc < p.tilesC; ++tc) {
+                int r0 = tr * C::TR, c0 = tc * C::TC;
+                for (int t = 0; t < DT_NT; ++t) fwd1_load<C>(p, sx, t, b, r0, c0);
+                for (int t = 0; t < DT_NT; ++t) fwd1_cols<C>(p, sx, sLo, sHi, t);
+                for (int t = 0; t < DT_NT; ++t) fwd1_rows<C>(p, sLo, sHi, t, b, r0, c0);
+            }
+    return 0;
+}
+
+template <class C>
+static int run_fwd2(Fwd2Params p) {
+    p.tilesR = cdiv(p.LR / 2, C::TR); p.tilesC = cdiv(p.LC / 2, C::TC);
+    std::vector<float> smem(C::LDS_FLOATS + 4);
+    float *base = smem.data();
+    while (((uintptr_t)base) & 15) ++base;
+    float *sx = base, *sLo = sx + C::SX, *sHi = sLo + C::SL;
+    for (int b = 0; b < p.B; ++b)
+        for (int tr = 0; tr < p.tilesR; ++tr)
+            for (int tc = 0; tc < p.tilesC; ++tc) {
+                int r0 = tr * C::TR, c0 = tc * C::TC;
+                for (int t = 0; t < DT_NT; ++t) fwd2_load<C>(p, sx, t, b, r0, c0);
+                for (int t = 0; t < DT_NT; ++t) fwd2_cols<C>(p, sx, sLo, sHi, t);
+                for (int t = 0; t < DT_NT; ++t) fwd2_rows<C>(p, sLo, sHi, t, b, r0, c0);
+            }
+    return 0;
+}
+
+template <class C>
+static int run_inv1(Inv1Params p) {
+    p.tilesR = cdiv(p.R, C::TR); p.tilesC = cdiv(p.C, C::TC);
+    std::vector<float> smem(C::LDS_FLOATS + 4);
+    float *base = smem.data();
+    while (((uintptr_t)base) & 15) ++base;
+    float *s0 = base, *s1 = s0 + C::SP, *s2 = s1 + C::SP, *s3 = s2 + C::SP;
+    float *y1 = s3 + C::SP, *y2 = y1 + C::SY;
+    for (int b = 0; b < p.B; ++b)
+        for (int tr = 0; tr < p.tilesR; ++tr)
+            for (int tc = 0; tc < p.tilesC; ++tc) {
+                int r0 = tr * C::TR, c0 = tc * C::TC;
+                for (int t = 0; t < DT_NT; ++t) inv1_load<C>(p, s0, s1, s2, s3, t, b, r0, c0);
+                for (int t = 0; t < DT_NT; ++t) inv1_cols<C>(p, s0, s1, s2, s3, y1, y2, t);
+                for (int t = 0; t < DT_NT; ++t) inv1_rows<C>(p, y1, y2, t, b, r0, c0);
+            }
+    return 0;
+}
+
+template <class C>
+static int run_inv2(Inv2Params p) {
+    p.tilesR = cdiv(p.zr, C::TR); p.tilesC = cdiv(p.zc, C::TC);
+    std::vector<float> smem(C::LDS_FLOATS + 4);
+    float *base = smem.data();
+    while (((uintptr_t)base) & 15) ++base;
+    float *s0 = base, *s1 = s0 + C::SP, *s2 = s1 + C::SP, *s3 = s2 + C::SP;
+    float *y1 = s3 + C::SP, *y2 = y1 + C::SY;
+    for (int b = 0; b < p.B; ++b)
+        for (int tr = 0; tr < p.tilesR; ++tr)
+            for (int tc = 0; tc < p.tilesC; ++tc) {
+                int r0 = tr * C::TR, c0 = tc * C::TC;
+                for (int t = 0; t < DT_NT; ++t) inv2_load<C>(p, s0, s1, s2, s3, t, b, r0, c0);
+                for (int t = 0; t < DT_NT; ++t) inv2_cols<C>(p, s0, s1, s2, s3, y1, y2, t);
+                for (int t = 0; t < DT_NT; ++t) inv2_rows<C>(p, y1, y2, t, b, r0, c0);
+            }
+    return 0;
+}
+
+#define EMU_FWD1(TR, TC, A, B_) if (m0 == A && m1 == B_) return run_fwd1<Fwd1Cfg<TR, TC, A, B_>>(p);
+#define EMU_INV1(TR, TC, A, B_) if (m0 == A && m1 == B_) return run_inv1<Inv1Cfg<TR, TC, A, B_>>(p);
+#define EMU_FWD2(TR, TC, M) if (m == M) return run_fwd2<Fwd2Cfg<TR, TC, M>>(p);
+#define EMU_INV2(TR, TC, M) if (m == M) return run_inv2<Inv2Cfg<TR, TC, M>>(p);
+
+extern "C" {
+
+// all pointers are HOST pointers
+int emu_fwd1(int m0, int m1, const float *X, float *LoLo, float *Yh, int B, int inR, int inC,
+             const double *h0, const double *h1) {
+    Fwd1Params p{};
+    p.X = X; p.LoLo = LoLo; p.Yh = Yh; p.B = B; p.inR = inR; p.inC = inC;
+    p.LR = inR + (inR & 1); p.LC = inC + (inC & 1);
+    put_taps(p.h0, h0, m0); put_taps(p.h1, h1, m1);
+    DT_FWD1_TABLE(EMU_FWD1)
+    return -3;
+}
+
+int emu_fwd2(int m, const float *X, float *LoLo, float *Yh, int B, int inR, int inC,
+             const double *la, const double *lb, const double *ha, const double *hb) {
+    Fwd2Params p{};
+    p.X = X; p.LoLo = LoLo; p.Yh = Yh; p.B = B; p.inR = inR; p.inC = inC;
+    p.padR = (inR % 4) ? 1 : 0; p.padC = (inC % 4) ? 1 : 0;
+    p.LR = inR + 2 * p.padR; p.LC = inC + 2 * p.padC;
+    put_taps(p.l_a, la, m); put_taps(p.l_b, lb, m); put_taps(p.h_a, ha, m); put_taps(p.h_b, hb, m);
+    p.lo_a_first = dotd(la, lb, m) > 0; p.hi_a_first = dotd(ha, hb, m) > 0;
+    DT_FWD2_TABLE(EMU_FWD2)
+    return -3;
+}
+
+int emu_inv1(int m0, int m1, const float *Z, const float *Yh, float *X, int B, int R, int C,
+             const double *gain6, const double *g0, const double *g1) {
+    Inv1Params p{};
+    p.Z = Z; p.Yh = Yh; p.X = X; p.B = B; p.R = R; p.C = C;
+    for (int d = 0; d < 6; ++d) p.g[d] = (float)(0.70710678118654752440 * gain6[d]);
+    put_taps(p.g0, g0, m0); put_taps(p.g1, g1, m1);
+    DT_INV1_TABLE(EMU_INV1)
+    return -3;
+}
+
+int emu_inv2(int m, const float *Z, const float *Yh, float *Out, int B, int zr, int zc, int cropR,
+             int cropC, const double *gain6, const double *la, const double *lb, const double *ha,
+             const double *hb) {
+    Inv2Params p{};
+    p.Z = Z; p.Yh = Yh; p.Out = Out; p.B = B; p.zr = zr; p.zc = zc; p.cropR = cropR; p.cropC = cropC;
+    for (int d = 0; d < 6; ++d) p.g[d] = (float)(0.70710678118654752440 * gain6[d]);
+    put_taps(p.l_a, la, m); put_taps(p.l_b, lb, m); put_taps(p.h_a, ha, m); put_taps(p.h_b, hb, m);
+    p.lo_pos = dotd(la, lb, m) > 0; p.hi_pos = dotd(ha, hb, m) > 0;
+    DT_INV2_TABLE(EMU_INV2)
+    return -3;
+}
+
+}  // extern "C"

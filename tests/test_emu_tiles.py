@@ -1,0 +1,165 @@
+"""Index algebra of the fused gfx950 tile programs, stepped on the CPU.
+
+tests/emu/emu.hip compiles the same __host__ __device__ phase functions the kernels in
+dtcwt_amd/csrc/fused2d.hip call and walks them workgroup by workgroup on the host; here
+each level kernel is compared with the oracle's statement of that level.  (The GPU suite
+repeats the comparison on the real kernels through the C ABI.)
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import dtcwt_oracle as o
+from dtcwt_amd.coeffs import biort, qshift
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+EMU_SRC = os.path.join(HERE, 'emu', 'emu.hip')
+EMU_LIB = os.path.join(HERE, 'emu', 'libdtcwt_emu.so')
+HIPCC = '/opt/rocm/bin/hipcc'
+
+TOL = 2e-6
+
+
+def _build():
+    deps = [EMU_SRC, os.path.join(ROOT, 'dtcwt_amd', 'csrc', 'fused2d_tiles.hpp'),
+            os.path.join(ROOT, 'dtcwt_amd', 'csrc', 'fused2d_table.hpp')]
+    if os.path.exists(EMU_LIB) and all(os.path.getmtime(EMU_LIB) >= os.path.getmtime(d) for d in deps):
+        return
+    if not os.path.exists(HIPCC):
+        pytest.skip('hipcc not available to build the emulator')
+    subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-O2', '-std=c++17', '-fPIC', '-shared',
+                           '-I' + os.path.join(ROOT, 'dtcwt_amd', 'csrc'), '-I' + os.path.join(ROOT, 'include'),
+                           EMU_SRC, '-o', EMU_LIB])
+
+
+@pytest.fixture(scope='module')
+def emu():
+    _build()
+    return ctypes.CDLL(EMU_LIB)
+
+
+def _d(a):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1))
+    return a, a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _f(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def rel(a, b):
+    return np.abs(a.astype(np.complex128) - b.astype(np.complex128)).max() / max(np.abs(b).max(), 1e-30)
+
+
+def emu_fwd1(emu, X, h0o, h1o):
+    B, r, c = X.shape
+    R, C = r + (r & 1), c + (c & 1)
+    lolo = np.full((B, R, C), np.nan, np.float32)
+    yh = np.full((B, R // 2, C // 2, 12), np.nan, np.float32)
+    h0, p0 = _d(h0o); h1, p1 = _d(h1o)
+    rc = emu.emu_fwd1(len(h0), len(h1), _f(X), _f(lolo), _f(yh), B, r, c, p0, p1)
+    assert rc == 0
+    return lolo, yh.view(np.complex64)
+
+
+def emu_fwd2(emu, X, q):
+    B, r, c = X.shape
+    LR, LC = r + (2 if r % 4 else 0), c + (2 if c % 4 else 0)
+    lolo = np.full((B, LR // 2, LC // 2), np.nan, np.float32)
+    yh = np.full((B, LR // 4, LC // 4, 12), np.nan, np.float32)
+    h0a, h0b, g0a, g0b, h1a, h1b, g1a, g1b = q[:8]
+    la, pla = _d(h0b); lb, plb = _d(h0a); ha, pha = _d(h1b); hb, phb = _d(h1a)
+    rc = emu.emu_fwd2(len(la), _f(X), _f(lolo), _f(yh), B, r, c, pla, plb, pha, phb)
+    assert rc == 0
+    return lolo, yh.view(np.complex64)
+
+
+def emu_inv1(emu, Z, Yh, g0o, g1o, gain):
+    B, R, C = Z.shape
+    X = np.full((B, R, C), np.nan, np.float32)
+    g0, p0 = _d(g0o); g1, p1 = _d(g1o); gn, pg = _d(gain)
+    yh = np.ascontiguousarray(Yh).view(np.float32)
+    rc = emu.emu_inv1(len(g0), len(g1), _f(Z), _f(yh), _f(X), B, R, C, pg, p0, p1)
+    assert rc == 0
+    return X
+
+
+def emu_inv2(emu, Z, Yh, q, gain, cropR, cropC):
+    B, zr, zc = Z.shape
+    out = np.full((B, 2 * zr - 2 * cropR, 2 * zc - 2 * cropC), np.nan, np.float32)
+    h0a, h0b, g0a, g0b, h1a, h1b, g1a, g1b = q[:8]
+    la, pla = _d(g0b); lb, plb = _d(g0a); ha, pha = _d(g1b); hb, phb = _d(g1a)
+    gn, pg = _d(gain)
+    yh = np.ascontiguousarray(Yh).view(np.float32)
+    rc = emu.emu_inv2(len(la), _f(Z), _f(yh), _f(out), B, zr, zc, cropR, cropC, pg, pla, plb, pha, phb)
+    assert rc == 0
+    return out
+
+
+BIORTS = ['near_sym_a', 'antonini', 'legall', 'near_sym_b']
+QSHIFTS = ['qshift_a', 'qshift_b', 'qshift_c', 'qshift_d', 'qshift_32']
+
+
+@pytest.mark.parametrize('bn', BIORTS)
+@pytest.mark.parametrize('shape', [(64, 128), (33, 47), (70, 36), (2, 6)])
+def test_emu_level1_forward_inverse(emu, bn, shape):
+    rs = np.random.RandomState(3)
+    X = rs.standard_normal((2,) + shape).astype(np.float32)
+    b = biort(bn)
+    lolo, yh = emu_fwd1(emu, X, b[0], b[2])
+    t = o.Transform2d(b, qshift('qshift_a'))
+    for i in range(2):
+        p = t.forward(X[i], nlevels=1)
+        assert rel(lolo[i], p.lowpass) < TOL
+        assert rel(yh[i], p.highpasses[0]) < TOL
+    gain = np.array([1.0, 0.5, 0.0, 2.0, 1.5, 0.7])
+    Z = emu_inv1(emu, lolo, yh, b[1], b[3], gain)
+    for i in range(2):
+        want = t.inverse(o.Pyramid(lolo[i], (yh[i],)), gain.reshape(6, 1))
+        assert rel(Z[i], want) < TOL
+
+
+@pytest.mark.parametrize('qn', QSHIFTS)
+@pytest.mark.parametrize('shape', [(64, 64), (36, 52), (18, 72), (4, 8), (130, 66)])
+def test_emu_level2_forward_inverse(emu, qn, shape):
+    rs = np.random.RandomState(5)
+    X = rs.standard_normal((2,) + shape).astype(np.float32)
+    q = qshift(qn)
+    lolo, yh = emu_fwd2(emu, X, q)
+    h0a, h0b, g0a, g0b, h1a, h1b, g1a, g1b = q[:8]
+    rows = lambda fn, A, *h: fn(A.T, *h).T
+    gain = np.array([1.0, 0.5, 0.0, 2.0, 1.5, 0.7])
+    padR, padC = int(shape[0] % 4 != 0), int(shape[1] % 4 != 0)
+    Zi = emu_inv2(emu, lolo, yh, q, gain, padR, padC)
+    for i in range(2):
+        L = X[i]
+        if padR:
+            L = np.concatenate((L[:1], L, L[-1:]), 0)
+        if padC:
+            L = np.concatenate((L[:, :1], L, L[:, -1:]), 1)
+        Lo = o.coldfilt(L, h0b, h0a)
+        Hi = o.coldfilt(L, h1b, h1a)
+        ll = rows(o.coldfilt, Lo, h0b, h0a)
+        want = np.zeros((ll.shape[0] >> 1, ll.shape[1] >> 1, 6), np.complex64)
+        want[:, :, 0:6:5] = o.q2c(rows(o.coldfilt, Hi, h0b, h0a))
+        want[:, :, 2:4:1] = o.q2c(rows(o.coldfilt, Lo, h1b, h1a))
+        want[:, :, 1:5:3] = o.q2c(rows(o.coldfilt, Hi, h1b, h1a))
+        assert rel(lolo[i], ll) < TOL
+        assert rel(yh[i], want) < TOL
+        # inverse of this level (transform2d.py:242-268)
+        lh = o.c2q(want[:, :, [0, 5]], gain[[0, 5]])
+        hl = o.c2q(want[:, :, [2, 3]], gain[[2, 3]])
+        hh = o.c2q(want[:, :, [1, 4]], gain[[1, 4]])
+        y1 = o.colifilt(ll, g0b, g0a) + o.colifilt(lh, g1b, g1a)
+        y2 = o.colifilt(hl, g0b, g0a) + o.colifilt(hh, g1b, g1a)
+        Z = rows(o.colifilt, y1, g0b, g0a) + rows(o.colifilt, y2, g1b, g1a)
+        if padR:
+            Z = Z[1:-1]
+        if padC:
+            Z = Z[:, 1:-1]
+        assert Z.shape == Zi[i].shape
+        assert rel(Zi[i], Z) < 4 * TOL

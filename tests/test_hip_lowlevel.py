@@ -1,0 +1,127 @@
+"""colfilter / coldfilt / colifilt of the hip backend.
+
+Shape and ValueError behaviour mirrors the reference's tests/test_colfilter.py:19-50,
+test_coldfilt.py:20-40, test_colifilt.py:20-53; numerics mirror the accelerated-vs-gold
+pattern of tests/test_openclcolfilter.py:22-84 etc. with the oracle (and the golden vectors
+from the reference itself) as gold."""
+import numpy as np
+import pytest
+
+from oracle import dtcwt_oracle as o
+from dtcwt_amd.coeffs import biort, qshift
+from dtcwt_amd.hip.lowlevel import colfilter, coldfilt, colifilt
+from tests import _golden as G
+from tests._hip import assert_close, LOW_TOL, F64_TOL
+
+
+# ---- argument checking happens on the host, before any device call: runs anywhere ----
+def test_coldfilt_argument_errors():
+    X = np.zeros((512, 512), np.float32)
+    with pytest.raises(ValueError):
+        coldfilt(X, (-1, 1), (1, -1, 0))          # different size
+    with pytest.raises(ValueError):
+        coldfilt(X, (-1, 2, 1), (1, 2, -1))       # odd filter
+    with pytest.raises(ValueError):
+        coldfilt(X[:511, :], (-1, 1), (1, -1))    # bad input size
+
+
+def test_colifilt_argument_errors():
+    X = np.zeros((512, 512), np.float32)
+    with pytest.raises(ValueError):
+        colifilt(X, (-1, 1), (1, -1, 0))
+    with pytest.raises(ValueError):
+        colifilt(X, (-1, 2, 1), (1, 2, -1))
+    with pytest.raises(ValueError):
+        colifilt(X[:511, :], (-1, 1), (1, -1))
+
+
+pytestmark_gpu = pytest.mark.gpu
+
+
+def _mandrill():
+    return G.load('mandrill')['mandrill']
+
+
+@pytest.mark.gpu
+def test_colfilter_shapes_and_zero():
+    m = _mandrill()
+    assert colfilter(m, (-1, 2, -1)).shape == m.shape            # odd
+    assert colfilter(m, (-1, 1)).shape == (m.shape[0] + 1, m.shape[1])   # even
+    assert colfilter(m[:, :481], (-1, 2, -1)).shape == (512, 481)
+    z = colfilter(np.zeros_like(m), biort('antonini')[0])
+    assert z.shape == m.shape and not np.any(z)
+    assert colfilter(m, biort('antonini')[0]).dtype == np.float32
+    assert coldfilt(m, (-1, 1), (1, -1)).shape == (256, 512)
+    assert colifilt(m, (-1, 1), (1, -1)).shape == (1024, 512)
+    assert not np.any(colifilt(np.zeros_like(m), (-1, 1), (1, -1)))
+    assert colfilter(m.tolist()[:8], (1, 2, 1)).dtype == np.float64     # list input -> float64
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dt', ['float32', 'float64'])
+def test_lowlevel_vs_oracle_mandrill(dt):
+    m = _mandrill().astype(dt)
+    tol = LOW_TOL if dt == 'float32' else F64_TOL
+    filt = [biort('near_sym_a')[0], biort('near_sym_a')[2], biort('near_sym_b')[2], (-1, 1),
+            qshift('qshift_a')[0], (1, 2, 3, 4, 5, 6)]
+    for h in filt:
+        got = colfilter(m, h)
+        assert got.dtype == m.dtype
+        assert_close(got, o.colfilter(m, h), tol, 'colfilter m=%d' % len(np.ravel(h)))
+    d = qshift('qshift_d')
+    pairs = []
+    for q in ('qshift_a', 'qshift_b', 'qshift_c', 'qshift_d', 'qshift_32'):
+        t = qshift(q)
+        pairs += [(t[1], t[0]), (t[0], t[1]), (t[5], t[4]), (t[7], t[6])]
+    pairs += [((-1, 1), (1, -1)), ((1, 1), (1, 1)), ((-1, 0, 0, 1), (1, 0, 0, -1)),
+              (d[4][1:-1], d[5][1:-1])]                           # tests/test_openclcolifilt.py:97-109
+    for ha, hb in pairs:
+        assert_close(coldfilt(m, ha, hb), o.coldfilt(m, ha, hb), tol, 'coldfilt')
+        assert_close(colifilt(m, ha, hb), o.colifilt(m, ha, hb), tol, 'colifilt')
+
+
+@pytest.mark.gpu
+def test_lowlevel_golden():
+    s = G.load('lowlevel')
+    X = s['X']
+    for k in s:
+        parts = k.split('/')
+        if parts[0] == 'colfilter' and parts[2] in ('float64', 'float32'):
+            got = colfilter(X.astype(parts[2]), s['colfilter/%s/h' % parts[1]])
+        elif parts[0] == 'coldfilt':
+            got = coldfilt(X.astype(parts[2]), s['pair/%s/ha' % parts[1]], s['pair/%s/hb' % parts[1]])
+        elif parts[0] == 'colifilt':
+            got = colifilt(X.astype(parts[2]), s['pair/%s/ha' % parts[1]], s['pair/%s/hb' % parts[1]])
+        else:
+            continue
+        assert got.dtype == s[k].dtype
+        assert_close(got, s[k], LOW_TOL if parts[2] == 'float32' else F64_TOL, k)
+    d = qshift('qshift_d')
+    for r in (2, 4, 8):                                            # multi-bounce reflection
+        Xs = s['tiny/X%d' % r]
+        assert_close(colfilter(Xs, biort('near_sym_b')[2]), s['tiny/colfilter%d' % r], F64_TOL)
+        if r % 4 == 0:
+            assert_close(coldfilt(Xs, d[1], d[0]), s['tiny/coldfilt%d' % r], F64_TOL)
+        assert_close(colifilt(Xs, d[1], d[0]), s['tiny/colifilt%d' % r], F64_TOL)
+
+
+@pytest.mark.gpu
+def test_lowlevel_ragged_shapes():
+    rs = np.random.RandomState(9)
+    q = qshift('qshift_b')
+    for shape in ((4, 1), (8, 3), (12, 129), (100, 7), (4, 1000)):
+        X = rs.standard_normal(shape).astype(np.float32)
+        assert_close(colfilter(X, biort('near_sym_b')[0]), o.colfilter(X, biort('near_sym_b')[0]), LOW_TOL)
+        assert_close(coldfilt(X, q[1], q[0]), o.coldfilt(X, q[1], q[0]), LOW_TOL)
+        assert_close(colifilt(X, q[3], q[2]), o.colifilt(X, q[3], q[2]), LOW_TOL)
+
+
+@pytest.mark.gpu
+def test_device_array_in_device_array_out():
+    from dtcwt_amd.hip import default_context, DeviceArray
+    ctx = default_context()
+    m = _mandrill()
+    d = ctx.to_device(m)
+    y = colfilter(d, biort('near_sym_a')[0])
+    assert isinstance(y, DeviceArray)
+    assert_close(y.get(), o.colfilter(m, biort('near_sym_a')[0]), LOW_TOL)

@@ -1,0 +1,141 @@
+"""Transform1d / Transform3d of the hip backend against the oracle and the golden vectors
+(patterns: the reference's tests/test_xfm1.py, test_ifm1.py, test_xfm3.py)."""
+import numpy as np
+import pytest
+
+from oracle import dtcwt_oracle as o
+from dtcwt_amd.coeffs import biort, qshift
+from dtcwt_amd.hip import Transform1d, Transform3d, Pyramid
+from tests import _golden as G
+from tests._hip import assert_close, assert_pyramids_close, XFM_TOL, INV_TOL, F64_TOL
+
+pytestmark = pytest.mark.gpu
+
+
+def _haar():
+    h0 = np.array((1.0, 1.0)) / 2
+    g0 = h0.copy()
+    h1 = g0 * np.cumprod(-np.ones_like(g0))
+    g1 = -h0 * np.cumprod(-np.ones_like(h0))
+    return (h0, g0, h1, g1)
+
+
+# ------------------------------------------------------------------------------ 1-D
+def test_1d_golden():
+    s = G.load('transform1d')
+    for case in s['cases']:
+        xn, bn, qn, nl, dt = G.parse_case(str(case))
+        nl = int(nl[2:])
+        tol = 1e-12 if dt == 'float64' else 2e-6
+        t = Transform1d(bn, qn)
+        p = t.forward(s[xn].astype(dt), nlevels=nl, include_scale=True)
+        G.check_pyramid(s, case + '/fwd', p, tol)
+        G.check_stored(s, case + '/inv', t.inverse(p), tol * 10)
+        if nl:
+            G.check_stored(s, case + '/inv_gain', t.inverse(p, s[case + '/gain_mask']), tol * 10)
+
+
+@pytest.mark.parametrize('shape', [(630,), (630, 20), (64, 3), (16,), (100, 1)])
+def test_1d_vs_oracle(shape):
+    rs = np.random.RandomState(2)
+    for dt, tol, itol in ((np.float32, XFM_TOL, INV_TOL), (np.float64, F64_TOL, 1e-11)):
+        X = rs.standard_normal(shape).astype(dt)
+        t, to = Transform1d(), o.Transform1d(biort('near_sym_a'), qshift('qshift_a'))
+        for nl in (1, 2, 4):
+            p = t.forward(X, nlevels=nl, include_scale=True)
+            want = to.forward(X, nlevels=nl, include_scale=True)
+            assert_pyramids_close(p, want, tol)
+            z = t.inverse(p)
+            assert z.shape == X.shape and z.dtype == X.dtype
+            assert_close(z, X, itol * 3, 'PR')
+
+
+def test_1d_errors_and_zero_levels():
+    t = Transform1d()
+    with pytest.raises(ValueError):
+        t.forward(np.zeros(15))                         # transform1d.py:70-71
+    X = np.arange(16.0)
+    p = t.forward(X, nlevels=0)
+    assert np.array_equal(np.ravel(p.lowpass), X)
+    p = t.forward(np.random.RandomState(0).standard_normal(64), nlevels=3)
+    bad = Pyramid(p.lowpass, (p.highpasses[0], p.highpasses[0], p.highpasses[2]))
+    with pytest.raises(ValueError):
+        t.inverse(bad)
+
+
+# ------------------------------------------------------------------------------ 3-D
+def _volume(s, xn):
+    if xn == 'e32':
+        g = slice(-16, 16)
+        X, Y, Z = np.mgrid[g, g, g]
+        r = np.sqrt(X * X + (Y * 1.2) ** 2 + (Z * 1.4) ** 2)
+        return np.where(r <= 0.4 * 32, 1.0, 0.0)
+    return s[xn]
+
+
+def test_3d_golden():
+    s = G.load('transform3d')
+    for case in s['cases']:
+        xn, bn, qn, nl, ext, d, dt = G.parse_case(str(case))
+        nl, ext, d = int(nl[2:]), int(ext[3:]), bool(int(d[1:]))
+        tol = 1e-12 if dt == 'float64' else 2e-6
+        b = _haar() if bn == 'haar' else bn
+        t = Transform3d(b, qn, ext_mode=ext)
+        p = t.forward(_volume(s, xn).astype(dt), nlevels=nl, include_scale=True, discard_level_1=d)
+        G.check_pyramid(s, case + '/fwd', p, tol)
+        G.check_stored(s, case + '/inv', t.inverse(p), tol * 10)
+
+
+@pytest.mark.parametrize('shape,ext', [((16, 24, 32), 4), ((30, 26, 22), 4), ((36, 28, 20), 8), ((8, 8, 8), 4)])
+def test_3d_vs_oracle_and_pr(shape, ext):
+    rs = np.random.RandomState(6)
+    for dt, tol, ptol in ((np.float32, XFM_TOL, 2e-5), (np.float64, F64_TOL, 1e-11)):
+        X = rs.standard_normal(shape).astype(dt)
+        t = Transform3d(ext_mode=ext)
+        to = o.Transform3d(biort('near_sym_a'), qshift('qshift_a'), ext_mode=ext)
+        for nl in (1, 2, 3):
+            p = t.forward(X, nlevels=nl, include_scale=True)
+            want = to.forward(X, nlevels=nl, include_scale=True)
+            assert p.highpasses[0].dtype == (np.complex64 if dt == np.float32 else np.complex128)
+            assert p.highpasses[0].shape[-1] == 28
+            assert_pyramids_close(p, want, tol)
+            z = t.inverse(p)
+            assert z.shape == X.shape
+            assert_close(z, X, ptol, 'PR nl=%d' % nl)
+
+
+def test_3d_discard_level_1_and_errors():
+    rs = np.random.RandomState(8)
+    X = rs.standard_normal((16, 20, 12))
+    t = Transform3d()
+    p = t.forward(X, nlevels=3, discard_level_1=True)
+    q = t.forward(X, nlevels=3)
+    assert p.highpasses[0] is None
+    assert_close(p.lowpass, q.lowpass, F64_TOL)
+    for a, b in zip(p.highpasses[1:], q.highpasses[1:]):
+        assert_close(a, b, F64_TOL)
+    to = o.Transform3d(biort('near_sym_a'), qshift('qshift_a'))
+    assert_close(t.inverse(p), to.inverse(to.forward(X, nlevels=3, discard_level_1=True)), 1e-11)
+    with pytest.raises(ValueError):
+        Transform3d(ext_mode=5).forward(X)
+    with pytest.raises(ValueError):
+        Transform3d().forward(np.zeros((5, 4, 4)))
+    with pytest.raises(ValueError):
+        Transform3d(ext_mode=8).forward(np.zeros((6, 4, 4)))
+
+
+def test_3d_medium_volume_config_c4_shape():
+    """BASELINE config[3] (256^3, nlevels=3) at a reduced 64^3 the oracle finishes quickly,
+    plus shape/PR checks; the full 256^3 volume is covered by linearity + PR."""
+    rs = np.random.RandomState(2)
+    X = rs.standard_normal((64, 64, 64)).astype(np.float32)
+    t = Transform3d()
+    p = t.forward(X, nlevels=3)
+    want = o.Transform3d(biort('near_sym_a'), qshift('qshift_a')).forward(X, nlevels=3)
+    assert_pyramids_close(p, want, XFM_TOL)
+    V = rs.standard_normal((256, 256, 256)).astype(np.float32)
+    p = t.forward(V, nlevels=3)
+    assert p.lowpass.shape == (64, 64, 64)
+    assert [y.shape for y in p.highpasses] == [(128, 128, 128, 28), (64, 64, 64, 28), (32, 32, 32, 28)]
+    z = t.inverse(p)
+    assert np.abs(z - V).max() < 3e-5 * np.abs(V).max()

@@ -1,0 +1,233 @@
+"""Transform2d of the hip backend against the oracle and the reference's golden vectors.
+
+Pattern: the reference's tests/test_openclxfm2.py:25-90 (accelerated vs gold, odd sizes,
+_bp wavelets, nlevels=0, 1-D row input), tests/test_xfm2.py / test_ifm2.py (shapes, dtypes,
+perfect reconstruction) and tests/test_tfTransform2d.py:193-263,434-453 (batched layouts,
+random gain masks).  Everything goes through the C ABI."""
+import numpy as np
+import pytest
+
+from oracle import dtcwt_oracle as o
+from dtcwt_amd.coeffs import biort, qshift
+from dtcwt_amd.hip import Transform2d, Pyramid, DeviceArray, default_context
+from tests import _golden as G
+from tests._hip import assert_close, assert_pyramids_close, XFM_TOL, INV_TOL, F64_TOL
+
+pytestmark = pytest.mark.gpu
+
+WAVES = [('near_sym_a', 'qshift_a'), ('antonini', 'qshift_06'), ('legall', 'qshift_c'),
+         ('near_sym_b', 'qshift_d'), ('near_sym_b', 'qshift_b'), ('near_sym_b_bp', 'qshift_b_bp'),
+         ('near_sym_a', 'qshift_32')]
+
+
+def _mandrill():
+    return G.load('mandrill')['mandrill']
+
+
+def test_plan_is_used_for_float32():
+    t = Transform2d()
+    assert t.plan(1, 64, 64, 3) is not None
+    with pytest.raises(NotImplementedError):
+        Transform2d('near_sym_b_bp', 'qshift_b_bp').plan(1, 64, 64, 3)
+
+
+@pytest.mark.parametrize('bn,qn', WAVES)
+@pytest.mark.parametrize('shape', [(64, 64), (36, 52), (33, 47), (130, 70), (8, 8), (2, 2), (100, 6)])
+def test_forward_inverse_vs_oracle_f32(bn, qn, shape):
+    rs = np.random.RandomState(17)
+    X = rs.standard_normal(shape).astype(np.float32)
+    t, to = Transform2d(bn, qn), o.Transform2d(biort(bn), qshift(qn))
+    for nl in (1, 2, 3, 4):
+        try:
+            want = to.forward(X, nlevels=nl, include_scale=True)
+        except Exception:
+            continue                       # shapes the reference itself cannot transform
+        p = t.forward(X, nlevels=nl, include_scale=True)
+        assert p.lowpass.dtype == np.float32 and all(y.dtype == np.complex64 for y in p.highpasses)
+        assert_pyramids_close(p, want, XFM_TOL)
+        gm = rs.uniform(0.3, 1.4, size=(6, nl)) * (rs.uniform(size=(6, nl)) > 0.25)
+        for g in (None, gm):
+            z = t.inverse(want, g)
+            assert z.dtype == np.float32
+            assert_close(z, to.inverse(want, g), INV_TOL, 'inverse nl=%d' % nl)
+
+
+@pytest.mark.parametrize('bn,qn', [('near_sym_a', 'qshift_a'), ('near_sym_b_bp', 'qshift_b_bp')])
+def test_forward_inverse_vs_oracle_f64(bn, qn):
+    rs = np.random.RandomState(18)
+    X = rs.standard_normal((36, 52))
+    t, to = Transform2d(bn, qn), o.Transform2d(biort(bn), qshift(qn))
+    want = to.forward(X, nlevels=3, include_scale=True)
+    p = t.forward(X, nlevels=3, include_scale=True)
+    assert p.lowpass.dtype == np.float64 and p.highpasses[0].dtype == np.complex128
+    assert_pyramids_close(p, want, F64_TOL)
+    assert_close(t.inverse(p), X, 1e-11, 'PR f64')
+    gm = rs.uniform(0.3, 1.4, size=(6, 3))
+    assert_close(t.inverse(want, gm), to.inverse(want, gm), F64_TOL)
+
+
+def test_golden_fixtures():
+    s = G.load('transform2d')
+    for case in s['cases']:
+        xn, bn, qn, nl, dt = G.parse_case(str(case))
+        nl = int(nl[2:])
+        tol = 1e-12 if dt == 'float64' else 2e-6
+        t = Transform2d(bn, qn)
+        p = t.forward(s[xn].astype(dt), nlevels=nl, include_scale=True)
+        G.check_pyramid(s, case + '/fwd', p, tol)
+        if case + '/fwd/Yl/data' in s:
+            ref = G.StoredPyramid(s, case + '/fwd')
+            G.check_stored(s, case + '/inv', t.inverse(ref), tol * 10)
+            if nl:
+                G.check_stored(s, case + '/inv_gain', t.inverse(ref, s[case + '/gain_mask']), tol * 10)
+
+
+def test_mandrill_golden_summaries_config_c1():
+    """BASELINE config[0]: 512x512 mandrill, near_sym_a/qshift_a, nlevels=3 (and 4), checked
+    against the reference's outputs through its own test reduction (tests/util.py:46-60)."""
+    s = G.load('mandrill')
+    mand = s['mandrill']
+    for nl in (3, 4):
+        for bn, qn in (('near_sym_a', 'qshift_a'), ('near_sym_b_bp', 'qshift_b_bp')):
+            key = 'nl%d-%s-%s-float32' % (nl, bn, qn)
+            p = Transform2d(bn, qn).forward(mand, nlevels=nl, include_scale=True)
+            assert np.abs(G.summarise_mat(p.lowpass) - s[key + '/Yl']).max() <= 1e-5
+            for l in range(nl):
+                assert np.abs(G.summarise_mat(p.highpasses[l]) - s[key + '/Yh%d' % l]).max() <= 1e-5
+                assert np.abs(G.summarise_mat(p.scales[l]) - s[key + '/Ys%d' % l]).max() <= 1e-5
+            # and against the float64 reference outputs
+            key64 = 'nl%d-%s-%s-float64' % (nl, bn, qn)
+            for l in range(nl):
+                e = (np.abs(p.highpasses[l].astype(np.complex128)) ** 2).sum()
+                assert abs(e - float(s[key64 + '/Yh%d_energy' % l])) <= 1e-5 * float(s[key64 + '/Yh%d_energy' % l])
+    p = Transform2d().forward(mand, nlevels=3)
+    assert p.lowpass.shape == (128, 128)
+    assert abs(p.lowpass.astype(np.float64).sum() - 33183.462677941905) < 0.05
+    assert abs(p.highpasses[2][5, 7, 3] - (-0.2492147741 - 0.0642030041j)) < 1e-6
+
+
+def test_odd_sizes_and_crops():
+    s = G.load('mandrill')
+    mand = s['mandrill']
+    t = Transform2d()
+    for name, crop, nl in (('r509', mand[:509, :], 3), ('c509', mand[:, :509], 3),
+                           ('rc509', mand[:509, :509], 3), ('crop233x301', mand[:233, :301], 4)):
+        p = t.forward(crop, nlevels=nl)
+        G.check_pyramid(s, name + '/fwd', p, 2e-6, check_dtype=False)
+        z = t.inverse(p)
+        G.check_stored(s, name + '/inv', z, 1e-5, check_dtype=False)
+        assert np.abs(z[:crop.shape[0], :crop.shape[1]] - crop).max() < 5e-6
+
+
+def test_shapes_like_reference():
+    t = Transform2d()
+    m = _mandrill()
+    p = t.forward(m[:509, :], nlevels=2)
+    assert p.lowpass.shape == (256, 256)
+    assert [y.shape for y in p.highpasses] == [(255, 256, 6), (128, 128, 6)]
+    assert t.inverse(p).shape == (510, 512)
+    p = t.forward(m[:36, :52], nlevels=3)
+    assert p.lowpass.shape == (10, 14)
+    assert [y.shape[:2] for y in p.highpasses] == [(18, 26), (9, 13), (5, 7)]
+    p = t.forward(m[:233, :301], nlevels=4)
+    assert p.lowpass.shape == (30, 38)
+    assert [y.shape[:2] for y in p.highpasses] == [(117, 151), (59, 76), (30, 38), (15, 19)]
+
+
+def test_zero_levels_and_row_vector_and_errors():
+    m = _mandrill()
+    t = Transform2d()
+    p = t.forward(m, nlevels=0)
+    assert np.array_equal(p.lowpass, m) and p.highpasses == ()
+    assert np.array_equal(t.inverse(p), m)
+    p = t.forward(m[0, :], nlevels=3)                     # tests/test_openclxfm2.py:44-48
+    want = o.Transform2d(biort('near_sym_a'), qshift('qshift_a')).forward(m[0, :], nlevels=3)
+    assert_pyramids_close(p, want, XFM_TOL)
+    with pytest.raises(ValueError):
+        t.forward(np.dstack((m, m)))
+    with pytest.raises(ValueError):
+        Transform2d(biort=biort('near_sym_a')[:3]).forward(m)
+    # inconsistent pyramid
+    p = t.forward(m, nlevels=3)
+    bad = Pyramid(p.lowpass, (p.highpasses[0], p.highpasses[2], p.highpasses[2]))
+    with pytest.raises(ValueError):
+        t.inverse(bad)
+
+
+def test_integer_input_is_float64():
+    m = (np.arange(64 * 48).reshape(64, 48) % 17).astype(np.int32)
+    p = Transform2d().forward(m, nlevels=2)
+    assert p.lowpass.dtype == np.float64 and p.highpasses[0].dtype == np.complex128
+    want = o.Transform2d(biort('near_sym_a'), qshift('qshift_a')).forward(m, nlevels=2)
+    assert_pyramids_close(p, want, F64_TOL)
+
+
+def test_device_resident_pyramid():
+    ctx = default_context()
+    m = _mandrill()
+    t = Transform2d()
+    d = ctx.to_device(m)
+    p = t.forward(d, nlevels=4, include_scale=True)
+    assert isinstance(p.hip_lowpass, DeviceArray)
+    assert all(isinstance(y, DeviceArray) for y in p.hip_highpasses)
+    assert all(isinstance(y, DeviceArray) for y in p.hip_scales)
+    z = t.inverse(p, device_output=True)
+    assert isinstance(z, DeviceArray)
+    assert np.abs(z.get() - m).max() < 5e-6
+    assert p.lowpass is p.lowpass                          # memoised host copy
+
+
+@pytest.mark.parametrize('fmt', ['nhw', 'chw', 'hwn', 'hwc', 'nchw', 'nhwc'])
+def test_batched_channels(fmt):
+    rs = np.random.RandomState(4)
+    imgs = rs.standard_normal((6, 40, 72)).astype(np.float32)          # [N, h, w]
+    t, to = Transform2d(), o.Transform2d(biort('near_sym_a'), qshift('qshift_a'))
+    if fmt in ('nhw', 'chw'):
+        X = imgs
+        pick = lambda A, i: A[i]
+    elif fmt in ('hwn', 'hwc'):
+        X = np.moveaxis(imgs, 0, 2)
+        pick = lambda A, i: A[:, :, i]
+    elif fmt == 'nchw':
+        X = imgs.reshape(2, 3, 40, 72)
+        pick = lambda A, i: A[i // 3, i % 3]
+    else:
+        X = np.moveaxis(imgs.reshape(2, 3, 40, 72), 1, 3)
+        pick = lambda A, i: A[i // 3, :, :, i % 3]
+    p = t.forward_channels(X, fmt, nlevels=3, include_scale=True)
+    for i in range(6):
+        want = to.forward(imgs[i], nlevels=3, include_scale=True)
+        assert_close(pick(p.lowpass, i), want.lowpass, XFM_TOL)
+        for l in range(3):
+            assert_close(pick(p.highpasses[l], i), want.highpasses[l], XFM_TOL)
+            assert_close(pick(p.scales[l], i), want.scales[l], XFM_TOL)
+    gm = rs.uniform(0.5, 1.5, size=(6, 3))
+    z = t.inverse_channels(p, fmt, gain_mask=gm)
+    assert z.shape == X.shape
+    for i in range(6):
+        want = to.forward(imgs[i], nlevels=3)
+        assert_close(pick(z, i), to.inverse(want, gm), INV_TOL)
+
+
+def test_perfect_reconstruction_large_and_linear():
+    """Size-independent properties at BASELINE's bench size (config[1]): 4096x4096 float32,
+    nlevels=4 -- perfect reconstruction, linearity, energy of the tight-ish frame."""
+    rs = np.random.RandomState(0)
+    X = rs.standard_normal((4096, 4096)).astype(np.float32)
+    Y = rs.standard_normal((4096, 4096)).astype(np.float32)
+    t = Transform2d()
+    p = t.forward(X, nlevels=4)
+    assert p.lowpass.shape == (512, 512)
+    assert [y.shape for y in p.highpasses] == [(2048, 2048, 6), (1024, 1024, 6), (512, 512, 6), (256, 256, 6)]
+    z = t.inverse(p)
+    assert np.abs(z - X).max() < 2e-5 * np.abs(X).max()        # reference's own f32 PR: 1.2e-6 * max on N(0,1)
+    q = t.forward(Y, nlevels=4)
+    r = t.forward(2.0 * X - 0.5 * Y, nlevels=4)
+    assert_close(r.lowpass, 2.0 * p.lowpass - 0.5 * q.lowpass, 2e-6)
+    for l in range(4):
+        assert_close(r.highpasses[l], 2.0 * p.highpasses[l] - 0.5 * q.highpasses[l], 2e-6)
+    # a corner block of the big transform equals the oracle on a crop that contains its support
+    crop = X[:256, :256]
+    want = o.Transform2d(biort('near_sym_a'), qshift('qshift_a')).forward(crop, nlevels=2)
+    assert_close(p.highpasses[0][:96, :96], want.highpasses[0][:96, :96], XFM_TOL)
+    assert_close(p.highpasses[1][:40, :40], want.highpasses[1][:40, :40], XFM_TOL)
