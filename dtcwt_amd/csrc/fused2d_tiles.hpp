@@ -313,27 +313,24 @@ DT_HD void inv_load_quads(const float *Yhb, int zr, int zc, const float *g, floa
         const f4 *rec = reinterpret_cast<const f4 *>(Yhb + ((int64_t)U * hc + V) * 12);
         f4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
         // slots: 0=(r0.x,r0.y) 1=(r0.z,r0.w) 2=(r1.x,r1.y) 3=(r1.z,r1.w) 4=(r2.x,r2.y) 5=(r2.z,r2.w)
-        float q1[2][2], q2[2][2], q3[2][2];
-        {   // pair (0,5)
-            float ar = r0.x * g[0], ai = r0.y * g[0], br = r2.z * g[5], bi = r2.w * g[5];
-            q1[0][0] = ar + br; q1[0][1] = ai + bi; q1[1][0] = ai - bi; q1[1][1] = -(ar - br);
-        }
-        {   // pair (2,3)
-            float ar = r1.x * g[2], ai = r1.y * g[2], br = r1.z * g[3], bi = r1.w * g[3];
-            q2[0][0] = ar + br; q2[0][1] = ai + bi; q2[1][0] = ai - bi; q2[1][1] = -(ar - br);
-        }
-        {   // pair (1,4)
-            float ar = r0.z * g[1], ai = r0.w * g[1], br = r2.x * g[4], bi = r2.y * g[4];
-            q3[0][0] = ar + br; q3[0][1] = ai + bi; q3[1][0] = ai - bi; q3[1][1] = -(ar - br);
-        }
-        // window row 2uw+e holds plane row 2U + (e ^ fr); same for columns
+        // c2q of one subband pair: a = Re P, b = Im P, c = Im Q, d = -Re Q with
+        // P = w0 + w1, Q = w0 - w1 (gains and sqrt(1/2) folded into g).  The window may
+        // be a mirrored copy of the quad: swap rows when fr, columns when fc (selects,
+        // no runtime-indexed arrays: those would live in scratch).
         int base = (2 * uw) * NC + 2 * vw;
-        *reinterpret_cast<f2 *>(s1 + base) = f2{q1[fr][fc], q1[fr][fc ^ 1]};
-        *reinterpret_cast<f2 *>(s1 + base + NC) = f2{q1[fr ^ 1][fc], q1[fr ^ 1][fc ^ 1]};
-        *reinterpret_cast<f2 *>(s2 + base) = f2{q2[fr][fc], q2[fr][fc ^ 1]};
-        *reinterpret_cast<f2 *>(s2 + base + NC) = f2{q2[fr ^ 1][fc], q2[fr ^ 1][fc ^ 1]};
-        *reinterpret_cast<f2 *>(s3 + base) = f2{q3[fr][fc], q3[fr][fc ^ 1]};
-        *reinterpret_cast<f2 *>(s3 + base + NC) = f2{q3[fr ^ 1][fc], q3[fr ^ 1][fc ^ 1]};
+#define DT_QUAD(S, W0R, W0I, W1R, W1I, G0, G1)                                     \
+        {                                                                           \
+            float ar = (W0R) * (G0), ai = (W0I) * (G0), br = (W1R) * (G1), bi = (W1I) * (G1); \
+            float qa = ar + br, qb = ai + bi, qc = ai - bi, qd = -(ar - br);        \
+            float t0 = fr ? qc : qa, t1 = fr ? qd : qb;                             \
+            float b0 = fr ? qa : qc, b1 = fr ? qb : qd;                             \
+            *reinterpret_cast<f2 *>((S) + base) = fc ? f2{t1, t0} : f2{t0, t1};     \
+            *reinterpret_cast<f2 *>((S) + base + NC) = fc ? f2{b1, b0} : f2{b0, b1}; \
+        }
+        DT_QUAD(s1, r0.x, r0.y, r2.z, r2.w, g[0], g[5])      // subbands (0, 5)
+        DT_QUAD(s2, r1.x, r1.y, r1.z, r1.w, g[2], g[3])      // subbands (2, 3)
+        DT_QUAD(s3, r0.z, r0.w, r2.x, r2.y, g[1], g[4])      // subbands (1, 4)
+#undef DT_QUAD
     }
 }
 

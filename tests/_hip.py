@@ -14,7 +14,18 @@ def assert_close(a, b, tol, what=''):
     assert e <= tol, '%s rel err %.3e > %g' % (what, e, tol)
 
 
-def assert_pyramids_close(p, q, tol, inv=False):
+def as_f64(X):
+    return np.asarray(X, dtype=np.float64)
+
+
+def cast_pyramid(p, real):
+    """Pyramid-like with arrays cast to real / matching complex dtype."""
+    from oracle import dtcwt_oracle as o
+    cplx = np.complex64 if real == np.float32 else np.complex128
+    return o.Pyramid(p.lowpass.astype(real), tuple(None if y is None else y.astype(cplx) for y in p.highpasses))
+
+
+def assert_pyramids_close(p, q, tol, same_dtype=True):
     assert p.lowpass.shape == q.lowpass.shape
     assert_close(p.lowpass, q.lowpass, tol, 'Yl')
     assert len(p.highpasses) == len(q.highpasses)
@@ -22,7 +33,8 @@ def assert_pyramids_close(p, q, tol, inv=False):
         if a is None or b is None:
             assert a is None and b is None
             continue
-        assert a.dtype == b.dtype, (a.dtype, b.dtype)
+        if same_dtype:
+            assert a.dtype == b.dtype, (a.dtype, b.dtype)
         assert_close(a, b, tol, 'Yh[%d]' % l)
     if q.scales is not None:
         assert p.scales is not None
