@@ -50,10 +50,11 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     dist = None
     torch = None
-    try:
-        import torch                                   # plumbing: barrier, device sync, RCCL
-    except Exception:
-        torch = None
+    # torch is plumbing only (RCCL barrier / broadcast, device sync): imported for N > 1 or
+    # on request; at N = 1 the bracket is hipDeviceSynchronize() through the library, which is
+    # what torch.cuda.synchronize() calls (and a cold `import torch` costs minutes on a fresh box).
+    if world > 1 or os.environ.get('DTCWT_BENCH_TORCH', '0') == '1':
+        import torch
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -100,7 +101,7 @@ def main():
             dist.barrier()
         if torch is not None and torch.cuda.is_available():
             torch.cuda.synchronize()
-        ctx.sync()
+        ctx.device_sync()
 
     for _ in range(args.warmup):
         step()

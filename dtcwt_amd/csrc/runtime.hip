@@ -82,6 +82,13 @@ int dtcwt_hip_sync(dtcwt_hip_ctx *c) {
     return 0;
 }
 
+int dtcwt_hip_device_sync(dtcwt_hip_ctx *c) {
+    DT_REQUIRE(c, "ctx is NULL");
+    DT_CHECK_HIP(hipSetDevice(c->device));
+    DT_CHECK_HIP(hipDeviceSynchronize());
+    return 0;
+}
+
 void *dtcwt_hip_ctx_stream(dtcwt_hip_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
 int dtcwt_hip_malloc(dtcwt_hip_ctx *c, size_t bytes, void **dptr) {

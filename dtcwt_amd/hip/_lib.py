@@ -60,6 +60,7 @@ SIGNATURES = {
     'dtcwt_hip_ctx_destroy': (_i, [_vp]),
     'dtcwt_hip_sync': (_i, [_vp]),
     'dtcwt_hip_ctx_stream': (_vp, [_vp]),
+    'dtcwt_hip_device_sync': (_i, [_vp]),
     'dtcwt_hip_malloc': (_i, [_vp, _sz, ctypes.POINTER(_vp)]),
     'dtcwt_hip_free': (_i, [_vp, _vp]),
     'dtcwt_hip_memcpy_h2d': (_i, [_vp, _vp, _vp, _sz]),
@@ -201,6 +202,10 @@ class Context(object):
 
     def sync(self):
         check(self._lib.dtcwt_hip_sync(self._h))
+
+    def device_sync(self):
+        """hipDeviceSynchronize(): every stream of this device."""
+        check(self._lib.dtcwt_hip_device_sync(self._h))
 
     def empty(self, shape, dtype):
         return DeviceArray(self, shape, dtype)

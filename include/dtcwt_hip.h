@@ -56,7 +56,8 @@ int dtcwt_hip_device_info(int device, char *name, int *cus, size_t *mem_bytes);
  * (dtcwt/opencl/transform2d.py:108-110, dtcwt/opencl/lowlevel.py:154-167). */
 int dtcwt_hip_ctx_create(int device, void *stream, dtcwt_hip_ctx **ctx);
 int dtcwt_hip_ctx_destroy(dtcwt_hip_ctx *ctx);
-int dtcwt_hip_sync(dtcwt_hip_ctx *ctx);
+int dtcwt_hip_sync(dtcwt_hip_ctx *ctx);            /* the context's stream */
+int dtcwt_hip_device_sync(dtcwt_hip_ctx *ctx);     /* hipDeviceSynchronize(): all streams */
 void *dtcwt_hip_ctx_stream(dtcwt_hip_ctx *ctx);
 
 /* Device buffers: replace to_device/to_array/empty of dtcwt/opencl/lowlevel.py:169-181. */
