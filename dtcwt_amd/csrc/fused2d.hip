@@ -5,10 +5,12 @@
 // float32 batches: one kernel launch per level and direction, all intermediates of a
 // level in LDS, LoLo of each level in HBM (it is the next level's input and the
 // `scales` output), Yh written/read as whole 48-byte 6-subband records.
+#include <cstdlib>
 #include <vector>
 
 #include "common.hpp"
 #include "fused2d_tiles.hpp"
+#include "fused2d_tiles_v2.hpp"
 #include "fused2d_table.hpp"
 
 using namespace dt2d;
@@ -16,43 +18,49 @@ using namespace dt2d;
 namespace {
 
 // -------------------------------------------------------------------------- kernels
+// Level-1 forward: column pass straight from global memory into two LDS planes, one
+// barrier, row pass + q2c with wave-staged coalesced record stores (fused2d_tiles_v2.hpp).
 template <class C>
 __global__ void __launch_bounds__(DT_NT) k_fwd1(Fwd1Params p) {
-    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS + 4 * STAGE_FLOATS_PER_WAVE];
     const int ntile = p.tilesR * p.tilesC * p.B;
-    int t = xcd_tile(blockIdx.x, ntile);
+    int t = tile_of(blockIdx.x, ntile, p.xcd_order);
     if (t >= ntile) return;
     int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
-    float *sx = smem, *sLo = smem + C::SX, *sHi = sLo + C::SL;
+    float *sLo = smem, *sHi = sLo + C::SL, *stage = sHi + C::SL;
     int r0 = tr * C::TR, c0 = tc * C::TC;
-    fwd1_load<C>(p, sx, threadIdx.x, b, r0, c0);
+    fwd1d_cols<C>(p, sLo, sHi, threadIdx.x, b, r0, c0);
     __syncthreads();
-    fwd1_cols<C>(p, sx, sLo, sHi, threadIdx.x);
-    __syncthreads();
-    fwd1_rows<C>(p, sLo, sHi, threadIdx.x, b, r0, c0);
+    constexpr int NQ = (C::TR / 2) * (C::TC / 2);
+    for (int base = 0; base < NQ; base += DT_NT) {
+        fwd1s_rows_compute<C>(p, sLo, sHi, stage, threadIdx.x, base, b, r0, c0);
+        fwd1s_rows_flush<C>(p, stage, threadIdx.x, base, b, r0, c0);
+    }
 }
 
+// Level >= 2 forward: same structure as k_fwd1 (direct column pass, staged record stores).
 template <class C>
 __global__ void __launch_bounds__(DT_NT) k_fwd2(Fwd2Params p) {
-    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS + 4 * STAGE_FLOATS_PER_WAVE];
     const int ntile = p.tilesR * p.tilesC * p.B;
-    int t = xcd_tile(blockIdx.x, ntile);
+    int t = tile_of(blockIdx.x, ntile, p.xcd_order);
     if (t >= ntile) return;
     int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
-    float *sx = smem, *sLo = smem + C::SX, *sHi = sLo + C::SL;
+    float *sLo = smem, *sHi = sLo + C::SL, *stage = sHi + C::SL;
     int r0 = tr * C::TR, c0 = tc * C::TC;
-    fwd2_load<C>(p, sx, threadIdx.x, b, r0, c0);
+    fwd2d_cols<C>(p, sLo, sHi, threadIdx.x, b, r0, c0);
     __syncthreads();
-    fwd2_cols<C>(p, sx, sLo, sHi, threadIdx.x);
-    __syncthreads();
-    fwd2_rows<C>(p, sLo, sHi, threadIdx.x, b, r0, c0);
+    for (int base = 0; base < C::TI * C::TJ; base += DT_NT) {
+        fwd2s_rows_compute<C>(p, sLo, sHi, stage, threadIdx.x, base, b, r0, c0);
+        fwd2s_rows_flush<C>(p, stage, threadIdx.x, base, b, r0, c0);
+    }
 }
 
 template <class C>
 __global__ void __launch_bounds__(DT_NT) k_inv1(Inv1Params p) {
     __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
     const int ntile = p.tilesR * p.tilesC * p.B;
-    int t = xcd_tile(blockIdx.x, ntile);
+    int t = tile_of(blockIdx.x, ntile, p.xcd_order);
     if (t >= ntile) return;
     int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
     float *s0 = smem, *s1 = s0 + C::SP, *s2 = s1 + C::SP, *s3 = s2 + C::SP;
@@ -69,7 +77,7 @@ template <class C>
 __global__ void __launch_bounds__(DT_NT) k_inv2(Inv2Params p) {
     __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
     const int ntile = p.tilesR * p.tilesC * p.B;
-    int t = xcd_tile(blockIdx.x, ntile);
+    int t = tile_of(blockIdx.x, ntile, p.xcd_order);
     if (t >= ntile) return;
     int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
     float *s0 = smem, *s1 = s0 + C::SP, *s2 = s1 + C::SP, *s3 = s2 + C::SP;
@@ -113,9 +121,9 @@ int launch_inv2(Inv2Params &p, hipStream_t s) {
 
 // Tile shapes and supported tap lengths live in fused2d_table.hpp (shared with the
 // test-only host emulator so both step through identical configurations).
-#define DT_CASE_FWD1(TR, TC, A, B) if (m0 == A && m1 == B) return launch_fwd1<Fwd1Cfg<TR, TC, A, B>>(p, s);
+#define DT_CASE_FWD1(TR, TC, RS, A, B) if (m0 == A && m1 == B) return launch_fwd1<Fwd1DCfg<TR, TC, RS, A, B>>(p, s);
 #define DT_CASE_INV1(TR, TC, A, B) if (m0 == A && m1 == B) return launch_inv1<Inv1Cfg<TR, TC, A, B>>(p, s);
-#define DT_CASE_FWD2(TR, TC, M) if (m == M) return launch_fwd2<Fwd2Cfg<TR, TC, M>>(p, s);
+#define DT_CASE_FWD2(TR, TC, PS, M) if (m == M) return launch_fwd2<Fwd2DCfg<TR, TC, PS, M>>(p, s);
 #define DT_CASE_INV2(TR, TC, M) if (m == M) return launch_inv2<Inv2Cfg<TR, TC, M>>(p, s);
 int dispatch_fwd1(int m0, int m1, Fwd1Params &p, hipStream_t s) { DT_FWD1_TABLE(DT_CASE_FWD1) return -3; }
 int dispatch_inv1(int m0, int m1, Inv1Params &p, hipStream_t s) { DT_INV1_TABLE(DT_CASE_INV1) return -3; }
@@ -123,10 +131,11 @@ int dispatch_fwd2(int m, Fwd2Params &p, hipStream_t s) { DT_FWD2_TABLE(DT_CASE_F
 int dispatch_inv2(int m, Inv2Params &p, hipStream_t s) { DT_INV2_TABLE(DT_CASE_INV2) return -3; }
 
 #define DT_HAS2(TR, TC, A, B) if (m0 == A && m1 == B) return true;
+#define DT_HAS2F(TR, TC, RS, A, B) if (m0 == A && m1 == B) return true;
 #define DT_HAS1(TR, TC, M) if (m == M) return true;
-bool fwd1_supported(int m0, int m1) { DT_FWD1_TABLE(DT_HAS2) return false; }
+bool fwd1_supported(int m0, int m1) { DT_FWD1_TABLE(DT_HAS2F) return false; }
 bool inv1_supported(int m0, int m1) { DT_INV1_TABLE(DT_HAS2) return false; }
-bool q_supported(int m) { DT_FWD2_TABLE(DT_HAS1) return false; }
+bool q_supported(int m) { DT_INV2_TABLE(DT_HAS1) return false; }
 
 double dotd(const std::vector<double> &a, const std::vector<double> &b) {
     double s = 0;
@@ -157,6 +166,7 @@ struct dtcwt_hip_plan2d {
     std::vector<float *> work;        // LoLo / Z per level (level nlevels-1 unused on fwd)
     bool profiling = false;           // record an event pair around every level kernel
     std::vector<hipEvent_t> ev;       // [fwd: 2 per level][inv: 2 per level]
+    int xcd_order = -1;               // -1: per-kernel default, 0/1: forced (DTCWT_HIP_XCD_ORDER)
 };
 
 extern "C" {
@@ -179,6 +189,7 @@ int dtcwt_hip_plan2d_create(dtcwt_hip_ctx *ctx, int batch, int rows, int cols, i
     p->ctx = ctx; p->batch = batch; p->rows = rows; p->cols = cols; p->nlevels = nlevels;
     for (int i = 0; i < 4; ++i) p->biort[i].assign(biort_host[i], biort_host[i] + biort_len[i]);
     for (int i = 0; i < 8; ++i) p->qshift[i].assign(qshift_host[i], qshift_host[i] + qshift_len[i]);
+    { const char *e = getenv("DTCWT_HIP_XCD_ORDER"); p->xcd_order = e ? (e[0] == '1' ? 1 : 0) : -1; }
     p->extR = rows + (rows & 1);
     p->extC = cols + (cols & 1);
     Level l0{rows, cols, 0, 0, p->extR, p->extC, p->extR, p->extC, p->extR / 2, p->extC / 2};
@@ -270,13 +281,14 @@ int dtcwt_hip_plan2d_forward(dtcwt_hip_plan2d *p, const float *X, float *Yl, voi
             Fwd1Params q{};
             q.X = in; q.LoLo = lo; q.Yh = (float *)Yh[l];
             q.B = p->batch; q.inR = L.inR; q.inC = L.inC; q.LR = L.LR; q.LC = L.LC;
+            q.xcd_order = p->xcd_order < 0 ? 0 : p->xcd_order;      // write-heavy: linear order
             put_taps(q.h0, p->biort[0]); put_taps(q.h1, p->biort[2]);
             rc = dispatch_fwd1((int)p->biort[0].size(), (int)p->biort[2].size(), q, s);
         } else {
             Fwd2Params q{};
             q.X = in; q.LoLo = lo; q.Yh = (float *)Yh[l];
             q.B = p->batch; q.inR = L.inR; q.inC = L.inC; q.padR = L.padR; q.padC = L.padC;
-            q.LR = L.LR; q.LC = L.LC;
+            q.LR = L.LR; q.LC = L.LC; q.xcd_order = p->xcd_order < 0 ? 1 : p->xcd_order;
             // coldfilt(X, h0b, h0a) / coldfilt(X, h1b, h1a)   (transform2d.py:143-157)
             put_taps(q.l_a, p->qshift[1]); put_taps(q.l_b, p->qshift[0]);
             put_taps(q.h_a, p->qshift[5]); put_taps(q.h_b, p->qshift[4]);
@@ -315,7 +327,7 @@ int dtcwt_hip_plan2d_inverse(dtcwt_hip_plan2d *p, const float *Yl, const void *c
         if (l == 0) {
             Inv1Params q{};
             q.Z = in; q.Yh = (const float *)Yh[0]; q.X = Z;
-            q.B = p->batch; q.R = L.LR; q.C = L.LC;
+            q.B = p->batch; q.R = L.LR; q.C = L.LC; q.xcd_order = p->xcd_order < 0 ? 1 : p->xcd_order;
             for (int d = 0; d < 6; ++d) q.g[d] = g[d];
             put_taps(q.g0, p->biort[1]); put_taps(q.g1, p->biort[3]);
             rc = dispatch_inv1((int)p->biort[1].size(), (int)p->biort[3].size(), q, s);
@@ -324,6 +336,7 @@ int dtcwt_hip_plan2d_inverse(dtcwt_hip_plan2d *p, const float *Yl, const void *c
             float *out = p->work[l - 1];          // size of LoLo_{l-1} = this level's input
             q.Z = in; q.Yh = (const float *)Yh[l]; q.Out = out;
             q.B = p->batch; q.zr = L.loR; q.zc = L.loC; q.cropR = L.padR; q.cropC = L.padC;
+            q.xcd_order = p->xcd_order < 0 ? 1 : p->xcd_order;
             for (int d = 0; d < 6; ++d) q.g[d] = g[d];
             // colifilt(X, g0b, g0a) / colifilt(X, g1b, g1a)   (transform2d.py:248-260)
             put_taps(q.l_a, p->qshift[3]); put_taps(q.l_b, p->qshift[2]);

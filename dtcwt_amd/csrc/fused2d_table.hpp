@@ -3,22 +3,26 @@
 // shipped biort sets; level >= 2 keys are the q-shift length.  Anything else goes
 // through the generic filters (still on the GPU).
 #pragma once
+/* level-1 forward: X(tile rows, tile cols, rows per column-pass strip, len h0o, len h1o) */
 #define DT_FWD1_TABLE(X) \
-    X(32, 64, 5, 7)      /* near_sym_a */ \
-    X(32, 64, 9, 7)      /* antonini   */ \
-    X(32, 64, 5, 3)      /* legall     */ \
-    X(32, 64, 13, 19)    /* near_sym_b */
+    X(32, 64, 8, 5, 7)      /* near_sym_a */ \
+    X(32, 64, 8, 9, 7)      /* antonini   */ \
+    X(32, 64, 8, 5, 3)      /* legall     */ \
+    X(32, 64, 8, 13, 19)    /* near_sym_b */
 #define DT_INV1_TABLE(X) \
     X(32, 32, 7, 5) \
     X(32, 32, 7, 9) \
     X(32, 32, 3, 5) \
     X(32, 32, 19, 13)
+/* level >= 2 forward: X(tile rows, tile cols, (A,B) pairs per column-pass strip, q-shift length);
+ * tile cols chosen so that the input window 2*TC + 2*M - 4 is 128 columns (2 strips x 128 =
+ * one task per thread in the column pass) */
 #define DT_FWD2_TABLE(X) \
-    X(32, 32, 10)        /* qshift_a, qshift_06 */ \
-    X(32, 32, 14)        /* qshift_b */ \
-    X(32, 32, 16)        /* qshift_c */ \
-    X(32, 32, 18)        /* qshift_d */ \
-    X(16, 16, 32)        /* qshift_32 */
+    X(16, 56, 4, 10)        /* qshift_a, qshift_06 */ \
+    X(16, 52, 4, 14)        /* qshift_b */ \
+    X(16, 50, 4, 16)        /* qshift_c */ \
+    X(16, 48, 4, 18)        /* qshift_d */ \
+    X(16, 34, 2, 32)        /* qshift_32 */
 #define DT_INV2_TABLE(X) \
     X(32, 32, 10) \
     X(32, 32, 14) \

@@ -33,6 +33,12 @@ struct alignas(16) f4 { float x, y, z, w; };
 struct alignas(8) f2 { float x, y; };
 
 DT_HD int reflect_i(int u, int n) {     // half-sample symmetric, multi-bounce safe
+    // one bounce (-n <= u < 2n) is the only case tiles of ordinary images ever see: two
+    // selects instead of an integer modulo (~30 VALU instructions on gfx950)
+    if ((unsigned)(u + n) < (unsigned)(3 * n)) {
+        u = u < 0 ? -1 - u : u;
+        return u >= n ? 2 * n - 1 - u : u;
+    }
     int p = 2 * n;
     int j = u % p;
     if (j < 0) j += p;
@@ -51,6 +57,7 @@ struct Fwd1Params {
     int B, inR, inC;      // real input size (may be odd)
     int LR, LC;           // even-extended logical size (transform2d.py:86-94)
     int tilesR, tilesC;
+    int xcd_order;        // 1: XCD-contiguous tile runs, 0: linear order
     float h0[DT_MAXT], h1[DT_MAXT];
 };
 
@@ -185,6 +192,7 @@ struct Fwd2Params {
     int padR, padC;       // 0/1: one replicated row/col each side (transform2d.py:134-140)
     int LR, LC;           // inR + 2 padR, multiples of 4
     int tilesR, tilesC;
+    int xcd_order;        // 1: XCD-contiguous tile runs, 0: linear order
     int lo_a_first, hi_a_first;   // sign of sum(ha*hb) of the lo / hi pair (lowlevel.py:143)
     // coldfilt(X, ha, hb) is called as (h0b, h0a) and (h1b, h1a): "a" arrays hold the
     // first argument, "b" the second.
@@ -356,6 +364,7 @@ struct Inv1Params {
     float *X;             // [B][R][C]
     int B, R, C;
     int tilesR, tilesC;
+    int xcd_order;        // 1: XCD-contiguous tile runs, 0: linear order
     float g[6];           // gain_mask column * sqrt(1/2)
     float g0[DT_MAXT], g1[DT_MAXT];
 };
@@ -468,6 +477,7 @@ struct Inv2Params {
     int B, zr, zc;
     int cropR, cropC;     // 0/1
     int tilesR, tilesC;
+    int xcd_order;        // 1: XCD-contiguous tile runs, 0: linear order
     int lo_pos, hi_pos;   // sum(ha*hb) > 0 of the g0 / g1 pair
     float g[6];
     // colifilt(X, ha, hb) is called as (g0b, g0a) and (g1b, g1a)
@@ -601,6 +611,13 @@ DT_HD int xcd_tile(int bid, int ntiles) {
     int per = (ntiles + 7) / 8;
     int t = (bid % 8) * per + bid / 8;
     return t;       // may be >= ntiles: caller must skip
+}
+// Measured on MI355X (tools/kbench): for these write-heavy kernels the plain linear order
+// is FASTER than the XCD-contiguous one (82.6 vs 93.1 us for level-1 forward at 4096^2) --
+// neighbouring tiles in flight together keep the HBM write streams dense -- so linear is
+// the default and the remap stays selectable (DTCWT_HIP_XCD_ORDER=1) for experiments.
+DT_HD int tile_of(int bid, int ntiles, int xcd_order) {
+    return xcd_order ? xcd_tile(bid, ntiles) : bid;
 }
 
 }  // namespace dt2d

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "fused2d_tiles.hpp"
+#include "fused2d_tiles_v2.hpp"
 #include "fused2d_table.hpp"
 
 using namespace dt2d;
@@ -27,17 +28,20 @@ static double dotd(const double *a, const double *b, int m) {
 template <class C>
 static int run_fwd1(Fwd1Params p) {
     p.tilesR = cdiv(p.LR, C::TR); p.tilesC = cdiv(p.LC, C::TC);
-    std::vector<float> smem(C::LDS_FLOATS + 4);
+    std::vector<float> smem(C::LDS_FLOATS + 4 * STAGE_FLOATS_PER_WAVE + 4);
     float *base = smem.data();
     while (((uintptr_t)base) & 15) ++base;
-    float *sx = base, *sLo = sx + C::SX, *sHi = sLo + C::SL;
+    float *sLo = base, *sHi = sLo + C::SL, *stage = sHi + C::SL;
+    constexpr int NQ = (C::TR / 2) * (C::TC / 2);
     for (int b = 0; b < p.B; ++b)
         for (int tr = 0; tr < p.tilesR; ++tr)
             for (int tc = 0; tc < p.tilesC; ++tc) {
                 int r0 = tr * C::TR, c0 = tc * C::TC;
-                for (int t = 0; t < DT_NT; ++t) fwd1_load<C>(p, sx, t, b, r0, c0);
-                for (int t = 0; t < DT_NT; ++t) fwd1_cols<C>(p, sx, sLo, sHi, t);
-                for (int t = 0; t < DT_NT; ++t) fwd1_rows<C>(p, sLo, sHi, t, b, r0, c0);
+                for (int t = 0; t < DT_NT; ++t) fwd1d_cols<C>(p, sLo, sHi, t, b, r0, c0);
+                for (int q = 0; q < NQ; q += DT_NT) {      // a wave's two halves run as two passes
+                    for (int t = 0; t < DT_NT; ++t) fwd1s_rows_compute<C>(p, sLo, sHi, stage, t, q, b, r0, c0);
+                    for (int t = 0; t < DT_NT; ++t) fwd1s_rows_flush<C>(p, stage, t, q, b, r0, c0);
+                }
             }
     return 0;
 }
@@ -45,17 +49,19 @@ static int run_fwd1(Fwd1Params p) {
 template <class C>
 static int run_fwd2(Fwd2Params p) {
     p.tilesR = cdiv(p.LR / 2, C::TR); p.tilesC = cdiv(p.LC / 2, C::TC);
-    std::vector<float> smem(C::LDS_FLOATS + 4);
+    std::vector<float> smem(C::LDS_FLOATS + 4 * STAGE_FLOATS_PER_WAVE + 4);
     float *base = smem.data();
     while (((uintptr_t)base) & 15) ++base;
-    float *sx = base, *sLo = sx + C::SX, *sHi = sLo + C::SL;
+    float *sLo = base, *sHi = sLo + C::SL, *stage = sHi + C::SL;
     for (int b = 0; b < p.B; ++b)
         for (int tr = 0; tr < p.tilesR; ++tr)
             for (int tc = 0; tc < p.tilesC; ++tc) {
                 int r0 = tr * C::TR, c0 = tc * C::TC;
-                for (int t = 0; t < DT_NT; ++t) fwd2_load<C>(p, sx, t, b, r0, c0);
-                for (int t = 0; t < DT_NT; ++t) fwd2_cols<C>(p, sx, sLo, sHi, t);
-                for (int t = 0; t < DT_NT; ++t) fwd2_rows<C>(p, sLo, sHi, t, b, r0, c0);
+                for (int t = 0; t < DT_NT; ++t) fwd2d_cols<C>(p, sLo, sHi, t, b, r0, c0);
+                for (int q = 0; q < C::TI * C::TJ; q += DT_NT) {
+                    for (int t = 0; t < DT_NT; ++t) fwd2s_rows_compute<C>(p, sLo, sHi, stage, t, q, b, r0, c0);
+                    for (int t = 0; t < DT_NT; ++t) fwd2s_rows_flush<C>(p, stage, t, q, b, r0, c0);
+                }
             }
     return 0;
 }
@@ -98,9 +104,9 @@ static int run_inv2(Inv2Params p) {
     return 0;
 }
 
-#define EMU_FWD1(TR, TC, A, B_) if (m0 == A && m1 == B_) return run_fwd1<Fwd1Cfg<TR, TC, A, B_>>(p);
+#define EMU_FWD1(TR, TC, RS, A, B_) if (m0 == A && m1 == B_) return run_fwd1<Fwd1DCfg<TR, TC, RS, A, B_>>(p);
 #define EMU_INV1(TR, TC, A, B_) if (m0 == A && m1 == B_) return run_inv1<Inv1Cfg<TR, TC, A, B_>>(p);
-#define EMU_FWD2(TR, TC, M) if (m == M) return run_fwd2<Fwd2Cfg<TR, TC, M>>(p);
+#define EMU_FWD2(TR, TC, PS, M) if (m == M) return run_fwd2<Fwd2DCfg<TR, TC, PS, M>>(p);
 #define EMU_INV2(TR, TC, M) if (m == M) return run_inv2<Inv2Cfg<TR, TC, M>>(p);
 
 extern "C" {

@@ -38,6 +38,59 @@ __global__ void __launch_bounds__(256) k_copy_4r1w(const f4 *__restrict__ in, f4
     }
 }
 
+// write-pattern probes: 12 B/px of "records" written (a) one 48-byte record per lane as three
+// 16-byte stores at a 48-byte lane stride, (b) as fully coalesced 16-byte stores.
+__global__ void __launch_bounds__(256) k_wr_lane48(f4 *__restrict__ out, size_t nrec) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrec) return;
+    float x = (float)i;
+    out[3 * i] = f4{x, x, x, x}; out[3 * i + 1] = f4{x, 1, x, x}; out[3 * i + 2] = f4{x, 2, x, x};
+}
+__global__ void __launch_bounds__(256) k_wr_coal(f4 *__restrict__ out, size_t nrec) {
+    size_t b = (size_t)blockIdx.x * blockDim.x * 3;
+    float x = (float)b;
+    if (b + 3 * blockDim.x > 3 * nrec) return;
+    out[b + threadIdx.x] = f4{x, x, x, x};
+    out[b + 256 + threadIdx.x] = f4{x, 1, x, x};
+    out[b + 512 + threadIdx.x] = f4{x, 2, x, x};
+}
+__global__ void __launch_bounds__(256) k_copy_stream(const f4 *__restrict__ in, f4 *__restrict__ out, size_t n4) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) out[i] = in[i];
+}
+__global__ void __launch_bounds__(256) k_copy_1r4w_coal(const f4 *__restrict__ in, f4 *__restrict__ out, size_t n4) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) {
+        f4 v = in[i];
+        out[i] = v; out[i + n4] = v; out[i + 2 * n4] = v; out[i + 3 * n4] = v;
+    }
+}
+
+// VALU throughput calibration: 8 independent accumulators, N rounds of scalar or packed FMA
+typedef float v2f __attribute__((ext_vector_type(2)));
+__global__ void __launch_bounds__(256) k_valu_fma(float *out, int n, float a, float b) {
+    float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+    for (int i = 0; i < n; ++i) {
+        x0 = fmaf(x0, a, b); x1 = fmaf(x1, a, b); x2 = fmaf(x2, a, b); x3 = fmaf(x3, a, b);
+        x4 = fmaf(x4, a, b); x5 = fmaf(x5, a, b); x6 = fmaf(x6, a, b); x7 = fmaf(x7, a, b);
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+}
+__global__ void __launch_bounds__(256) k_valu_pkfma(float *out, int n, float a, float b) {
+    v2f A = {a, a}, Bv = {b, b};
+    v2f x0 = {(float)threadIdx.x, 1.f}, x1 = x0 + 1.f, x2 = x0 + 2.f, x3 = x0 + 3.f, x4 = x0 + 4.f, x5 = x0 + 5.f, x6 = x0 + 6.f, x7 = x0 + 7.f;
+    for (int i = 0; i < n; ++i) {
+        x0 = __builtin_elementwise_fma(x0, A, Bv); x1 = __builtin_elementwise_fma(x1, A, Bv);
+        x2 = __builtin_elementwise_fma(x2, A, Bv); x3 = __builtin_elementwise_fma(x3, A, Bv);
+        x4 = __builtin_elementwise_fma(x4, A, Bv); x5 = __builtin_elementwise_fma(x5, A, Bv);
+        x6 = __builtin_elementwise_fma(x6, A, Bv); x7 = __builtin_elementwise_fma(x7, A, Bv);
+    }
+    v2f s = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+    out[blockIdx.x * 256 + threadIdx.x] = s.x + s.y;
+}
+
 // ---- kernel wrappers ------------------------------------------------------------------
 template <class C>
 __global__ void __launch_bounds__(DT_NT) k_fwd1_v0(Fwd1Params p) {
@@ -68,6 +121,238 @@ __global__ void __launch_bounds__(DT_NT, MINW) k_fwd1_d(Fwd1Params p) {
     __syncthreads();
     fwd1d_rows<C, false>(p, sLo, sHi, nullptr, threadIdx.x, b, r0, c0);
 }
+
+template <class C, bool XCD>
+__global__ void __launch_bounds__(DT_NT) k_fwd1_s(Fwd1Params p) {
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS + 4 * STAGE_FLOATS_PER_WAVE];
+    const int ntile = p.tilesR * p.tilesC * p.B;
+    int t = XCD ? xcd_tile(blockIdx.x, ntile) : (int)blockIdx.x;
+    if (t >= ntile) return;
+    int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    float *sLo = smem, *sHi = sLo + C::SL, *stage = sHi + C::SL;
+    int r0 = tr * C::TR, c0 = tc * C::TC;
+    fwd1d_cols<C>(p, sLo, sHi, threadIdx.x, b, r0, c0);
+    __syncthreads();
+    constexpr int NQ = (C::TR / 2) * (C::TC / 2);
+    for (int base = 0; base < NQ; base += DT_NT) {
+        fwd1s_rows_compute<C>(p, sLo, sHi, stage, threadIdx.x, base, b, r0, c0);
+        fwd1s_rows_flush<C>(p, stage, threadIdx.x, base, b, r0, c0);
+    }
+}
+template <class C, bool XCD>
+void launch_s(Fwd1Params &p) {
+    p.tilesR = cdiv(p.LR, C::TR); p.tilesC = cdiv(p.LC, C::TC);
+    int nt = p.tilesR * p.tilesC * p.B;
+    k_fwd1_s<C, XCD><<<cdiv(nt, 8) * 8, DT_NT>>>(p);
+}
+
+template <class C>
+__global__ void __launch_bounds__(DT_NT) k_fwd2_v0(Fwd2Params p) {
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
+    const int ntile = p.tilesR * p.tilesC * p.B;
+    int t = tile_of(blockIdx.x, ntile, p.xcd_order);
+    if (t >= ntile) return;
+    int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    float *sx = smem, *sLo = smem + C::SX, *sHi = sLo + C::SL;
+    int r0 = tr * C::TR, c0 = tc * C::TC;
+    fwd2_load<C>(p, sx, threadIdx.x, b, r0, c0);
+    __syncthreads();
+    fwd2_cols<C>(p, sx, sLo, sHi, threadIdx.x);
+    __syncthreads();
+    fwd2_rows<C>(p, sLo, sHi, threadIdx.x, b, r0, c0);
+}
+template <class C>
+__global__ void __launch_bounds__(DT_NT) k_fwd2_s(Fwd2Params p) {
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS + 4 * STAGE_FLOATS_PER_WAVE];
+    const int ntile = p.tilesR * p.tilesC * p.B;
+    int t = tile_of(blockIdx.x, ntile, p.xcd_order);
+    if (t >= ntile) return;
+    int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    float *sLo = smem, *sHi = sLo + C::SL, *stage = sHi + C::SL;
+    int r0 = tr * C::TR, c0 = tc * C::TC;
+    fwd2d_cols<C>(p, sLo, sHi, threadIdx.x, b, r0, c0);
+    __syncthreads();
+    for (int base = 0; base < C::TI * C::TJ; base += DT_NT) {
+        fwd2s_rows_compute<C>(p, sLo, sHi, stage, threadIdx.x, base, b, r0, c0);
+        fwd2s_rows_flush<C>(p, stage, threadIdx.x, base, b, r0, c0);
+    }
+}
+template <class C>
+void launch2_v0(Fwd2Params &p) {
+    p.tilesR = cdiv(p.LR / 2, C::TR); p.tilesC = cdiv(p.LC / 2, C::TC);
+    int nt = p.tilesR * p.tilesC * p.B;
+    k_fwd2_v0<C><<<cdiv(nt, 8) * 8, DT_NT>>>(p);
+}
+template <class C>
+void launch2_s(Fwd2Params &p) {
+    p.tilesR = cdiv(p.LR / 2, C::TR); p.tilesC = cdiv(p.LC / 2, C::TC);
+    int nt = p.tilesR * p.tilesC * p.B;
+    k_fwd2_s<C><<<cdiv(nt, 8) * 8, DT_NT>>>(p);
+}
+template <class C>
+__global__ void __launch_bounds__(DT_NT) k_inv1_v0(Inv1Params p) {
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
+    const int ntile = p.tilesR * p.tilesC * p.B;
+    int t = tile_of(blockIdx.x, ntile, p.xcd_order);
+    if (t >= ntile) return;
+    int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    float *s0 = smem, *s1 = s0 + C::SP, *s2 = s1 + C::SP, *s3 = s2 + C::SP;
+    float *y1 = s3 + C::SP, *y2 = y1 + C::SY;
+    int r0 = tr * C::TR, c0 = tc * C::TC;
+    inv1_load<C>(p, s0, s1, s2, s3, threadIdx.x, b, r0, c0);
+    __syncthreads();
+    inv1_cols<C>(p, s0, s1, s2, s3, y1, y2, threadIdx.x);
+    __syncthreads();
+    inv1_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0);
+}
+template <class C>
+__global__ void __launch_bounds__(DT_NT) k_inv1_d(Inv1Params p) {
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
+    const int ntile = p.tilesR * p.tilesC * p.B;
+    int t = tile_of(blockIdx.x, ntile, p.xcd_order);
+    if (t >= ntile) return;
+    int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    float *s1 = smem, *s2 = s1 + C::SP, *s3 = s2 + C::SP, *y1 = s3 + C::SP, *y2 = y1 + C::SY;
+    float *slab = y1;
+    int r0 = tr * C::TR, c0 = tc * C::TC;
+    const float *Yhb = p.Yh + (int64_t)b * (p.R / 2) * (p.C / 2) * 12;
+    for (int r = 0; r < C::ROUNDS; ++r) {
+        inv_rec_fetch(Yhb, p.R, p.C, slab, C::NR, C::NC, r0 - C::HE, c0 - C::HE, threadIdx.x, r);
+        inv_rec_expand(slab, p.R, p.C, p.g, s1, s2, s3, C::NR, C::NC, r0 - C::HE, c0 - C::HE, threadIdx.x, r);
+    }
+    __syncthreads();
+    inv1d_cols<C>(p, s1, s2, s3, y1, y2, threadIdx.x, b, r0, c0);
+    __syncthreads();
+    inv1d_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0);
+}
+template <class C>
+__global__ void __launch_bounds__(DT_NT) k_inv2_v0(Inv2Params p) {
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
+    const int ntile = p.tilesR * p.tilesC * p.B;
+    int t = tile_of(blockIdx.x, ntile, p.xcd_order);
+    if (t >= ntile) return;
+    int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    float *s0 = smem, *s1 = s0 + C::SP, *s2 = s1 + C::SP, *s3 = s2 + C::SP;
+    float *y1 = s3 + C::SP, *y2 = y1 + C::SY;
+    int r0 = tr * C::TR, c0 = tc * C::TC;
+    inv2_load<C>(p, s0, s1, s2, s3, threadIdx.x, b, r0, c0);
+    __syncthreads();
+    inv2_cols<C>(p, s0, s1, s2, s3, y1, y2, threadIdx.x);
+    __syncthreads();
+    inv2_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0);
+}
+template <class C>
+__global__ void __launch_bounds__(DT_NT) k_inv2_d(Inv2Params p) {
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
+    const int ntile = p.tilesR * p.tilesC * p.B;
+    int t = tile_of(blockIdx.x, ntile, p.xcd_order);
+    if (t >= ntile) return;
+    int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    float *s1 = smem, *s2 = s1 + C::SP, *s3 = s2 + C::SP, *y1 = s3 + C::SP, *y2 = y1 + C::SY;
+    float *slab = y1;
+    int r0 = tr * C::TR, c0 = tc * C::TC;
+    const float *Yhb = p.Yh + (int64_t)b * (p.zr / 2) * (p.zc / 2) * 12;
+    for (int r = 0; r < C::ROUNDS; ++r) {
+        inv_rec_fetch(Yhb, p.zr, p.zc, slab, C::NR, C::NC, r0 + C::ORG, c0 + C::ORG, threadIdx.x, r);
+        inv_rec_expand(slab, p.zr, p.zc, p.g, s1, s2, s3, C::NR, C::NC, r0 + C::ORG, c0 + C::ORG, threadIdx.x, r);
+    }
+    __syncthreads();
+    inv2d_cols<C>(p, s1, s2, s3, y1, y2, threadIdx.x, b, r0, c0);
+    __syncthreads();
+    inv2_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0);
+}
+template <class C>
+__global__ void __launch_bounds__(DT_NT) k_inv1_p(Inv1Params p) {
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
+    const int ntile = p.tilesR * p.tilesC * p.B;
+    int t = tile_of(blockIdx.x, ntile, p.xcd_order);
+    if (t >= ntile) return;
+    int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    float *s1 = smem, *s2 = s1 + C::SP, *s3 = s2 + C::SP, *y1 = s3 + C::SP, *y2 = y1 + C::SY;
+    float *slab = y1;
+    int r0 = tr * C::TR, c0 = tc * C::TC;
+    const float *Yhb = p.Yh + (int64_t)b * (p.R / 2) * (p.C / 2) * 12;
+    float wz[C::WN];
+    inv1p_fetch<C>(p, wz, threadIdx.x, b, r0, c0);
+    inv_rec_load_wave<C::NR, C::NC>(Yhb, p.R, p.C, p.g, slab, s1, s2, s3, r0 - C::HE, c0 - C::HE, threadIdx.x >> 6);
+    __syncthreads();
+    inv1p_cols<C>(p, wz, s1, s2, s3, y1, y2, threadIdx.x);
+    __syncthreads();
+    inv1d_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0);
+}
+template <class C>
+__global__ void __launch_bounds__(DT_NT) k_inv2_p(Inv2Params p) {
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
+    const int ntile = p.tilesR * p.tilesC * p.B;
+    int t = tile_of(blockIdx.x, ntile, p.xcd_order);
+    if (t >= ntile) return;
+    int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    float *s1 = smem, *s2 = s1 + C::SP, *s3 = s2 + C::SP, *y1 = s3 + C::SP, *y2 = y1 + C::SY;
+    float *slab = y1;
+    int r0 = tr * C::TR, c0 = tc * C::TC;
+    const float *Yhb = p.Yh + (int64_t)b * (p.zr / 2) * (p.zc / 2) * 12;
+    float wz[C::WS];
+    inv2p_fetch<C>(p, wz, threadIdx.x, b, r0, c0);
+    inv_rec_load_wave<C::NR, C::NC>(Yhb, p.zr, p.zc, p.g, slab, s1, s2, s3, r0 + C::ORG, c0 + C::ORG, threadIdx.x >> 6);
+    __syncthreads();
+    inv2p_cols<C>(p, wz, s1, s2, s3, y1, y2, threadIdx.x);
+    __syncthreads();
+    inv2_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0);
+}
+template <class C>
+__global__ void __launch_bounds__(DT_NT) k_inv1_r(Inv1Params p) {
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
+    const int ntile = p.tilesR * p.tilesC * p.B;
+    int t = tile_of(blockIdx.x, ntile, p.xcd_order);
+    if (t >= ntile) return;
+    int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    float *srec = smem, *y1 = srec + C::SREC, *y2 = y1 + C::SY;
+    int r0 = tr * C::TR, c0 = tc * C::TC;
+    const float *Yhb = p.Yh + (int64_t)b * (p.R / 2) * (p.C / 2) * 12;
+    float wz[C::WN];
+    inv1r_fetch<C>(p, wz, threadIdx.x, b, r0, c0);
+    inv_rec_stage(Yhb, p.R, p.C, srec, C::QR, C::QC, r0 - C::HE, c0 - C::HE, threadIdx.x);
+    __syncthreads();
+    inv1r_cols<C>(p, wz, srec, y1, y2, threadIdx.x, r0, c0);
+    __syncthreads();
+    inv1d_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0);
+}
+template <class C> void launchi1_r(Inv1Params &p) {
+    p.tilesR = cdiv(p.R, C::TR); p.tilesC = cdiv(p.C, C::TC);
+    k_inv1_r<C><<<cdiv(p.tilesR * p.tilesC * p.B, 8) * 8, DT_NT>>>(p);
+}
+template <class C> void launchi1_p(Inv1Params &p) {
+    p.tilesR = cdiv(p.R, C::TR); p.tilesC = cdiv(p.C, C::TC);
+    k_inv1_p<C><<<cdiv(p.tilesR * p.tilesC * p.B, 8) * 8, DT_NT>>>(p);
+}
+template <class C> void launchi2_p(Inv2Params &p) {
+    p.tilesR = cdiv(p.zr, C::TR); p.tilesC = cdiv(p.zc, C::TC);
+    k_inv2_p<C><<<cdiv(p.tilesR * p.tilesC * p.B, 8) * 8, DT_NT>>>(p);
+}
+template <class C> void launchi1_v0(Inv1Params &p) {
+    p.tilesR = cdiv(p.R, C::TR); p.tilesC = cdiv(p.C, C::TC);
+    k_inv1_v0<C><<<cdiv(p.tilesR * p.tilesC * p.B, 8) * 8, DT_NT>>>(p);
+}
+template <class C> void launchi1_d(Inv1Params &p) {
+    p.tilesR = cdiv(p.R, C::TR); p.tilesC = cdiv(p.C, C::TC);
+    k_inv1_d<C><<<cdiv(p.tilesR * p.tilesC * p.B, 8) * 8, DT_NT>>>(p);
+}
+template <class C> void launchi2_v0(Inv2Params &p) {
+    p.tilesR = cdiv(p.zr, C::TR); p.tilesC = cdiv(p.zc, C::TC);
+    k_inv2_v0<C><<<cdiv(p.tilesR * p.tilesC * p.B, 8) * 8, DT_NT>>>(p);
+}
+template <class C> void launchi2_d(Inv2Params &p) {
+    p.tilesR = cdiv(p.zr, C::TR); p.tilesC = cdiv(p.zc, C::TC);
+    k_inv2_d<C><<<cdiv(p.tilesR * p.tilesC * p.B, 8) * 8, DT_NT>>>(p);
+}
+struct VariantI1 { std::string name; std::function<void(Inv1Params &)> launch; int xcd; };
+struct VariantI2 { std::string name; std::function<void(Inv2Params &)> launch; int xcd; };
+
+struct Variant2 {
+    std::string name;
+    std::function<void(Fwd2Params &)> launch;
+    int xcd;
+};
 
 struct Variant {
     std::string name;
@@ -118,12 +403,20 @@ int main(int argc, char **argv) {
     vs.push_back({"d 16x120 rs4 xcd", launch_d<Fwd1DCfg<16, 120, 4, 5, 7>, true, 1>});
     vs.push_back({"d 16x248 rs8 xcd", launch_d<Fwd1DCfg<16, 248, 8, 5, 7>, true, 1>});
     vs.push_back({"d 64x56 rs8 xcd", launch_d<Fwd1DCfg<64, 56, 8, 5, 7>, true, 1>});
-    vs.push_back({"d 32x56 rs8 xcd w2", launch_d<Fwd1DCfg<32, 56, 8, 5, 7>, true, 2>});
+    vs.push_back({"s 32x64 rs8 xcd", launch_s<Fwd1DCfg<32, 64, 8, 5, 7>, true>});
+    vs.push_back({"s 32x64 rs8 lin", launch_s<Fwd1DCfg<32, 64, 8, 5, 7>, false>});
+    vs.push_back({"s 16x128 rs8 xcd", launch_s<Fwd1DCfg<16, 128, 8, 5, 7>, true>});
+    vs.push_back({"s 16x120 rs8 xcd", launch_s<Fwd1DCfg<16, 120, 8, 5, 7>, true>});
+    vs.push_back({"s 32x120 rs8 xcd", launch_s<Fwd1DCfg<32, 120, 8, 5, 7>, true>});
+    vs.push_back({"s 32x56 rs8 xcd", launch_s<Fwd1DCfg<32, 56, 8, 5, 7>, true>});
+    vs.push_back({"s 16x248 rs8 xcd", launch_s<Fwd1DCfg<16, 248, 8, 5, 7>, true>});
+    vs.push_back({"s 8x248 rs8 xcd", launch_s<Fwd1DCfg<8, 248, 8, 5, 7>, true>});
+    vs.push_back({"s 16x64 rs8 xcd", launch_s<Fwd1DCfg<16, 64, 8, 5, 7>, true>});
 
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<float> ref_lo, ref_yh, lo(npx), yh(npx * 3);
-    const int reps = 20;
+    const int reps = argc > 2 ? atoi(argv[2]) : 20;
     // copy ceilings
     {
         f4 *a = (f4 *)dX, *o = (f4 *)dYh;   // 64 MiB in, 256 MiB out needs npx*16 bytes: use Yh(192MiB)+Lo
@@ -140,9 +433,43 @@ int main(int argc, char **argv) {
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
         printf("%-22s %8.1f us  %7.1f GB/s (4 read : 1 write copy)\n", "copy_4r1w", ms * 1e3, n4 * 80.0 / ms / 1e6);
+        auto timeit = [&](const char *nm, double bytes, std::function<void()> fn) {
+            for (int w = 0; w < 3; ++w) fn();
+            CK(hipEventRecord(e0));
+            for (int r = 0; r < reps; ++r) fn();
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float t; CK(hipEventElapsedTime(&t, e0, e1)); t /= reps;
+            printf("%-22s %8.1f us  %7.1f GB/s (%.0f MB)\n", nm, t * 1e3, bytes / t / 1e6, bytes / 1e6);
+        };
+        {
+            const int nb = 256 * 8 * 4, n = 2000;      // 8 blocks/CU x 4 waves... enough to fill
+            for (int w = 0; w < 2; ++w) k_valu_fma<<<nb, 256>>>(dLo, n, 0.999f, 0.001f);
+            CK(hipEventRecord(e0));
+            k_valu_fma<<<nb, 256>>>(dLo, n, 0.999f, 0.001f);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float t; CK(hipEventElapsedTime(&t, e0, e1));
+            double winstr = (double)nb * 4 * n * 8;     // wave-instructions
+            printf("valu_fma     %8.1f us  %.2f cycles/wave-instr/SIMD @2.4GHz  %.1f TFLOP/s\n", t * 1e3,
+                   t * 1e-3 * 2.4e9 / (winstr / 1024), winstr * 128 / t / 1e9);
+            for (int w = 0; w < 2; ++w) k_valu_pkfma<<<nb, 256>>>(dLo, n, 0.999f, 0.001f);
+            CK(hipEventRecord(e0));
+            k_valu_pkfma<<<nb, 256>>>(dLo, n, 0.999f, 0.001f);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&t, e0, e1));
+            printf("valu_pkfma   %8.1f us  %.2f cycles/wave-instr/SIMD @2.4GHz  %.1f TFLOP/s\n", t * 1e3,
+                   t * 1e-3 * 2.4e9 / (winstr / 1024), winstr * 256 / t / 1e9);
+        }
+        size_t nrec = npx / 4;
+        timeit("wr_lane48 (201MB)", nrec * 48.0, [&] { k_wr_lane48<<<(unsigned)(nrec / 256), 256>>>((f4 *)dYh, nrec); });
+        timeit("wr_coal (201MB)", nrec * 48.0, [&] { k_wr_coal<<<(unsigned)(nrec / 256), 256>>>((f4 *)dYh, nrec); });
+        size_t n4s = npx * 3 / 4;     // 201 MB stream copy Yh -> Yh (in-place halves)
+        timeit("copy_stream 1r1w", n4s * 16.0, [&] { k_copy_stream<<<2048, 256>>>((f4 *)dYh, (f4 *)dYh + n4s / 2, n4s / 2); });
+        timeit("copy_1r4w_coal", n4 * 80.0, [&] { k_copy_1r4w_coal<<<2048, 256>>>(a, o, n4); });
         CK(hipMemcpy(dX, hX.data(), npx * 4, hipMemcpyHostToDevice));
     }
+    const char *filter = argc > 1 ? argv[1] : nullptr;
     for (size_t i = 0; i < vs.size(); ++i) {
+        if (filter && i > 0 && vs[i].name.find(filter) == std::string::npos) continue;
         CK(hipMemset(dLo, 0xff, npx * 4)); CK(hipMemset(dYh, 0xff, npx * 12));
         for (int w = 0; w < 3; ++w) vs[i].launch(p);
         CK(hipGetLastError());
@@ -161,6 +488,150 @@ int main(int argc, char **argv) {
         }
         printf("%-22s %8.1f us  %7.1f GB/s algorithmic  maxdiff %.2e\n", vs[i].name.c_str(), ms * 1e3,
                npx * 20.0 / ms / 1e6, dmax);
+    }
+    // ------------------------------------------------------------------ level 2 forward
+    {
+        Fwd2Params q{};
+        q.X = dX; q.LoLo = dLo; q.Yh = dYh; q.B = 1; q.inR = R; q.inC = Cc; q.padR = 0; q.padC = 0;
+        q.LR = R; q.LC = Cc; q.lo_a_first = 1; q.hi_a_first = 0;
+        for (int k = 0; k < 10; ++k) {
+            q.l_a[k] = 0.1f * (k + 1) - 0.3f; q.l_b[k] = 0.1f * (10 - k) - 0.3f;
+            q.h_a[k] = (k & 1 ? -1.f : 1.f) * q.l_b[k]; q.h_b[k] = (k & 1 ? 1.f : -1.f) * q.l_a[k];
+        }
+        std::vector<Variant2> v2;
+        v2.push_back({"L2 v0 32x32 xcd", launch2_v0<Fwd2Cfg<32, 32, 10>>, 1});
+        v2.push_back({"L2 v0 32x32 lin", launch2_v0<Fwd2Cfg<32, 32, 10>>, 0});
+        v2.push_back({"L2 s 16x56 ps4 xcd", launch2_s<Fwd2DCfg<16, 56, 4, 10>>, 1});
+        v2.push_back({"L2 s 16x56 ps4 lin", launch2_s<Fwd2DCfg<16, 56, 4, 10>>, 0});
+        v2.push_back({"L2 s 32x56 ps4 lin", launch2_s<Fwd2DCfg<32, 56, 4, 10>>, 0});
+        v2.push_back({"L2 s 32x56 ps4 xcd", launch2_s<Fwd2DCfg<32, 56, 4, 10>>, 1});
+        v2.push_back({"L2 s 16x56 ps2 lin", launch2_s<Fwd2DCfg<16, 56, 2, 10>>, 0});
+        v2.push_back({"L2 s 16x56 ps8 lin", launch2_s<Fwd2DCfg<16, 56, 8, 10>>, 0});
+        v2.push_back({"L2 s 16x120 ps4 lin", launch2_s<Fwd2DCfg<16, 120, 4, 10>>, 0});
+        v2.push_back({"L2 s 8x120 ps4 lin", launch2_s<Fwd2DCfg<8, 120, 4, 10>>, 0});
+        v2.push_back({"L2 s 32x24 ps4 lin", launch2_s<Fwd2DCfg<32, 24, 4, 10>>, 0});
+        v2.push_back({"L2 s 32x32 ps4 lin", launch2_s<Fwd2DCfg<32, 32, 4, 10>>, 0});
+        const size_t nlo = npx / 4, nyh = npx / 16 * 12;
+        std::vector<float> rlo, ryh, lo2(nlo), yh2(nyh);
+        for (size_t i = 0; i < v2.size(); ++i) {
+            if (filter && i > 0 && v2[i].name.find(filter) == std::string::npos) continue;
+            q.xcd_order = v2[i].xcd;
+            CK(hipMemset(dLo, 0xff, nlo * 4)); CK(hipMemset(dYh, 0xff, nyh * 4));
+            for (int w = 0; w < 3; ++w) v2[i].launch(q);
+            CK(hipGetLastError());
+            CK(hipEventRecord(e0));
+            for (int r = 0; r < reps; ++r) v2[i].launch(q);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            CK(hipGetLastError());
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+            CK(hipMemcpy(lo2.data(), dLo, nlo * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(yh2.data(), dYh, nyh * 4, hipMemcpyDeviceToHost));
+            double dmax = 0;
+            if (i == 0) { rlo = lo2; ryh = yh2; }
+            else {
+                for (size_t k = 0; k < nlo; ++k) { double d = fabs((double)lo2[k] - rlo[k]); if (!(d <= dmax)) dmax = d; }
+                for (size_t k = 0; k < nyh; ++k) { double d = fabs((double)yh2[k] - ryh[k]); if (!(d <= dmax)) dmax = d; }
+            }
+            printf("%-22s %8.1f us  %7.1f GB/s algorithmic  maxdiff %.2e\n", v2[i].name.c_str(), ms * 1e3,
+                   npx * 8.0 / ms / 1e6, dmax);
+        }
+    }
+    // ------------------------------------------------------------------ inverse kernels
+    {
+        std::vector<float> hY(npx * 3);
+        for (auto &v : hY) v = (float)rand() / (float)RAND_MAX * 2.f - 1.f;
+        CK(hipMemcpy(dYh, hY.data(), npx * 12, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dX, hX.data(), npx * 4, hipMemcpyHostToDevice));
+        std::vector<float> ref, out(npx);
+        auto run = [&](const std::string &name, std::function<void()> fn, double bytes, bool first) {
+            if (filter && !first && name.find(filter) == std::string::npos) return;
+            CK(hipMemset(dLo, 0xff, npx * 4));
+            for (int w = 0; w < 3; ++w) fn();
+            CK(hipGetLastError());
+            CK(hipEventRecord(e0));
+            for (int r = 0; r < reps; ++r) fn();
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            CK(hipGetLastError());
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+            CK(hipMemcpy(out.data(), dLo, npx * 4, hipMemcpyDeviceToHost));
+            double dmax = 0;
+            if (first) ref = out;
+            else for (size_t k = 0; k < npx; ++k) { double d = fabs((double)out[k] - ref[k]); if (!(d <= dmax)) dmax = d; }
+            printf("%-22s %8.1f us  %7.1f GB/s algorithmic  maxdiff %.2e\n", name.c_str(), ms * 1e3, bytes / ms / 1e6, dmax);
+        };
+        {
+            Inv1Params q{};
+            q.Z = dX; q.Yh = dYh; q.X = dLo; q.B = 1; q.R = R; q.C = Cc;
+            for (int d = 0; d < 6; ++d) q.g[d] = 0.7071f * (1.f + 0.1f * d);
+            for (int k = 0; k < 7; ++k) q.g0[k] = 0.1f * (k + 1) - 0.25f;
+            for (int k = 0; k < 5; ++k) q.g1[k] = 0.2f * (k + 1) - 0.55f;
+            std::vector<VariantI1> vi;
+            vi.push_back({"I1 v0 32x32 xcd", launchi1_v0<Inv1Cfg<32, 32, 7, 5>>, 1});
+            vi.push_back({"I1 v0 32x32 lin", launchi1_v0<Inv1Cfg<32, 32, 7, 5>>, 0});
+            vi.push_back({"I1 r 32x56 rs8 xcd", launchi1_r<Inv1RCfg<32, 56, 8, 7, 5>>, 1});
+            vi.push_back({"I1 r 32x56 rs8 lin", launchi1_r<Inv1RCfg<32, 56, 8, 7, 5>>, 0});
+            vi.push_back({"I1 r 16x56 rs4 xcd", launchi1_r<Inv1RCfg<16, 56, 4, 7, 5>>, 1});
+            vi.push_back({"I1 r 32x24 rs4 xcd", launchi1_r<Inv1RCfg<32, 24, 4, 7, 5>>, 1});
+            vi.push_back({"I1 r 64x24 rs8 xcd", launchi1_r<Inv1RCfg<64, 24, 8, 7, 5>>, 1});
+            vi.push_back({"I1 r 16x120 rs8 xcd", launchi1_r<Inv1RCfg<16, 120, 8, 7, 5>>, 1});
+            vi.push_back({"I1 r 32x56 rs16 xcd", launchi1_r<Inv1RCfg<32, 56, 16, 7, 5>>, 1});
+            vi.push_back({"I1 p 16x56 rs4 xcd", launchi1_p<Inv1DCfg<16, 56, 4, 7, 5>>, 1});
+            vi.push_back({"I1 p 16x56 rs8 xcd", launchi1_p<Inv1DCfg<16, 56, 8, 7, 5>>, 1});
+            vi.push_back({"I1 p 16x56 rs4 lin", launchi1_p<Inv1DCfg<16, 56, 4, 7, 5>>, 0});
+            vi.push_back({"I1 p 32x56 rs8 xcd", launchi1_p<Inv1DCfg<32, 56, 8, 7, 5>>, 1});
+            vi.push_back({"I1 p 32x24 rs4 xcd", launchi1_p<Inv1DCfg<32, 24, 4, 7, 5>>, 1});
+            vi.push_back({"I1 p 32x24 rs8 xcd", launchi1_p<Inv1DCfg<32, 24, 8, 7, 5>>, 1});
+            vi.push_back({"I1 p 8x56 rs4 xcd", launchi1_p<Inv1DCfg<8, 56, 4, 7, 5>>, 1});
+            vi.push_back({"I1 p 8x120 rs8 xcd", launchi1_p<Inv1DCfg<8, 120, 8, 7, 5>>, 1});
+            vi.push_back({"I1 p 16x120 rs8 xcd", launchi1_p<Inv1DCfg<16, 120, 8, 7, 5>>, 1});
+            vi.push_back({"I1 p 16x24 rs4 xcd", launchi1_p<Inv1DCfg<16, 24, 4, 7, 5>>, 1});
+            vi.push_back({"I1 d 32x56 rs8 xcd", launchi1_d<Inv1DCfg<32, 56, 8, 7, 5>>, 1});
+            vi.push_back({"I1 d 32x56 rs8 lin", launchi1_d<Inv1DCfg<32, 56, 8, 7, 5>>, 0});
+            vi.push_back({"I1 d 16x56 rs4 xcd", launchi1_d<Inv1DCfg<16, 56, 4, 7, 5>>, 1});
+            vi.push_back({"I1 d 16x56 rs4 lin", launchi1_d<Inv1DCfg<16, 56, 4, 7, 5>>, 0});
+            vi.push_back({"I1 d 16x56 rs8 xcd", launchi1_d<Inv1DCfg<16, 56, 8, 7, 5>>, 1});
+            vi.push_back({"I1 d 16x120 rs8 xcd", launchi1_d<Inv1DCfg<16, 120, 8, 7, 5>>, 1});
+            vi.push_back({"I1 d 8x120 rs8 xcd", launchi1_d<Inv1DCfg<8, 120, 8, 7, 5>>, 1});
+            vi.push_back({"I1 d 32x24 rs4 xcd", launchi1_d<Inv1DCfg<32, 24, 4, 7, 5>>, 1});
+            vi.push_back({"I1 d 32x32 rs8 xcd", launchi1_d<Inv1DCfg<32, 32, 8, 7, 5>>, 1});
+            for (size_t i = 0; i < vi.size(); ++i) {
+                q.xcd_order = vi[i].xcd;
+                run(vi[i].name, [&] { vi[i].launch(q); }, npx * 20.0, i == 0);
+            }
+        }
+        {
+            Inv2Params q{};
+            q.Z = dX; q.Yh = dYh; q.Out = dLo; q.B = 1; q.zr = R / 2; q.zc = Cc / 2; q.cropR = 0; q.cropC = 0;
+            q.lo_pos = 1; q.hi_pos = 0;
+            for (int d = 0; d < 6; ++d) q.g[d] = 0.7071f * (1.f + 0.1f * d);
+            for (int k = 0; k < 10; ++k) {
+                q.l_a[k] = 0.1f * (k + 1) - 0.3f; q.l_b[k] = 0.1f * (10 - k) - 0.3f;
+                q.h_a[k] = (k & 1 ? -1.f : 1.f) * q.l_b[k]; q.h_b[k] = (k & 1 ? 1.f : -1.f) * q.l_a[k];
+            }
+            std::vector<VariantI2> vi;
+            vi.push_back({"I2 v0 32x32 xcd", launchi2_v0<Inv2Cfg<32, 32, 10>>, 1});
+            vi.push_back({"I2 v0 32x32 lin", launchi2_v0<Inv2Cfg<32, 32, 10>>, 0});
+            vi.push_back({"I2 p 16x56 js4 xcd", launchi2_p<Inv2DCfg<16, 56, 4, 10>>, 1});
+            vi.push_back({"I2 p 16x56 js2 xcd", launchi2_p<Inv2DCfg<16, 56, 2, 10>>, 1});
+            vi.push_back({"I2 p 16x24 js2 xcd", launchi2_p<Inv2DCfg<16, 24, 2, 10>>, 1});
+            vi.push_back({"I2 p 32x24 js4 xcd", launchi2_p<Inv2DCfg<32, 24, 4, 10>>, 1});
+            vi.push_back({"I2 p 32x24 js2 xcd", launchi2_p<Inv2DCfg<32, 24, 2, 10>>, 1});
+            vi.push_back({"I2 p 8x56 js2 xcd", launchi2_p<Inv2DCfg<8, 56, 2, 10>>, 1});
+            vi.push_back({"I2 p 8x56 js4 xcd", launchi2_p<Inv2DCfg<8, 56, 4, 10>>, 1});
+            vi.push_back({"I2 p 8x120 js4 xcd", launchi2_p<Inv2DCfg<8, 120, 4, 10>>, 1});
+            vi.push_back({"I2 d 32x24 js4 xcd", launchi2_d<Inv2DCfg<32, 24, 4, 10>>, 1});
+            vi.push_back({"I2 d 16x56 js4 xcd", launchi2_d<Inv2DCfg<16, 56, 4, 10>>, 1});
+            vi.push_back({"I2 d 16x56 js4 lin", launchi2_d<Inv2DCfg<16, 56, 4, 10>>, 0});
+            vi.push_back({"I2 d 16x56 js2 xcd", launchi2_d<Inv2DCfg<16, 56, 2, 10>>, 1});
+            vi.push_back({"I2 d 16x24 js4 xcd", launchi2_d<Inv2DCfg<16, 24, 4, 10>>, 1});
+            vi.push_back({"I2 d 16x24 js2 xcd", launchi2_d<Inv2DCfg<16, 24, 2, 10>>, 1});
+            vi.push_back({"I2 d 8x56 js4 xcd", launchi2_d<Inv2DCfg<8, 56, 4, 10>>, 1});
+            vi.push_back({"I2 d 32x32 js4 xcd", launchi2_d<Inv2DCfg<32, 32, 4, 10>>, 1});
+            for (size_t i = 0; i < vi.size(); ++i) {
+                q.xcd_order = vi[i].xcd;
+                run(vi[i].name, [&] { vi[i].launch(q); }, npx * 8.0, i == 0);
+            }
+        }
     }
     return 0;
 }
