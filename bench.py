@@ -69,18 +69,10 @@ def main():
     ctx = Context(local_rank % max(_lib.device_count(), 1))
 
     # filter taps: rank 0 owns the table, one RCCL broadcast over xGMI hands it to the others
-    bt = [np.asarray(h, np.float64).reshape(-1) for h in biort(BIORT)]
-    qt = [np.asarray(h, np.float64).reshape(-1) for h in qshift(QSHIFT)]
+    bt, qt = biort(BIORT), qshift(QSHIFT)
     if world > 1:
-        flat = np.concatenate(bt + qt)
-        buf = torch.from_numpy(flat if rank == 0 else np.zeros_like(flat)).cuda()
-        dist.broadcast(buf, src=0)
-        flat = buf.cpu().numpy()
-        sizes = [len(h) for h in bt + qt]
-        parts, off = [], 0
-        for n in sizes:
-            parts.append(flat[off:off + n].copy()); off += n
-        bt, qt = parts[:4], parts[4:]
+        from dtcwt_amd.hip.sharding import broadcast_taps
+        bt, qt = broadcast_taps(bt, qt, dist, device=torch.device('cuda', local_rank), src=0)
 
     B, R, C = args.batch, args.rows, args.cols
     t2 = dtcwt_amd.hip.Transform2d(tuple(bt), tuple(qt), ctx=ctx)

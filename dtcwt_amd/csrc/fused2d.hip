@@ -56,6 +56,8 @@ __global__ void __launch_bounds__(DT_NT) k_fwd2(Fwd2Params p) {
     }
 }
 
+// Level-1 inverse: records staged verbatim in LDS, c2q folded into the column pass, the
+// lowpass window prefetched straight from global memory (fused2d_tiles_v2.hpp).
 template <class C>
 __global__ void __launch_bounds__(DT_NT) k_inv1(Inv1Params p) {
     __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
@@ -63,14 +65,16 @@ __global__ void __launch_bounds__(DT_NT) k_inv1(Inv1Params p) {
     int t = tile_of(blockIdx.x, ntile, p.xcd_order);
     if (t >= ntile) return;
     int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
-    float *s0 = smem, *s1 = s0 + C::SP, *s2 = s1 + C::SP, *s3 = s2 + C::SP;
-    float *y1 = s3 + C::SP, *y2 = y1 + C::SY;
+    float *srec = smem, *y1 = srec + C::SREC, *y2 = y1 + C::SY;
     int r0 = tr * C::TR, c0 = tc * C::TC;
-    inv1_load<C>(p, s0, s1, s2, s3, threadIdx.x, b, r0, c0);
+    const float *Yhb = p.Yh + (int64_t)b * (p.R / 2) * (p.C / 2) * 12;
+    float wz[C::WN];
+    inv1r_fetch<C>(p, wz, threadIdx.x, b, r0, c0);
+    inv_rec_stage(Yhb, p.R, p.C, srec, C::QR, C::QC, r0 - C::HE, c0 - C::HE, threadIdx.x);
     __syncthreads();
-    inv1_cols<C>(p, s0, s1, s2, s3, y1, y2, threadIdx.x);
+    inv1r_cols<C>(p, wz, srec, y1, y2, threadIdx.x, r0, c0);
     __syncthreads();
-    inv1_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0);
+    inv1d_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0);
 }
 
 template <class C>
@@ -122,7 +126,7 @@ int launch_inv2(Inv2Params &p, hipStream_t s) {
 // Tile shapes and supported tap lengths live in fused2d_table.hpp (shared with the
 // test-only host emulator so both step through identical configurations).
 #define DT_CASE_FWD1(TR, TC, RS, A, B) if (m0 == A && m1 == B) return launch_fwd1<Fwd1DCfg<TR, TC, RS, A, B>>(p, s);
-#define DT_CASE_INV1(TR, TC, A, B) if (m0 == A && m1 == B) return launch_inv1<Inv1Cfg<TR, TC, A, B>>(p, s);
+#define DT_CASE_INV1(TR, TC, RS, A, B) if (m0 == A && m1 == B) return launch_inv1<Inv1RCfg<TR, TC, RS, A, B>>(p, s);
 #define DT_CASE_FWD2(TR, TC, PS, M) if (m == M) return launch_fwd2<Fwd2DCfg<TR, TC, PS, M>>(p, s);
 #define DT_CASE_INV2(TR, TC, M) if (m == M) return launch_inv2<Inv2Cfg<TR, TC, M>>(p, s);
 int dispatch_fwd1(int m0, int m1, Fwd1Params &p, hipStream_t s) { DT_FWD1_TABLE(DT_CASE_FWD1) return -3; }
@@ -134,7 +138,7 @@ int dispatch_inv2(int m, Inv2Params &p, hipStream_t s) { DT_INV2_TABLE(DT_CASE_I
 #define DT_HAS2F(TR, TC, RS, A, B) if (m0 == A && m1 == B) return true;
 #define DT_HAS1(TR, TC, M) if (m == M) return true;
 bool fwd1_supported(int m0, int m1) { DT_FWD1_TABLE(DT_HAS2F) return false; }
-bool inv1_supported(int m0, int m1) { DT_INV1_TABLE(DT_HAS2) return false; }
+bool inv1_supported(int m0, int m1) { DT_INV1_TABLE(DT_HAS2F) return false; }
 bool q_supported(int m) { DT_INV2_TABLE(DT_HAS1) return false; }
 
 double dotd(const std::vector<double> &a, const std::vector<double> &b) {
