@@ -53,9 +53,10 @@ def main():
     # torch is plumbing only (RCCL barrier / broadcast, device sync): imported for N > 1 or
     # on request; at N = 1 the bracket is hipDeviceSynchronize() through the library, which is
     # what torch.cuda.synchronize() calls (and a cold `import torch` costs minutes on a fresh box).
-    if world > 1 or os.environ.get('DTCWT_BENCH_TORCH', '0') == '1':
+    use_dist = world > 1 or os.environ.get('DTCWT_BENCH_FORCE_DIST', '0') == '1'   # latter: exercise RCCL at N=1
+    if use_dist or os.environ.get('DTCWT_BENCH_TORCH', '0') == '1':
         import torch
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
@@ -70,7 +71,7 @@ def main():
 
     # filter taps: rank 0 owns the table, one RCCL broadcast over xGMI hands it to the others
     bt, qt = biort(BIORT), qshift(QSHIFT)
-    if world > 1:
+    if use_dist:
         from dtcwt_amd.hip.sharding import broadcast_taps
         bt, qt = broadcast_taps(bt, qt, dist, device=torch.device('cuda', local_rank), src=0)
 
@@ -89,7 +90,7 @@ def main():
 
     def fence():
         ctx.sync()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         if torch is not None and torch.cuda.is_available():
             torch.cuda.synchronize()
@@ -103,7 +104,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -168,7 +169,7 @@ def main():
         out['cpu_baseline'] = None
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -77,6 +77,7 @@ __global__ void __launch_bounds__(DT_NT) k_inv1(Inv1Params p) {
     inv1d_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0);
 }
 
+// Level >= 2 inverse: same structure as k_inv1 with the polyphase interpolating filters.
 template <class C>
 __global__ void __launch_bounds__(DT_NT) k_inv2(Inv2Params p) {
     __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
@@ -84,12 +85,14 @@ __global__ void __launch_bounds__(DT_NT) k_inv2(Inv2Params p) {
     int t = tile_of(blockIdx.x, ntile, p.xcd_order);
     if (t >= ntile) return;
     int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
-    float *s0 = smem, *s1 = s0 + C::SP, *s2 = s1 + C::SP, *s3 = s2 + C::SP;
-    float *y1 = s3 + C::SP, *y2 = y1 + C::SY;
+    float *srec = smem, *y1 = srec + C::SREC, *y2 = y1 + C::SY;
     int r0 = tr * C::TR, c0 = tc * C::TC;
-    inv2_load<C>(p, s0, s1, s2, s3, threadIdx.x, b, r0, c0);
+    const float *Yhb = p.Yh + (int64_t)b * (p.zr / 2) * (p.zc / 2) * 12;
+    float wz[C::WS];
+    inv2r_fetch<C>(p, wz, threadIdx.x, b, r0, c0);
+    inv_rec_stage(Yhb, p.zr, p.zc, srec, C::QR, C::QC, r0 + C::ORG, c0 + C::ORG, threadIdx.x);
     __syncthreads();
-    inv2_cols<C>(p, s0, s1, s2, s3, y1, y2, threadIdx.x);
+    inv2r_cols<C>(p, wz, srec, y1, y2, threadIdx.x, r0, c0);
     __syncthreads();
     inv2_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0);
 }
@@ -128,15 +131,21 @@ int launch_inv2(Inv2Params &p, hipStream_t s) {
 #define DT_CASE_FWD1(TR, TC, RS, A, B) if (m0 == A && m1 == B) return launch_fwd1<Fwd1DCfg<TR, TC, RS, A, B>>(p, s);
 #define DT_CASE_INV1(TR, TC, RS, A, B) if (m0 == A && m1 == B) return launch_inv1<Inv1RCfg<TR, TC, RS, A, B>>(p, s);
 #define DT_CASE_FWD2(TR, TC, PS, M) if (m == M) return launch_fwd2<Fwd2DCfg<TR, TC, PS, M>>(p, s);
-#define DT_CASE_INV2(TR, TC, M) if (m == M) return launch_inv2<Inv2Cfg<TR, TC, M>>(p, s);
+#define DT_CASE_INV2(TR, TC, JS, M) if (m == M) return launch_inv2<Inv2RCfg<TR, TC, JS, M>>(p, s);
 int dispatch_fwd1(int m0, int m1, Fwd1Params &p, hipStream_t s) { DT_FWD1_TABLE(DT_CASE_FWD1) return -3; }
 int dispatch_inv1(int m0, int m1, Inv1Params &p, hipStream_t s) { DT_INV1_TABLE(DT_CASE_INV1) return -3; }
-int dispatch_fwd2(int m, Fwd2Params &p, hipStream_t s) { DT_FWD2_TABLE(DT_CASE_FWD2) return -3; }
-int dispatch_inv2(int m, Inv2Params &p, hipStream_t s) { DT_INV2_TABLE(DT_CASE_INV2) return -3; }
+int dispatch_fwd2(int m, Fwd2Params &p, hipStream_t s, bool small) {
+    if (small) { DT_FWD2_SMALL_TABLE(DT_CASE_FWD2) }
+    DT_FWD2_TABLE(DT_CASE_FWD2) return -3;
+}
+int dispatch_inv2(int m, Inv2Params &p, hipStream_t s, bool small) {
+    if (small) { DT_INV2_SMALL_TABLE(DT_CASE_INV2) }
+    DT_INV2_TABLE(DT_CASE_INV2) return -3;
+}
 
 #define DT_HAS2(TR, TC, A, B) if (m0 == A && m1 == B) return true;
 #define DT_HAS2F(TR, TC, RS, A, B) if (m0 == A && m1 == B) return true;
-#define DT_HAS1(TR, TC, M) if (m == M) return true;
+#define DT_HAS1(TR, TC, JS, M) if (m == M) return true;
 bool fwd1_supported(int m0, int m1) { DT_FWD1_TABLE(DT_HAS2F) return false; }
 bool inv1_supported(int m0, int m1) { DT_INV1_TABLE(DT_HAS2F) return false; }
 bool q_supported(int m) { DT_INV2_TABLE(DT_HAS1) return false; }
@@ -171,6 +180,7 @@ struct dtcwt_hip_plan2d {
     bool profiling = false;           // record an event pair around every level kernel
     std::vector<hipEvent_t> ev;       // [fwd: 2 per level][inv: 2 per level]
     int xcd_order = -1;               // -1: per-kernel default, 0/1: forced (DTCWT_HIP_XCD_ORDER)
+    int small_tiles = -1;             // -1: by size, 0/1: forced (DTCWT_HIP_SMALL_TILES)
 };
 
 extern "C" {
@@ -194,6 +204,7 @@ int dtcwt_hip_plan2d_create(dtcwt_hip_ctx *ctx, int batch, int rows, int cols, i
     for (int i = 0; i < 4; ++i) p->biort[i].assign(biort_host[i], biort_host[i] + biort_len[i]);
     for (int i = 0; i < 8; ++i) p->qshift[i].assign(qshift_host[i], qshift_host[i] + qshift_len[i]);
     { const char *e = getenv("DTCWT_HIP_XCD_ORDER"); p->xcd_order = e ? (e[0] == '1' ? 1 : 0) : -1; }
+    { const char *e = getenv("DTCWT_HIP_SMALL_TILES"); p->small_tiles = e ? (e[0] == '1' ? 1 : 0) : -1; }
     p->extR = rows + (rows & 1);
     p->extC = cols + (cols & 1);
     Level l0{rows, cols, 0, 0, p->extR, p->extC, p->extR, p->extC, p->extR / 2, p->extC / 2};
@@ -298,7 +309,10 @@ int dtcwt_hip_plan2d_forward(dtcwt_hip_plan2d *p, const float *X, float *Yl, voi
             put_taps(q.h_a, p->qshift[5]); put_taps(q.h_b, p->qshift[4]);
             q.lo_a_first = dotd(p->qshift[1], p->qshift[0]) > 0;
             q.hi_a_first = dotd(p->qshift[5], p->qshift[4]) > 0;
-            rc = dispatch_fwd2((int)p->qshift[0].size(), q, s);
+            // default tile 16 x ~56: use the small shape when that gives too few workgroups
+            bool small = p->small_tiles >= 0 ? p->small_tiles != 0
+                                             : (int64_t)cdiv(L.loR, 16) * cdiv(L.loC, 56) * p->batch < DT_SMALL_TILE_THRESHOLD;
+            rc = dispatch_fwd2((int)p->qshift[0].size(), q, s, small);
         }
         if (rc) return dtcwt_set_error(rc, "no fused forward kernel at level %d", l);
         DT_CHECK_HIP(hipGetLastError());
@@ -347,7 +361,9 @@ int dtcwt_hip_plan2d_inverse(dtcwt_hip_plan2d *p, const float *Yl, const void *c
             put_taps(q.h_a, p->qshift[7]); put_taps(q.h_b, p->qshift[6]);
             q.lo_pos = dotd(p->qshift[3], p->qshift[2]) > 0;
             q.hi_pos = dotd(p->qshift[7], p->qshift[6]) > 0;
-            rc = dispatch_inv2((int)p->qshift[0].size(), q, s);
+            bool small = p->small_tiles >= 0 ? p->small_tiles != 0
+                                             : (int64_t)cdiv(L.loR, 16) * cdiv(L.loC, 56) * p->batch < DT_SMALL_TILE_THRESHOLD;
+            rc = dispatch_inv2((int)p->qshift[0].size(), q, s, small);
             in = out;
         }
         if (rc) return dtcwt_set_error(rc, "no fused inverse kernel at level %d", l);

@@ -26,9 +26,28 @@
     X(16, 50, 4, 16)        /* qshift_c */ \
     X(16, 48, 4, 18)        /* qshift_d */ \
     X(16, 34, 2, 32)        /* qshift_32 */
+/* level >= 2 inverse: X(tile rows, tile cols (INPUT samples), j's per column-pass strip,
+ * q-shift length); tile cols + window - 2 = 64 columns */
 #define DT_INV2_TABLE(X) \
-    X(32, 32, 10) \
-    X(32, 32, 14) \
-    X(32, 32, 16) \
-    X(32, 32, 18) \
-    X(16, 16, 32)
+    X(16, 56, 2, 10) \
+    X(16, 52, 2, 14) \
+    X(16, 48, 2, 16) \
+    X(16, 48, 2, 18) \
+    X(16, 32, 2, 32)
+
+/* Smaller tiles for coarse levels (more workgroups).  Measured on MI355X (4096^2, levels 3-4):
+ * no gain -- those launches sit at a ~6-9 us floor either way -- so they are only used when
+ * forced with DTCWT_HIP_SMALL_TILES=1 (threshold 0 = never automatically). */
+#define DT_SMALL_TILE_THRESHOLD 0
+#define DT_FWD2_SMALL_TABLE(X) \
+    X(8, 24, 2, 10) \
+    X(8, 20, 2, 14) \
+    X(8, 18, 2, 16) \
+    X(8, 16, 2, 18) \
+    X(16, 34, 2, 32)
+#define DT_INV2_SMALL_TABLE(X) \
+    X(8, 24, 2, 10) \
+    X(8, 20, 2, 14) \
+    X(8, 16, 2, 16) \
+    X(8, 16, 2, 18) \
+    X(16, 32, 2, 32)

@@ -721,6 +721,44 @@ DT_HD void inv_rec_stage(const float *Yhb, int zr, int zc, float *srec, int QR, 
     }
 }
 
+// Register-staged variant of inv_rec_stage for software pipelining: fetch the pieces of
+// the NEXT tile into registers while the current tile is being computed, write them to
+// LDS once the current tile's column pass is done.  NP = pieces per thread.
+template <int QR, int QC>
+struct RecRegs {
+    static constexpr int NPIECE = 3 * QR * QC;
+    static constexpr int NP = (NPIECE + DT_NT - 1) / DT_NT;
+    float x[NP], y[NP], z[NP], w[NP];
+};
+
+template <int QR, int QC>
+DT_HD void inv_rec_fetch_regs(const float *Yhb, int zr, int zc, RecRegs<QR, QC> &rg, int ro, int co, int tid) {
+    const int hc = zc / 2;
+    const bool interior = ro >= 0 && ro + 2 * QR <= zr && co >= 0 && co + 2 * QC <= zc;
+#pragma unroll
+    for (int k = 0; k < RecRegs<QR, QC>::NP; ++k) {
+        int piece = tid + k * DT_NT;
+        if (piece < RecRegs<QR, QC>::NPIECE) {
+            int rec = piece / 3, part = piece - 3 * rec;
+            int uw = rec / QC, vw = rec - uw * QC;
+            int ur = ro + 2 * uw, vc = co + 2 * vw;
+            if (!interior) { ur = reflect_i(ur, zr); vc = reflect_i(vc, zc); }
+            f4 v = reinterpret_cast<const f4 *>(Yhb + ((int64_t)(ur >> 1) * hc + (vc >> 1)) * 12)[part];
+            rg.x[k] = v.x; rg.y[k] = v.y; rg.z[k] = v.z; rg.w[k] = v.w;
+        }
+    }
+}
+
+template <int QR, int QC>
+DT_HD void inv_rec_store_regs(float *srec, const RecRegs<QR, QC> &rg, int tid) {
+    f4 *dst = reinterpret_cast<f4 *>(srec);
+#pragma unroll
+    for (int k = 0; k < RecRegs<QR, QC>::NP; ++k) {
+        int piece = tid + k * DT_NT;
+        if (piece < RecRegs<QR, QC>::NPIECE) dst[piece] = f4{rg.x[k], rg.y[k], rg.z[k], rg.w[k]};
+    }
+}
+
 // column-pass task of a thread: parity uniform per wavefront
 struct ColTask { int strip, e, i, valid; };
 template <class C>
@@ -821,6 +859,18 @@ DT_HD void inv1r_cols(const Inv1Params &p, const float (&w0)[C::WN], const float
     }
 }
 
+// lowpass window from an LDS plane s0[NR][NC] (staged by inv_load_low) instead of global:
+// direct global reads re-fetch every lowpass row (RS + 2*HE)/RS times through L1, which is
+// the scarcer resource (measured ~40 B/clk/CU) -- see DESIGN.md section 3.
+template <class C>
+DT_HD void inv1r_fetch_lds(const float *s0, float (&w0)[C::WN], int tid) {
+    const ColTask t = inv_col_task<C>(tid);
+    if (!t.valid) return;
+    const int cc = 2 * t.i + t.e;
+#pragma unroll
+    for (int j = 0; j < C::WN; ++j) w0[j] = s0[(t.strip * C::RS + j) * C::NC + cc];
+}
+
 // prefetching variant of the level >= 2 inverse column pass (see inv1p_fetch)
 template <class C>
 DT_HD void inv2p_fetch(const Inv2Params &p, float (&w0)[C::WS], int tid, int b, int r0, int c0) {
@@ -880,6 +930,91 @@ DT_HD void inv2p_cols(const Inv2Params &p, const float (&w0)[C::WS], const float
         ifilt4<C>(w + 2 * q, p.h_a, p.h_b, p.hi_pos, t);
 #pragma unroll
         for (int e = 0; e < 4; ++e) y2[(4 * (strip * C::JS + q) + e) * C::NC + cc] = acc[q][e] + t[e];
+    }
+}
+
+// ---- level >= 2 inverse with raw records (c2q folded into the column pass) --------------
+template <int TR_, int TC_, int JS_, int M_>
+struct Inv2RCfg {
+    static constexpr int TR = TR_, TC = TC_, JS = JS_, M = M_;     // TR x TC INPUT samples per tile
+    static constexpr int M2 = M / 2;
+    static constexpr bool ODD = (M2 % 2) == 1;
+    static constexpr int WN = ODD ? M : M + 2;
+    static constexpr int ORG = ODD ? 1 - M2 : -M2;
+    static constexpr int NR = TR + WN - 2, NC = TC + WN - 2;
+    static constexpr int QR = NR / 2, QC = NC / 2, NREC = QR * QC;
+    static constexpr int NJ = TR / 2;
+    static constexpr int NS = NJ / JS;
+    static constexpr int WS = 2 * JS + WN - 2;
+    static constexpr int RS = 2 * JS;                              // window rows advanced per strip
+    static constexpr int SREC = NREC * 12;
+    static constexpr int SY = 2 * TR * NC;
+    static constexpr int LDS_FLOATS = SREC + 2 * SY;
+    static_assert(M % 2 == 0 && TR % 2 == 0 && TC % 2 == 0 && NJ % JS == 0, "even taps / tile");
+    static_assert(NS * QC <= 128, "column-pass tasks: two wavefronts per column parity");
+};
+
+template <class C>
+DT_HD void inv2r_fetch(const Inv2Params &p, float (&w0)[C::WS], int tid, int b, int r0, int c0) {
+    const ColTask t = inv_col_task<C>(tid);
+    if (!t.valid) return;
+    const float *Zb = p.Z + (int64_t)b * p.zr * p.zc;
+    const int ro = r0 + C::ORG, co = c0 + C::ORG;
+    const bool interior = ro >= 0 && ro + C::NR <= p.zr && co >= 0 && co + C::NC <= p.zc;
+    const int cc = 2 * t.i + t.e, rs = C::RS * t.strip;
+    if (interior) {
+        const float *src = Zb + (int64_t)(ro + rs) * p.zc + (co + cc);
+#pragma unroll
+        for (int j = 0; j < C::WS; ++j) w0[j] = src[(int64_t)j * p.zc];
+    } else {
+        int gc = reflect_i(co + cc, p.zc);
+#pragma unroll
+        for (int j = 0; j < C::WS; ++j) w0[j] = Zb[(int64_t)reflect_i(ro + rs + j, p.zr) * p.zc + gc];
+    }
+}
+
+template <class C>
+DT_HD void inv2r_cols(const Inv2Params &p, const float (&w0)[C::WS], const float *srec, float *y1,
+                      float *y2, int tid, int r0, int c0) {
+    const ColTask t = inv_col_task<C>(tid);
+    if (!t.valid) return;
+    const int ro = r0 + C::ORG, co = c0 + C::ORG;
+    const bool interior = ro >= 0 && ro + C::NR <= p.zr && co >= 0 && co + C::NC <= p.zc;
+    const int cc = 2 * t.i + t.e, rs = C::RS * t.strip;
+    float w1[C::WS], w2[C::WS], w3[C::WS];
+    const float *rbase = srec + ((rs / 2) * C::QC + t.i) * 12;
+    if (interior) {
+#pragma unroll
+        for (int ru = 0; ru < C::WS / 2; ++ru) {
+            float top[3], bot[3];
+            rec_samples(rbase + ru * C::QC * 12, p.g, t.e, top, bot);
+            w1[2 * ru] = top[0]; w1[2 * ru + 1] = bot[0];
+            w2[2 * ru] = top[1]; w2[2 * ru + 1] = bot[1];
+            w3[2 * ru] = top[2]; w3[2 * ru + 1] = bot[2];
+        }
+    } else {
+        const int fc = reflect_i(co + 2 * t.i, p.zc) & 1;
+#pragma unroll
+        for (int ru = 0; ru < C::WS / 2; ++ru) {
+            const int fr = reflect_i(ro + rs + 2 * ru, p.zr) & 1;
+            float top[3], bot[3];
+            rec_samples(rbase + ru * C::QC * 12, p.g, t.e ^ fc, top, bot);
+            w1[2 * ru] = fr ? bot[0] : top[0]; w1[2 * ru + 1] = fr ? top[0] : bot[0];
+            w2[2 * ru] = fr ? bot[1] : top[1]; w2[2 * ru + 1] = fr ? top[1] : bot[1];
+            w3[2 * ru] = fr ? bot[2] : top[2]; w3[2 * ru + 1] = fr ? top[2] : bot[2];
+        }
+    }
+    float a[4], tt[4];
+#pragma unroll
+    for (int q = 0; q < C::JS; ++q) {
+        ifilt4<C>(w0 + 2 * q, p.l_a, p.l_b, p.lo_pos, a);
+        ifilt4<C>(w1 + 2 * q, p.h_a, p.h_b, p.hi_pos, tt);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y1[(4 * (t.strip * C::JS + q) + e) * C::NC + cc] = a[e] + tt[e];
+        ifilt4<C>(w2 + 2 * q, p.l_a, p.l_b, p.lo_pos, a);
+        ifilt4<C>(w3 + 2 * q, p.h_a, p.h_b, p.hi_pos, tt);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y2[(4 * (t.strip * C::JS + q) + e) * C::NC + cc] = a[e] + tt[e];
     }
 }
 

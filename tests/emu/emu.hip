@@ -94,14 +94,17 @@ static int run_inv2(Inv2Params p) {
     std::vector<float> smem(C::LDS_FLOATS + 4);
     float *base = smem.data();
     while (((uintptr_t)base) & 15) ++base;
-    float *s0 = base, *s1 = s0 + C::SP, *s2 = s1 + C::SP, *s3 = s2 + C::SP;
-    float *y1 = s3 + C::SP, *y2 = y1 + C::SY;
+    float *srec = base, *y1 = srec + C::SREC, *y2 = y1 + C::SY;
+    static float wz[DT_NT][C::WS];
     for (int b = 0; b < p.B; ++b)
         for (int tr = 0; tr < p.tilesR; ++tr)
             for (int tc = 0; tc < p.tilesC; ++tc) {
                 int r0 = tr * C::TR, c0 = tc * C::TC;
-                for (int t = 0; t < DT_NT; ++t) inv2_load<C>(p, s0, s1, s2, s3, t, b, r0, c0);
-                for (int t = 0; t < DT_NT; ++t) inv2_cols<C>(p, s0, s1, s2, s3, y1, y2, t);
+                const float *Yhb = p.Yh + (int64_t)b * (p.zr / 2) * (p.zc / 2) * 12;
+                for (int t = 0; t < DT_NT; ++t) inv2r_fetch<C>(p, wz[t], t, b, r0, c0);
+                for (int t = 0; t < DT_NT; ++t)
+                    inv_rec_stage(Yhb, p.zr, p.zc, srec, C::QR, C::QC, r0 + C::ORG, c0 + C::ORG, t);
+                for (int t = 0; t < DT_NT; ++t) inv2r_cols<C>(p, wz[t], srec, y1, y2, t, r0, c0);
                 for (int t = 0; t < DT_NT; ++t) inv2_rows<C>(p, y1, y2, t, b, r0, c0);
             }
     return 0;
@@ -110,7 +113,7 @@ static int run_inv2(Inv2Params p) {
 #define EMU_FWD1(TR, TC, RS, A, B_) if (m0 == A && m1 == B_) return run_fwd1<Fwd1DCfg<TR, TC, RS, A, B_>>(p);
 #define EMU_INV1(TR, TC, RS, A, B_) if (m0 == A && m1 == B_) return run_inv1<Inv1RCfg<TR, TC, RS, A, B_>>(p);
 #define EMU_FWD2(TR, TC, PS, M) if (m == M) return run_fwd2<Fwd2DCfg<TR, TC, PS, M>>(p);
-#define EMU_INV2(TR, TC, M) if (m == M) return run_inv2<Inv2Cfg<TR, TC, M>>(p);
+#define EMU_INV2(TR, TC, JS, M) if (m == M) return run_inv2<Inv2RCfg<TR, TC, JS, M>>(p);
 
 extern "C" {
 

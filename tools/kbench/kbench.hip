@@ -317,6 +317,167 @@ __global__ void __launch_bounds__(DT_NT) k_inv1_r(Inv1Params p) {
     __syncthreads();
     inv1d_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0);
 }
+// persistent, software-pipelined: each workgroup walks tiles t = blockIdx.x + k*gridDim.x and
+// prefetches the next tile's records + lowpass window into registers during the current
+// tile's column and row passes
+#define DT_RAW_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
+template <class C>
+__global__ void __launch_bounds__(DT_NT) k_inv1_rp(Inv1Params p) {
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
+    const int ntile = p.tilesR * p.tilesC * p.B;
+    float *srec = smem, *y1 = srec + C::SREC, *y2 = y1 + C::SY;
+    RecRegs<C::QR, C::QC> rg;
+    float wz[C::WN], wn[C::WN];
+    int t = blockIdx.x;
+    if (t >= ntile) return;
+    int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    int r0 = tr * C::TR, c0 = tc * C::TC;
+    inv1r_fetch<C>(p, wz, threadIdx.x, b, r0, c0);
+    inv_rec_fetch_regs<C::QR, C::QC>(p.Yh + (int64_t)b * (p.R / 2) * (p.C / 2) * 12, p.R, p.C, rg, r0 - C::HE, c0 - C::HE, threadIdx.x);
+    for (;;) {
+        inv_rec_store_regs<C::QR, C::QC>(srec, rg, threadIdx.x);
+        __syncthreads();
+        const int tn = t + gridDim.x;
+        int bn = 0, rn = 0, cn = 0;
+        if (tn < ntile) {
+            int tcn = tn % p.tilesC, trn = (tn / p.tilesC) % p.tilesR;
+            bn = tn / (p.tilesC * p.tilesR); rn = trn * C::TR; cn = tcn * C::TC;
+            inv1r_fetch<C>(p, wn, threadIdx.x, bn, rn, cn);
+            inv_rec_fetch_regs<C::QR, C::QC>(p.Yh + (int64_t)bn * (p.R / 2) * (p.C / 2) * 12, p.R, p.C, rg, rn - C::HE, cn - C::HE, threadIdx.x);
+        }
+        inv1r_cols<C>(p, wz, srec, y1, y2, threadIdx.x, r0, c0);
+        __syncthreads();
+        inv1d_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0);
+        if (tn >= ntile) break;
+        t = tn; b = bn; r0 = rn; c0 = cn;
+#pragma unroll
+        for (int j = 0; j < C::WN; ++j) wz[j] = wn[j];
+    }
+}
+template <class C>
+__global__ void __launch_bounds__(DT_NT) k_inv1_rq(Inv1Params p) {
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
+    const int ntile = p.tilesR * p.tilesC * p.B;
+    float *srec = smem, *y1 = srec + C::SREC, *y2 = y1 + C::SY;
+    RecRegs<C::QR, C::QC> rg;
+    float wz[C::WN], wn[C::WN];
+    int t = blockIdx.x;
+    if (t >= ntile) return;
+    int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    int r0 = tr * C::TR, c0 = tc * C::TC;
+    inv1r_fetch<C>(p, wz, threadIdx.x, b, r0, c0);
+    inv_rec_fetch_regs<C::QR, C::QC>(p.Yh + (int64_t)b * (p.R / 2) * (p.C / 2) * 12, p.R, p.C, rg, r0 - C::HE, c0 - C::HE, threadIdx.x);
+    for (;;) {
+        inv_rec_store_regs<C::QR, C::QC>(srec, rg, threadIdx.x);
+        DT_RAW_BARRIER();
+        const int tn = t + gridDim.x;
+        int bn = 0, rn = 0, cn = 0;
+        if (tn < ntile) {
+            int tcn = tn % p.tilesC, trn = (tn / p.tilesC) % p.tilesR;
+            bn = tn / (p.tilesC * p.tilesR); rn = trn * C::TR; cn = tcn * C::TC;
+            inv1r_fetch<C>(p, wn, threadIdx.x, bn, rn, cn);
+            inv_rec_fetch_regs<C::QR, C::QC>(p.Yh + (int64_t)bn * (p.R / 2) * (p.C / 2) * 12, p.R, p.C, rg, rn - C::HE, cn - C::HE, threadIdx.x);
+        }
+        inv1r_cols<C>(p, wz, srec, y1, y2, threadIdx.x, r0, c0);
+        DT_RAW_BARRIER();
+        inv1d_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0);
+        if (tn >= ntile) break;
+        t = tn; b = bn; r0 = rn; c0 = cn;
+#pragma unroll
+        for (int j = 0; j < C::WN; ++j) wz[j] = wn[j];
+    }
+}
+template <class C, int BPC> void launchi1_rp(Inv1Params &p) {
+    p.tilesR = cdiv(p.R, C::TR); p.tilesC = cdiv(p.C, C::TC);
+    int nt = p.tilesR * p.tilesC * p.B;
+    int grid = nt < 256 * BPC ? nt : 256 * BPC;
+    k_inv1_rp<C><<<grid, DT_NT>>>(p);
+}
+// ablation of k_inv1_r: AB bit0 = skip record staging, bit1 = skip lowpass fetch, bit2 = skip
+// column pass, bit3 = skip row pass compute+store, bit4 = skip only the global store
+template <class C, int AB>
+__global__ void __launch_bounds__(DT_NT) k_inv1_abl(Inv1Params p) {
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
+    const int ntile = p.tilesR * p.tilesC * p.B;
+    int t = tile_of(blockIdx.x, ntile, p.xcd_order);
+    if (t >= ntile) return;
+    int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    float *srec = smem, *y1 = srec + C::SREC, *y2 = y1 + C::SY;
+    int r0 = tr * C::TR, c0 = tc * C::TC;
+    if (AB & 32) { r0 = (tr & 7) * C::TR + 64; c0 = (tc & 7) * C::TC + 64; }   // cache-resident inputs
+    const float *Yhb = p.Yh + (int64_t)b * (p.R / 2) * (p.C / 2) * 12;
+    float wz[C::WN];
+    if (!(AB & 2)) inv1r_fetch<C>(p, wz, threadIdx.x, b, r0, c0);
+    else for (int j = 0; j < C::WN; ++j) wz[j] = (float)(threadIdx.x + j);
+    if (!(AB & 1)) inv_rec_stage(Yhb, p.R, p.C, srec, C::QR, C::QC, r0 - C::HE, c0 - C::HE, threadIdx.x);
+    __syncthreads();
+    if (!(AB & 4)) inv1r_cols<C>(p, wz, srec, y1, y2, threadIdx.x, r0, c0);
+    else { float a = 0; for (int j = 0; j < C::WN; ++j) a += wz[j]; y1[threadIdx.x] = a + srec[threadIdx.x]; }
+    __syncthreads();
+    if (!(AB & 8)) {
+        if (!(AB & 16)) inv1d_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0);
+        else {
+            Inv1Params q = p; q.X = p.X; q.R = p.R;
+            // compute but store to a tiny region: redirect by clamping the row count
+            inv1d_rows<C>(q, y1, y2, threadIdx.x, 0, r0 & 15, c0 & 63);
+        }
+    } else if (threadIdx.x == 0 && y1[5] == 123.456f) p.X[0] = y2[7];
+}
+template <class C, int AB> void launchi1_abl(Inv1Params &p) {
+    p.tilesR = cdiv(p.R, C::TR); p.tilesC = cdiv(p.C, C::TC);
+    k_inv1_abl<C, AB><<<cdiv(p.tilesR * p.tilesC * p.B, 8) * 8, DT_NT>>>(p);
+}
+template <class C, int BPC> void launchi1_rq(Inv1Params &p) {
+    p.tilesR = cdiv(p.R, C::TR); p.tilesC = cdiv(p.C, C::TC);
+    int nt = p.tilesR * p.tilesC * p.B;
+    int grid = nt < 256 * BPC ? nt : 256 * BPC;
+    k_inv1_rq<C><<<grid, DT_NT>>>(p);
+}
+template <class C>
+__global__ void __launch_bounds__(DT_NT) k_inv1_rz(Inv1Params p) {
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS + C::NR * C::NC];
+    const int ntile = p.tilesR * p.tilesC * p.B;
+    int t = tile_of(blockIdx.x, ntile, p.xcd_order);
+    if (t >= ntile) return;
+    int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    float *srec = smem, *y1 = srec + C::SREC, *y2 = y1 + C::SY, *s0 = y2 + C::SY;
+    int r0 = tr * C::TR, c0 = tc * C::TC;
+    const float *Yhb = p.Yh + (int64_t)b * (p.R / 2) * (p.C / 2) * 12;
+    inv_load_low(p.Z + (int64_t)b * p.R * p.C, p.R, p.C, s0, C::NR, C::NC, r0 - C::HE, c0 - C::HE, threadIdx.x);
+    inv_rec_stage(Yhb, p.R, p.C, srec, C::QR, C::QC, r0 - C::HE, c0 - C::HE, threadIdx.x);
+    __syncthreads();
+    float wz[C::WN];
+    inv1r_fetch_lds<C>(s0, wz, threadIdx.x);
+    inv1r_cols<C>(p, wz, srec, y1, y2, threadIdx.x, r0, c0);
+    __syncthreads();
+    inv1d_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0);
+}
+template <class C> void launchi1_rz(Inv1Params &p) {
+    p.tilesR = cdiv(p.R, C::TR); p.tilesC = cdiv(p.C, C::TC);
+    k_inv1_rz<C><<<cdiv(p.tilesR * p.tilesC * p.B, 8) * 8, DT_NT>>>(p);
+}
+template <class C>
+__global__ void __launch_bounds__(DT_NT) k_inv2_r(Inv2Params p) {
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
+    const int ntile = p.tilesR * p.tilesC * p.B;
+    int t = tile_of(blockIdx.x, ntile, p.xcd_order);
+    if (t >= ntile) return;
+    int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    float *srec = smem, *y1 = srec + C::SREC, *y2 = y1 + C::SY;
+    int r0 = tr * C::TR, c0 = tc * C::TC;
+    const float *Yhb = p.Yh + (int64_t)b * (p.zr / 2) * (p.zc / 2) * 12;
+    float wz[C::WS];
+    inv2r_fetch<C>(p, wz, threadIdx.x, b, r0, c0);
+    inv_rec_stage(Yhb, p.zr, p.zc, srec, C::QR, C::QC, r0 + C::ORG, c0 + C::ORG, threadIdx.x);
+    __syncthreads();
+    inv2r_cols<C>(p, wz, srec, y1, y2, threadIdx.x, r0, c0);
+    __syncthreads();
+    inv2_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0);
+}
+template <class C> void launchi2_r(Inv2Params &p) {
+    p.tilesR = cdiv(p.zr, C::TR); p.tilesC = cdiv(p.zc, C::TC);
+    k_inv2_r<C><<<cdiv(p.tilesR * p.tilesC * p.B, 8) * 8, DT_NT>>>(p);
+}
 template <class C> void launchi1_r(Inv1Params &p) {
     p.tilesR = cdiv(p.R, C::TR); p.tilesC = cdiv(p.C, C::TC);
     k_inv1_r<C><<<cdiv(p.tilesR * p.tilesC * p.B, 8) * 8, DT_NT>>>(p);
@@ -568,6 +729,41 @@ int main(int argc, char **argv) {
             std::vector<VariantI1> vi;
             vi.push_back({"I1 v0 32x32 xcd", launchi1_v0<Inv1Cfg<32, 32, 7, 5>>, 1});
             vi.push_back({"I1 v0 32x32 lin", launchi1_v0<Inv1Cfg<32, 32, 7, 5>>, 0});
+            vi.push_back({"I1 rz 16x56 rs4 xcd", launchi1_rz<Inv1RCfg<16, 56, 4, 7, 5>>, 1});
+            vi.push_back({"I1 rz 16x56 rs4 lin", launchi1_rz<Inv1RCfg<16, 56, 4, 7, 5>>, 0});
+            vi.push_back({"I1 rz 32x56 rs8 xcd", launchi1_rz<Inv1RCfg<32, 56, 8, 7, 5>>, 1});
+            vi.push_back({"I1 rz 32x24 rs4 xcd", launchi1_rz<Inv1RCfg<32, 24, 4, 7, 5>>, 1});
+            vi.push_back({"I1 rz 64x24 rs8 xcd", launchi1_rz<Inv1RCfg<64, 24, 8, 7, 5>>, 1});
+            vi.push_back({"I1 rz 16x120 rs8 xcd", launchi1_rz<Inv1RCfg<16, 120, 8, 7, 5>>, 1});
+            vi.push_back({"I1 abl full", launchi1_abl<Inv1RCfg<16, 56, 4, 7, 5>, 0>, 1});
+            vi.push_back({"I1 abl -recs", launchi1_abl<Inv1RCfg<16, 56, 4, 7, 5>, 1>, 1});
+            vi.push_back({"I1 abl -z", launchi1_abl<Inv1RCfg<16, 56, 4, 7, 5>, 2>, 1});
+            vi.push_back({"I1 abl -recs-z", launchi1_abl<Inv1RCfg<16, 56, 4, 7, 5>, 3>, 1});
+            vi.push_back({"I1 abl -cols", launchi1_abl<Inv1RCfg<16, 56, 4, 7, 5>, 4>, 1});
+            vi.push_back({"I1 abl -rows", launchi1_abl<Inv1RCfg<16, 56, 4, 7, 5>, 8>, 1});
+            vi.push_back({"I1 abl -store", launchi1_abl<Inv1RCfg<16, 56, 4, 7, 5>, 16>, 1});
+            vi.push_back({"I1 abl -cols-rows", launchi1_abl<Inv1RCfg<16, 56, 4, 7, 5>, 12>, 1});
+            vi.push_back({"I1 abl loads only", launchi1_abl<Inv1RCfg<16, 56, 4, 7, 5>, 12>, 1});
+            vi.push_back({"I1 abl -recs-z-rows", launchi1_abl<Inv1RCfg<16, 56, 4, 7, 5>, 11>, 1});
+            vi.push_back({"I1 abl nothing", launchi1_abl<Inv1RCfg<16, 56, 4, 7, 5>, 15>, 1});
+            vi.push_back({"I1 abl loads cached", launchi1_abl<Inv1RCfg<16, 56, 4, 7, 5>, 12 + 32>, 1});
+            vi.push_back({"I1 abl recs cached", launchi1_abl<Inv1RCfg<16, 56, 4, 7, 5>, 14 + 32>, 1});
+            vi.push_back({"I1 abl z cached", launchi1_abl<Inv1RCfg<16, 56, 4, 7, 5>, 13 + 32>, 1});
+            vi.push_back({"I1 abl full cached-in", launchi1_abl<Inv1RCfg<16, 56, 4, 7, 5>, 32>, 1});
+            vi.push_back({"I1 abl -store cached", launchi1_abl<Inv1RCfg<16, 56, 4, 7, 5>, 16 + 32>, 1});
+            vi.push_back({"I1 rq 16x56 rs4 b6", launchi1_rq<Inv1RCfg<16, 56, 4, 7, 5>, 6>, 0});
+            vi.push_back({"I1 rq 16x56 rs4 b4", launchi1_rq<Inv1RCfg<16, 56, 4, 7, 5>, 4>, 0});
+            vi.push_back({"I1 rq 16x56 rs4 b3", launchi1_rq<Inv1RCfg<16, 56, 4, 7, 5>, 3>, 0});
+            vi.push_back({"I1 rq 32x56 rs8 b3", launchi1_rq<Inv1RCfg<32, 56, 8, 7, 5>, 3>, 0});
+            vi.push_back({"I1 rq 32x56 rs8 b2", launchi1_rq<Inv1RCfg<32, 56, 8, 7, 5>, 2>, 0});
+            vi.push_back({"I1 rq 32x24 rs4 b6", launchi1_rq<Inv1RCfg<32, 24, 4, 7, 5>, 6>, 0});
+            vi.push_back({"I1 rp 16x56 rs4 b6", launchi1_rp<Inv1RCfg<16, 56, 4, 7, 5>, 6>, 0});
+            vi.push_back({"I1 rp 16x56 rs4 b5", launchi1_rp<Inv1RCfg<16, 56, 4, 7, 5>, 5>, 0});
+            vi.push_back({"I1 rp 16x56 rs4 b4", launchi1_rp<Inv1RCfg<16, 56, 4, 7, 5>, 4>, 0});
+            vi.push_back({"I1 rp 16x56 rs4 b3", launchi1_rp<Inv1RCfg<16, 56, 4, 7, 5>, 3>, 0});
+            vi.push_back({"I1 rp 32x56 rs8 b3", launchi1_rp<Inv1RCfg<32, 56, 8, 7, 5>, 3>, 0});
+            vi.push_back({"I1 rp 32x56 rs8 b2", launchi1_rp<Inv1RCfg<32, 56, 8, 7, 5>, 2>, 0});
+            vi.push_back({"I1 rp 32x24 rs4 b6", launchi1_rp<Inv1RCfg<32, 24, 4, 7, 5>, 6>, 0});
             vi.push_back({"I1 r 32x56 rs8 xcd", launchi1_r<Inv1RCfg<32, 56, 8, 7, 5>>, 1});
             vi.push_back({"I1 r 32x56 rs8 lin", launchi1_r<Inv1RCfg<32, 56, 8, 7, 5>>, 0});
             vi.push_back({"I1 r 16x56 rs4 xcd", launchi1_r<Inv1RCfg<16, 56, 4, 7, 5>>, 1});
@@ -611,6 +807,13 @@ int main(int argc, char **argv) {
             std::vector<VariantI2> vi;
             vi.push_back({"I2 v0 32x32 xcd", launchi2_v0<Inv2Cfg<32, 32, 10>>, 1});
             vi.push_back({"I2 v0 32x32 lin", launchi2_v0<Inv2Cfg<32, 32, 10>>, 0});
+            vi.push_back({"I2 r 16x56 js2 xcd", launchi2_r<Inv2RCfg<16, 56, 2, 10>>, 1});
+            vi.push_back({"I2 r 16x56 js4 xcd", launchi2_r<Inv2RCfg<16, 56, 4, 10>>, 1});
+            vi.push_back({"I2 r 16x24 js2 xcd", launchi2_r<Inv2RCfg<16, 24, 2, 10>>, 1});
+            vi.push_back({"I2 r 32x24 js2 xcd", launchi2_r<Inv2RCfg<32, 24, 2, 10>>, 1});
+            vi.push_back({"I2 r 8x56 js2 xcd", launchi2_r<Inv2RCfg<8, 56, 2, 10>>, 1});
+            vi.push_back({"I2 r 8x56 js1 xcd", launchi2_r<Inv2RCfg<8, 56, 1, 10>>, 1});
+            vi.push_back({"I2 r 8x24 js2 xcd", launchi2_r<Inv2RCfg<8, 24, 2, 10>>, 1});
             vi.push_back({"I2 p 16x56 js4 xcd", launchi2_p<Inv2DCfg<16, 56, 4, 10>>, 1});
             vi.push_back({"I2 p 16x56 js2 xcd", launchi2_p<Inv2DCfg<16, 56, 2, 10>>, 1});
             vi.push_back({"I2 p 16x24 js2 xcd", launchi2_p<Inv2DCfg<16, 24, 2, 10>>, 1});
