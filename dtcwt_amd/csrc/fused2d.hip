@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(DT_NT) k_inv1(Inv1Params p) {
     const float *Yhb = p.Yh + (int64_t)b * (p.R / 2) * (p.C / 2) * 12;
     float wz[C::WN];
     inv1r_fetch<C>(p, wz, threadIdx.x, b, r0, c0);
-    inv_rec_stage(Yhb, p.R, p.C, srec, C::QR, C::QC, r0 - C::HE, c0 - C::HE, threadIdx.x);
+    inv_rec_stage<C::QR, C::QC>(Yhb, p.R, p.C, srec, r0 - C::HE, c0 - C::HE, threadIdx.x);
     __syncthreads();
     inv1r_cols<C>(p, wz, srec, y1, y2, threadIdx.x, r0, c0);
     __syncthreads();
@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(DT_NT) k_inv2(Inv2Params p) {
     const float *Yhb = p.Yh + (int64_t)b * (p.zr / 2) * (p.zc / 2) * 12;
     float wz[C::WS];
     inv2r_fetch<C>(p, wz, threadIdx.x, b, r0, c0);
-    inv_rec_stage(Yhb, p.zr, p.zc, srec, C::QR, C::QC, r0 + C::ORG, c0 + C::ORG, threadIdx.x);
+    inv_rec_stage<C::QR, C::QC>(Yhb, p.zr, p.zc, srec, r0 + C::ORG, c0 + C::ORG, threadIdx.x);
     __syncthreads();
     inv2r_cols<C>(p, wz, srec, y1, y2, threadIdx.x, r0, c0);
     __syncthreads();
@@ -219,6 +219,11 @@ int dtcwt_hip_plan2d_create(dtcwt_hip_ctx *ctx, int batch, int rows, int cols, i
         L.hR = L.LR / 4; L.hC = L.LC / 4;
         p->lv.push_back(L);
     }
+    for (const Level &L : p->lv)
+        if (L.LR < DT_MIN_FUSED_DIM || L.LC < DT_MIN_FUSED_DIM || L.loR < DT_MIN_FUSED_DIM / 2 || L.loC < DT_MIN_FUSED_DIM / 2) {
+            delete p;
+            return dtcwt_set_error(-3, "image too small for the fused kernels at some level (< %d samples): use the generic path", DT_MIN_FUSED_DIM);
+        }
     p->work.assign(nlevels, nullptr);
     for (int l = 0; l < nlevels; ++l) {
         size_t bytes = (size_t)batch * p->lv[l].loR * p->lv[l].loC * sizeof(float);

@@ -32,17 +32,19 @@ namespace dt2d {
 struct alignas(16) f4 { float x, y, z, w; };
 struct alignas(8) f2 { float x, y; };
 
-DT_HD int reflect_i(int u, int n) {     // half-sample symmetric, multi-bounce safe
-    // one bounce (-n <= u < 2n) is the only case tiles of ordinary images ever see: two
-    // selects instead of an integer modulo (~30 VALU instructions on gfx950)
-    if ((unsigned)(u + n) < (unsigned)(3 * n)) {
-        u = u < 0 ? -1 - u : u;
-        return u >= n ? 2 * n - 1 - u : u;
-    }
-    int p = 2 * n;
-    int j = u % p;
-    if (j < 0) j += p;
-    return j < n ? j : p - 1 - j;
+// Half-sample symmetric reflection, ONE bounce: valid for -n <= u < 2n.  Branch-free on
+// purpose: a data-dependent branch per index splits the load sequences of the tile
+// programs into basic blocks and serialises their memory latencies (profiles/ round 1).
+// The plan only uses the fused kernels when every level is at least DT_MIN_FUSED_DIM
+// samples wide (halos are < 40), so one bounce always suffices; smaller images take the
+// generic kernels (filters.hip), whose reflection is the multi-bounce modulo form.
+#define DT_MIN_FUSED_DIM 40
+DT_HD int reflect_i(int u, int n) {
+    u = u < 0 ? -1 - u : u;
+    u = u >= n ? 2 * n - 1 - u : u;
+    // rows/columns of partial edge tiles beyond one bounce are computed but never stored:
+    // keep their addresses inside the array
+    return u < 0 ? 0 : (u > n - 1 ? n - 1 : u);
 }
 DT_HD int clamp_i(int u, int lo, int hi) { return u < lo ? lo : (u > hi ? hi : u); }
 constexpr int cmax(int a, int b) { return a > b ? a : b; }

@@ -706,18 +706,31 @@ struct Inv1RCfg {
     static_assert(M0 % 2 == 1 && M1 % 2 == 1, "biort filters must have odd length");
 };
 
-// stage the window's records verbatim: srec[uw][vw][12], source record reflected
-DT_HD void inv_rec_stage(const float *Yhb, int zr, int zc, float *srec, int QR, int QC, int ro, int co,
-                         int tid) {
-    const int hc = zc / 2, npiece = 3 * QR * QC;
+// stage the window's records verbatim: srec[uw][vw][12], source record reflected.  All of a
+// thread's 16-byte pieces are requested before the first one is written to LDS (one memory
+// latency per tile, not one per piece).
+template <int QR, int QC>
+DT_HD void inv_rec_stage(const float *Yhb, int zr, int zc, float *srec, int ro, int co, int tid) {
+    constexpr int NPIECE = 3 * QR * QC, NP = (NPIECE + DT_NT - 1) / DT_NT;
+    const int hc = zc / 2;
     const bool interior = ro >= 0 && ro + 2 * QR <= zr && co >= 0 && co + 2 * QC <= zc;
-    f4 *dst = reinterpret_cast<f4 *>(srec);
-    for (int piece = tid; piece < npiece; piece += DT_NT) {
+    float px[NP], py[NP], pz[NP], pw[NP];       // scalar arrays: f4 arrays end up in scratch
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        int piece = tid + k * DT_NT;
+        if (NP * DT_NT > NPIECE && piece >= NPIECE) piece = NPIECE - 1;      // clamp: no branch
         int rec = piece / 3, part = piece - 3 * rec;
         int uw = rec / QC, vw = rec - uw * QC;
         int ur = ro + 2 * uw, vc = co + 2 * vw;
         if (!interior) { ur = reflect_i(ur, zr); vc = reflect_i(vc, zc); }
-        dst[piece] = reinterpret_cast<const f4 *>(Yhb + ((int64_t)(ur >> 1) * hc + (vc >> 1)) * 12)[part];
+        f4 t = reinterpret_cast<const f4 *>(Yhb + ((int64_t)(ur >> 1) * hc + (vc >> 1)) * 12)[part];
+        px[k] = t.x; py[k] = t.y; pz[k] = t.z; pw[k] = t.w;
+    }
+    f4 *dst = reinterpret_cast<f4 *>(srec);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        int piece = tid + k * DT_NT;
+        if (NP * DT_NT == NPIECE || piece < NPIECE) dst[piece] = f4{px[k], py[k], pz[k], pw[k]};
     }
 }
 

@@ -112,12 +112,29 @@ class _Plan2d(object):
 def _level_geometry(rows, cols, nlevels):
     """Shapes of every level exactly as dtcwt/numpy/transform2d.py:86-160 produces them."""
     R, C = rows + (rows & 1), cols + (cols & 1)
-    lv = [dict(inR=rows, inC=cols, padR=rows & 1, padC=cols & 1, loR=R, loC=C)]
+    lv = [dict(inR=rows, inC=cols, padR=rows & 1, padC=cols & 1, LR=R, LC=C, loR=R, loC=C)]
     for _ in range(1, nlevels):
         r, c = lv[-1]['loR'], lv[-1]['loC']
         pr, pc = int(r % 4 != 0), int(c % 4 != 0)
-        lv.append(dict(inR=r, inC=c, padR=pr, padC=pc, loR=(r + 2 * pr) // 2, loC=(c + 2 * pc) // 2))
+        lv.append(dict(inR=r, inC=c, padR=pr, padC=pc, LR=r + 2 * pr, LC=c + 2 * pc,
+                       loR=(r + 2 * pr) // 2, loC=(c + 2 * pc) // 2))
     return (R, C), lv
+
+
+_MIN_FUSED_DIM = 40     # == DT_MIN_FUSED_DIM (dtcwt_amd/csrc/fused2d_tiles.hpp)
+
+
+def _fused_levels(rows, cols, nlevels):
+    """How many leading levels are large enough for the fused kernels (one-bounce
+    reflection needs every level >= 40 samples wide); coarser levels of the same transform
+    run through the generic device filters."""
+    _, lv = _level_geometry(rows, cols, nlevels)
+    k = 0
+    for g in lv:
+        if min(g['LR'], g['LC']) < _MIN_FUSED_DIM or min(g['loR'], g['loC']) < _MIN_FUSED_DIM // 2:
+            break
+        k += 1
+    return k
 
 
 class Transform2d(object):
@@ -181,20 +198,58 @@ class Transform2d(object):
         a leading batch axis."""
         B, r, c = Xd.shape
         if Xd.dtype == np.float32:
-            plan = self._plan(B, r, c, nlevels)
+            k = _fused_levels(r, c, nlevels)
+            plan = self._plan(B, r, c, k) if k > 0 else None
             if plan is not None:
-                return plan.forward(Xd, include_scale)
+                Yl, Yh, Ys = plan.forward(Xd, include_scale)
+                if k == nlevels:
+                    return Yl, Yh, Ys
+                # coarse tail (levels too small for the fused tiles): generic device filters
+                Yl, Yh2, Ys2 = self._forward_generic(None, nlevels, include_scale, start_level=k, LoLo=Yl,
+                                                     shape=(B, r, c))
+                return Yl, Yh + Yh2, (Ys + Ys2) if include_scale else None
         return self._forward_generic(Xd, nlevels, include_scale)
 
-    def _forward_generic(self, Xd, nlevels, include_scale):
+    def _forward_generic(self, Xd, nlevels, include_scale, start_level=0, LoLo=None, shape=None):
+        """Levels start_level .. nlevels-1 with the generic device filters.  With
+        start_level > 0, *LoLo* is the lowpass of level start_level-1 and *shape* the
+        (B, rows, cols) of the original input."""
         biort, qshift = self._taps()
         h0o, g0o, h1o, g1o = biort[:4]
         h0a, h0b, g0a, g0b, h1a, h1b, g1a, g1b = qshift[:8]
         bp1, bp2 = len(biort) >= 6, len(qshift) >= 12
-        B, r, c = Xd.shape
-        cdt = np.complex64 if Xd.dtype == np.float32 else np.complex128
+        B, r, c = Xd.shape if Xd is not None else shape
+        src = Xd if Xd is not None else LoLo
+        ctx = src.ctx
+        cdt = np.complex64 if src.dtype == np.float32 else np.complex128
         (R, C), lv = _level_geometry(r, c, nlevels)
         Yh, Ys = [], []
+        if start_level == 0:
+            LoLo = self._forward_generic_level1(Xd, lv, cdt, Yh, Ys)
+        for level in range(max(start_level, 1), nlevels):        # :132-160
+            g = lv[level]
+            pr, pc = (g['padR'],) * 2, (g['padC'],) * 2
+            Lo = ll.axis_coldfilt(LoLo, h0b, h0a, axis=1, pad=pr)
+            Hi = ll.axis_coldfilt(LoLo, h1b, h1a, axis=1, pad=pr)
+            if bp2:
+                Ba = ll.axis_coldfilt(LoLo, qshift[9], qshift[8], axis=1, pad=pr)
+            LoLo = ll.axis_coldfilt(Lo, h0b, h0a, axis=2, pad=pc)
+            y = DeviceArray(ctx, (B, LoLo.shape[1] >> 1, LoLo.shape[2] >> 1, 6), cdt)
+            ll.q2c(ll.axis_coldfilt(Hi, h0b, h0a, axis=2, pad=pc), y, 0, 5)
+            ll.q2c(ll.axis_coldfilt(Lo, h1b, h1a, axis=2, pad=pc), y, 2, 3)
+            if bp2:
+                ll.q2c(ll.axis_coldfilt(Ba, qshift[9], qshift[8], axis=2, pad=pc), y, 1, 4)
+            else:
+                ll.q2c(ll.axis_coldfilt(Hi, h1b, h1a, axis=2, pad=pc), y, 1, 4)
+            Yh.append(y)
+            Ys.append(LoLo)
+        return LoLo, Yh, (Ys if include_scale else None)
+
+    def _forward_generic_level1(self, Xd, lv, cdt, Yh, Ys):
+        biort, qshift = self._taps()
+        h0o, g0o, h1o, g1o = biort[:4]
+        bp1 = len(biort) >= 6
+        B = Xd.shape[0]
         # level 1 (transform2d.py:112-130); odd sizes extended by index math (:86-94)
         pr, pc = (0, lv[0]['padR']), (0, lv[0]['padC'])
         Lo = ll.axis_colfilter(Xd, h0o, axis=1, pad=pr)
@@ -210,24 +265,7 @@ class Transform2d(object):
             ll.q2c(ll.axis_colfilter(Hi, h1o, axis=2, pad=pc), y, 1, 4)
         Yh.append(y)
         Ys.append(LoLo)
-        for level in range(1, nlevels):                      # :132-160
-            g = lv[level]
-            pr, pc = (g['padR'],) * 2, (g['padC'],) * 2
-            Lo = ll.axis_coldfilt(LoLo, h0b, h0a, axis=1, pad=pr)
-            Hi = ll.axis_coldfilt(LoLo, h1b, h1a, axis=1, pad=pr)
-            if bp2:
-                Ba = ll.axis_coldfilt(LoLo, qshift[9], qshift[8], axis=1, pad=pr)
-            LoLo = ll.axis_coldfilt(Lo, h0b, h0a, axis=2, pad=pc)
-            y = DeviceArray(Xd.ctx, (B, LoLo.shape[1] >> 1, LoLo.shape[2] >> 1, 6), cdt)
-            ll.q2c(ll.axis_coldfilt(Hi, h0b, h0a, axis=2, pad=pc), y, 0, 5)
-            ll.q2c(ll.axis_coldfilt(Lo, h1b, h1a, axis=2, pad=pc), y, 2, 3)
-            if bp2:
-                ll.q2c(ll.axis_coldfilt(Ba, qshift[9], qshift[8], axis=2, pad=pc), y, 1, 4)
-            else:
-                ll.q2c(ll.axis_coldfilt(Hi, h1b, h1a, axis=2, pad=pc), y, 1, 4)
-            Yh.append(y)
-            Ys.append(LoLo)
-        return LoLo, Yh, (Ys if include_scale else None)
+        return LoLo
 
     @staticmethod
     def _log_extension(original, extended):
@@ -316,14 +354,23 @@ class Transform2d(object):
         crops = self._check_shapes(Yl.shape[1:], [y.shape[1:] for y in Yh])
         R, C = 2 * Yh[0].shape[1], 2 * Yh[0].shape[2]
         if Yl.dtype == np.float32:
-            plan = self._plan(B, R, C, nl)
+            k = _fused_levels(R, C, nl)
+            plan = self._plan(B, R, C, k) if k > 0 else None
             if plan is not None:
-                if plan.low != tuple(Yl.shape[1:]) or any(plan.high[l] != tuple(Yh[l].shape[1:3]) for l in range(nl)):
+                if any(plan.high[l] != tuple(Yh[l].shape[1:3]) for l in range(k)):
                     raise ValueError('Sizes of highpasses are not valid for DTWAVEIFM2')
-                return plan.inverse(Yl, Yh, gain_mask)
+                Z = Yl
+                if k < nl:      # coarse tail first, with the generic device filters
+                    Z = self._inverse_generic(Yl, Yh, gain_mask, crops, stop_level=k)
+                if plan.low != tuple(Z.shape[1:]):
+                    raise ValueError('Sizes of highpasses are not valid for DTWAVEIFM2')
+                gm = None if gain_mask is None else np.asarray(gain_mask, dtype=np.float64)[:, :k]
+                return plan.inverse(Z, list(Yh[:k]), gm)
         return self._inverse_generic(Yl, Yh, gain_mask, crops)
 
-    def _inverse_generic(self, Z, Yh, gain_mask, crops):
+    def _inverse_generic(self, Z, Yh, gain_mask, crops, stop_level=0):
+        """Levels len(Yh) .. stop_level+1 with the generic device filters (stop_level = 0:
+        the whole inverse)."""
         biort, qshift = self._taps()
         h0o, g0o, h1o, g1o = biort[:4]
         h0a, h0b, g0a, g0b, h1a, h1b, g1a, g1b = qshift[:8]
@@ -331,7 +378,7 @@ class Transform2d(object):
         nl = len(Yh)
         gm = np.ones((6, nl)) if gain_mask is None else np.array(gain_mask, dtype=np.float64)
         level = nl
-        while level >= 2:                                    # transform2d.py:242-273
+        while level >= 2 and level > stop_level:             # transform2d.py:242-273
             w, g = Yh[level - 1], gm[:, level - 1]
             cr, cc = crops[level - 1]
             lh = ll.c2q(w, 0, 5, g[0], g[5])
@@ -349,7 +396,7 @@ class Transform2d(object):
             if bp2:
                 ll.axis_colifilt(y2bp, qshift[11], qshift[10], axis=2, crop=(cc, cc), out=Z, accumulate=True)
             level -= 1
-        if level == 1:                                       # :275-293
+        if level == 1 and stop_level == 0:                   # :275-293
             w, g = Yh[0], gm[:, 0]
             lh = ll.c2q(w, 0, 5, g[0], g[5])
             hl = ll.c2q(w, 2, 3, g[2], g[3])

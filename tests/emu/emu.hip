@@ -81,7 +81,7 @@ static int run_inv1(Inv1Params p) {
                 const float *Yhb = p.Yh + (int64_t)b * (p.R / 2) * (p.C / 2) * 12;
                 for (int t = 0; t < DT_NT; ++t) inv1r_fetch<C>(p, wz[t], t, b, r0, c0);
                 for (int t = 0; t < DT_NT; ++t)
-                    inv_rec_stage(Yhb, p.R, p.C, srec, C::QR, C::QC, r0 - C::HE, c0 - C::HE, t);
+                    inv_rec_stage<C::QR, C::QC>(Yhb, p.R, p.C, srec, r0 - C::HE, c0 - C::HE, t);
                 for (int t = 0; t < DT_NT; ++t) inv1r_cols<C>(p, wz[t], srec, y1, y2, t, r0, c0);
                 for (int t = 0; t < DT_NT; ++t) inv1d_rows<C>(p, y1, y2, t, b, r0, c0);
             }
@@ -103,7 +103,7 @@ static int run_inv2(Inv2Params p) {
                 const float *Yhb = p.Yh + (int64_t)b * (p.zr / 2) * (p.zc / 2) * 12;
                 for (int t = 0; t < DT_NT; ++t) inv2r_fetch<C>(p, wz[t], t, b, r0, c0);
                 for (int t = 0; t < DT_NT; ++t)
-                    inv_rec_stage(Yhb, p.zr, p.zc, srec, C::QR, C::QC, r0 + C::ORG, c0 + C::ORG, t);
+                    inv_rec_stage<C::QR, C::QC>(Yhb, p.zr, p.zc, srec, r0 + C::ORG, c0 + C::ORG, t);
                 for (int t = 0; t < DT_NT; ++t) inv2r_cols<C>(p, wz[t], srec, y1, y2, t, r0, c0);
                 for (int t = 0; t < DT_NT; ++t) inv2_rows<C>(p, y1, y2, t, b, r0, c0);
             }

@@ -27,9 +27,11 @@ def _mandrill():
 
 def test_plan_is_used_for_float32():
     t = Transform2d()
-    assert t.plan(1, 64, 64, 3) is not None
+    assert t.plan(1, 256, 256, 3) is not None
     with pytest.raises(NotImplementedError):
-        Transform2d('near_sym_b_bp', 'qshift_b_bp').plan(1, 64, 64, 3)
+        Transform2d('near_sym_b_bp', 'qshift_b_bp').plan(1, 256, 256, 3)
+    with pytest.raises(NotImplementedError):          # levels narrower than 40 samples: generic kernels
+        t.plan(1, 64, 64, 3)
 
 
 @pytest.mark.parametrize('bn,qn', WAVES)

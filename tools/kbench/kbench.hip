@@ -311,11 +311,57 @@ __global__ void __launch_bounds__(DT_NT) k_inv1_r(Inv1Params p) {
     const float *Yhb = p.Yh + (int64_t)b * (p.R / 2) * (p.C / 2) * 12;
     float wz[C::WN];
     inv1r_fetch<C>(p, wz, threadIdx.x, b, r0, c0);
-    inv_rec_stage(Yhb, p.R, p.C, srec, C::QR, C::QC, r0 - C::HE, c0 - C::HE, threadIdx.x);
+    inv_rec_stage<C::QR, C::QC>(Yhb, p.R, p.C, srec, r0 - C::HE, c0 - C::HE, threadIdx.x);
     __syncthreads();
     inv1r_cols<C>(p, wz, srec, y1, y2, threadIdx.x, r0, c0);
     __syncthreads();
     inv1d_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0);
+}
+template <class C, int PADF>
+__global__ void __launch_bounds__(DT_NT) k_inv1_ro(Inv1Params p) {
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS + PADF];
+    if (p.B == 12345) smem[C::LDS_FLOATS + PADF - 1] = 1.f;
+    const int ntile = p.tilesR * p.tilesC * p.B;
+    int t = tile_of(blockIdx.x, ntile, p.xcd_order);
+    if (t >= ntile) return;
+    int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    float *srec = smem, *y1 = srec + C::SREC, *y2 = y1 + C::SY;
+    int r0 = tr * C::TR, c0 = tc * C::TC;
+    const float *Yhb = p.Yh + (int64_t)b * (p.R / 2) * (p.C / 2) * 12;
+    float wz[C::WN];
+    inv1r_fetch<C>(p, wz, threadIdx.x, b, r0, c0);
+    inv_rec_stage<C::QR, C::QC>(Yhb, p.R, p.C, srec, r0 - C::HE, c0 - C::HE, threadIdx.x);
+    __syncthreads();
+    inv1r_cols<C>(p, wz, srec, y1, y2, threadIdx.x, r0, c0);
+    __syncthreads();
+    inv1d_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0);
+}
+template <class C, int PADF> void launchi1_ro(Inv1Params &p) {
+    p.tilesR = cdiv(p.R, C::TR); p.tilesC = cdiv(p.C, C::TC);
+    k_inv1_ro<C, PADF><<<cdiv(p.tilesR * p.tilesC * p.B, 8) * 8, DT_NT>>>(p);
+}
+template <class C, int DELAY>
+__global__ void __launch_bounds__(DT_NT) k_inv1_rs(Inv1Params p) {
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
+    const int ntile = p.tilesR * p.tilesC * p.B;
+    int t = tile_of(blockIdx.x, ntile, p.xcd_order);
+    if (t >= ntile) return;
+    int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    float *srec = smem, *y1 = srec + C::SREC, *y2 = y1 + C::SY;
+    int r0 = tr * C::TR, c0 = tc * C::TC;
+    const float *Yhb = p.Yh + (int64_t)b * (p.R / 2) * (p.C / 2) * 12;
+    { int ph = (blockIdx.x >> 3) % 3; for (int d = 0; d < ph * DELAY; ++d) __builtin_amdgcn_s_sleep(100); }
+    float wz[C::WN];
+    inv1r_fetch<C>(p, wz, threadIdx.x, b, r0, c0);
+    inv_rec_stage<C::QR, C::QC>(Yhb, p.R, p.C, srec, r0 - C::HE, c0 - C::HE, threadIdx.x);
+    __syncthreads();
+    inv1r_cols<C>(p, wz, srec, y1, y2, threadIdx.x, r0, c0);
+    __syncthreads();
+    inv1d_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0);
+}
+template <class C, int DELAY> void launchi1_rs(Inv1Params &p) {
+    p.tilesR = cdiv(p.R, C::TR); p.tilesC = cdiv(p.C, C::TC);
+    k_inv1_rs<C, DELAY><<<cdiv(p.tilesR * p.tilesC * p.B, 8) * 8, DT_NT>>>(p);
 }
 // persistent, software-pipelined: each workgroup walks tiles t = blockIdx.x + k*gridDim.x and
 // prefetches the next tile's records + lowpass window into registers during the current
@@ -395,9 +441,10 @@ template <class C, int BPC> void launchi1_rp(Inv1Params &p) {
 }
 // ablation of k_inv1_r: AB bit0 = skip record staging, bit1 = skip lowpass fetch, bit2 = skip
 // column pass, bit3 = skip row pass compute+store, bit4 = skip only the global store
-template <class C, int AB>
+template <class C, int AB, int PADF = 0>
 __global__ void __launch_bounds__(DT_NT) k_inv1_abl(Inv1Params p) {
-    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS + PADF];
+    if (p.B == 12345) smem[C::LDS_FLOATS + PADF - 1] = 1.f;
     const int ntile = p.tilesR * p.tilesC * p.B;
     int t = tile_of(blockIdx.x, ntile, p.xcd_order);
     if (t >= ntile) return;
@@ -409,7 +456,7 @@ __global__ void __launch_bounds__(DT_NT) k_inv1_abl(Inv1Params p) {
     float wz[C::WN];
     if (!(AB & 2)) inv1r_fetch<C>(p, wz, threadIdx.x, b, r0, c0);
     else for (int j = 0; j < C::WN; ++j) wz[j] = (float)(threadIdx.x + j);
-    if (!(AB & 1)) inv_rec_stage(Yhb, p.R, p.C, srec, C::QR, C::QC, r0 - C::HE, c0 - C::HE, threadIdx.x);
+    if (!(AB & 1)) inv_rec_stage<C::QR, C::QC>(Yhb, p.R, p.C, srec, r0 - C::HE, c0 - C::HE, threadIdx.x);
     __syncthreads();
     if (!(AB & 4)) inv1r_cols<C>(p, wz, srec, y1, y2, threadIdx.x, r0, c0);
     else { float a = 0; for (int j = 0; j < C::WN; ++j) a += wz[j]; y1[threadIdx.x] = a + srec[threadIdx.x]; }
@@ -423,9 +470,9 @@ __global__ void __launch_bounds__(DT_NT) k_inv1_abl(Inv1Params p) {
         }
     } else if (threadIdx.x == 0 && y1[5] == 123.456f) p.X[0] = y2[7];
 }
-template <class C, int AB> void launchi1_abl(Inv1Params &p) {
+template <class C, int AB, int PADF = 0> void launchi1_abl(Inv1Params &p) {
     p.tilesR = cdiv(p.R, C::TR); p.tilesC = cdiv(p.C, C::TC);
-    k_inv1_abl<C, AB><<<cdiv(p.tilesR * p.tilesC * p.B, 8) * 8, DT_NT>>>(p);
+    k_inv1_abl<C, AB, PADF><<<cdiv(p.tilesR * p.tilesC * p.B, 8) * 8, DT_NT>>>(p);
 }
 template <class C, int BPC> void launchi1_rq(Inv1Params &p) {
     p.tilesR = cdiv(p.R, C::TR); p.tilesC = cdiv(p.C, C::TC);
@@ -444,7 +491,7 @@ __global__ void __launch_bounds__(DT_NT) k_inv1_rz(Inv1Params p) {
     int r0 = tr * C::TR, c0 = tc * C::TC;
     const float *Yhb = p.Yh + (int64_t)b * (p.R / 2) * (p.C / 2) * 12;
     inv_load_low(p.Z + (int64_t)b * p.R * p.C, p.R, p.C, s0, C::NR, C::NC, r0 - C::HE, c0 - C::HE, threadIdx.x);
-    inv_rec_stage(Yhb, p.R, p.C, srec, C::QR, C::QC, r0 - C::HE, c0 - C::HE, threadIdx.x);
+    inv_rec_stage<C::QR, C::QC>(Yhb, p.R, p.C, srec, r0 - C::HE, c0 - C::HE, threadIdx.x);
     __syncthreads();
     float wz[C::WN];
     inv1r_fetch_lds<C>(s0, wz, threadIdx.x);
@@ -468,7 +515,7 @@ __global__ void __launch_bounds__(DT_NT) k_inv2_r(Inv2Params p) {
     const float *Yhb = p.Yh + (int64_t)b * (p.zr / 2) * (p.zc / 2) * 12;
     float wz[C::WS];
     inv2r_fetch<C>(p, wz, threadIdx.x, b, r0, c0);
-    inv_rec_stage(Yhb, p.zr, p.zc, srec, C::QR, C::QC, r0 + C::ORG, c0 + C::ORG, threadIdx.x);
+    inv_rec_stage<C::QR, C::QC>(Yhb, p.zr, p.zc, srec, r0 + C::ORG, c0 + C::ORG, threadIdx.x);
     __syncthreads();
     inv2r_cols<C>(p, wz, srec, y1, y2, threadIdx.x, r0, c0);
     __syncthreads();
@@ -735,6 +782,26 @@ int main(int argc, char **argv) {
             vi.push_back({"I1 rz 32x24 rs4 xcd", launchi1_rz<Inv1RCfg<32, 24, 4, 7, 5>>, 1});
             vi.push_back({"I1 rz 64x24 rs8 xcd", launchi1_rz<Inv1RCfg<64, 24, 8, 7, 5>>, 1});
             vi.push_back({"I1 rz 16x120 rs8 xcd", launchi1_rz<Inv1RCfg<16, 120, 8, 7, 5>>, 1});
+            vi.push_back({"I1 stag d1", launchi1_rs<Inv1RCfg<16, 56, 4, 7, 5>, 1>, 1});
+            vi.push_back({"I1 stag d4", launchi1_rs<Inv1RCfg<16, 56, 4, 7, 5>, 4>, 1});
+            vi.push_back({"I1 stag d16", launchi1_rs<Inv1RCfg<16, 56, 4, 7, 5>, 16>, 1});
+            vi.push_back({"I1 stag d0", launchi1_rs<Inv1RCfg<16, 56, 4, 7, 5>, 0>, 1});
+            vi.push_back({"I1 one full", launchi1_abl<Inv1RCfg<16, 56, 4, 7, 5>, 0, 33000>, 1});
+            vi.push_back({"I1 one -recs", launchi1_abl<Inv1RCfg<16, 56, 4, 7, 5>, 1, 33000>, 1});
+            vi.push_back({"I1 one -z", launchi1_abl<Inv1RCfg<16, 56, 4, 7, 5>, 2, 33000>, 1});
+            vi.push_back({"I1 one -recs-z", launchi1_abl<Inv1RCfg<16, 56, 4, 7, 5>, 3, 33000>, 1});
+            vi.push_back({"I1 one -cols", launchi1_abl<Inv1RCfg<16, 56, 4, 7, 5>, 4, 33000>, 1});
+            vi.push_back({"I1 one -rows", launchi1_abl<Inv1RCfg<16, 56, 4, 7, 5>, 8, 33000>, 1});
+            vi.push_back({"I1 one -store", launchi1_abl<Inv1RCfg<16, 56, 4, 7, 5>, 16, 33000>, 1});
+            vi.push_back({"I1 one loadsonly", launchi1_abl<Inv1RCfg<16, 56, 4, 7, 5>, 12, 33000>, 1});
+            vi.push_back({"I1 one nothing", launchi1_abl<Inv1RCfg<16, 56, 4, 7, 5>, 15, 33000>, 1});
+            vi.push_back({"I1 one cached", launchi1_abl<Inv1RCfg<16, 56, 4, 7, 5>, 32, 33000>, 1});
+            vi.push_back({"I1 occ 6 (26.6K)", launchi1_ro<Inv1RCfg<16, 56, 4, 7, 5>, 0>, 1});
+            vi.push_back({"I1 occ 5 (32K)", launchi1_ro<Inv1RCfg<16, 56, 4, 7, 5>, 1400>, 1});
+            vi.push_back({"I1 occ 4 (40K)", launchi1_ro<Inv1RCfg<16, 56, 4, 7, 5>, 3400>, 1});
+            vi.push_back({"I1 occ 3 (53K)", launchi1_ro<Inv1RCfg<16, 56, 4, 7, 5>, 6700>, 1});
+            vi.push_back({"I1 occ 2 (80K)", launchi1_ro<Inv1RCfg<16, 56, 4, 7, 5>, 13500>, 1});
+            vi.push_back({"I1 occ 1 (159K)", launchi1_ro<Inv1RCfg<16, 56, 4, 7, 5>, 33000>, 1});
             vi.push_back({"I1 abl full", launchi1_abl<Inv1RCfg<16, 56, 4, 7, 5>, 0>, 1});
             vi.push_back({"I1 abl -recs", launchi1_abl<Inv1RCfg<16, 56, 4, 7, 5>, 1>, 1});
             vi.push_back({"I1 abl -z", launchi1_abl<Inv1RCfg<16, 56, 4, 7, 5>, 2>, 1});
