@@ -788,11 +788,12 @@ DT_HD ColTask inv_col_task(int tid) {
 
 // Samples (top, bottom) of the three planes at column parity e from one raw record
 // (A.4 with gains folded in): plane "lh" = subbands (0,5), "hl" = (2,3), "hh" = (1,4).
-DT_HD void rec_samples(const float *rec, const float *g, int e, float (&top)[3], float (&bot)[3]) {
+template <int E>
+DT_HD void rec_samples_t(const float *rec, const float *g, float (&top)[3], float (&bot)[3]) {
     const f4 r0 = reinterpret_cast<const f4 *>(rec)[0];
     const f4 r1 = reinterpret_cast<const f4 *>(rec)[1];
     const f4 r2 = reinterpret_cast<const f4 *>(rec)[2];
-    if (e == 0) {        // a = Re(g0 w0 + g1 w1), c = Im(g0 w0 - g1 w1)
+    if (E == 0) {        // a = Re(g0 w0 + g1 w1), c = Im(g0 w0 - g1 w1)
         top[0] = r0.x * g[0] + r2.z * g[5]; bot[0] = r0.y * g[0] - r2.w * g[5];
         top[1] = r1.x * g[2] + r1.z * g[3]; bot[1] = r1.y * g[2] - r1.w * g[3];
         top[2] = r0.z * g[1] + r2.x * g[4]; bot[2] = r0.w * g[1] - r2.y * g[4];
@@ -802,6 +803,23 @@ DT_HD void rec_samples(const float *rec, const float *g, int e, float (&top)[3],
         top[2] = r0.w * g[1] + r2.y * g[4]; bot[2] = r2.x * g[4] - r0.z * g[1];
     }
 }
+// runtime-parity form (border tiles: reflection can flip the column parity per lane);
+// branch-free: both parities are cheap enough to compute and select
+DT_HD void rec_samples(const float *rec, const float *g, int e, float (&top)[3], float (&bot)[3]) {
+    float t0[3], b0[3], t1[3], b1[3];
+    rec_samples_t<0>(rec, g, t0, b0);
+    rec_samples_t<1>(rec, g, t1, b1);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { top[k] = e ? t1[k] : t0[k]; bot[k] = e ? b1[k] : b0[k]; }
+}
+
+// The column parity of a thread's task is uniform per wavefront (inv_col_task): tell the
+// compiler (scalar branch, straight-line bodies, batched LDS reads).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DT_WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#else
+#define DT_WAVE_UNIFORM(x) (x)
+#endif
 
 template <class C>
 DT_HD void inv1r_fetch(const Inv1Params &p, float (&w0)[C::WN], int tid, int b, int r0, int c0) {
@@ -823,9 +841,9 @@ DT_HD void inv1r_fetch(const Inv1Params &p, float (&w0)[C::WN], int tid, int b, 
     }
 }
 
-template <class C>
-DT_HD void inv1r_cols(const Inv1Params &p, const float (&w0)[C::WN], const float *srec, float *y1,
-                      float *y2, int tid, int r0, int c0) {
+template <class C, int E>
+DT_HD void inv1r_cols_e(const Inv1Params &p, const float (&w0)[C::WN], const float *srec, float *y1,
+                        float *y2, int tid, int r0, int c0) {
     const ColTask t = inv_col_task<C>(tid);
     if (!t.valid) return;
     const int ro = r0 - C::HE, co = c0 - C::HE;
@@ -837,7 +855,7 @@ DT_HD void inv1r_cols(const Inv1Params &p, const float (&w0)[C::WN], const float
 #pragma unroll
         for (int ru = 0; ru < C::WN / 2; ++ru) {
             float top[3], bot[3];
-            rec_samples(rbase + ru * C::QC * 12, p.g, t.e, top, bot);
+            rec_samples_t<E>(rbase + ru * C::QC * 12, p.g, top, bot);
             w1[2 * ru] = top[0]; w1[2 * ru + 1] = bot[0];
             w2[2 * ru] = top[1]; w2[2 * ru + 1] = bot[1];
             w3[2 * ru] = top[2]; w3[2 * ru + 1] = bot[2];
@@ -870,6 +888,13 @@ DT_HD void inv1r_cols(const Inv1Params &p, const float (&w0)[C::WN], const float
         y1[(t.strip * C::RS + q) * C::NC + cc] = a;
         y2[(t.strip * C::RS + q) * C::NC + cc] = bq;
     }
+}
+
+template <class C>
+DT_HD void inv1r_cols(const Inv1Params &p, const float (&w0)[C::WN], const float *srec, float *y1,
+                      float *y2, int tid, int r0, int c0) {
+    if (DT_WAVE_UNIFORM((tid >> 6) & 1)) inv1r_cols_e<C, 1>(p, w0, srec, y1, y2, tid, r0, c0);
+    else inv1r_cols_e<C, 0>(p, w0, srec, y1, y2, tid, r0, c0);
 }
 
 // lowpass window from an LDS plane s0[NR][NC] (staged by inv_load_low) instead of global:
@@ -986,9 +1011,9 @@ DT_HD void inv2r_fetch(const Inv2Params &p, float (&w0)[C::WS], int tid, int b, 
     }
 }
 
-template <class C>
-DT_HD void inv2r_cols(const Inv2Params &p, const float (&w0)[C::WS], const float *srec, float *y1,
-                      float *y2, int tid, int r0, int c0) {
+template <class C, int E>
+DT_HD void inv2r_cols_e(const Inv2Params &p, const float (&w0)[C::WS], const float *srec, float *y1,
+                        float *y2, int tid, int r0, int c0) {
     const ColTask t = inv_col_task<C>(tid);
     if (!t.valid) return;
     const int ro = r0 + C::ORG, co = c0 + C::ORG;
@@ -1000,7 +1025,7 @@ DT_HD void inv2r_cols(const Inv2Params &p, const float (&w0)[C::WS], const float
 #pragma unroll
         for (int ru = 0; ru < C::WS / 2; ++ru) {
             float top[3], bot[3];
-            rec_samples(rbase + ru * C::QC * 12, p.g, t.e, top, bot);
+            rec_samples_t<E>(rbase + ru * C::QC * 12, p.g, top, bot);
             w1[2 * ru] = top[0]; w1[2 * ru + 1] = bot[0];
             w2[2 * ru] = top[1]; w2[2 * ru + 1] = bot[1];
             w3[2 * ru] = top[2]; w3[2 * ru + 1] = bot[2];
@@ -1029,6 +1054,13 @@ DT_HD void inv2r_cols(const Inv2Params &p, const float (&w0)[C::WS], const float
 #pragma unroll
         for (int e = 0; e < 4; ++e) y2[(4 * (t.strip * C::JS + q) + e) * C::NC + cc] = a[e] + tt[e];
     }
+}
+
+template <class C>
+DT_HD void inv2r_cols(const Inv2Params &p, const float (&w0)[C::WS], const float *srec, float *y1,
+                      float *y2, int tid, int r0, int c0) {
+    if (DT_WAVE_UNIFORM((tid >> 6) & 1)) inv2r_cols_e<C, 1>(p, w0, srec, y1, y2, tid, r0, c0);
+    else inv2r_cols_e<C, 0>(p, w0, srec, y1, y2, tid, r0, c0);
 }
 
 }  // namespace dt2d

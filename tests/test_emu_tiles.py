@@ -25,8 +25,8 @@ TOL = 2e-6
 
 
 def _build():
-    deps = [EMU_SRC, os.path.join(ROOT, 'dtcwt_amd', 'csrc', 'fused2d_tiles.hpp'),
-            os.path.join(ROOT, 'dtcwt_amd', 'csrc', 'fused2d_table.hpp')]
+    deps = [EMU_SRC] + [os.path.join(ROOT, 'dtcwt_amd', 'csrc', f) for f in
+                        ('fused2d_tiles.hpp', 'fused2d_tiles_v2.hpp', 'fused2d_table.hpp')]
     if os.path.exists(EMU_LIB) and all(os.path.getmtime(EMU_LIB) >= os.path.getmtime(d) for d in deps):
         return
     if not os.path.exists(HIPCC):

@@ -238,3 +238,49 @@ def test_perfect_reconstruction_large_and_linear():
     want = o.Transform2d(biort('near_sym_a'), qshift('qshift_a')).forward(crop, nlevels=2)
     assert_close(p.highpasses[0][:96, :96], want.highpasses[0][:96, :96], XFM_TOL)
     assert_close(p.highpasses[1][:40, :40], want.highpasses[1][:40, :40], XFM_TOL)
+
+
+def test_compat_wrappers_follow_backend():
+    """dtcwt_amd.compat mirrors dtcwt/compat.py on the active (hip) backend."""
+    from dtcwt_amd import compat
+    m = _mandrill()
+    Yl, Yh = compat.dtwavexfm2(m, 3)
+    want = o.Transform2d(biort('near_sym_a'), qshift('qshift_a')).forward(as_f64(m), nlevels=3)
+    assert_close(Yl, want.lowpass, XFM_TOL)
+    assert_close(Yh[2], want.highpasses[2], XFM_TOL)
+    assert np.abs(compat.dtwaveifm2(Yl, Yh) - m).max() < 5e-6
+    Yl, Yh, Ys = compat.dtwavexfm2b(m[:64, :64], 2, 'near_sym_b_bp', 'qshift_b_bp', include_scale=True)
+    assert len(Ys) == 2 and Yh[0].shape == (32, 32, 6)
+    v = m[:, 0].astype(np.float64)
+    Yl1, Yh1 = compat.dtwavexfm(v, 4)
+    assert np.abs(compat.dtwaveifm(Yl1, Yh1) - v).max() < 1e-10
+    V = np.random.RandomState(1).standard_normal((16, 16, 16))
+    Yl3, Yh3 = compat.dtwavexfm3(V, 2)
+    assert np.abs(compat.dtwaveifm3(Yl3, Yh3) - V).max() < 1e-10
+
+
+def test_batched_config_c3_shape():
+    """BASELINE config[2] (batched 64 x 1024 x 1024 f32, nlevels=5), reduced to 6 images for the
+    oracle comparison; the full batch is checked through per-image consistency + PR."""
+    rs = np.random.RandomState(1)
+    X = rs.standard_normal((6, 1024, 1024)).astype(np.float32)
+    t = Transform2d()
+    p = t.forward_channels(X, 'nhw', nlevels=5)
+    assert p.lowpass.shape == (6, 64, 64)
+    assert [y.shape for y in p.highpasses] == [(6, 512, 512, 6), (6, 256, 256, 6), (6, 128, 128, 6),
+                                               (6, 64, 64, 6), (6, 32, 32, 6)]
+    to = o.Transform2d(biort('near_sym_a'), qshift('qshift_a'))
+    for i in (0, 5):
+        want = to.forward(as_f64(X[i]), nlevels=5)
+        assert_close(p.lowpass[i], want.lowpass, XFM_TOL)
+        for l in range(5):
+            assert_close(p.highpasses[l][i], want.highpasses[l], XFM_TOL)
+    z = t.inverse_channels(p, 'nhw')
+    assert np.abs(z - X).max() < 2e-5 * np.abs(X).max()
+    # full batch of 64: every image equals the same image transformed alone
+    ctx = default_context()
+    Xb = rs.standard_normal((64, 1024, 1024)).astype(np.float32)
+    pb = t.forward_channels(ctx.to_device(Xb), 'nhw', nlevels=5)
+    single = t.forward(Xb[37], nlevels=5)
+    assert np.array_equal(pb.highpasses[0][37], single.highpasses[0])
+    assert np.array_equal(pb.lowpass[37], single.lowpass)
