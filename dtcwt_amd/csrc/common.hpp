@@ -5,6 +5,8 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <unordered_map>
+#include <vector>
 
 #include "dtcwt_hip.h"
 
@@ -13,6 +15,14 @@ struct dtcwt_hip_ctx {
     hipStream_t stream;
     bool owns_stream;
     int cus;
+    // Size-bucketed cache of freed device buffers.  Every buffer of a context is used on
+    // the context's single stream, so handing a freed buffer to the next allocation of the
+    // same size is safe without synchronising (stream order) -- and it keeps
+    // hipMalloc/hipFree (each a device-wide sync of ~100 us) out of the level loops.
+    std::unordered_map<size_t, std::vector<void *>> pool;   // size -> free buffers
+    std::unordered_map<void *, size_t> live;                // buffer -> size
+    size_t pooled_bytes = 0;
+    size_t pool_limit = (size_t)16 << 30;                   // DTCWT_HIP_POOL_MB overrides
 };
 
 struct dtcwt_hip_event {

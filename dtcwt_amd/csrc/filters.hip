@@ -31,12 +31,30 @@ struct Geo {
     int64_t nwrite;   // nout - crop_lo - crop_hi
     int32_t inner_fast;
     int32_t accumulate;
+    int32_t idx32;    // every extent and the thread count fit in 31 bits: 32-bit index decode
 };
 
 __device__ inline bool decode(const Geo &g, int64_t &o, int64_t &grp, int64_t &i) {
     int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t total = g.outer * g.ngroups * g.inner;
     if (id >= total) return false;
+    if (g.idx32) {      // 64-bit integer division costs hundreds of instructions on gfx950
+        uint32_t u = (uint32_t)id, inner = (uint32_t)g.inner, ng = (uint32_t)g.ngroups;
+        if (g.inner_fast) {
+            uint32_t t = u / inner;
+            i = u - t * inner;
+            uint32_t oo = t / ng;
+            grp = t - oo * ng;
+            o = oo;
+        } else {
+            uint32_t t = u / ng;
+            grp = u - t * ng;
+            uint32_t oo = t / inner;
+            i = t - oo * inner;
+            o = oo;
+        }
+        return true;
+    }
     if (g.inner_fast) {
         i = id % g.inner;
         int64_t t = id / g.inner;
@@ -51,10 +69,16 @@ __device__ inline bool decode(const Geo &g, int64_t &o, int64_t &grp, int64_t &i
     return true;
 }
 
-// logical sample u (any integer) -> real input sample
+// logical sample u (any integer) -> real input sample.  Reflection by repeated bouncing:
+// one iteration for every ordinary signal (|overshoot| < L), a few for signals shorter than
+// the filter; never an integer modulo.
 __device__ inline int64_t src_index(const Geo &g, int64_t u) {
-    int64_t r = dt_reflect(u, g.L) - g.pad_lo;
-    return dt_clamp(r, 0, g.n - 1);
+    int r = (int)u;
+    const int L = (int)g.L;
+    while ((unsigned)r >= (unsigned)L) r = r < 0 ? -1 - r : 2 * L - 1 - r;
+    r -= g.pad_lo;
+    const int n1 = (int)g.n - 1;
+    return r < 0 ? 0 : (r > n1 ? n1 : r);
 }
 
 template <typename T>
@@ -277,6 +301,9 @@ int make_geo(const dtcwt_hip_view *v, int64_t nout_of_L(int64_t, int), int m, in
     g.inner_fast = (v->xsi == 1 && v->ysi == 1) || v->inner == 1 ? 1 : 0;
     if (v->inner > 1 && v->xsn == 1 && v->ysn == 1) g.inner_fast = 0;
     g.accumulate = (flags & DTCWT_HIP_ACCUMULATE) ? 1 : 0;
+    DT_REQUIRE(g.L < ((int64_t)1 << 30), "filter axis too long");
+    int64_t total = g.outer * g.ngroups * g.inner;
+    g.idx32 = (total < ((int64_t)1 << 31) && g.inner < ((int64_t)1 << 31) && g.ngroups < ((int64_t)1 << 31)) ? 1 : 0;
     return 0;
 }
 

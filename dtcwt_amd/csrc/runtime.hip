@@ -1,4 +1,5 @@
 // Runtime part of the C ABI: contexts, device buffers, events (include/dtcwt_hip.h).
+#include <cstdlib>
 #include <cstring>
 
 #include "common.hpp"
@@ -63,6 +64,7 @@ int dtcwt_hip_ctx_create(int device, void *stream, dtcwt_hip_ctx **out) {
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, device) == hipSuccess) c->cus = p.multiProcessorCount;
     else c->cus = 256;
+    if (const char *e = getenv("DTCWT_HIP_POOL_MB")) c->pool_limit = (size_t)atoll(e) << 20;
     *out = c;
     return 0;
 }
@@ -71,6 +73,9 @@ int dtcwt_hip_ctx_destroy(dtcwt_hip_ctx *c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    for (auto &kv : c->pool)
+        for (void *b : kv.second) (void)hipFree(b);
+    c->pool.clear();
     if (c->owns_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -93,19 +98,56 @@ void *dtcwt_hip_ctx_stream(dtcwt_hip_ctx *c) { return c ? (void *)c->stream : nu
 
 int dtcwt_hip_malloc(dtcwt_hip_ctx *c, size_t bytes, void **dptr) {
     DT_REQUIRE(c && dptr, "NULL argument");
-    DT_CHECK_HIP(hipSetDevice(c->device));
     *dptr = nullptr;
     if (bytes == 0) bytes = 16;
-    DT_CHECK_HIP(hipMalloc(dptr, bytes));
+    bytes = (bytes + 255) & ~(size_t)255;
+    auto it = c->pool.find(bytes);
+    if (it != c->pool.end() && !it->second.empty()) {
+        *dptr = it->second.back();
+        it->second.pop_back();
+        c->pooled_bytes -= bytes;
+        c->live[*dptr] = bytes;
+        return 0;
+    }
+    DT_CHECK_HIP(hipSetDevice(c->device));
+    hipError_t e = hipMalloc(dptr, bytes);
+    if (e != hipSuccess && c->pooled_bytes) {        // out of memory: drop the cache and retry
+        (void)hipGetLastError();
+        dtcwt_hip_trim(c);
+        e = hipMalloc(dptr, bytes);
+    }
+    if (e != hipSuccess)
+        return dtcwt_set_error(-2, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    c->live[*dptr] = bytes;
     return 0;
 }
 
 int dtcwt_hip_free(dtcwt_hip_ctx *c, void *dptr) {
     DT_REQUIRE(c, "ctx is NULL");
     if (!dptr) return 0;
+    auto it = c->live.find(dptr);
+    if (it == c->live.end()) return dtcwt_set_error(-1, "free of a pointer this context did not allocate");
+    size_t bytes = it->second;
+    c->live.erase(it);
+    if (c->pooled_bytes + bytes <= c->pool_limit) {
+        c->pool[bytes].push_back(dptr);
+        c->pooled_bytes += bytes;
+        return 0;
+    }
     DT_CHECK_HIP(hipSetDevice(c->device));
     DT_CHECK_HIP(hipStreamSynchronize(c->stream));
     DT_CHECK_HIP(hipFree(dptr));
+    return 0;
+}
+
+int dtcwt_hip_trim(dtcwt_hip_ctx *c) {
+    DT_REQUIRE(c, "ctx is NULL");
+    DT_CHECK_HIP(hipSetDevice(c->device));
+    DT_CHECK_HIP(hipStreamSynchronize(c->stream));
+    for (auto &kv : c->pool)
+        for (void *b : kv.second) (void)hipFree(b);
+    c->pool.clear();
+    c->pooled_bytes = 0;
     return 0;
 }
 

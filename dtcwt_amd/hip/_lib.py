@@ -63,6 +63,7 @@ SIGNATURES = {
     'dtcwt_hip_device_sync': (_i, [_vp]),
     'dtcwt_hip_malloc': (_i, [_vp, _sz, ctypes.POINTER(_vp)]),
     'dtcwt_hip_free': (_i, [_vp, _vp]),
+    'dtcwt_hip_trim': (_i, [_vp]),
     'dtcwt_hip_memcpy_h2d': (_i, [_vp, _vp, _vp, _sz]),
     'dtcwt_hip_memcpy_d2h': (_i, [_vp, _vp, _vp, _sz]),
     'dtcwt_hip_memcpy_d2d': (_i, [_vp, _vp, _vp, _sz]),
@@ -203,6 +204,10 @@ class Context(object):
     def sync(self):
         check(self._lib.dtcwt_hip_sync(self._h))
 
+    def trim(self):
+        """Return cached (freed) device buffers to the driver."""
+        check(self._lib.dtcwt_hip_trim(self._h))
+
     def device_sync(self):
         """hipDeviceSynchronize(): every stream of this device."""
         check(self._lib.dtcwt_hip_device_sync(self._h))
@@ -329,7 +334,7 @@ class DeviceArray(object):
 
     def __del__(self):
         try:
-            if getattr(self, '_owned', False) and self.ptr:
+            if getattr(self, '_owned', False) and self.ptr and getattr(self.ctx, '_h', None):
                 self.ctx._lib.dtcwt_hip_free(self.ctx.handle, self.ptr)
                 self.ptr = 0
         except Exception:

@@ -63,6 +63,9 @@ void *dtcwt_hip_ctx_stream(dtcwt_hip_ctx *ctx);
 /* Device buffers: replace to_device/to_array/empty of dtcwt/opencl/lowlevel.py:169-181. */
 int dtcwt_hip_malloc(dtcwt_hip_ctx *ctx, size_t bytes, void **dptr);
 int dtcwt_hip_free(dtcwt_hip_ctx *ctx, void *dptr);
+/* malloc/free go through a per-context cache of freed buffers (stream-ordered reuse);
+ * trim() returns the cached buffers to the driver (env DTCWT_HIP_POOL_MB caps the cache). */
+int dtcwt_hip_trim(dtcwt_hip_ctx *ctx);
 int dtcwt_hip_memcpy_h2d(dtcwt_hip_ctx *ctx, void *dst, const void *src_host, size_t bytes);
 int dtcwt_hip_memcpy_d2h(dtcwt_hip_ctx *ctx, void *dst_host, const void *src, size_t bytes);
 int dtcwt_hip_memcpy_d2d(dtcwt_hip_ctx *ctx, void *dst, const void *src, size_t bytes);
