@@ -56,43 +56,49 @@ __global__ void __launch_bounds__(DT_NT) k_fwd2(Fwd2Params p) {
     }
 }
 
-// Level-1 inverse: records staged verbatim in LDS, c2q folded into the column pass, the
-// lowpass window prefetched straight from global memory (fused2d_tiles_v2.hpp).
+// Level-1 inverse: records copied verbatim into LDS (coalesced 16-byte pieces, all requested
+// up front together with the lowpass window), quad-plane samples gathered from them with
+// c2q folded in (column parity uniform per wavefront), barrier, column FIR writing y1/y2
+// OVER the record buffer, barrier, row pass with 16-byte stores (fused2d_tiles_v2.hpp).
 template <class C>
 __global__ void __launch_bounds__(DT_NT) k_inv1(Inv1Params p) {
-    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_ALIASED];
     const int ntile = p.tilesR * p.tilesC * p.B;
     int t = tile_of(blockIdx.x, ntile, p.xcd_order);
     if (t >= ntile) return;
     int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
-    float *srec = smem, *y1 = srec + C::SREC, *y2 = y1 + C::SY;
+    float *srec = smem, *y1 = smem, *y2 = y1 + C::SY;
     int r0 = tr * C::TR, c0 = tc * C::TC;
     const float *Yhb = p.Yh + (int64_t)b * (p.R / 2) * (p.C / 2) * 12;
-    float wz[C::WN];
+    float wz[C::WN], w1[C::WN], w2[C::WN], w3[C::WN];
     inv1r_fetch<C>(p, wz, threadIdx.x, b, r0, c0);
     inv_rec_stage<C::QR, C::QC>(Yhb, p.R, p.C, srec, r0 - C::HE, c0 - C::HE, threadIdx.x);
     __syncthreads();
-    inv1r_cols<C>(p, wz, srec, y1, y2, threadIdx.x, r0, c0);
+    inv1r_gather<C>(p, srec, w1, w2, w3, threadIdx.x, r0, c0);
+    __syncthreads();
+    inv1r_fir<C>(p, wz, w1, w2, w3, y1, y2, threadIdx.x);
     __syncthreads();
     inv1d_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0);
 }
 
-// Level >= 2 inverse: same structure as k_inv1 with the polyphase interpolating filters.
+// Level >= 2 inverse: same structure with the polyphase interpolating filters.
 template <class C>
 __global__ void __launch_bounds__(DT_NT) k_inv2(Inv2Params p) {
-    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_ALIASED];
     const int ntile = p.tilesR * p.tilesC * p.B;
     int t = tile_of(blockIdx.x, ntile, p.xcd_order);
     if (t >= ntile) return;
     int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
-    float *srec = smem, *y1 = srec + C::SREC, *y2 = y1 + C::SY;
+    float *srec = smem, *y1 = smem, *y2 = y1 + C::SY;
     int r0 = tr * C::TR, c0 = tc * C::TC;
     const float *Yhb = p.Yh + (int64_t)b * (p.zr / 2) * (p.zc / 2) * 12;
-    float wz[C::WS];
+    float wz[C::WS], w1[C::WS], w2[C::WS], w3[C::WS];
     inv2r_fetch<C>(p, wz, threadIdx.x, b, r0, c0);
     inv_rec_stage<C::QR, C::QC>(Yhb, p.zr, p.zc, srec, r0 + C::ORG, c0 + C::ORG, threadIdx.x);
     __syncthreads();
-    inv2r_cols<C>(p, wz, srec, y1, y2, threadIdx.x, r0, c0);
+    inv2r_gather<C>(p, srec, w1, w2, w3, threadIdx.x, r0, c0);
+    __syncthreads();
+    inv2r_fir<C>(p, wz, w1, w2, w3, y1, y2, threadIdx.x);
     __syncthreads();
     inv2_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0);
 }

@@ -10,13 +10,13 @@
     X(32, 64, 8, 5, 3)      /* legall     */ \
     X(32, 64, 8, 13, 19)    /* near_sym_b */
 /* level-1 inverse: X(tile rows, tile cols, rows per column-pass strip, len g0o, len g1o);
- * tile cols + 2*even-halo = 64 or 32 columns so that the column-pass tasks
- * (strips x columns) are one per thread */
+ * tile cols + 2*even-halo = 128 columns: (strips x column pairs) = one column-pass task per
+ * thread, parity uniform per wavefront */
 #define DT_INV1_TABLE(X) \
-    X(16, 56, 4, 7, 5)      /* near_sym_a */ \
-    X(16, 56, 4, 7, 9)      /* antonini   */ \
-    X(16, 56, 4, 3, 5)      /* legall     */ \
-    X(16, 44, 4, 19, 13)    /* near_sym_b */
+    X(16, 120, 8, 7, 5)      /* near_sym_a */ \
+    X(16, 120, 8, 7, 9)      /* antonini   */ \
+    X(16, 124, 8, 3, 5)      /* legall     */ \
+    X(16, 108, 8, 19, 13)    /* near_sym_b */
 /* level >= 2 forward: X(tile rows, tile cols, (A,B) pairs per column-pass strip, q-shift length);
  * tile cols chosen so that the input window 2*TC + 2*M - 4 is 128 columns (2 strips x 128 =
  * one task per thread in the column pass) */

@@ -701,6 +701,7 @@ struct Inv1RCfg {
     static constexpr int SREC = NREC * 12;
     static constexpr int SY = TR * NC;
     static constexpr int LDS_FLOATS = SREC + 2 * SY;
+    static constexpr int LDS_ALIASED = SREC > 2 * SY ? SREC : 2 * SY;   // y planes over the records
     static_assert(TR % RS == 0 && RS % 2 == 0 && TC % 4 == 0, "tile shape");
     static_assert(NS * QC <= 128, "column-pass tasks: two wavefronts per column parity");
     static_assert(M0 % 2 == 1 && M1 % 2 == 1, "biort filters must have odd length");
@@ -890,6 +891,70 @@ DT_HD void inv1r_cols_e(const Inv1Params &p, const float (&w0)[C::WN], const flo
     }
 }
 
+// Two-step form of the column pass: (1) gather the three quad-plane windows from the raw
+// records into registers, (2) after a workgroup barrier, filter and write y1/y2 -- which may
+// then ALIAS the record buffer (LDS per workgroup = max(records, y planes): 8 workgroups
+// per CU instead of 6).
+template <class C, int E>
+DT_HD void inv1r_gather_e(const Inv1Params &p, const float *srec, float (&w1)[C::WN], float (&w2)[C::WN],
+                          float (&w3)[C::WN], int tid, int r0, int c0) {
+    const ColTask t = inv_col_task<C>(tid);
+    if (!t.valid) return;
+    const int ro = r0 - C::HE, co = c0 - C::HE;
+    const bool interior = ro >= 0 && ro + C::NR <= p.R && co >= 0 && co + C::NC <= p.C;
+    const float *rbase = srec + ((t.strip * C::RS / 2) * C::QC + t.i) * 12;
+    if (interior) {
+#pragma unroll
+        for (int ru = 0; ru < C::WN / 2; ++ru) {
+            float top[3], bot[3];
+            rec_samples_t<E>(rbase + ru * C::QC * 12, p.g, top, bot);
+            w1[2 * ru] = top[0]; w1[2 * ru + 1] = bot[0];
+            w2[2 * ru] = top[1]; w2[2 * ru + 1] = bot[1];
+            w3[2 * ru] = top[2]; w3[2 * ru + 1] = bot[2];
+        }
+    } else {
+        const int fc = reflect_i(co + 2 * t.i, p.C) & 1;
+#pragma unroll
+        for (int ru = 0; ru < C::WN / 2; ++ru) {
+            const int fr = reflect_i(ro + t.strip * C::RS + 2 * ru, p.R) & 1;
+            float top[3], bot[3];
+            rec_samples(rbase + ru * C::QC * 12, p.g, t.e ^ fc, top, bot);
+            w1[2 * ru] = fr ? bot[0] : top[0]; w1[2 * ru + 1] = fr ? top[0] : bot[0];
+            w2[2 * ru] = fr ? bot[1] : top[1]; w2[2 * ru + 1] = fr ? top[1] : bot[1];
+            w3[2 * ru] = fr ? bot[2] : top[2]; w3[2 * ru + 1] = fr ? top[2] : bot[2];
+        }
+    }
+}
+template <class C>
+DT_HD void inv1r_gather(const Inv1Params &p, const float *srec, float (&w1)[C::WN], float (&w2)[C::WN],
+                        float (&w3)[C::WN], int tid, int r0, int c0) {
+    if (DT_WAVE_UNIFORM((tid >> 6) & 1)) inv1r_gather_e<C, 1>(p, srec, w1, w2, w3, tid, r0, c0);
+    else inv1r_gather_e<C, 0>(p, srec, w1, w2, w3, tid, r0, c0);
+}
+template <class C>
+DT_HD void inv1r_fir(const Inv1Params &p, const float (&w0)[C::WN], const float (&w1)[C::WN],
+                     const float (&w2)[C::WN], const float (&w3)[C::WN], float *y1, float *y2, int tid) {
+    const ColTask t = inv_col_task<C>(tid);
+    if (!t.valid) return;
+    const int cc = 2 * t.i + t.e;
+#pragma unroll
+    for (int q = 0; q < C::RS; ++q) {
+        float a = 0.f, bq = 0.f;
+#pragma unroll
+        for (int k = 0; k < C::M0; ++k) {
+            a += p.g0[k] * w0[q + C::HE + C::H0 - k];
+            bq += p.g0[k] * w2[q + C::HE + C::H0 - k];
+        }
+#pragma unroll
+        for (int k = 0; k < C::M1; ++k) {
+            a += p.g1[k] * w1[q + C::HE + C::H1 - k];
+            bq += p.g1[k] * w3[q + C::HE + C::H1 - k];
+        }
+        y1[(t.strip * C::RS + q) * C::NC + cc] = a;
+        y2[(t.strip * C::RS + q) * C::NC + cc] = bq;
+    }
+}
+
 template <class C>
 DT_HD void inv1r_cols(const Inv1Params &p, const float (&w0)[C::WN], const float *srec, float *y1,
                       float *y2, int tid, int r0, int c0) {
@@ -988,6 +1053,7 @@ struct Inv2RCfg {
     static constexpr int SREC = NREC * 12;
     static constexpr int SY = 2 * TR * NC;
     static constexpr int LDS_FLOATS = SREC + 2 * SY;
+    static constexpr int LDS_ALIASED = SREC > 2 * SY ? SREC : 2 * SY;
     static_assert(M % 2 == 0 && TR % 2 == 0 && TC % 2 == 0 && NJ % JS == 0, "even taps / tile");
     static_assert(NS * QC <= 128, "column-pass tasks: two wavefronts per column parity");
 };
@@ -1061,6 +1127,65 @@ DT_HD void inv2r_cols(const Inv2Params &p, const float (&w0)[C::WS], const float
                       float *y2, int tid, int r0, int c0) {
     if (DT_WAVE_UNIFORM((tid >> 6) & 1)) inv2r_cols_e<C, 1>(p, w0, srec, y1, y2, tid, r0, c0);
     else inv2r_cols_e<C, 0>(p, w0, srec, y1, y2, tid, r0, c0);
+}
+
+// two-step (gather / barrier / filter) form of the level >= 2 inverse column pass, so that
+// y1/y2 may alias the record buffer (see inv1r_gather)
+template <class C, int E>
+DT_HD void inv2r_gather_e(const Inv2Params &p, const float *srec, float (&w1)[C::WS], float (&w2)[C::WS],
+                          float (&w3)[C::WS], int tid, int r0, int c0) {
+    const ColTask t = inv_col_task<C>(tid);
+    if (!t.valid) return;
+    const int ro = r0 + C::ORG, co = c0 + C::ORG;
+    const bool interior = ro >= 0 && ro + C::NR <= p.zr && co >= 0 && co + C::NC <= p.zc;
+    const int rs = C::RS * t.strip;
+    const float *rbase = srec + ((rs / 2) * C::QC + t.i) * 12;
+    if (interior) {
+#pragma unroll
+        for (int ru = 0; ru < C::WS / 2; ++ru) {
+            float top[3], bot[3];
+            rec_samples_t<E>(rbase + ru * C::QC * 12, p.g, top, bot);
+            w1[2 * ru] = top[0]; w1[2 * ru + 1] = bot[0];
+            w2[2 * ru] = top[1]; w2[2 * ru + 1] = bot[1];
+            w3[2 * ru] = top[2]; w3[2 * ru + 1] = bot[2];
+        }
+    } else {
+        const int fc = reflect_i(co + 2 * t.i, p.zc) & 1;
+#pragma unroll
+        for (int ru = 0; ru < C::WS / 2; ++ru) {
+            const int fr = reflect_i(ro + rs + 2 * ru, p.zr) & 1;
+            float top[3], bot[3];
+            rec_samples(rbase + ru * C::QC * 12, p.g, t.e ^ fc, top, bot);
+            w1[2 * ru] = fr ? bot[0] : top[0]; w1[2 * ru + 1] = fr ? top[0] : bot[0];
+            w2[2 * ru] = fr ? bot[1] : top[1]; w2[2 * ru + 1] = fr ? top[1] : bot[1];
+            w3[2 * ru] = fr ? bot[2] : top[2]; w3[2 * ru + 1] = fr ? top[2] : bot[2];
+        }
+    }
+}
+template <class C>
+DT_HD void inv2r_gather(const Inv2Params &p, const float *srec, float (&w1)[C::WS], float (&w2)[C::WS],
+                        float (&w3)[C::WS], int tid, int r0, int c0) {
+    if (DT_WAVE_UNIFORM((tid >> 6) & 1)) inv2r_gather_e<C, 1>(p, srec, w1, w2, w3, tid, r0, c0);
+    else inv2r_gather_e<C, 0>(p, srec, w1, w2, w3, tid, r0, c0);
+}
+template <class C>
+DT_HD void inv2r_fir(const Inv2Params &p, const float (&w0)[C::WS], const float (&w1)[C::WS],
+                     const float (&w2)[C::WS], const float (&w3)[C::WS], float *y1, float *y2, int tid) {
+    const ColTask t = inv_col_task<C>(tid);
+    if (!t.valid) return;
+    const int cc = 2 * t.i + t.e;
+    float a[4], tt[4];
+#pragma unroll
+    for (int q = 0; q < C::JS; ++q) {
+        ifilt4<C>(w0 + 2 * q, p.l_a, p.l_b, p.lo_pos, a);
+        ifilt4<C>(w1 + 2 * q, p.h_a, p.h_b, p.hi_pos, tt);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y1[(4 * (t.strip * C::JS + q) + e) * C::NC + cc] = a[e] + tt[e];
+        ifilt4<C>(w2 + 2 * q, p.l_a, p.l_b, p.lo_pos, a);
+        ifilt4<C>(w3 + 2 * q, p.h_a, p.h_b, p.hi_pos, tt);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y2[(4 * (t.strip * C::JS + q) + e) * C::NC + cc] = a[e] + tt[e];
+    }
 }
 
 }  // namespace dt2d

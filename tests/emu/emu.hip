@@ -69,11 +69,11 @@ static int run_fwd2(Fwd2Params p) {
 template <class C>
 static int run_inv1(Inv1Params p) {
     p.tilesR = cdiv(p.R, C::TR); p.tilesC = cdiv(p.C, C::TC);
-    std::vector<float> smem(C::LDS_FLOATS + 4);
+    std::vector<float> smem(C::LDS_ALIASED + 4);
     float *base = smem.data();
     while (((uintptr_t)base) & 15) ++base;
-    float *srec = base, *y1 = srec + C::SREC, *y2 = y1 + C::SY;
-    static float wz[DT_NT][C::WN];          // per-thread registers living across the barrier
+    float *srec = base, *y1 = base, *y2 = y1 + C::SY;          // y planes alias the records
+    static float wz[DT_NT][C::WN], w1[DT_NT][C::WN], w2[DT_NT][C::WN], w3[DT_NT][C::WN];
     for (int b = 0; b < p.B; ++b)
         for (int tr = 0; tr < p.tilesR; ++tr)
             for (int tc = 0; tc < p.tilesC; ++tc) {
@@ -82,7 +82,8 @@ static int run_inv1(Inv1Params p) {
                 for (int t = 0; t < DT_NT; ++t) inv1r_fetch<C>(p, wz[t], t, b, r0, c0);
                 for (int t = 0; t < DT_NT; ++t)
                     inv_rec_stage<C::QR, C::QC>(Yhb, p.R, p.C, srec, r0 - C::HE, c0 - C::HE, t);
-                for (int t = 0; t < DT_NT; ++t) inv1r_cols<C>(p, wz[t], srec, y1, y2, t, r0, c0);
+                for (int t = 0; t < DT_NT; ++t) inv1r_gather<C>(p, srec, w1[t], w2[t], w3[t], t, r0, c0);
+                for (int t = 0; t < DT_NT; ++t) inv1r_fir<C>(p, wz[t], w1[t], w2[t], w3[t], y1, y2, t);
                 for (int t = 0; t < DT_NT; ++t) inv1d_rows<C>(p, y1, y2, t, b, r0, c0);
             }
     return 0;
@@ -91,11 +92,11 @@ static int run_inv1(Inv1Params p) {
 template <class C>
 static int run_inv2(Inv2Params p) {
     p.tilesR = cdiv(p.zr, C::TR); p.tilesC = cdiv(p.zc, C::TC);
-    std::vector<float> smem(C::LDS_FLOATS + 4);
+    std::vector<float> smem(C::LDS_ALIASED + 4);
     float *base = smem.data();
     while (((uintptr_t)base) & 15) ++base;
-    float *srec = base, *y1 = srec + C::SREC, *y2 = y1 + C::SY;
-    static float wz[DT_NT][C::WS];
+    float *srec = base, *y1 = base, *y2 = y1 + C::SY;
+    static float wz[DT_NT][C::WS], w1[DT_NT][C::WS], w2[DT_NT][C::WS], w3[DT_NT][C::WS];
     for (int b = 0; b < p.B; ++b)
         for (int tr = 0; tr < p.tilesR; ++tr)
             for (int tc = 0; tc < p.tilesC; ++tc) {
@@ -104,7 +105,8 @@ static int run_inv2(Inv2Params p) {
                 for (int t = 0; t < DT_NT; ++t) inv2r_fetch<C>(p, wz[t], t, b, r0, c0);
                 for (int t = 0; t < DT_NT; ++t)
                     inv_rec_stage<C::QR, C::QC>(Yhb, p.zr, p.zc, srec, r0 + C::ORG, c0 + C::ORG, t);
-                for (int t = 0; t < DT_NT; ++t) inv2r_cols<C>(p, wz[t], srec, y1, y2, t, r0, c0);
+                for (int t = 0; t < DT_NT; ++t) inv2r_gather<C>(p, srec, w1[t], w2[t], w3[t], t, r0, c0);
+                for (int t = 0; t < DT_NT; ++t) inv2r_fir<C>(p, wz[t], w1[t], w2[t], w3[t], y1, y2, t);
                 for (int t = 0; t < DT_NT; ++t) inv2_rows<C>(p, y1, y2, t, b, r0, c0);
             }
     return 0;

@@ -139,6 +139,30 @@ __global__ void __launch_bounds__(DT_NT) k_fwd1_s(Fwd1Params p) {
         fwd1s_rows_flush<C>(p, stage, threadIdx.x, base, b, r0, c0);
     }
 }
+template <class C, bool XCD, int PADF>
+__global__ void __launch_bounds__(DT_NT) k_fwd1_so(Fwd1Params p) {
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS + 4 * STAGE_FLOATS_PER_WAVE + PADF];
+    if (p.B == 12345) smem[C::LDS_FLOATS + 4 * STAGE_FLOATS_PER_WAVE + PADF - 1] = 1.f;
+    const int ntile = p.tilesR * p.tilesC * p.B;
+    int t = XCD ? xcd_tile(blockIdx.x, ntile) : (int)blockIdx.x;
+    if (t >= ntile) return;
+    int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    float *sLo = smem, *sHi = sLo + C::SL, *stage = sHi + C::SL;
+    int r0 = tr * C::TR, c0 = tc * C::TC;
+    fwd1d_cols<C>(p, sLo, sHi, threadIdx.x, b, r0, c0);
+    __syncthreads();
+    constexpr int NQ = (C::TR / 2) * (C::TC / 2);
+    for (int base = 0; base < NQ; base += DT_NT) {
+        fwd1s_rows_compute<C>(p, sLo, sHi, stage, threadIdx.x, base, b, r0, c0);
+        fwd1s_rows_flush<C>(p, stage, threadIdx.x, base, b, r0, c0);
+    }
+}
+template <class C, bool XCD, int PADF>
+void launch_so(Fwd1Params &p) {
+    p.tilesR = cdiv(p.LR, C::TR); p.tilesC = cdiv(p.LC, C::TC);
+    int nt = p.tilesR * p.tilesC * p.B;
+    k_fwd1_so<C, XCD, PADF><<<cdiv(nt, 8) * 8, DT_NT>>>(p);
+}
 template <class C, bool XCD>
 void launch_s(Fwd1Params &p) {
     p.tilesR = cdiv(p.LR, C::TR); p.tilesC = cdiv(p.LC, C::TC);
@@ -525,6 +549,56 @@ template <class C> void launchi2_r(Inv2Params &p) {
     p.tilesR = cdiv(p.zr, C::TR); p.tilesC = cdiv(p.zc, C::TC);
     k_inv2_r<C><<<cdiv(p.tilesR * p.tilesC * p.B, 8) * 8, DT_NT>>>(p);
 }
+template <class C>
+__global__ void __launch_bounds__(DT_NT) k_inv1_r8(Inv1Params p) {
+    constexpr int LDSF = C::SREC > 2 * C::SY ? C::SREC : 2 * C::SY;
+    __shared__ __attribute__((aligned(16))) float smem[LDSF];
+    const int ntile = p.tilesR * p.tilesC * p.B;
+    int t = tile_of(blockIdx.x, ntile, p.xcd_order);
+    if (t >= ntile) return;
+    int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    float *srec = smem, *y1 = smem, *y2 = y1 + C::SY;
+    int r0 = tr * C::TR, c0 = tc * C::TC;
+    const float *Yhb = p.Yh + (int64_t)b * (p.R / 2) * (p.C / 2) * 12;
+    float wz[C::WN], w1[C::WN], w2[C::WN], w3[C::WN];
+    inv1r_fetch<C>(p, wz, threadIdx.x, b, r0, c0);
+    inv_rec_stage<C::QR, C::QC>(Yhb, p.R, p.C, srec, r0 - C::HE, c0 - C::HE, threadIdx.x);
+    __syncthreads();
+    inv1r_gather<C>(p, srec, w1, w2, w3, threadIdx.x, r0, c0);
+    __syncthreads();
+    inv1r_fir<C>(p, wz, w1, w2, w3, y1, y2, threadIdx.x);
+    __syncthreads();
+    inv1d_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0);
+}
+template <class C> void launchi1_r8(Inv1Params &p) {
+    p.tilesR = cdiv(p.R, C::TR); p.tilesC = cdiv(p.C, C::TC);
+    k_inv1_r8<C><<<cdiv(p.tilesR * p.tilesC * p.B, 8) * 8, DT_NT>>>(p);
+}
+template <class C>
+__global__ void __launch_bounds__(DT_NT) k_inv2_r8(Inv2Params p) {
+    constexpr int LDSF = C::SREC > 2 * C::SY ? C::SREC : 2 * C::SY;
+    __shared__ __attribute__((aligned(16))) float smem[LDSF];
+    const int ntile = p.tilesR * p.tilesC * p.B;
+    int t = tile_of(blockIdx.x, ntile, p.xcd_order);
+    if (t >= ntile) return;
+    int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    float *srec = smem, *y1 = smem, *y2 = y1 + C::SY;
+    int r0 = tr * C::TR, c0 = tc * C::TC;
+    const float *Yhb = p.Yh + (int64_t)b * (p.zr / 2) * (p.zc / 2) * 12;
+    float wz[C::WS], w1[C::WS], w2[C::WS], w3[C::WS];
+    inv2r_fetch<C>(p, wz, threadIdx.x, b, r0, c0);
+    inv_rec_stage<C::QR, C::QC>(Yhb, p.zr, p.zc, srec, r0 + C::ORG, c0 + C::ORG, threadIdx.x);
+    __syncthreads();
+    inv2r_gather<C>(p, srec, w1, w2, w3, threadIdx.x, r0, c0);
+    __syncthreads();
+    inv2r_fir<C>(p, wz, w1, w2, w3, y1, y2, threadIdx.x);
+    __syncthreads();
+    inv2_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0);
+}
+template <class C> void launchi2_r8(Inv2Params &p) {
+    p.tilesR = cdiv(p.zr, C::TR); p.tilesC = cdiv(p.zc, C::TC);
+    k_inv2_r8<C><<<cdiv(p.tilesR * p.tilesC * p.B, 8) * 8, DT_NT>>>(p);
+}
 template <class C> void launchi1_r(Inv1Params &p) {
     p.tilesR = cdiv(p.R, C::TR); p.tilesC = cdiv(p.C, C::TC);
     k_inv1_r<C><<<cdiv(p.tilesR * p.tilesC * p.B, 8) * 8, DT_NT>>>(p);
@@ -611,6 +685,14 @@ int main(int argc, char **argv) {
     vs.push_back({"d 16x120 rs4 xcd", launch_d<Fwd1DCfg<16, 120, 4, 5, 7>, true, 1>});
     vs.push_back({"d 16x248 rs8 xcd", launch_d<Fwd1DCfg<16, 248, 8, 5, 7>, true, 1>});
     vs.push_back({"d 64x56 rs8 xcd", launch_d<Fwd1DCfg<64, 56, 8, 5, 7>, true, 1>});
+    vs.push_back({"F1 occ5 30K", launch_so<Fwd1DCfg<32, 64, 8, 5, 7>, false, 1>});
+    vs.push_back({"F1 occ4 40K", launch_so<Fwd1DCfg<32, 64, 8, 5, 7>, false, 2500>});
+    vs.push_back({"F1 occ3 53K", launch_so<Fwd1DCfg<32, 64, 8, 5, 7>, false, 5800>});
+    vs.push_back({"F1 occ2 80K", launch_so<Fwd1DCfg<32, 64, 8, 5, 7>, false, 12500>});
+    vs.push_back({"F1 occ1 159K", launch_so<Fwd1DCfg<32, 64, 8, 5, 7>, false, 32500>});
+    vs.push_back({"F1 16x64 occ7", launch_so<Fwd1DCfg<16, 64, 8, 5, 7>, false, 1>});
+    vs.push_back({"F1 16x56 occ8", launch_so<Fwd1DCfg<16, 56, 8, 5, 7>, false, 1>});
+    vs.push_back({"F1 16x120 rs8", launch_so<Fwd1DCfg<16, 120, 8, 5, 7>, false, 1>});
     vs.push_back({"s 32x64 rs8 xcd", launch_s<Fwd1DCfg<32, 64, 8, 5, 7>, true>});
     vs.push_back({"s 32x64 rs8 lin", launch_s<Fwd1DCfg<32, 64, 8, 5, 7>, false>});
     vs.push_back({"s 16x128 rs8 xcd", launch_s<Fwd1DCfg<16, 128, 8, 5, 7>, true>});
@@ -802,6 +884,11 @@ int main(int argc, char **argv) {
             vi.push_back({"I1 occ 3 (53K)", launchi1_ro<Inv1RCfg<16, 56, 4, 7, 5>, 6700>, 1});
             vi.push_back({"I1 occ 2 (80K)", launchi1_ro<Inv1RCfg<16, 56, 4, 7, 5>, 13500>, 1});
             vi.push_back({"I1 occ 1 (159K)", launchi1_ro<Inv1RCfg<16, 56, 4, 7, 5>, 33000>, 1});
+            vi.push_back({"I1 r8 16x56 rs4 xcd", launchi1_r8<Inv1RCfg<16, 56, 4, 7, 5>>, 1});
+            vi.push_back({"I1 r8 16x56 rs4 lin", launchi1_r8<Inv1RCfg<16, 56, 4, 7, 5>>, 0});
+            vi.push_back({"I1 r8 32x24 rs4 xcd", launchi1_r8<Inv1RCfg<32, 24, 4, 7, 5>>, 1});
+            vi.push_back({"I1 r8 32x56 rs8 xcd", launchi1_r8<Inv1RCfg<32, 56, 8, 7, 5>>, 1});
+            vi.push_back({"I1 r8 16x120 rs8 xcd", launchi1_r8<Inv1RCfg<16, 120, 8, 7, 5>>, 1});
             vi.push_back({"I1 abl full", launchi1_abl<Inv1RCfg<16, 56, 4, 7, 5>, 0>, 1});
             vi.push_back({"I1 abl -recs", launchi1_abl<Inv1RCfg<16, 56, 4, 7, 5>, 1>, 1});
             vi.push_back({"I1 abl -z", launchi1_abl<Inv1RCfg<16, 56, 4, 7, 5>, 2>, 1});
@@ -874,6 +961,12 @@ int main(int argc, char **argv) {
             std::vector<VariantI2> vi;
             vi.push_back({"I2 v0 32x32 xcd", launchi2_v0<Inv2Cfg<32, 32, 10>>, 1});
             vi.push_back({"I2 v0 32x32 lin", launchi2_v0<Inv2Cfg<32, 32, 10>>, 0});
+            vi.push_back({"I2 r8 16x56 js2 xcd", launchi2_r8<Inv2RCfg<16, 56, 2, 10>>, 1});
+            vi.push_back({"I2 r8 16x120 js4 xcd", launchi2_r8<Inv2RCfg<16, 120, 4, 10>>, 1});
+            vi.push_back({"I2 r8 16x120 js4 lin", launchi2_r8<Inv2RCfg<16, 120, 4, 10>>, 0});
+            vi.push_back({"I2 r8 32x56 js4 xcd", launchi2_r8<Inv2RCfg<32, 56, 4, 10>>, 1});
+
+            vi.push_back({"I2 r8 8x120 js2 xcd", launchi2_r8<Inv2RCfg<8, 120, 2, 10>>, 1});
             vi.push_back({"I2 r 16x56 js2 xcd", launchi2_r<Inv2RCfg<16, 56, 2, 10>>, 1});
             vi.push_back({"I2 r 16x56 js4 xcd", launchi2_r<Inv2RCfg<16, 56, 4, 10>>, 1});
             vi.push_back({"I2 r 16x24 js2 xcd", launchi2_r<Inv2RCfg<16, 24, 2, 10>>, 1});
