@@ -104,6 +104,110 @@ __global__ void __launch_bounds__(256) k_colfilter(const T *__restrict__ X, T *_
     put(g, Yb, lo, acc);
 }
 
+// Two undecimated filters of the same length parity applied to the same input in one pass
+// (the 3-D level loops always filter a volume with the lo AND the hi filter,
+// dtcwt/numpy/transform3d.py:256-273): every input sample is loaded once and feeds both.
+template <typename T>
+__global__ void __launch_bounds__(256) k_colfilter2(const T *__restrict__ X, T *__restrict__ Y0,
+                                                    T *__restrict__ Y1, Geo g, Taps<T> taps, int m0, int m1) {
+    int64_t o, i, grp;
+    if (!decode(g, o, grp, i)) return;
+    const T *Xb = X + o * g.xso + i * g.xsi;
+    int64_t lo = grp + g.crop_lo;
+    // Y[i] = sum_k h[k] X[i + (m-1-m/2) - k]: offsets d = (m-1-m/2) - k
+    const int c0 = (m0 - 1) - m0 / 2, c1 = (m1 - 1) - m1 / 2;
+    const int dmin = (c0 - (m0 - 1)) < (c1 - (m1 - 1)) ? (c0 - (m0 - 1)) : (c1 - (m1 - 1));
+    const int dmax = c0 > c1 ? c0 : c1;
+    T a0 = 0, a1 = 0;
+    for (int d = dmax; d >= dmin; --d) {
+        T x = Xb[src_index(g, lo + d) * g.xsn];
+        int k0 = c0 - d, k1 = c1 - d;
+        if (k0 >= 0 && k0 < m0) a0 += taps.a[k0] * x;
+        if (k1 >= 0 && k1 < m1) a1 += taps.b[k1] * x;
+    }
+    put(g, Y0 + o * g.yso + i * g.ysi, lo, a0);
+    put(g, Y1 + o * g.yso + i * g.ysi, lo, a1);
+}
+
+// y = colfilter(X0, h0) + colfilter(X1, h1) in one pass (the 3-D inverse merges,
+// transform3d.py:425-435): no read-modify-write of the output.
+template <typename T>
+__global__ void __launch_bounds__(256) k_colfilter_sum2(const T *__restrict__ X0, const T *__restrict__ X1,
+                                                        T *__restrict__ Y, Geo g, Taps<T> taps, int m0, int m1) {
+    int64_t o, i, grp;
+    if (!decode(g, o, grp, i)) return;
+    const T *P0 = X0 + o * g.xso + i * g.xsi, *P1 = X1 + o * g.xso + i * g.xsi;
+    int64_t lo = grp + g.crop_lo;
+    T acc = 0;
+    int64_t b0 = lo + (m0 - 1) - m0 / 2, b1 = lo + (m1 - 1) - m1 / 2;
+    for (int k = 0; k < m0; ++k) acc += taps.a[k] * P0[src_index(g, b0 - k) * g.xsn];
+    for (int k = 0; k < m1; ++k) acc += taps.b[k] * P1[src_index(g, b1 - k) * g.xsn];
+    put(g, Y + o * g.yso + i * g.ysi, lo, acc);
+}
+
+// Two dual-tree decimating filter pairs on the same input in one pass (taps.a/b = pair 0,
+// taps2.a/b = pair 1), cf. k_coldfilt.
+template <typename T>
+__global__ void __launch_bounds__(256) k_coldfilt2(const T *__restrict__ X, T *__restrict__ Y0,
+                                                   T *__restrict__ Y1, Geo g, Taps<T> taps, Taps<T> taps2,
+                                                   int m, int a_first0, int a_first1) {
+    int64_t o, i, grp;
+    if (!decode(g, o, grp, i)) return;
+    const T *Xb = X + o * g.xso + i * g.xsi;
+    int p = m / 2;
+    T A0 = 0, B0 = 0, A1 = 0, B1 = 0;
+    for (int k = 0; k < p; ++k) {
+        int64_t b = 4 * (grp + p - 1 - k) - m;
+        T x4 = Xb[src_index(g, b + 4) * g.xsn], x2 = Xb[src_index(g, b + 2) * g.xsn];
+        T x5 = Xb[src_index(g, b + 5) * g.xsn], x3 = Xb[src_index(g, b + 3) * g.xsn];
+        A0 += taps.a[2 * k] * x4; A0 += taps.a[2 * k + 1] * x2;
+        B0 += taps.b[2 * k] * x5; B0 += taps.b[2 * k + 1] * x3;
+        A1 += taps2.a[2 * k] * x4; A1 += taps2.a[2 * k + 1] * x2;
+        B1 += taps2.b[2 * k] * x5; B1 += taps2.b[2 * k + 1] * x3;
+    }
+    T *P0 = Y0 + o * g.yso + i * g.ysi, *P1 = Y1 + o * g.yso + i * g.ysi;
+    put(g, P0, 2 * grp, a_first0 ? A0 : B0); put(g, P0, 2 * grp + 1, a_first0 ? B0 : A0);
+    put(g, P1, 2 * grp, a_first1 ? A1 : B1); put(g, P1, 2 * grp + 1, a_first1 ? B1 : A1);
+}
+
+// y = colifilt(X0, pair 0) + colifilt(X1, pair 1) in one pass (transform3d.py:485-495)
+template <typename T>
+__global__ void __launch_bounds__(256) k_colifilt_sum2(const T *__restrict__ X0, const T *__restrict__ X1,
+                                                       T *__restrict__ Y, Geo g, Taps<T> taps, Taps<T> taps2,
+                                                       int m, int pos0, int pos1) {
+    int64_t o, i, grp;
+    if (!decode(g, o, grp, i)) return;
+    int m2 = m / 2, n = m2;
+    T y0 = 0, y1 = 0, y2 = 0, y3 = 0;
+    for (int s = 0; s < 2; ++s) {
+        const T *Xb = (s ? X1 : X0) + o * g.xso + i * g.xsi;
+        const Taps<T> &tp = s ? taps2 : taps;
+        const int pos = s ? pos1 : pos0;
+        if ((m2 & 1) == 0) {
+            for (int k = 0; k < n; ++k) {
+                int64_t t = 3 + 2 * (grp + n - 1 - k);
+                int64_t ta = pos ? t : t - 1, tb = pos ? t - 1 : t;
+                y0 += tp.a[2 * k + 1] * Xb[src_index(g, tb - 2 - m2) * g.xsn];
+                y1 += tp.b[2 * k + 1] * Xb[src_index(g, ta - 2 - m2) * g.xsn];
+                y2 += tp.a[2 * k] * Xb[src_index(g, tb - m2) * g.xsn];
+                y3 += tp.b[2 * k] * Xb[src_index(g, ta - m2) * g.xsn];
+            }
+        } else {
+            for (int k = 0; k < n; ++k) {
+                int64_t t = 2 + 2 * (grp + n - 1 - k);
+                int64_t ta = pos ? t : t - 1, tb = pos ? t - 1 : t;
+                T xb = Xb[src_index(g, tb - m2) * g.xsn];
+                T xa = Xb[src_index(g, ta - m2) * g.xsn];
+                y0 += tp.a[2 * k] * xb; y1 += tp.b[2 * k] * xa;
+                y2 += tp.a[2 * k + 1] * xb; y3 += tp.b[2 * k + 1] * xa;
+            }
+        }
+    }
+    T *Yb = Y + o * g.yso + i * g.ysi;
+    put(g, Yb, 4 * grp, y0); put(g, Yb, 4 * grp + 1, y1);
+    put(g, Yb, 4 * grp + 2, y2); put(g, Yb, 4 * grp + 3, y3);
+}
+
 // coldfilt (dtcwt/numpy/lowlevel.py:82-154): with p = m/2, b_k = 4(i+p-1-k) - m
 //   A[i] = sum_k ha[2k] X[rho(b_k+4)] + ha[2k+1] X[rho(b_k+2)]
 //   B[i] = sum_k hb[2k] X[rho(b_k+5)] + hb[2k+1] X[rho(b_k+3)]
@@ -406,6 +510,102 @@ int dtcwt_hip_colifilt(dtcwt_hip_ctx *ctx, int dtype, const void *X, void *Y,
     } else {
         Taps<double> t; load_taps(t, ha, hb, m);
         k_colifilt<double><<<blocks_for(total), 256, 0, ctx->stream>>>((const double *)X, (double *)Y, g, t, m, pos);
+    }
+    DT_LAUNCH_CHECK();
+    return 0;
+}
+
+#define DT_DISPATCH_T(CALLF, CALLD)                                                     \
+    do {                                                                               \
+        if (dtype == DTCWT_HIP_F32) { CALLF; } else { CALLD; }                          \
+        DT_LAUNCH_CHECK();                                                             \
+    } while (0)
+
+int dtcwt_hip_colfilter2(dtcwt_hip_ctx *ctx, int dtype, const void *X, void *Y0, void *Y1,
+                         const dtcwt_hip_view *v, const double *h0, int m0, const double *h1, int m1) {
+    DT_REQUIRE(ctx && X && Y0 && Y1 && h0 && h1, "NULL argument");
+    DT_REQUIRE(m0 >= 1 && m0 <= DTCWT_HIP_MAX_TAPS && m1 >= 1 && m1 <= DTCWT_HIP_MAX_TAPS, "filter length out of range");
+    DT_REQUIRE((m0 & 1) == (m1 & 1), "both filters must have odd or both even length");
+    DT_REQUIRE(dtype == DTCWT_HIP_F32 || dtype == DTCWT_HIP_F64, "bad dtype %d", dtype);
+    Geo g;
+    int rc = make_geo(v, nout_colfilter, m0, 1, 0, g);
+    if (rc) return rc;
+    int64_t total = g.outer * g.ngroups * g.inner;
+    if (total == 0) return 0;
+    DT_CHECK_HIP(hipSetDevice(ctx->device));
+    Taps<float> tf; Taps<double> td;
+    load_taps(tf, h0, nullptr, m0); load_taps(td, h0, nullptr, m0);
+    for (int k = 0; k < DTCWT_HIP_MAX_TAPS; ++k) { tf.b[k] = k < m1 ? (float)h1[k] : 0.f; td.b[k] = k < m1 ? h1[k] : 0.0; }
+    DT_DISPATCH_T((k_colfilter2<float><<<blocks_for(total), 256, 0, ctx->stream>>>((const float *)X, (float *)Y0, (float *)Y1, g, tf, m0, m1)),
+                  (k_colfilter2<double><<<blocks_for(total), 256, 0, ctx->stream>>>((const double *)X, (double *)Y0, (double *)Y1, g, td, m0, m1)));
+    return 0;
+}
+
+int dtcwt_hip_colfilter_sum2(dtcwt_hip_ctx *ctx, int dtype, const void *X0, const void *X1, void *Y,
+                             const dtcwt_hip_view *v, const double *h0, int m0, const double *h1, int m1) {
+    DT_REQUIRE(ctx && X0 && X1 && Y && h0 && h1, "NULL argument");
+    DT_REQUIRE(m0 >= 1 && m0 <= DTCWT_HIP_MAX_TAPS && m1 >= 1 && m1 <= DTCWT_HIP_MAX_TAPS, "filter length out of range");
+    DT_REQUIRE((m0 & 1) == (m1 & 1), "both filters must have odd or both even length");
+    DT_REQUIRE(dtype == DTCWT_HIP_F32 || dtype == DTCWT_HIP_F64, "bad dtype %d", dtype);
+    Geo g;
+    int rc = make_geo(v, nout_colfilter, m0, 1, 0, g);
+    if (rc) return rc;
+    int64_t total = g.outer * g.ngroups * g.inner;
+    if (total == 0) return 0;
+    DT_CHECK_HIP(hipSetDevice(ctx->device));
+    Taps<float> tf; Taps<double> td;
+    load_taps(tf, h0, nullptr, m0); load_taps(td, h0, nullptr, m0);
+    for (int k = 0; k < DTCWT_HIP_MAX_TAPS; ++k) { tf.b[k] = k < m1 ? (float)h1[k] : 0.f; td.b[k] = k < m1 ? h1[k] : 0.0; }
+    DT_DISPATCH_T((k_colfilter_sum2<float><<<blocks_for(total), 256, 0, ctx->stream>>>((const float *)X0, (const float *)X1, (float *)Y, g, tf, m0, m1)),
+                  (k_colfilter_sum2<double><<<blocks_for(total), 256, 0, ctx->stream>>>((const double *)X0, (const double *)X1, (double *)Y, g, td, m0, m1)));
+    return 0;
+}
+
+int dtcwt_hip_coldfilt2(dtcwt_hip_ctx *ctx, int dtype, const void *X, void *Y0, void *Y1,
+                        const dtcwt_hip_view *v, const double *ha0, const double *hb0, const double *ha1,
+                        const double *hb1, int m) {
+    DT_REQUIRE(ctx && X && Y0 && Y1 && ha0 && hb0 && ha1 && hb1, "NULL argument");
+    DT_REQUIRE(m >= 2 && m <= DTCWT_HIP_MAX_TAPS && (m % 2) == 0, "Lengths of ha and hb must be even (and <= %d)", DTCWT_HIP_MAX_TAPS);
+    DT_REQUIRE(dtype == DTCWT_HIP_F32 || dtype == DTCWT_HIP_F64, "bad dtype %d", dtype);
+    Geo g;
+    int rc = make_geo(v, nout_coldfilt, m, 2, 0, g);
+    if (rc) return rc;
+    DT_REQUIRE(g.L % 4 == 0, "No. of rows in X must be a multiple of 4");
+    int64_t total = g.outer * g.ngroups * g.inner;
+    if (total == 0) return 0;
+    int f0 = dot(ha0, hb0, m) > 0, f1 = dot(ha1, hb1, m) > 0;
+    DT_CHECK_HIP(hipSetDevice(ctx->device));
+    if (dtype == DTCWT_HIP_F32) {
+        Taps<float> t0, t1; load_taps(t0, ha0, hb0, m); load_taps(t1, ha1, hb1, m);
+        k_coldfilt2<float><<<blocks_for(total), 256, 0, ctx->stream>>>((const float *)X, (float *)Y0, (float *)Y1, g, t0, t1, m, f0, f1);
+    } else {
+        Taps<double> t0, t1; load_taps(t0, ha0, hb0, m); load_taps(t1, ha1, hb1, m);
+        k_coldfilt2<double><<<blocks_for(total), 256, 0, ctx->stream>>>((const double *)X, (double *)Y0, (double *)Y1, g, t0, t1, m, f0, f1);
+    }
+    DT_LAUNCH_CHECK();
+    return 0;
+}
+
+int dtcwt_hip_colifilt_sum2(dtcwt_hip_ctx *ctx, int dtype, const void *X0, const void *X1, void *Y,
+                            const dtcwt_hip_view *v, const double *ha0, const double *hb0, const double *ha1,
+                            const double *hb1, int m) {
+    DT_REQUIRE(ctx && X0 && X1 && Y && ha0 && hb0 && ha1 && hb1, "NULL argument");
+    DT_REQUIRE(m >= 2 && m <= DTCWT_HIP_MAX_TAPS && (m % 2) == 0, "Lengths of ha and hb must be even (and <= %d)", DTCWT_HIP_MAX_TAPS);
+    DT_REQUIRE(dtype == DTCWT_HIP_F32 || dtype == DTCWT_HIP_F64, "bad dtype %d", dtype);
+    Geo g;
+    int rc = make_geo(v, nout_colifilt, m, 4, 0, g);
+    if (rc) return rc;
+    DT_REQUIRE(g.L % 2 == 0, "No. of rows in X must be a multiple of 2");
+    int64_t total = g.outer * g.ngroups * g.inner;
+    if (total == 0) return 0;
+    int p0 = dot(ha0, hb0, m) > 0, p1 = dot(ha1, hb1, m) > 0;
+    DT_CHECK_HIP(hipSetDevice(ctx->device));
+    if (dtype == DTCWT_HIP_F32) {
+        Taps<float> t0, t1; load_taps(t0, ha0, hb0, m); load_taps(t1, ha1, hb1, m);
+        k_colifilt_sum2<float><<<blocks_for(total), 256, 0, ctx->stream>>>((const float *)X0, (const float *)X1, (float *)Y, g, t0, t1, m, p0, p1);
+    } else {
+        Taps<double> t0, t1; load_taps(t0, ha0, hb0, m); load_taps(t1, ha1, hb1, m);
+        k_colifilt_sum2<double><<<blocks_for(total), 256, 0, ctx->stream>>>((const double *)X0, (const double *)X1, (double *)Y, g, t0, t1, m, p0, p1);
     }
     DT_LAUNCH_CHECK();
     return 0;

@@ -19,7 +19,8 @@ from dtcwt_amd.hip import _lib
 from dtcwt_amd.hip._lib import DeviceArray, View, check, dtype_code, taps_arg
 
 __all__ = ['colfilter', 'coldfilt', 'colifilt', 'axis_colfilter', 'axis_coldfilt',
-           'axis_colifilt', 'q2c', 'c2q']
+           'axis_colifilt', 'axis_colfilter2', 'axis_colfilter_sum2', 'axis_coldfilt2',
+           'axis_colifilt_sum2', 'q2c', 'c2q']
 
 
 def _prod(t):
@@ -105,6 +106,82 @@ def axis_colifilt(X, ha, hb, axis=0, out=None, accumulate=False, pad=(0, 0), cro
     v = _view(X, axis, nwrite, pad, crop)
     check(_lib.lib().dtcwt_hip_colifilt(X.ctx.handle, dtype_code(X.dtype), X.ptr, Y.ptr, ctypes.byref(v),
                                         pa, pb, m, _lib.ACCUMULATE if accumulate else 0))
+    return Y
+
+
+# ---- fused pairs (one pass over the data instead of two) -------------------------------
+def axis_colfilter2(X, h0, h1, axis=0, pad=(0, 0), crop=(0, 0)):
+    """(colfilter(X, h0), colfilter(X, h1)) along *axis* in one kernel; falls back to two
+    calls when the filter lengths differ in parity (different output lengths)."""
+    axis = axis % X.ndim
+    k0, p0, m0 = taps_arg(h0)
+    k1, p1, m1 = taps_arg(h1)
+    if (m0 & 1) != (m1 & 1):
+        return (axis_colfilter(X, h0, axis=axis, pad=pad, crop=crop),
+                axis_colfilter(X, h1, axis=axis, pad=pad, crop=crop))
+    L = X.shape[axis] + pad[0] + pad[1]
+    nwrite = (L if m0 % 2 else L + 1) - crop[0] - crop[1]
+    Y0, Y1 = _out(X, axis, nwrite, None, False), _out(X, axis, nwrite, None, False)
+    v = _view(X, axis, nwrite, pad, crop)
+    check(_lib.lib().dtcwt_hip_colfilter2(X.ctx.handle, dtype_code(X.dtype), X.ptr, Y0.ptr, Y1.ptr,
+                                          ctypes.byref(v), p0, m0, p1, m1))
+    return Y0, Y1
+
+
+def axis_colfilter_sum2(X0, X1, h0, h1, axis=0, crop=(0, 0)):
+    """colfilter(X0, h0) + colfilter(X1, h1) along *axis* in one kernel."""
+    axis = axis % X0.ndim
+    k0, p0, m0 = taps_arg(h0)
+    k1, p1, m1 = taps_arg(h1)
+    if X0.shape != X1.shape or X0.dtype != X1.dtype:
+        raise ValueError('operands of a fused sum must have equal shape and dtype')
+    if (m0 & 1) != (m1 & 1):
+        Y = axis_colfilter(X0, h0, axis=axis, crop=crop)
+        return axis_colfilter(X1, h1, axis=axis, crop=crop, out=Y, accumulate=True)
+    L = X0.shape[axis]
+    nwrite = (L if m0 % 2 else L + 1) - crop[0] - crop[1]
+    Y = _out(X0, axis, nwrite, None, False)
+    v = _view(X0, axis, nwrite, (0, 0), crop)
+    check(_lib.lib().dtcwt_hip_colfilter_sum2(X0.ctx.handle, dtype_code(X0.dtype), X0.ptr, X1.ptr, Y.ptr,
+                                              ctypes.byref(v), p0, m0, p1, m1))
+    return Y
+
+
+def axis_coldfilt2(X, pair0, pair1, axis=0, pad=(0, 0), crop=(0, 0)):
+    """(coldfilt(X, *pair0), coldfilt(X, *pair1)) along *axis* in one kernel."""
+    axis = axis % X.ndim
+    ka, pa0, pb0, m = _pair_args(*pair0)
+    kb, pa1, pb1, m1 = _pair_args(*pair1)
+    if m != m1:
+        raise ValueError('Shapes of the two filter pairs must be the same')
+    L = X.shape[axis] + pad[0] + pad[1]
+    if L % 4 != 0:
+        raise ValueError('No. of rows in X must be a multiple of 4')
+    nwrite = L // 2 - crop[0] - crop[1]
+    Y0, Y1 = _out(X, axis, nwrite, None, False), _out(X, axis, nwrite, None, False)
+    v = _view(X, axis, nwrite, pad, crop)
+    check(_lib.lib().dtcwt_hip_coldfilt2(X.ctx.handle, dtype_code(X.dtype), X.ptr, Y0.ptr, Y1.ptr,
+                                         ctypes.byref(v), pa0, pb0, pa1, pb1, m))
+    return Y0, Y1
+
+
+def axis_colifilt_sum2(X0, X1, pair0, pair1, axis=0, crop=(0, 0)):
+    """colifilt(X0, *pair0) + colifilt(X1, *pair1) along *axis* in one kernel."""
+    axis = axis % X0.ndim
+    ka, pa0, pb0, m = _pair_args(*pair0)
+    kb, pa1, pb1, m1 = _pair_args(*pair1)
+    if m != m1:
+        raise ValueError('Shapes of the two filter pairs must be the same')
+    if X0.shape != X1.shape or X0.dtype != X1.dtype:
+        raise ValueError('operands of a fused sum must have equal shape and dtype')
+    L = X0.shape[axis]
+    if L % 2 != 0:
+        raise ValueError('No. of rows in X must be a multiple of 2')
+    nwrite = 2 * L - crop[0] - crop[1]
+    Y = _out(X0, axis, nwrite, None, False)
+    v = _view(X0, axis, nwrite, (0, 0), crop)
+    check(_lib.lib().dtcwt_hip_colifilt_sum2(X0.ctx.handle, dtype_code(X0.dtype), X0.ptr, X1.ptr, Y.ptr,
+                                             ctypes.byref(v), pa0, pb0, pa1, pb1, m))
     return Y
 
 

@@ -88,14 +88,12 @@ class Transform1d(object):
         if Xd is None:
             Xd = self.ctx.to_device(X)
         Yh, Ys = [], []
-        Hi = ll.axis_colfilter(Xd, h1o, axis=0)
-        Lo = ll.axis_colfilter(Xd, h0o, axis=0)
+        Lo, Hi = ll.axis_colfilter2(Xd, h0o, h1o, axis=0)
         Yh.append(_pack(Hi))
         Ys.append(Lo)
         for level in range(1, nlevels):
             pad = (1, 1) if Lo.shape[0] % 4 != 0 else (0, 0)      # transform1d.py:95-96
-            Hi = ll.axis_coldfilt(Lo, h1b, h1a, axis=0, pad=pad)
-            Lo = ll.axis_coldfilt(Lo, h0b, h0a, axis=0, pad=pad)
+            Lo, Hi = ll.axis_coldfilt2(Lo, (h0b, h0a), (h1b, h1a), axis=0, pad=pad)
             Yh.append(_pack(Hi))
             Ys.append(Lo)
         if include_scale:
@@ -132,15 +130,12 @@ class Transform1d(object):
             if full - 2 * crop[0] != want or Lo.shape[1] != Yh[level - 1].shape[1] or \
                     Hi.shape != Lo.shape:
                 raise ValueError('Yh sizes are not valid for DTWAVEIFM')
-            Z = ll.axis_colifilt(Lo, g0b, g0a, axis=0, crop=crop)
-            ll.axis_colifilt(Hi, g1b, g1a, axis=0, crop=crop, out=Z, accumulate=True)
-            Lo = Z
+            Lo = ll.axis_colifilt_sum2(Lo, Hi, (g0b, g0a), (g1b, g1a), axis=0, crop=crop)
             level -= 1
         Hi = _unpack(Yh[0], gain_mask[0])
         if Hi.shape != Lo.shape:
             raise ValueError('Yh sizes are not valid for DTWAVEIFM')
-        Z = ll.axis_colfilter(Lo, g0o, axis=0)
-        ll.axis_colfilter(Hi, g1o, axis=0, out=Z, accumulate=True)
+        Z = ll.axis_colfilter_sum2(Lo, Hi, g0o, g1o, axis=0)
         if device_output:
             return Z
         Zh = Z.get()

@@ -79,14 +79,14 @@ class Transform3d(object):
 
     # ------------------------------------------------------------------ forward
     @staticmethod
-    def _split(V, fn, lo, hi, pads):
-        """volume -> {(a0, a1, a2): octant}; axis order 2, 1, 0."""
+    def _split(V, fn2, lo, hi, pads):
+        """volume -> {(a0, a1, a2): octant}; axis order 2, 1, 0.  *fn2* filters one volume
+        with the lo and the hi filter (pair) in a single pass."""
         parts = {(): V}
         for axis in (2, 1, 0):
             nxt = {}
             for key, vol in parts.items():
-                nxt[(0,) + key] = fn(vol, *lo, axis=axis, pad=pads[axis])
-                nxt[(1,) + key] = fn(vol, *hi, axis=axis, pad=pads[axis])
+                nxt[(0,) + key], nxt[(1,) + key] = fn2(vol, lo, hi, axis=axis, pad=pads[axis])
             parts = nxt
         return parts
 
@@ -123,13 +123,13 @@ class Transform3d(object):
                         Yl = ll.axis_colfilter(Yl, h0o, axis=axis)
                 else:
                     sub = Yl.shape      # even-length taps: octants are (N+1)^3, packed from [:N]
-                    parts = self._split(Yl, ll.axis_colfilter, (h0o,), (h1o,), nopad)
+                    parts = self._split(Yl, ll.axis_colfilter2, h0o, h1o, nopad)
                     Yl = parts[(0, 0, 0)]
                     Yh[0] = self._pack(parts, sub, cdt)
             else:                                              # :317-383
                 mult, npad = (4, 1) if self.ext_mode == 4 else (8, 2)
                 pads = tuple((npad, npad) if Yl.shape[a] % mult else (0, 0) for a in range(3))
-                parts = self._split(Yl, ll.axis_coldfilt, (h0b, h0a), (h1b, h1a), pads)
+                parts = self._split(Yl, ll.axis_coldfilt2, (h0b, h0a), (h1b, h1a), pads)
                 Yl = parts[(0, 0, 0)]
                 Yh[level] = self._pack(parts, Yl.shape, cdt)
             Ys[level] = Yl
@@ -139,25 +139,20 @@ class Transform3d(object):
 
     # ------------------------------------------------------------------ inverse
     @staticmethod
-    def _merge(Yl, Yh, fn, lo, hi, crops):
-        """8 octants -> one volume; axis order 1, 0, 2 (transform3d.py:425-435, :485-495)."""
+    def _merge(Yl, Yh, fsum, lo, hi, crops):
+        """8 octants -> one volume; axis order 1, 0, 2 (transform3d.py:425-435, :485-495).
+        *fsum* computes filter(lo-branch) + filter(hi-branch) in a single pass."""
         parts = {(0, 0, 0): Yl}
         for n, o in enumerate(_OCTANTS):
             parts[o] = _c2cube(Yh, n)
         p1 = {}
         for a0 in (0, 1):
             for a2 in (0, 1):
-                y = fn(parts[(a0, 0, a2)], *lo, axis=1, crop=crops[1])
-                fn(parts[(a0, 1, a2)], *hi, axis=1, crop=crops[1], out=y, accumulate=True)
-                p1[(a0, a2)] = y
+                p1[(a0, a2)] = fsum(parts[(a0, 0, a2)], parts[(a0, 1, a2)], lo, hi, axis=1, crop=crops[1])
         p0 = {}
         for a2 in (0, 1):
-            y = fn(p1[(0, a2)], *lo, axis=0, crop=crops[0])
-            fn(p1[(1, a2)], *hi, axis=0, crop=crops[0], out=y, accumulate=True)
-            p0[a2] = y
-        y = fn(p0[0], *lo, axis=2, crop=crops[2])
-        fn(p0[1], *hi, axis=2, crop=crops[2], out=y, accumulate=True)
-        return y
+            p0[a2] = fsum(p1[(0, a2)], p1[(1, a2)], lo, hi, axis=0, crop=crops[0])
+        return fsum(p0[0], p0[1], lo, hi, axis=2, crop=crops[2])
 
     def inverse(self, pyramid, device_output=False):
         """Perform an *n*-level dual-tree complex wavelet (DTCWT) 3D reconstruction
@@ -189,11 +184,11 @@ class Transform3d(object):
                     # block, N -> N+1 per axis, then drop sample 0 of every axis.
                     n0, n1, n2 = (2 * s for s in cur.shape[:3])
                     low = self.ctx.to_device(np.ascontiguousarray(Yl.get()[:n0, :n1, :n2]))
-                    Yl = self._merge(low, cur, ll.axis_colfilter, (g0o,), (g1o,), ((1, 0),) * 3)
+                    Yl = self._merge(low, cur, ll.axis_colfilter_sum2, g0o, g1o, ((1, 0),) * 3)
                 else:
                     if tuple(Yl.shape) != tuple(2 * s for s in cur.shape[:3]):
                         raise ValueError('Sizes of highpasses are not valid for the 3D inverse')
-                    Yl = self._merge(Yl, cur, ll.axis_colfilter, (g0o,), (g1o,), nocrop)
+                    Yl = self._merge(Yl, cur, ll.axis_colfilter_sum2, g0o, g1o, nocrop)
             else:                                              # :460-526
                 if tuple(Yl.shape) != tuple(2 * s for s in cur.shape[:3]):
                     raise ValueError('Sizes of highpasses are not valid for the 3D inverse')
@@ -201,5 +196,5 @@ class Transform3d(object):
                 prev = tuple(nxt.shape[:3]) if nxt is not None else tuple(2 * s for s in cur.shape[:3])
                 c = 1 if self.ext_mode == 4 else 2
                 crops = tuple((c, c) if cur.shape[a] * 2 != prev[a] else (0, 0) for a in range(3))
-                Yl = self._merge(Yl, cur, ll.axis_colifilt, (g0b, g0a), (g1b, g1a), crops)
+                Yl = self._merge(Yl, cur, ll.axis_colifilt_sum2, (g0b, g0a), (g1b, g1a), crops)
         return Yl if device_output else Yl.get()

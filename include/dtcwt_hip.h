@@ -111,6 +111,27 @@ int dtcwt_hip_colifilt(dtcwt_hip_ctx *ctx, int dtype, const void *X, void *Y,
                        const dtcwt_hip_view *v, const double *ha_host, const double *hb_host,
                        int m, int flags);
 
+/* Fused pairs used by the 3-D (and 1-D) level loops, which always apply a lo AND a hi filter
+ * to the same array (forward, dtcwt/numpy/transform3d.py:256-273, :353-369) or sum a lo- and
+ * a hi-filtered array (inverse, :425-435, :485-495): one pass over the data instead of two.
+ *   colfilter2:      Y0 = colfilter(X, h0),  Y1 = colfilter(X, h1)        (same length parity)
+ *   colfilter_sum2:  Y  = colfilter(X0, h0) + colfilter(X1, h1)
+ *   coldfilt2:       Y0 = coldfilt(X, ha0, hb0),  Y1 = coldfilt(X, ha1, hb1)
+ *   colifilt_sum2:   Y  = colifilt(X0, ha0, hb0) + colifilt(X1, ha1, hb1)
+ * X0/X1 (and Y0/Y1) share one view. */
+int dtcwt_hip_colfilter2(dtcwt_hip_ctx *ctx, int dtype, const void *X, void *Y0, void *Y1,
+                         const dtcwt_hip_view *v, const double *h0_host, int m0,
+                         const double *h1_host, int m1);
+int dtcwt_hip_colfilter_sum2(dtcwt_hip_ctx *ctx, int dtype, const void *X0, const void *X1, void *Y,
+                             const dtcwt_hip_view *v, const double *h0_host, int m0,
+                             const double *h1_host, int m1);
+int dtcwt_hip_coldfilt2(dtcwt_hip_ctx *ctx, int dtype, const void *X, void *Y0, void *Y1,
+                        const dtcwt_hip_view *v, const double *ha0_host, const double *hb0_host,
+                        const double *ha1_host, const double *hb1_host, int m);
+int dtcwt_hip_colifilt_sum2(dtcwt_hip_ctx *ctx, int dtype, const void *X0, const void *X1, void *Y,
+                            const dtcwt_hip_view *v, const double *ha0_host, const double *hb0_host,
+                            const double *ha1_host, const double *hb1_host, int m);
+
 /* q2c: replaces dtcwt/numpy/transform2d.py:301-322 plus the slice-assign into Yh
  * (:122-127).  y: [batch][rows][cols] real plane (strides in elements), rows, cols even;
  * Yh: [batch][rows/2][cols/2][6] interleaved complex; the pair goes to subbands

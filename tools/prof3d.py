@@ -10,3 +10,6 @@ for _ in range(3):
 ctx.device_sync()
 t0 = time.perf_counter(); p = t3.forward(V, nlevels=3); ctx.device_sync(); print('fwd wall', time.perf_counter() - t0)
 t0 = time.perf_counter(); z = t3.inverse(p, device_output=True); ctx.device_sync(); print('inv wall', time.perf_counter() - t0)
+t0 = time.perf_counter(); z = t3.inverse(p, device_output=True); ctx.device_sync(); print('inv wall (warm)', time.perf_counter() - t0)
+import numpy as np
+print('PR err', float(np.abs(z.get() - V.get()).max()))
