@@ -1,0 +1,229 @@
+// Fused per-level tile programs of the float32 3-D DT-CWT forward transform.
+//
+// Level 1 (dtcwt/numpy/transform3d.py:208-289, odd-length biort filters, no decimation)
+// ------------------------------------------------------------------------------------
+// One workgroup (256 threads) owns a TJ x TK (axis 1 x axis 2) column of the volume and
+// MARCHES along axis 0 over a chunk of slices.  Per thread a register ring holds the last
+// 2H+1 raw input slices of a handful of (j, k) positions of the haloed tile; each step
+//
+//   axis 0   lo/hi of the ring (registers)                      -> S0[2][PJ][PK]   (LDS)
+//   axis 2   lo/hi along k of both, 4 outputs per task          -> S1[4][PJ][TK]   (LDS)
+//   axis 1   lo/hi along j of all four for the thread's 2x2 (j,k) cell  -> 8 octants
+//
+// and every second slice the 2x2x2 cells of the seven highpass octants are packed by
+// cube2c (:532-579) into whole 224-byte records of Yh[n0/2][n1/2][n2/2][28] complex64,
+// while the LLL octant goes to the level-1 lowpass volume.  The input is read once (plus
+// halo, served by L2), every output is written once: 36 B/voxel against the ~130 B/voxel
+// of three separate axis passes plus seven cube2c passes.
+//
+// The filters are separable and linear, so applying axis 0 first (the reference filters
+// axis 2, 1, 0) changes float32 rounding only; symmetric extension commutes with the
+// other axes' filters, so halo positions are simply reflected loads of X.
+//
+// Same conventions as fused2d_tiles.hpp: every phase is a __host__ __device__ function so
+// the test-only emulator (tests/emu/) steps the identical index algebra on the CPU.
+#pragma once
+#include "fused2d_tiles.hpp"
+
+namespace dt3d {
+
+using dt2d::cmax;
+using dt2d::f2;
+using dt2d::f4;
+using dt2d::reflect_i;
+
+struct Fwd3L1Params {
+    const float *X;      // [n0][n1][n2]
+    float *LLL;          // [n0][n1][n2]
+    float *Yh;           // [n0/2][n1/2][n2/2][56 floats]
+    int n0, n1, n2;      // all even
+    int chunk;           // slices marched by one workgroup (even)
+    int tilesJ, tilesK, chunks;
+    float h0[DT_MAXT], h1[DT_MAXT];
+};
+
+template <int M0_, int M1_>
+struct Fwd3L1Cfg {
+    static constexpr int M0 = M0_, M1 = M1_;
+    static constexpr int H0 = M0 / 2, H1 = M1 / 2, H = cmax(H0, H1);
+    static constexpr int MR = 2 * H + 1;                  // ring depth (slices i-H .. i+H)
+    static constexpr int TJ = 16, TK = 64;                // outputs per slice
+    static constexpr int PJ = TJ + 2 * H, PK = TK + 2 * H;
+    static constexpr int S0S = TK + 8;                    // S0 row stride: 16-byte aligned windows
+    static constexpr int NPOS = PJ * PK;
+    static constexpr int NPT = (NPOS + DT_NT - 1) / DT_NT;    // ring positions per thread
+    static constexpr int S0F = 2 * PJ * S0S, S1F = 4 * PJ * TK;
+    static constexpr int LDS_FLOATS = S0F + S1F;
+    static constexpr int NT2 = 2 * PJ * (TK / 4);         // axis-2 tasks (4 outputs each)
+    static constexpr int WK = 4 + 2 * H;                  // axis-2 window (<= 12)
+    static_assert(M0 % 2 == 1 && M1 % 2 == 1, "biort filters must have odd length");
+    static_assert(H <= 4, "axis-2 window must fit three float4");
+    static_assert((TJ / 2) * (TK / 2) == DT_NT, "one 2x2 cell per thread");
+};
+
+// per-thread registers carried across the steps of the march
+template <class C>
+struct Fwd3L1State {
+    float ring[C::NPT][C::MR];
+    float nxt[C::NPT];
+    int goff[C::NPT];         // j*n2 + k of the position (reflected), constant over slices
+    int soff[C::NPT];         // pj*S0S + pk, or -1 for the unused tail
+    float ev[8][4];           // octant values of the even slice of the current pair
+};
+
+template <class C>
+DT_HD void f3l1_init(const Fwd3L1Params &p, Fwd3L1State<C> &st, int tid, int j0, int k0) {
+#pragma unroll
+    for (int s = 0; s < C::NPT; ++s) {
+        int q = tid + DT_NT * s;
+        int pj = q / C::PK, pk = q - pj * C::PK;
+        bool ok = q < C::NPOS;
+        if (!ok) { pj = 0; pk = 0; }
+        int j = reflect_i(j0 - C::H + pj, p.n1), k = reflect_i(k0 - C::H + pk, p.n2);
+        st.goff[s] = j * p.n2 + k;
+        st.soff[s] = ok ? pj * C::S0S + pk : -1;
+    }
+}
+
+// ring <- slices i0-H .. i0+H-1 (slots 1..2H), nxt <- slice i0+H: all loads in one batch
+template <class C>
+DT_HD void f3l1_prologue(const Fwd3L1Params &p, Fwd3L1State<C> &st, int i0) {
+    const int64_t ss = (int64_t)p.n1 * p.n2;
+#pragma unroll
+    for (int t = 0; t < 2 * C::H; ++t) {
+        const float *sl = p.X + ss * reflect_i(i0 - C::H + t, p.n0);
+#pragma unroll
+        for (int s = 0; s < C::NPT; ++s) st.ring[s][t + 1] = sl[st.goff[s]];
+    }
+    const float *sl = p.X + ss * reflect_i(i0 + C::H, p.n0);
+#pragma unroll
+    for (int s = 0; s < C::NPT; ++s) st.nxt[s] = sl[st.goff[s]];
+}
+
+// rotate the ring, take in the prefetched slice, prefetch slice i+1+H, filter along axis 0
+template <class C>
+DT_HD void f3l1_axis0(const Fwd3L1Params &p, Fwd3L1State<C> &st, float *S0, int i, bool more) {
+#pragma unroll
+    for (int s = 0; s < C::NPT; ++s) {
+#pragma unroll
+        for (int t = 0; t < C::MR - 1; ++t) st.ring[s][t] = st.ring[s][t + 1];
+        st.ring[s][C::MR - 1] = st.nxt[s];
+    }
+    if (more) {
+        const float *sl = p.X + (int64_t)p.n1 * p.n2 * reflect_i(i + 1 + C::H, p.n0);
+#pragma unroll
+        for (int s = 0; s < C::NPT; ++s) st.nxt[s] = sl[st.goff[s]];
+    }
+#pragma unroll
+    for (int s = 0; s < C::NPT; ++s) {
+        float lo = 0.f, hi = 0.f;
+#pragma unroll
+        for (int k = 0; k < C::M0; ++k) lo += p.h0[k] * st.ring[s][C::H + C::H0 - k];
+#pragma unroll
+        for (int k = 0; k < C::M1; ++k) hi += p.h1[k] * st.ring[s][C::H + C::H1 - k];
+        if (st.soff[s] >= 0) {
+            S0[st.soff[s]] = lo;
+            S0[C::PJ * C::S0S + st.soff[s]] = hi;
+        }
+    }
+}
+
+// S1[2*a0 + a2][pj][k] = (axis-2 filter a2) of S0[a0][pj][.]
+template <class C>
+DT_HD void f3l1_axis2(const Fwd3L1Params &p, const float *S0, float *S1, int tid) {
+    constexpr int G = C::TK / 4;
+#pragma unroll
+    for (int r = 0; r < (C::NT2 + DT_NT - 1) / DT_NT; ++r) {
+        int it = tid + DT_NT * r;
+        if (it >= C::NT2) break;
+        int vol = it / (C::PJ * G), rem = it - vol * (C::PJ * G);
+        int pj = rem / G, c = rem - pj * G;
+        const f4 *src = reinterpret_cast<const f4 *>(S0 + (vol * C::PJ + pj) * C::S0S + 4 * c);
+        float w[12];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            f4 v = src[q];
+            w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+        }
+        float lo[4], hi[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int k = 0; k < C::M0; ++k) a += p.h0[k] * w[e + C::H + C::H0 - k];
+#pragma unroll
+            for (int k = 0; k < C::M1; ++k) b += p.h1[k] * w[e + C::H + C::H1 - k];
+            lo[e] = a; hi[e] = b;
+        }
+        float *d = S1 + ((2 * vol) * C::PJ + pj) * C::TK + 4 * c;
+        *reinterpret_cast<f4 *>(d) = f4{lo[0], lo[1], lo[2], lo[3]};
+        *reinterpret_cast<f4 *>(d + C::PJ * C::TK) = f4{hi[0], hi[1], hi[2], hi[3]};
+    }
+}
+
+// cube2c of one octant (transform3d.py:532-579): cube corners A..H = (di, dj, dk) in
+// {000, 010, 100, 110, 001, 011, 101, 111}; ev/od hold [dj*2+dk] of slice 2u / 2u+1
+DT_HD void cube2c_record(float *rec, const float (&ev)[4], const float (&od)[4]) {
+    const float A = ev[0], B = ev[2], Cc = od[0], D = od[2], E = ev[1], F = ev[3], G = od[1], Hh = od[3];
+    const float h = 0.5f;
+    f4 *o = reinterpret_cast<f4 *>(rec);
+    o[0] = f4{(A - G - D - F) * h, (B - Hh + Cc + E) * h, (A - G + D + F) * h, (-B + Hh + Cc + E) * h};
+    o[1] = f4{(A + G + D - F) * h, (B + Hh - Cc + E) * h, (A + G - D + F) * h, (-B - Hh - Cc + E) * h};
+}
+
+// axis-1 filters for the thread's 2x2 (j, k) cell, LLL store, and on odd slices the pack
+template <class C>
+DT_HD void f3l1_axis1_pack(const Fwd3L1Params &p, Fwd3L1State<C> &st, const float *S1, int tid, int i,
+                           int j0, int k0) {
+    const int cj = tid / (C::TK / 2), ck = tid - cj * (C::TK / 2);
+    const int j = j0 + 2 * cj, k = k0 + 2 * ck;
+    float cur[8][4];          // [a0*4 + a1*2 + a2][dj*2 + dk]
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        float u[2 * C::H + 2][2];
+#pragma unroll
+        for (int r = 0; r < 2 * C::H + 2; ++r) {
+            f2 t = *reinterpret_cast<const f2 *>(S1 + (v * C::PJ + 2 * cj + r) * C::TK + 2 * ck);
+            u[r][0] = t.x; u[r][1] = t.y;
+        }
+        const int a0 = v >> 1, a2 = v & 1;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                float lo = 0.f, hi = 0.f;
+#pragma unroll
+                for (int t = 0; t < C::M0; ++t) lo += p.h0[t] * u[e + C::H + C::H0 - t][c];
+#pragma unroll
+                for (int t = 0; t < C::M1; ++t) hi += p.h1[t] * u[e + C::H + C::H1 - t][c];
+                cur[a0 * 4 + a2][e * 2 + c] = lo;
+                cur[a0 * 4 + 2 + a2][e * 2 + c] = hi;
+            }
+    }
+    const bool live = j < p.n1 && k < p.n2;
+    if (live) {
+        float *L = p.LLL + ((int64_t)i * p.n1 + j) * p.n2 + k;
+        *reinterpret_cast<f2 *>(L) = f2{cur[0][0], cur[0][1]};
+        *reinterpret_cast<f2 *>(L + p.n2) = f2{cur[0][2], cur[0][3]};
+    }
+    if ((i & 1) == 0) {
+#pragma unroll
+        for (int o = 1; o < 8; ++o)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st.ev[o][e] = cur[o][e];
+        return;
+    }
+    if (!live) return;
+    float *rec = p.Yh + (((int64_t)(i >> 1) * (p.n1 / 2) + (j >> 1)) * (p.n2 / 2) + (k >> 1)) * 56;
+    // record slots in the reference's concatenation order (transform3d.py:278-289):
+    // (a0,a1,a2) = 010, 100, 110, 001, 011, 101, 111
+    cube2c_record(rec + 0, st.ev[2], cur[2]);
+    cube2c_record(rec + 8, st.ev[4], cur[4]);
+    cube2c_record(rec + 16, st.ev[6], cur[6]);
+    cube2c_record(rec + 24, st.ev[1], cur[1]);
+    cube2c_record(rec + 32, st.ev[3], cur[3]);
+    cube2c_record(rec + 40, st.ev[5], cur[5]);
+    cube2c_record(rec + 48, st.ev[7], cur[7]);
+}
+
+}  // namespace dt3d

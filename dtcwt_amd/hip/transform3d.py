@@ -12,6 +12,9 @@ One deliberate difference: the reference's highpass-free level-1 inverse
 (``_level1_ifm_no_highpass``, :442-458) forgets a transpose, so it swaps axes 0 and 2 of
 cubic volumes and raises on non-cubic ones; this backend returns the intended result.
 """
+import ctypes
+import os
+
 import numpy as np
 
 from dtcwt_amd.coeffs import biort as _biort, qshift as _qshift
@@ -35,6 +38,26 @@ def _cube2c(vol, sub, Yh, octant):
     s0, s1 = vol.shape[1] * vol.shape[2], vol.shape[2]
     check(_lib.lib().dtcwt_hip_cube2c(vol.ctx.handle, dtype_code(vol.dtype), vol.ptr, d0, d1, d2, s0, s1,
                                       Yh.ptr, octant))
+
+
+def _fused_level1(Xd, h0o, h1o):
+    """Level 1 in one launch (dtcwt_hip_fwd3_level1) -> (LLL, Yh), or None when these taps /
+    this volume only have the generic axis passes."""
+    if Xd.dtype != np.float32:
+        return None
+    h0, h1 = flat_taps(h0o), flat_taps(h1o)
+    if h0.shape[0] % 2 == 0 or h1.shape[0] % 2 == 0:
+        return None
+    n0, n1, n2 = Xd.shape
+    LLL = DeviceArray(Xd.ctx, (n0, n1, n2), np.float32)
+    Yh = DeviceArray(Xd.ctx, (n0 // 2, n1 // 2, n2 // 2, 28), np.complex64)
+    pd = ctypes.POINTER(ctypes.c_double)
+    rc = _lib.lib().dtcwt_hip_fwd3_level1(Xd.ctx.handle, Xd.ptr, n0, n1, n2, h0.ctypes.data_as(pd), h0.shape[0],
+                                          h1.ctypes.data_as(pd), h1.shape[0], LLL.ptr, Yh.ptr)
+    if rc == -3:
+        return None
+    check(rc)
+    return LLL, Yh
 
 
 def _c2cube(Yh, octant):
@@ -61,6 +84,7 @@ class Transform3d(object):
             self.qshift = qshift
         self.ext_mode = ext_mode
         self._ctx = ctx
+        self.fused = os.environ.get('DTCWT_HIP_FUSED3D', '1') != '0'   # False: generic axis passes only
 
     @property
     def ctx(self):
@@ -122,10 +146,14 @@ class Transform3d(object):
                     for axis in (2, 1, 0):
                         Yl = ll.axis_colfilter(Yl, h0o, axis=axis)
                 else:
-                    sub = Yl.shape      # even-length taps: octants are (N+1)^3, packed from [:N]
-                    parts = self._split(Yl, ll.axis_colfilter2, h0o, h1o, nopad)
-                    Yl = parts[(0, 0, 0)]
-                    Yh[0] = self._pack(parts, sub, cdt)
+                    fused = _fused_level1(Yl, h0o, h1o) if self.fused else None
+                    if fused is not None:
+                        Yl, Yh[0] = fused
+                    else:
+                        sub = Yl.shape  # even-length taps: octants are (N+1)^3, packed from [:N]
+                        parts = self._split(Yl, ll.axis_colfilter2, h0o, h1o, nopad)
+                        Yl = parts[(0, 0, 0)]
+                        Yh[0] = self._pack(parts, sub, cdt)
             else:                                              # :317-383
                 mult, npad = (4, 1) if self.ext_mode == 4 else (8, 2)
                 pads = tuple((npad, npad) if Yl.shape[a] % mult else (0, 0) for a in range(3))

@@ -143,6 +143,15 @@ int dtcwt_hip_q2c(dtcwt_hip_ctx *ctx, int dtype, const void *y, int64_t batch, i
 int dtcwt_hip_c2q(dtcwt_hip_ctx *ctx, int dtype, const void *Yh, int64_t batch, int64_t rows,
                   int64_t cols, int slot0, int slot1, double gain0, double gain1, void *x,
                   int64_t x_sb, int64_t x_sr);
+/* Fused float32 level 1 of the 3-D forward transform: replaces `_level1_xfm`
+ * (dtcwt/numpy/transform3d.py:208-289) for odd-length biort filters -- the three axis
+ * passes (h0o/h1o along axes 2, 1, 0) and the seven cube2c packings in ONE launch.
+ * X, LLL: [n0][n1][n2] contiguous float32 (n* even); Yh: [n0/2][n1/2][n2/2][28] complex64,
+ * octants in the reference's order (:278-289).  Returns -3 (use the generic colfilter2 +
+ * cube2c path) when no fused kernel exists for the tap lengths or the volume is tiny. */
+int dtcwt_hip_fwd3_level1(dtcwt_hip_ctx *ctx, const float *X, int64_t n0, int64_t n1, int64_t n2,
+                          const double *h0o, int m0, const double *h1o, int m1, float *LLL,
+                          float *Yh);
 /* cube2c: replaces dtcwt/numpy/transform3d.py:532-579 for one octant.
  * y: real volume view [d0][d1][d2] with element strides (s0, s1, 1), d* even;
  * Yh: [d0/2][d1/2][d2/2][28] complex; writes components 4*octant .. 4*octant+3. */

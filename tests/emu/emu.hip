@@ -12,6 +12,7 @@
 #include "fused2d_tiles.hpp"
 #include "fused2d_tiles_v2.hpp"
 #include "fused2d_table.hpp"
+#include "fused3d_tiles.hpp"
 
 using namespace dt2d;
 
@@ -112,6 +113,31 @@ static int run_inv2(Inv2Params p) {
     return 0;
 }
 
+template <class C>
+static int run_fwd3_l1(dt3d::Fwd3L1Params p, int chunk) {
+    using namespace dt3d;
+    p.tilesJ = cdiv(p.n1, C::TJ); p.tilesK = cdiv(p.n2, C::TK);
+    p.chunk = chunk; p.chunks = cdiv(p.n0, chunk);
+    std::vector<float> smem(C::LDS_FLOATS + 4);
+    float *base = smem.data();
+    while (((uintptr_t)base) & 15) ++base;
+    float *S0 = base, *S1 = base + C::S0F;
+    static Fwd3L1State<C> st[DT_NT];
+    for (int ch = 0; ch < p.chunks; ++ch)
+        for (int tj = 0; tj < p.tilesJ; ++tj)
+            for (int tk = 0; tk < p.tilesK; ++tk) {
+                int j0 = tj * C::TJ, k0 = tk * C::TK, i0 = ch * p.chunk;
+                int iend = i0 + p.chunk < p.n0 ? i0 + p.chunk : p.n0;
+                for (int t = 0; t < DT_NT; ++t) { f3l1_init<C>(p, st[t], t, j0, k0); f3l1_prologue<C>(p, st[t], i0); }
+                for (int i = i0; i < iend; ++i) {
+                    for (int t = 0; t < DT_NT; ++t) f3l1_axis0<C>(p, st[t], S0, i, i + 1 < iend);
+                    for (int t = 0; t < DT_NT; ++t) f3l1_axis2<C>(p, S0, S1, t);
+                    for (int t = 0; t < DT_NT; ++t) f3l1_axis1_pack<C>(p, st[t], S1, t, i, j0, k0);
+                }
+            }
+    return 0;
+}
+
 #define EMU_FWD1(TR, TC, RS, A, B_) if (m0 == A && m1 == B_) return run_fwd1<Fwd1DCfg<TR, TC, RS, A, B_>>(p);
 #define EMU_INV1(TR, TC, RS, A, B_) if (m0 == A && m1 == B_) return run_inv1<Inv1RCfg<TR, TC, RS, A, B_>>(p);
 #define EMU_FWD2(TR, TC, PS, M) if (m == M) return run_fwd2<Fwd2DCfg<TR, TC, PS, M>>(p);
@@ -161,6 +187,17 @@ int emu_inv2(int m, const float *Z, const float *Yh, float *Out, int B, int zr, 
     put_taps(p.l_a, la, m); put_taps(p.l_b, lb, m); put_taps(p.h_a, ha, m); put_taps(p.h_b, hb, m);
     p.lo_pos = dotd(la, lb, m) > 0; p.hi_pos = dotd(ha, hb, m) > 0;
     DT_INV2_TABLE(EMU_INV2)
+    return -3;
+}
+
+int emu_fwd3_l1(int m0, int m1, const float *X, float *LLL, float *Yh, int n0, int n1, int n2, int chunk,
+                const double *h0, const double *h1) {
+    dt3d::Fwd3L1Params p{};
+    p.X = X; p.LLL = LLL; p.Yh = Yh; p.n0 = n0; p.n1 = n1; p.n2 = n2;
+    put_taps(p.h0, h0, m0); put_taps(p.h1, h1, m1);
+    if (m0 == 5 && m1 == 7) return run_fwd3_l1<dt3d::Fwd3L1Cfg<5, 7>>(p, chunk);
+    if (m0 == 9 && m1 == 7) return run_fwd3_l1<dt3d::Fwd3L1Cfg<9, 7>>(p, chunk);
+    if (m0 == 5 && m1 == 3) return run_fwd3_l1<dt3d::Fwd3L1Cfg<5, 3>>(p, chunk);
     return -3;
 }
 

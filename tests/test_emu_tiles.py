@@ -26,7 +26,7 @@ TOL = 2e-6
 
 def _build():
     deps = [EMU_SRC] + [os.path.join(ROOT, 'dtcwt_amd', 'csrc', f) for f in
-                        ('fused2d_tiles.hpp', 'fused2d_tiles_v2.hpp', 'fused2d_table.hpp')]
+                        ('fused2d_tiles.hpp', 'fused2d_tiles_v2.hpp', 'fused2d_table.hpp', 'fused3d_tiles.hpp')]
     if os.path.exists(EMU_LIB) and all(os.path.getmtime(EMU_LIB) >= os.path.getmtime(d) for d in deps):
         return
     if not os.path.exists(HIPCC):
@@ -164,3 +164,27 @@ def test_emu_level2_forward_inverse(emu, qn, shape):
             Z = Z[:, 1:-1]
         assert Z.shape == Zi[i].shape
         assert rel(Zi[i], Z) < 4 * TOL
+
+
+# ------------------------------------------------------------------------------ 3-D
+def emu_fwd3_l1(emu, X, h0o, h1o, chunk):
+    n0, n1, n2 = X.shape
+    LLL = np.full(X.shape, np.nan, np.float32)
+    Yh = np.full((n0 // 2, n1 // 2, n2 // 2, 56), np.nan, np.float32)
+    h0, p0 = _d(h0o)
+    h1, p1 = _d(h1o)
+    rc = emu.emu_fwd3_l1(len(h0), len(h1), _f(X), _f(LLL), _f(Yh), n0, n1, n2, chunk, p0, p1)
+    assert rc == 0
+    return LLL, Yh.view(np.complex64)
+
+
+@pytest.mark.parametrize('shape,chunk', [((8, 8, 8), 8), ((12, 20, 70), 4), ((10, 34, 130), 6), ((16, 16, 64), 16)])
+@pytest.mark.parametrize('bname', ['near_sym_a', 'antonini', 'legall'])
+def test_fwd3_level1_tiles(emu, shape, chunk, bname):
+    X = np.random.RandomState(11).standard_normal(shape).astype(np.float32)
+    b = biort(bname)
+    LLL, Yh = emu_fwd3_l1(emu, X, b[0], b[2], chunk)
+    want = o.Transform3d(b, qshift('qshift_a')).forward(X.astype(np.float64), nlevels=1)
+    assert rel(LLL, want.lowpass) < TOL
+    assert Yh.shape == want.highpasses[0].shape
+    assert rel(Yh, want.highpasses[0]) < TOL

@@ -141,3 +141,23 @@ def test_3d_medium_volume_config_c4_shape():
     assert [y.shape for y in p.highpasses] == [(128, 128, 128, 28), (64, 64, 64, 28), (32, 32, 32, 28)]
     z = t.inverse(p)
     assert np.abs(z - V).max() < 3e-5 * np.abs(V).max()
+
+
+@pytest.mark.parametrize('shape', [(8, 8, 8), (12, 20, 70), (34, 18, 130), (64, 48, 80), (96, 160, 72)])
+@pytest.mark.parametrize('bname', ['near_sym_a', 'antonini', 'legall'])
+def test_3d_fused_level1_matches_generic_and_oracle(shape, bname):
+    """The single-launch level 1 (dtcwt_hip_fwd3_level1) against the generic axis passes and,
+    on the small shapes, the oracle."""
+    X = np.random.RandomState(12).standard_normal(shape).astype(np.float32)
+    t = Transform3d(biort=bname)
+    assert t.fused
+    g = Transform3d(biort=bname)
+    g.fused = False
+    for nl in (1, 2):
+        p, q = t.forward(X, nlevels=nl), g.forward(X, nlevels=nl)
+        assert_pyramids_close(p, q, XFM_TOL)
+        if X.size <= 70000:
+            want = o.Transform3d(biort(bname), qshift('qshift_a')).forward(X, nlevels=nl)
+            assert_pyramids_close(p, want, XFM_TOL)
+        z = t.inverse(p)
+        assert_close(z, X, 2e-5, 'PR')
