@@ -6,6 +6,7 @@
 // launch that reads the volume once and writes the lowpass volume and the 28-subband
 // highpass records once.
 #include "common.hpp"
+#include "fused2d_table.hpp"
 #include "fused3d_tiles.hpp"
 
 using namespace dt3d;
@@ -33,7 +34,40 @@ __global__ void __launch_bounds__(DT_NT) k_fwd3_l1(Fwd3L1Params p) {
     }
 }
 
+// Level >= 2, pass A: the 2-D level-2 tile program over every slice, four planes out.
+template <class C>
+__global__ void __launch_bounds__(DT_NT) k_fwd3_l2_planes(dt2d::Fwd2Params p, float *planes, int64_t pstride) {
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
+    const int t = blockIdx.x;
+    const int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    float *sLo = smem, *sHi = sLo + C::SL;
+    const int r0 = tr * C::TR, c0 = tc * C::TC;
+    dt2d::fwd2d_cols<C>(p, sLo, sHi, threadIdx.x, b, r0, c0);
+    __syncthreads();
+    for (int base = 0; base < C::TI * C::TJ; base += DT_NT)
+        fwd2p_rows<C>(p, sLo, sHi, planes, pstride, threadIdx.x, base, b, r0, c0);
+}
+
+// Level >= 2, pass B: axis-0 decimating filters + cube2c, one thread per output cell.
+template <int M>
+__global__ void __launch_bounds__(DT_NT) k_fwd3_l2_axis0(Fwd3L2Params p) {
+    f3l2_axis0_pack<M>(p, (int)(blockIdx.x * DT_NT + threadIdx.x));
+}
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+template <class C>
+int launch_l2_planes(dt2d::Fwd2Params &p, float *planes, int64_t pstride, hipStream_t s) {
+    p.tilesR = cdiv(p.LR / 2, C::TR); p.tilesC = cdiv(p.LC / 2, C::TC);
+    k_fwd3_l2_planes<C><<<(unsigned)(p.tilesR * p.tilesC * p.B), DT_NT, 0, s>>>(p, planes, pstride);
+    return 0;
+}
+template <class C>
+int launch_l2_axis0(Fwd3L2Params &p, hipStream_t s) {
+    int cells = (p.O0 / 2) * (p.O1 / 2) * (p.O2 / 2);
+    k_fwd3_l2_axis0<C::M><<<(unsigned)cdiv(cells, DT_NT), DT_NT, 0, s>>>(p);
+    return 0;
+}
 
 template <class C>
 int launch_fwd3_l1(Fwd3L1Params &p, int cus, hipStream_t s) {
@@ -83,4 +117,53 @@ extern "C" int dtcwt_hip_fwd3_level1(dtcwt_hip_ctx *ctx, const float *X, int64_t
     DT_FWD3_L1_TABLE(X_)
 #undef X_
     return dtcwt_set_error(-3, "no fused 3-D level-1 kernel for %d/%d-tap biort filters", m0, m1);
+}
+
+// 0: pad-free multiple of 4; ext_mode 4 pads 1 plane per side, ext_mode 8 pads 2
+extern "C" int dtcwt_hip_fwd3_level2(dtcwt_hip_ctx *ctx, const float *X, int64_t n0, int64_t n1, int64_t n2,
+                                     int pad0, int pad1, int pad2, const double *h0b, const double *h0a,
+                                     const double *h1b, const double *h1a, int m, float *LLL, float *Yh) {
+    DT_REQUIRE(ctx && X && h0b && h0a && h1b && h1a && LLL && Yh, "NULL argument");
+    DT_REQUIRE(m > 0 && m % 2 == 0 && m <= DT_MAXT, "q-shift filters must have even length <= %d", DT_MAXT);
+    DT_REQUIRE(pad0 >= 0 && pad1 >= 0 && pad2 >= 0 && pad0 <= 2 && pad1 <= 2 && pad2 <= 2, "bad padding");
+    const int64_t L0 = n0 + 2 * pad0, L1 = n1 + 2 * pad1, L2 = n2 + 2 * pad2;
+    DT_REQUIRE(n0 > 0 && n1 > 0 && n2 > 0 && L0 % 4 == 0 && L1 % 4 == 0 && L2 % 4 == 0,
+               "padded extents must be multiples of 4 (transform3d.py:322-335)");
+    if (L1 < DT_MIN_FUSED_DIM || L2 < DT_MIN_FUSED_DIM || n0 * L1 * L2 >= ((int64_t)1 << 31))
+        return dtcwt_set_error(-3, "fused 3-D level >= 2 needs slices of at least %d x %d", DT_MIN_FUSED_DIM,
+                               DT_MIN_FUSED_DIM);
+    const int O0 = (int)(L0 / 2), O1 = (int)(L1 / 2), O2 = (int)(L2 / 2);
+    dt2d::Fwd2Params a{};
+    a.X = X; a.B = (int)n0; a.inR = (int)n1; a.inC = (int)n2; a.padR = pad1; a.padC = pad2;
+    a.LR = (int)L1; a.LC = (int)L2;
+    put_taps(a.l_a, h0b, m); put_taps(a.l_b, h0a, m); put_taps(a.h_a, h1b, m); put_taps(a.h_b, h1a, m);
+    double dl = 0, dh = 0;
+    for (int k = 0; k < m; ++k) { dl += h0b[k] * h0a[k]; dh += h1b[k] * h1a[k]; }
+    a.lo_a_first = dl > 0; a.hi_a_first = dh > 0;
+    Fwd3L2Params b{};
+    b.pstride = n0 * (int64_t)O1 * O2;
+    b.LLL = LLL; b.Yh = Yh; b.n0 = (int)n0; b.pad0 = pad0; b.L0 = (int)L0; b.O0 = O0; b.O1 = O1; b.O2 = O2;
+    b.lo_a_first = a.lo_a_first; b.hi_a_first = a.hi_a_first;
+    put_taps(b.l_a, h0b, m); put_taps(b.l_b, h0a, m); put_taps(b.h_a, h1b, m); put_taps(b.h_b, h1a, m);
+    bool have = false;
+#define X_(TR, TC, PS, M) if (m == M) have = true;
+    DT_FWD2_TABLE(X_)
+#undef X_
+    if (!have) return dtcwt_set_error(-3, "no fused 3-D level >= 2 kernel for %d-tap q-shift filters", m);
+    void *planes = nullptr;
+    int rc = dtcwt_hip_malloc(ctx, (size_t)(4 * b.pstride) * sizeof(float), &planes);
+    if (rc) return rc;
+    b.P = (const float *)planes;
+    DT_CHECK_HIP(hipSetDevice(ctx->device));
+#define X_(TR, TC, PS, M)                                                                   \
+    if (m == M) {                                                                           \
+        launch_l2_planes<dt2d::Fwd2DCfg<TR, TC, PS, M>>(a, (float *)planes, b.pstride, ctx->stream); \
+        launch_l2_axis0<dt2d::Fwd2DCfg<TR, TC, PS, M>>(b, ctx->stream);                     \
+    }
+    DT_FWD2_TABLE(X_)
+#undef X_
+    hipError_t e = hipGetLastError();
+    dtcwt_hip_free(ctx, planes);        // stream-ordered reuse (common.hpp)
+    if (e != hipSuccess) return dtcwt_set_error(-2, "3-D level launch failed: %s", hipGetErrorString(e));
+    return 0;
 }

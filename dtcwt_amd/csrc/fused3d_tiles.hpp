@@ -24,6 +24,7 @@
 // the test-only emulator (tests/emu/) steps the identical index algebra on the CPU.
 #pragma once
 #include "fused2d_tiles.hpp"
+#include "fused2d_tiles_v2.hpp"
 
 namespace dt3d {
 
@@ -224,6 +225,119 @@ DT_HD void f3l1_axis1_pack(const Fwd3L1Params &p, Fwd3L1State<C> &st, const floa
     cube2c_record(rec + 32, st.ev[3], cur[3]);
     cube2c_record(rec + 40, st.ev[5], cur[5]);
     cube2c_record(rec + 48, st.ev[7], cur[7]);
+}
+
+// ======================================================================================
+// Level >= 2 (transform3d.py:317-383, even-length q-shift filters, decimation by 2).
+// ======================================================================================
+// A 2M-sample window per axis makes a single 3-D tile far larger than LDS, so a level is
+// two launches:
+//   pass A  every slice of the volume goes through the 2-D level-2 tile program
+//           (fwd2d_cols of fused2d_tiles_v2.hpp: axis 1 down the rows, then axis 2 along
+//           the columns), but instead of q2c records it stores the four (a1, a2) planes:
+//           P[2*a1 + a2][n0][O1][O2];
+//   pass B  one thread per 2x2x2 output cell filters the four plane-volumes down axis 0
+//           (window of 2M slices, lanes along axis 2) and packs all eight octants: LLL
+//           and the whole 224-byte highpass record.
+// Edge padding (ext_mode 4: one replicated plane per side, 8: two; :322-335) is index
+// arithmetic in both passes.
+
+template <class C>
+DT_HD void fwd2p_rows(const dt2d::Fwd2Params &p, const float *sLo, const float *sHi, float *planes,
+                      int64_t pstride, int tid, int base, int b, int r0, int c0) {
+    using dt2d::dfilt_pair;
+    const int OR = p.LR / 2, OC = p.LC / 2;
+    const int task = base + tid;
+    const int il = task / C::TJ, jl = task - il * C::TJ;
+    const int R = r0 + 2 * il, Cc = c0 + 2 * jl;
+    if (task >= C::TI * C::TJ || R >= OR || Cc >= OC) return;
+    float *o = planes + ((int64_t)b * OR + R) * OC + Cc;
+#pragma unroll
+    for (int er = 0; er < 2; ++er) {
+        float wl[2 * C::M], wh[2 * C::M];
+        const f4 *pl = reinterpret_cast<const f4 *>(sLo + (2 * il + er) * C::NCI + 4 * jl);
+        const f4 *ph = reinterpret_cast<const f4 *>(sHi + (2 * il + er) * C::NCI + 4 * jl);
+#pragma unroll
+        for (int j = 0; j < C::M / 2; ++j) {
+            f4 a = pl[j], c = ph[j];
+            wl[4 * j] = a.x; wl[4 * j + 1] = a.y; wl[4 * j + 2] = a.z; wl[4 * j + 3] = a.w;
+            wh[4 * j] = c.x; wh[4 * j + 1] = c.y; wh[4 * j + 2] = c.z; wh[4 * j + 3] = c.w;
+        }
+        float A, Bv;
+        float *q = o + (int64_t)er * OC;
+        dfilt_pair<C::M>(wl, p.l_a, p.l_b, A, Bv);      // a1 = 0, a2 = 0
+        *reinterpret_cast<f2 *>(q) = p.lo_a_first ? f2{A, Bv} : f2{Bv, A};
+        dfilt_pair<C::M>(wl, p.h_a, p.h_b, A, Bv);      // a1 = 0, a2 = 1
+        *reinterpret_cast<f2 *>(q + pstride) = p.hi_a_first ? f2{A, Bv} : f2{Bv, A};
+        dfilt_pair<C::M>(wh, p.l_a, p.l_b, A, Bv);      // a1 = 1, a2 = 0
+        *reinterpret_cast<f2 *>(q + 2 * pstride) = p.lo_a_first ? f2{A, Bv} : f2{Bv, A};
+        dfilt_pair<C::M>(wh, p.h_a, p.h_b, A, Bv);      // a1 = 1, a2 = 1
+        *reinterpret_cast<f2 *>(q + 3 * pstride) = p.hi_a_first ? f2{A, Bv} : f2{Bv, A};
+    }
+}
+
+struct Fwd3L2Params {
+    const float *P;       // [4][n0][O1][O2]
+    int64_t pstride;      // n0*O1*O2
+    float *LLL;           // [O0][O1][O2]
+    float *Yh;            // [O0/2][O1/2][O2/2][56 floats]
+    int n0, pad0, L0;     // real slices, replicated planes per side, L0 = n0 + 2 pad0 (% 4 == 0)
+    int O0, O1, O2;       // octant extents (L/2, all even)
+    int lo_a_first, hi_a_first;
+    float l_a[DT_MAXT], l_b[DT_MAXT], h_a[DT_MAXT], h_b[DT_MAXT];
+};
+
+// record slot of octant idx = a0*4 + a1*2 + a2 (reference order 010 100 110 001 011 101 111)
+DT_HD int octant_slot(int idx) { return (idx & 1) ? 3 + (idx >> 1) : (idx >> 1) - 1; }
+
+template <int M>
+DT_HD void f3l2_axis0_pack(const Fwd3L2Params &p, int id) {
+    using dt2d::dfilt_pair;
+    const int e2 = p.O2 / 2, e1 = p.O1 / 2, e0 = p.O0 / 2;
+    if (id >= e0 * e1 * e2) return;
+    const int c2 = id % e2, t = id / e2, c1 = t % e1, c0 = t / e1;
+    const int ss = p.O1 * p.O2;
+    int soff[2 * M];
+#pragma unroll
+    for (int j = 0; j < 2 * M; ++j) {
+        int r = 4 * c0 - M + 2 + j;                      // logical slice (A.2)
+        while ((unsigned)r >= (unsigned)p.L0) r = r < 0 ? -1 - r : 2 * p.L0 - 1 - r;
+        r -= p.pad0;
+        r = r < 0 ? 0 : (r > p.n0 - 1 ? p.n0 - 1 : r);
+        soff[j] = r * ss;
+    }
+    const int base = (2 * c1) * p.O2 + 2 * c2;
+    float *rec = p.Yh + (int64_t)id * 56;
+#pragma unroll 1
+    for (int v = 0; v < 4; ++v) {
+        const float *Pv = p.P + v * p.pstride + base;
+        float w[4][2 * M];                               // [dj*2 + dk][slice]
+#pragma unroll
+        for (int j = 0; j < 2 * M; ++j) {
+            f2 a = *reinterpret_cast<const f2 *>(Pv + soff[j]);
+            f2 b = *reinterpret_cast<const f2 *>(Pv + soff[j] + p.O2);
+            w[0][j] = a.x; w[1][j] = a.y; w[2][j] = b.x; w[3][j] = b.y;
+        }
+        float lev[4], lod[4], hev[4], hod[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float A, Bv;
+            dfilt_pair<M>(w[q], p.l_a, p.l_b, A, Bv);
+            lev[q] = p.lo_a_first ? A : Bv; lod[q] = p.lo_a_first ? Bv : A;
+            dfilt_pair<M>(w[q], p.h_a, p.h_b, A, Bv);
+            hev[q] = p.hi_a_first ? A : Bv; hod[q] = p.hi_a_first ? Bv : A;
+        }
+        if (v == 0) {
+            float *L = p.LLL + (int64_t)(2 * c0) * ss + base;
+            *reinterpret_cast<f2 *>(L) = f2{lev[0], lev[1]};
+            *reinterpret_cast<f2 *>(L + p.O2) = f2{lev[2], lev[3]};
+            *reinterpret_cast<f2 *>(L + ss) = f2{lod[0], lod[1]};
+            *reinterpret_cast<f2 *>(L + ss + p.O2) = f2{lod[2], lod[3]};
+        } else {
+            cube2c_record(rec + 8 * octant_slot(v), lev, lod);
+        }
+        cube2c_record(rec + 8 * octant_slot(4 + v), hev, hod);
+    }
 }
 
 }  // namespace dt3d

@@ -60,6 +60,27 @@ def _fused_level1(Xd, h0o, h1o):
     return LLL, Yh
 
 
+def _fused_level2(Xd, pads, h0b, h0a, h1b, h1a):
+    """One level >= 2 in two launches (dtcwt_hip_fwd3_level2) -> (LLL, Yh), or None."""
+    if Xd.dtype != np.float32:
+        return None
+    taps = [flat_taps(h) for h in (h0b, h0a, h1b, h1a)]
+    m = taps[0].shape[0]
+    if any(t.shape[0] != m for t in taps) or m % 2:
+        return None
+    n = Xd.shape
+    L = [n[a] + 2 * pads[a][0] for a in range(3)]
+    LLL = DeviceArray(Xd.ctx, tuple(l // 2 for l in L), np.float32)
+    Yh = DeviceArray(Xd.ctx, tuple(l // 4 for l in L) + (28,), np.complex64)
+    pd = ctypes.POINTER(ctypes.c_double)
+    rc = _lib.lib().dtcwt_hip_fwd3_level2(Xd.ctx.handle, Xd.ptr, n[0], n[1], n[2], pads[0][0], pads[1][0],
+                                          pads[2][0], *[t.ctypes.data_as(pd) for t in taps], m, LLL.ptr, Yh.ptr)
+    if rc == -3:
+        return None
+    check(rc)
+    return LLL, Yh
+
+
 def _c2cube(Yh, octant):
     e0, e1, e2 = Yh.shape[:3]
     rdt = np.float32 if Yh.dtype == np.complex64 else np.float64
@@ -157,9 +178,13 @@ class Transform3d(object):
             else:                                              # :317-383
                 mult, npad = (4, 1) if self.ext_mode == 4 else (8, 2)
                 pads = tuple((npad, npad) if Yl.shape[a] % mult else (0, 0) for a in range(3))
-                parts = self._split(Yl, ll.axis_coldfilt2, (h0b, h0a), (h1b, h1a), pads)
-                Yl = parts[(0, 0, 0)]
-                Yh[level] = self._pack(parts, Yl.shape, cdt)
+                fused = _fused_level2(Yl, pads, h0b, h0a, h1b, h1a) if self.fused else None
+                if fused is not None:
+                    Yl, Yh[level] = fused
+                else:
+                    parts = self._split(Yl, ll.axis_coldfilt2, (h0b, h0a), (h1b, h1a), pads)
+                    Yl = parts[(0, 0, 0)]
+                    Yh[level] = self._pack(parts, Yl.shape, cdt)
             Ys[level] = Yl
         if include_scale:
             return Pyramid(Yl, tuple(Yh), tuple(Ys))

@@ -152,6 +152,17 @@ int dtcwt_hip_c2q(dtcwt_hip_ctx *ctx, int dtype, const void *Yh, int64_t batch, 
 int dtcwt_hip_fwd3_level1(dtcwt_hip_ctx *ctx, const float *X, int64_t n0, int64_t n1, int64_t n2,
                           const double *h0o, int m0, const double *h1o, int m1, float *LLL,
                           float *Yh);
+/* Fused float32 level >= 2 of the 3-D forward transform: replaces `_level2_xfm`
+ * (dtcwt/numpy/transform3d.py:317-383) -- coldfilt(., h0b, h0a) / coldfilt(., h1b, h1a) along
+ * the three axes and the seven cube2c packings -- in two launches (per-slice 2-D tile
+ * program writing four planes to a pooled workspace, then axis 0 + pack).
+ * X: [n0][n1][n2] float32 lowpass of the previous level; pad_a in {0, 1, 2}: planes replicated
+ * per side on axis a (ext_mode 4 / 8, :322-335), n_a + 2 pad_a must be a multiple of 4.
+ * LLL: [(n0+2pad0)/2][(n1+2pad1)/2][(n2+2pad2)/2]; Yh: the same extents halved, [28] complex64.
+ * Returns -3 when no fused kernel exists for m-tap filters or slices are under 40 x 40. */
+int dtcwt_hip_fwd3_level2(dtcwt_hip_ctx *ctx, const float *X, int64_t n0, int64_t n1, int64_t n2,
+                          int pad0, int pad1, int pad2, const double *h0b, const double *h0a,
+                          const double *h1b, const double *h1a, int m, float *LLL, float *Yh);
 /* cube2c: replaces dtcwt/numpy/transform3d.py:532-579 for one octant.
  * y: real volume view [d0][d1][d2] with element strides (s0, s1, 1), d* even;
  * Yh: [d0/2][d1/2][d2/2][28] complex; writes components 4*octant .. 4*octant+3. */

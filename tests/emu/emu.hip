@@ -138,6 +138,26 @@ static int run_fwd3_l1(dt3d::Fwd3L1Params p, int chunk) {
     return 0;
 }
 
+template <class C>
+static int run_fwd3_l2(Fwd2Params a, dt3d::Fwd3L2Params b, float *planes) {
+    a.tilesR = cdiv(a.LR / 2, C::TR); a.tilesC = cdiv(a.LC / 2, C::TC);
+    std::vector<float> smem(C::LDS_FLOATS + 4);
+    float *base = smem.data();
+    while (((uintptr_t)base) & 15) ++base;
+    float *sLo = base, *sHi = sLo + C::SL;
+    for (int s = 0; s < a.B; ++s)
+        for (int tr = 0; tr < a.tilesR; ++tr)
+            for (int tc = 0; tc < a.tilesC; ++tc) {
+                int r0 = tr * C::TR, c0 = tc * C::TC;
+                for (int t = 0; t < DT_NT; ++t) fwd2d_cols<C>(a, sLo, sHi, t, s, r0, c0);
+                for (int q = 0; q < C::TI * C::TJ; q += DT_NT)
+                    for (int t = 0; t < DT_NT; ++t) dt3d::fwd2p_rows<C>(a, sLo, sHi, planes, b.pstride, t, q, s, r0, c0);
+            }
+    int cells = (b.O0 / 2) * (b.O1 / 2) * (b.O2 / 2);
+    for (int id = 0; id < cells; ++id) dt3d::f3l2_axis0_pack<C::M>(b, id);
+    return 0;
+}
+
 #define EMU_FWD1(TR, TC, RS, A, B_) if (m0 == A && m1 == B_) return run_fwd1<Fwd1DCfg<TR, TC, RS, A, B_>>(p);
 #define EMU_INV1(TR, TC, RS, A, B_) if (m0 == A && m1 == B_) return run_inv1<Inv1RCfg<TR, TC, RS, A, B_>>(p);
 #define EMU_FWD2(TR, TC, PS, M) if (m == M) return run_fwd2<Fwd2DCfg<TR, TC, PS, M>>(p);
@@ -198,6 +218,24 @@ int emu_fwd3_l1(int m0, int m1, const float *X, float *LLL, float *Yh, int n0, i
     if (m0 == 5 && m1 == 7) return run_fwd3_l1<dt3d::Fwd3L1Cfg<5, 7>>(p, chunk);
     if (m0 == 9 && m1 == 7) return run_fwd3_l1<dt3d::Fwd3L1Cfg<9, 7>>(p, chunk);
     if (m0 == 5 && m1 == 3) return run_fwd3_l1<dt3d::Fwd3L1Cfg<5, 3>>(p, chunk);
+    return -3;
+}
+
+int emu_fwd3_l2(int m, const float *X, float *planes, float *LLL, float *Yh, int n0, int n1, int n2, int pad0,
+                int pad1, int pad2, const double *h0b, const double *h0a, const double *h1b, const double *h1a) {
+    Fwd2Params a{};
+    a.X = X; a.B = n0; a.inR = n1; a.inC = n2; a.padR = pad1; a.padC = pad2;
+    a.LR = n1 + 2 * pad1; a.LC = n2 + 2 * pad2;
+    put_taps(a.l_a, h0b, m); put_taps(a.l_b, h0a, m); put_taps(a.h_a, h1b, m); put_taps(a.h_b, h1a, m);
+    a.lo_a_first = dotd(h0b, h0a, m) > 0; a.hi_a_first = dotd(h1b, h1a, m) > 0;
+    dt3d::Fwd3L2Params b{};
+    b.P = planes; b.LLL = LLL; b.Yh = Yh; b.n0 = n0; b.pad0 = pad0; b.L0 = n0 + 2 * pad0;
+    b.O0 = b.L0 / 2; b.O1 = a.LR / 2; b.O2 = a.LC / 2;
+    b.pstride = (int64_t)n0 * b.O1 * b.O2;
+    b.lo_a_first = a.lo_a_first; b.hi_a_first = a.hi_a_first;
+    put_taps(b.l_a, h0b, m); put_taps(b.l_b, h0a, m); put_taps(b.h_a, h1b, m); put_taps(b.h_b, h1a, m);
+#define EMU_L2(TR, TC, PS, M) if (m == M) return run_fwd3_l2<Fwd2DCfg<TR, TC, PS, M>>(a, b, planes);
+    DT_FWD2_TABLE(EMU_L2)
     return -3;
 }
 

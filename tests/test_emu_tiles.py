@@ -188,3 +188,33 @@ def test_fwd3_level1_tiles(emu, shape, chunk, bname):
     assert rel(LLL, want.lowpass) < TOL
     assert Yh.shape == want.highpasses[0].shape
     assert rel(Yh, want.highpasses[0]) < TOL
+
+
+def _oracle_level2(X, q, ext):
+    t = o.Transform3d(biort('near_sym_a'), q, ext_mode=ext)
+    h0a, h0b, h1a, h1b = [np.asarray(v, dtype=np.float64) for v in (q[0], q[1], q[4], q[5])]
+    return t._level2_xfm(X, h0a, h0b, h1a, h1b)
+
+
+@pytest.mark.parametrize('shape,ext', [((8, 40, 44), 4), ((14, 42, 50), 4), ((20, 44, 60), 8), ((4, 48, 40), 8)])
+@pytest.mark.parametrize('qname', ['qshift_a', 'qshift_b', 'qshift_d'])
+def test_fwd3_level2_tiles(emu, shape, ext, qname):
+    """Level >= 2 (two passes) against the oracle's level 2 given the same input volume."""
+    X = np.random.RandomState(13).standard_normal(shape).astype(np.float32)
+    q = qshift(qname)
+    h0a, h0b, h1a, h1b = q[0], q[1], q[4], q[5]
+    mult, npad = (4, 1) if ext == 4 else (8, 2)
+    pads = [npad if s % mult else 0 for s in shape]
+    L = [s + 2 * p for s, p in zip(shape, pads)]
+    O = [l // 2 for l in L]
+    planes = np.full((4, shape[0], O[1], O[2]), np.nan, np.float32)
+    LLL = np.full(O, np.nan, np.float32)
+    Yh = np.full((O[0] // 2, O[1] // 2, O[2] // 2, 56), np.nan, np.float32)
+    t = [_d(h) for h in (h0b, h0a, h1b, h1a)]
+    rc = emu.emu_fwd3_l2(len(t[0][0]), _f(X), _f(planes), _f(LLL), _f(Yh), shape[0], shape[1], shape[2],
+                         pads[0], pads[1], pads[2], t[0][1], t[1][1], t[2][1], t[3][1])
+    assert rc == 0
+    lo, hi = _oracle_level2(X.astype(np.float64), q, ext)
+    assert LLL.shape == lo.shape and rel(LLL, lo) < TOL
+    Yc = Yh.view(np.complex64)
+    assert Yc.shape == hi.shape and rel(Yc, hi) < TOL

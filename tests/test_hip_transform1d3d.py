@@ -161,3 +161,23 @@ def test_3d_fused_level1_matches_generic_and_oracle(shape, bname):
             assert_pyramids_close(p, want, XFM_TOL)
         z = t.inverse(p)
         assert_close(z, X, 2e-5, 'PR')
+
+
+@pytest.mark.parametrize('shape,ext', [((42, 46, 90), 4), ((44, 52, 84), 8), ((80, 80, 80), 4), ((48, 40, 200), 8)])
+@pytest.mark.parametrize('qname', ['qshift_a', 'qshift_b', 'qshift_d'])
+def test_3d_fused_level2_matches_generic_and_oracle(shape, ext, qname):
+    """Levels >= 2 through dtcwt_hip_fwd3_level2 (edge padding of both ext_modes as index math)
+    against the generic axis passes and the oracle."""
+    X = np.random.RandomState(14).standard_normal(shape).astype(np.float32)
+    t = Transform3d(qshift=qname, ext_mode=ext)
+    g = Transform3d(qshift=qname, ext_mode=ext)
+    g.fused = False
+    p, q = t.forward(X, nlevels=3, include_scale=True), g.forward(X, nlevels=3, include_scale=True)
+    assert_pyramids_close(p, q, XFM_TOL)
+    want = o.Transform3d(biort('near_sym_a'), qshift(qname), ext_mode=ext).forward(X, nlevels=3, include_scale=True)
+    assert_pyramids_close(p, want, XFM_TOL)
+    assert_close(t.inverse(p), want_inverse(want, qname, ext), 2e-5, 'inverse')
+
+
+def want_inverse(pyr, qname, ext):
+    return o.Transform3d(biort('near_sym_a'), qshift(qname), ext_mode=ext).inverse(pyr)
