@@ -14,9 +14,9 @@ using namespace dt3d;
 namespace {
 
 template <class C>
-__global__ void __launch_bounds__(DT_NT) k_fwd3_l1(Fwd3L1Params p) {
+__global__ void __launch_bounds__(C::NT, 2) k_fwd3_l1(Fwd3L1Params p) {
     __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
-    float *S0 = smem, *S1 = smem + C::S0F;
+    float *S0 = smem, *S1 = smem + C::S0F, *stage = S1 + C::S1F;
     const int bid = blockIdx.x;
     const int tk = bid % p.tilesK, tj = (bid / p.tilesK) % p.tilesJ, ch = bid / (p.tilesK * p.tilesJ);
     const int j0 = tj * C::TJ, k0 = tk * C::TK, i0 = ch * p.chunk;
@@ -25,12 +25,27 @@ __global__ void __launch_bounds__(DT_NT) k_fwd3_l1(Fwd3L1Params p) {
     Fwd3L1State<C> st;
     f3l1_init<C>(p, st, tid, j0, k0);
     f3l1_prologue<C>(p, st, i0);
-    for (int i = i0; i < iend; ++i) {
-        f3l1_axis0<C>(p, st, S0, i, i + 1 < iend);
+    // settle the prologue loads here so that no wait on them lands inside the march (where
+    // it would also drain the stores in flight): s_waitcnt vmcnt(0)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (int i = i0; i < iend; i += 2) {             // chunks start and end on even slices
+        f3l1_axis0<C>(p, st, S0, i, true);
         __syncthreads();
         f3l1_axis2<C>(p, S0, S1, tid);
         __syncthreads();
-        f3l1_axis1_pack<C>(p, st, S1, tid, i, j0, k0);
+        f3l1_rotate<C>(st);
+        f3l1_axis1<C>(p, st.ev, S1, tid, i, j0, k0);
+        f3l1_axis0<C>(p, st, S0, i + 1, i + 2 < iend);
+        __syncthreads();
+        f3l1_axis2<C>(p, S0, S1, tid);
+        __syncthreads();
+        f3l1_rotate<C>(st);
+        float od[8][4];
+        f3l1_axis1<C>(p, od, S1, tid, i + 1, j0, k0);
+        f3l1_pack_stage<C>(st.ev, od, stage, tid, 0);
+        f3l1_pack_flush<C>(p, stage, tid, 0, i + 1, j0, k0);
+        f3l1_pack_stage<C>(st.ev, od, stage, tid, 1);
+        f3l1_pack_flush<C>(p, stage, tid, 1, i + 1, j0, k0);
     }
 }
 
@@ -82,7 +97,7 @@ int launch_fwd3_l1(Fwd3L1Params &p, int cus, hipStream_t s) {
     }
     p.chunk = chunk;
     p.chunks = cdiv(p.n0, chunk);
-    k_fwd3_l1<C><<<(unsigned)(p.tilesJ * p.tilesK * p.chunks), DT_NT, 0, s>>>(p);
+    k_fwd3_l1<C><<<(unsigned)(p.tilesJ * p.tilesK * p.chunks), C::NT, 0, s>>>(p);
     return 0;
 }
 
@@ -90,9 +105,14 @@ void put_taps(float *dst, const double *src, int m) {
     for (int k = 0; k < DT_MAXT; ++k) dst[k] = k < m ? (float)src[k] : 0.f;
 }
 
+void put_centred(float *dst, const double *src, int m, int to) {
+    for (int k = 0; k < DT_MAXT; ++k) dst[k] = 0.f;
+    for (int k = 0; k < m; ++k) dst[k + (to - m) / 2] = (float)src[k];
+}
+
 }  // namespace
 
-#define DT_FWD3_L1_TABLE(X) X(5, 7) X(9, 7) X(5, 3) X(7, 5) X(7, 9) X(3, 5)
+#define DT_FWD3_L1_TABLE(X) X(5, 7) X(9, 7) X(7, 5) X(7, 9)
 
 extern "C" int dtcwt_hip_fwd3_level1(dtcwt_hip_ctx *ctx, const float *X, int64_t n0, int64_t n1, int64_t n2,
                                      const double *h0o, int m0, const double *h1o, int m1, float *LLL,
@@ -107,6 +127,9 @@ extern "C" int dtcwt_hip_fwd3_level1(dtcwt_hip_ctx *ctx, const float *X, int64_t
     p.X = X; p.LLL = LLL; p.Yh = Yh;
     p.n0 = (int)n0; p.n1 = (int)n1; p.n2 = (int)n2;
     put_taps(p.h0, h0o, m0); put_taps(p.h1, h1o, m1);
+    // 3-tap filters (legall) run as centred zero-padded 7-tap ones on the 5/7 kernels
+    if (m0 == 5 && m1 == 3) { put_centred(p.h1, h1o, 3, 7); m1 = 7; }
+    if (m0 == 3 && m1 == 5) { put_centred(p.h0, h0o, 3, 7); m0 = 7; }
     DT_CHECK_HIP(hipSetDevice(ctx->device));
 #define X_(A, B)                                                                           \
     if (m0 == A && m1 == B) {                                                              \

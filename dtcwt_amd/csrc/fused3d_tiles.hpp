@@ -26,6 +26,15 @@
 #include "fused2d_tiles.hpp"
 #include "fused2d_tiles_v2.hpp"
 
+// Keeps the consumption of a prefetched value (and so the s_waitcnt on it) at this program
+// point: left alone, the compiler sinks it below the record stores of the step, where the
+// wait also drains those stores.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DT_PIN_HERE(x) asm volatile("" : "+v"(x) : : "memory")
+#else
+#define DT_PIN_HERE(x) (void)(x)
+#endif
+
 namespace dt3d {
 
 using dt2d::cmax;
@@ -51,15 +60,18 @@ struct Fwd3L1Cfg {
     static constexpr int TJ = 16, TK = 64;                // outputs per slice
     static constexpr int PJ = TJ + 2 * H, PK = TK + 2 * H;
     static constexpr int S0S = TK + 8;                    // S0 row stride: 16-byte aligned windows
+    static constexpr int NT = 256;                        // threads per workgroup (4 wavefronts)
     static constexpr int NPOS = PJ * PK;
-    static constexpr int NPT = (NPOS + DT_NT - 1) / DT_NT;    // ring positions per thread
+    static constexpr int NPT = (NPOS + NT - 1) / NT;      // ring positions per thread
     static constexpr int S0F = 2 * PJ * S0S, S1F = 4 * PJ * TK;
-    static constexpr int LDS_FLOATS = S0F + S1F;
+    static constexpr int STAGE_W = 32 * 56;               // floats: 32 records per wavefront
+    static constexpr int LDS_FLOATS = S0F + S1F + (NT / 64) * STAGE_W;
     static constexpr int NT2 = 2 * PJ * (TK / 4);         // axis-2 tasks (4 outputs each)
     static constexpr int WK = 4 + 2 * H;                  // axis-2 window (<= 12)
     static_assert(M0 % 2 == 1 && M1 % 2 == 1, "biort filters must have odd length");
     static_assert(H <= 4, "axis-2 window must fit three float4");
-    static_assert((TJ / 2) * (TK / 2) == DT_NT, "one 2x2 cell per thread");
+    static constexpr int NCELL = (TJ / 2) * (TK / 2);
+    static_assert(NCELL == NT && TK / 2 == 32, "one 2x2 cell per thread, one cell row per half wavefront");
 };
 
 // per-thread registers carried across the steps of the march
@@ -69,14 +81,14 @@ struct Fwd3L1State {
     float nxt[C::NPT];
     int goff[C::NPT];         // j*n2 + k of the position (reflected), constant over slices
     int soff[C::NPT];         // pj*S0S + pk, or -1 for the unused tail
-    float ev[8][4];           // octant values of the even slice of the current pair
+    float ev[8][4];           // [a0*4 + a1*2 + a2][dj*2 + dk] of the even slice of the pair
 };
 
 template <class C>
 DT_HD void f3l1_init(const Fwd3L1Params &p, Fwd3L1State<C> &st, int tid, int j0, int k0) {
 #pragma unroll
     for (int s = 0; s < C::NPT; ++s) {
-        int q = tid + DT_NT * s;
+        int q = tid + C::NT * s;
         int pj = q / C::PK, pk = q - pj * C::PK;
         bool ok = q < C::NPOS;
         if (!ok) { pj = 0; pk = 0; }
@@ -86,30 +98,23 @@ DT_HD void f3l1_init(const Fwd3L1Params &p, Fwd3L1State<C> &st, int tid, int j0,
     }
 }
 
-// ring <- slices i0-H .. i0+H-1 (slots 1..2H), nxt <- slice i0+H: all loads in one batch
+// ring <- slices i0-H .. i0+H: all loads in one batch
 template <class C>
 DT_HD void f3l1_prologue(const Fwd3L1Params &p, Fwd3L1State<C> &st, int i0) {
     const int64_t ss = (int64_t)p.n1 * p.n2;
 #pragma unroll
-    for (int t = 0; t < 2 * C::H; ++t) {
+    for (int t = 0; t < C::MR; ++t) {
         const float *sl = p.X + ss * reflect_i(i0 - C::H + t, p.n0);
 #pragma unroll
-        for (int s = 0; s < C::NPT; ++s) st.ring[s][t + 1] = sl[st.goff[s]];
+        for (int s = 0; s < C::NPT; ++s) st.ring[s][t] = sl[st.goff[s]];
     }
-    const float *sl = p.X + ss * reflect_i(i0 + C::H, p.n0);
-#pragma unroll
-    for (int s = 0; s < C::NPT; ++s) st.nxt[s] = sl[st.goff[s]];
 }
 
-// rotate the ring, take in the prefetched slice, prefetch slice i+1+H, filter along axis 0
+// prefetch slice i+1+H, filter the ring (slices i-H .. i+H) along axis 0 into S0.
+// The prefetched values are only touched by f3l1_rotate two barriers later: a wait on them
+// here would also wait for the record stores of the previous step (vmcnt counts both).
 template <class C>
 DT_HD void f3l1_axis0(const Fwd3L1Params &p, Fwd3L1State<C> &st, float *S0, int i, bool more) {
-#pragma unroll
-    for (int s = 0; s < C::NPT; ++s) {
-#pragma unroll
-        for (int t = 0; t < C::MR - 1; ++t) st.ring[s][t] = st.ring[s][t + 1];
-        st.ring[s][C::MR - 1] = st.nxt[s];
-    }
     if (more) {
         const float *sl = p.X + (int64_t)p.n1 * p.n2 * reflect_i(i + 1 + C::H, p.n0);
 #pragma unroll
@@ -129,13 +134,25 @@ DT_HD void f3l1_axis0(const Fwd3L1Params &p, Fwd3L1State<C> &st, float *S0, int 
     }
 }
 
+// ring <- slices i+1-H .. i+1+H (called before the stores of step i are issued)
+template <class C>
+DT_HD void f3l1_rotate(Fwd3L1State<C> &st) {
+#pragma unroll
+    for (int s = 0; s < C::NPT; ++s) {
+#pragma unroll
+        for (int t = 0; t < C::MR - 1; ++t) st.ring[s][t] = st.ring[s][t + 1];
+        st.ring[s][C::MR - 1] = st.nxt[s];
+        DT_PIN_HERE(st.ring[s][C::MR - 1]);
+    }
+}
+
 // S1[2*a0 + a2][pj][k] = (axis-2 filter a2) of S0[a0][pj][.]
 template <class C>
 DT_HD void f3l1_axis2(const Fwd3L1Params &p, const float *S0, float *S1, int tid) {
     constexpr int G = C::TK / 4;
 #pragma unroll
-    for (int r = 0; r < (C::NT2 + DT_NT - 1) / DT_NT; ++r) {
-        int it = tid + DT_NT * r;
+    for (int r = 0; r < (C::NT2 + C::NT - 1) / C::NT; ++r) {
+        int it = tid + C::NT * r;
         if (it >= C::NT2) break;
         int vol = it / (C::PJ * G), rem = it - vol * (C::PJ * G);
         int pj = rem / G, c = rem - pj * G;
@@ -172,13 +189,15 @@ DT_HD void cube2c_record(float *rec, const float (&ev)[4], const float (&od)[4])
     o[1] = f4{(A + G + D - F) * h, (B + Hh - Cc + E) * h, (A + G - D + F) * h, (-B - Hh - Cc + E) * h};
 }
 
-// axis-1 filters for the thread's 2x2 (j, k) cell, LLL store, and on odd slices the pack
+// record slot of octant idx = a0*4 + a1*2 + a2 (reference order 010 100 110 001 011 101 111)
+DT_HD int octant_slot(int idx) { return (idx & 1) ? 3 + (idx >> 1) : (idx >> 1) - 1; }
+
+// axis-1 filters for the thread's 2x2 (j, k) cell -> out[a0*4 + a1*2 + a2][dj*2 + dk], LLL store
 template <class C>
-DT_HD void f3l1_axis1_pack(const Fwd3L1Params &p, Fwd3L1State<C> &st, const float *S1, int tid, int i,
-                           int j0, int k0) {
+DT_HD void f3l1_axis1(const Fwd3L1Params &p, float (&out)[8][4], const float *S1, int tid, int i, int j0,
+                      int k0) {
     const int cj = tid / (C::TK / 2), ck = tid - cj * (C::TK / 2);
     const int j = j0 + 2 * cj, k = k0 + 2 * ck;
-    float cur[8][4];          // [a0*4 + a1*2 + a2][dj*2 + dk]
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         float u[2 * C::H + 2][2];
@@ -197,34 +216,56 @@ DT_HD void f3l1_axis1_pack(const Fwd3L1Params &p, Fwd3L1State<C> &st, const floa
                 for (int t = 0; t < C::M0; ++t) lo += p.h0[t] * u[e + C::H + C::H0 - t][c];
 #pragma unroll
                 for (int t = 0; t < C::M1; ++t) hi += p.h1[t] * u[e + C::H + C::H1 - t][c];
-                cur[a0 * 4 + a2][e * 2 + c] = lo;
-                cur[a0 * 4 + 2 + a2][e * 2 + c] = hi;
+                out[a0 * 4 + a2][e * 2 + c] = lo;
+                out[a0 * 4 + 2 + a2][e * 2 + c] = hi;
             }
     }
-    const bool live = j < p.n1 && k < p.n2;
-    if (live) {
+    if (j < p.n1 && k < p.n2) {
         float *L = p.LLL + ((int64_t)i * p.n1 + j) * p.n2 + k;
-        *reinterpret_cast<f2 *>(L) = f2{cur[0][0], cur[0][1]};
-        *reinterpret_cast<f2 *>(L + p.n2) = f2{cur[0][2], cur[0][3]};
+        *reinterpret_cast<f2 *>(L) = f2{out[0][0], out[0][1]};
+        *reinterpret_cast<f2 *>(L + p.n2) = f2{out[0][2], out[0][3]};
     }
-    if ((i & 1) == 0) {
-#pragma unroll
-        for (int o = 1; o < 8; ++o)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) st.ev[o][e] = cur[o][e];
-        return;
-    }
-    if (!live) return;
-    float *rec = p.Yh + (((int64_t)(i >> 1) * (p.n1 / 2) + (j >> 1)) * (p.n2 / 2) + (k >> 1)) * 56;
+}
+
+// ---- staged record stores (odd slices) -------------------------------------------------
+// A lane-owned 224-byte record written as fourteen 16-byte stores at a 224-byte lane
+// stride turns every store instruction into 64 separate 16-byte write requests, and the
+// L2 request rate -- not bytes -- then bounds the kernel.  Each half wavefront owns one
+// row of 32 cells = 7168 contiguous bytes of Yh, so the halves take turns bouncing their
+// records through a wave-private LDS slab and the whole wavefront writes the row out as
+// seven consecutive 1 KiB runs.  Two functions because the host emulator runs them as two
+// passes; on the device they are called back to back (LDS operations of one wavefront
+// execute in order, no barrier needed).
+template <class C>
+DT_HD void f3l1_pack_stage(const float (&ev)[8][4], const float (&od)[8][4], float *stage, int tid, int half) {
+    const int lane = tid & 63, wave = tid >> 6;
+    if ((lane >> 5) != half) return;
+    float *rec = stage + wave * C::STAGE_W + (lane & 31) * 56;
     // record slots in the reference's concatenation order (transform3d.py:278-289):
     // (a0,a1,a2) = 010, 100, 110, 001, 011, 101, 111
-    cube2c_record(rec + 0, st.ev[2], cur[2]);
-    cube2c_record(rec + 8, st.ev[4], cur[4]);
-    cube2c_record(rec + 16, st.ev[6], cur[6]);
-    cube2c_record(rec + 24, st.ev[1], cur[1]);
-    cube2c_record(rec + 32, st.ev[3], cur[3]);
-    cube2c_record(rec + 40, st.ev[5], cur[5]);
-    cube2c_record(rec + 48, st.ev[7], cur[7]);
+    cube2c_record(rec + 0, ev[2], od[2]);
+    cube2c_record(rec + 8, ev[4], od[4]);
+    cube2c_record(rec + 16, ev[6], od[6]);
+    cube2c_record(rec + 24, ev[1], od[1]);
+    cube2c_record(rec + 32, ev[3], od[3]);
+    cube2c_record(rec + 40, ev[5], od[5]);
+    cube2c_record(rec + 48, ev[7], od[7]);
+}
+
+template <class C>
+DT_HD void f3l1_pack_flush(const Fwd3L1Params &p, const float *stage, int tid, int half, int i, int j0,
+                           int k0) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = j0 + 2 * (2 * wave + half);            // the half wavefront's cell row
+    if (j >= p.n1) return;
+    const f4 *slab = reinterpret_cast<const f4 *>(stage + wave * C::STAGE_W);
+    f4 *row = reinterpret_cast<f4 *>(p.Yh + (((int64_t)(i >> 1) * (p.n1 / 2) + (j >> 1)) * (p.n2 / 2) + (k0 >> 1)) * 56);
+    const int ncell = (p.n2 - k0) / 2 < 32 ? (p.n2 - k0) / 2 : 32;
+#pragma unroll
+    for (int it = 0; it < 7; ++it) {
+        int piece = it * 64 + lane;                      // 16-byte piece of the row's 32 records
+        if (piece < ncell * 14) row[piece] = slab[piece];
+    }
 }
 
 // ======================================================================================
@@ -286,9 +327,6 @@ struct Fwd3L2Params {
     int lo_a_first, hi_a_first;
     float l_a[DT_MAXT], l_b[DT_MAXT], h_a[DT_MAXT], h_b[DT_MAXT];
 };
-
-// record slot of octant idx = a0*4 + a1*2 + a2 (reference order 010 100 110 001 011 101 111)
-DT_HD int octant_slot(int idx) { return (idx & 1) ? 3 + (idx >> 1) : (idx >> 1) - 1; }
 
 template <int M>
 DT_HD void f3l2_axis0_pack(const Fwd3L2Params &p, int id) {

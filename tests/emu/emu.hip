@@ -121,18 +121,26 @@ static int run_fwd3_l1(dt3d::Fwd3L1Params p, int chunk) {
     std::vector<float> smem(C::LDS_FLOATS + 4);
     float *base = smem.data();
     while (((uintptr_t)base) & 15) ++base;
-    float *S0 = base, *S1 = base + C::S0F;
-    static Fwd3L1State<C> st[DT_NT];
+    float *S0 = base, *S1 = base + C::S0F, *stage = S1 + C::S1F;
+    static Fwd3L1State<C> st[C::NT];
     for (int ch = 0; ch < p.chunks; ++ch)
         for (int tj = 0; tj < p.tilesJ; ++tj)
             for (int tk = 0; tk < p.tilesK; ++tk) {
                 int j0 = tj * C::TJ, k0 = tk * C::TK, i0 = ch * p.chunk;
                 int iend = i0 + p.chunk < p.n0 ? i0 + p.chunk : p.n0;
-                for (int t = 0; t < DT_NT; ++t) { f3l1_init<C>(p, st[t], t, j0, k0); f3l1_prologue<C>(p, st[t], i0); }
-                for (int i = i0; i < iend; ++i) {
-                    for (int t = 0; t < DT_NT; ++t) f3l1_axis0<C>(p, st[t], S0, i, i + 1 < iend);
-                    for (int t = 0; t < DT_NT; ++t) f3l1_axis2<C>(p, S0, S1, t);
-                    for (int t = 0; t < DT_NT; ++t) f3l1_axis1_pack<C>(p, st[t], S1, t, i, j0, k0);
+                for (int t = 0; t < C::NT; ++t) { f3l1_init<C>(p, st[t], t, j0, k0); f3l1_prologue<C>(p, st[t], i0); }
+                static float od[C::NT][8][4];
+                for (int i = i0; i < iend; i += 2) {
+                    for (int t = 0; t < C::NT; ++t) f3l1_axis0<C>(p, st[t], S0, i, true);
+                    for (int t = 0; t < C::NT; ++t) f3l1_axis2<C>(p, S0, S1, t);
+                    for (int t = 0; t < C::NT; ++t) { f3l1_rotate<C>(st[t]); f3l1_axis1<C>(p, st[t].ev, S1, t, i, j0, k0); }
+                    for (int t = 0; t < C::NT; ++t) f3l1_axis0<C>(p, st[t], S0, i + 1, i + 2 < iend);
+                    for (int t = 0; t < C::NT; ++t) f3l1_axis2<C>(p, S0, S1, t);
+                    for (int t = 0; t < C::NT; ++t) { f3l1_rotate<C>(st[t]); f3l1_axis1<C>(p, od[t], S1, t, i + 1, j0, k0); }
+                    for (int half = 0; half < 2; ++half) {
+                        for (int t = 0; t < C::NT; ++t) f3l1_pack_stage<C>(st[t].ev, od[t], stage, t, half);
+                        for (int t = 0; t < C::NT; ++t) f3l1_pack_flush<C>(p, stage, t, half, i + 1, j0, k0);
+                    }
                 }
             }
     return 0;
@@ -217,7 +225,11 @@ int emu_fwd3_l1(int m0, int m1, const float *X, float *LLL, float *Yh, int n0, i
     put_taps(p.h0, h0, m0); put_taps(p.h1, h1, m1);
     if (m0 == 5 && m1 == 7) return run_fwd3_l1<dt3d::Fwd3L1Cfg<5, 7>>(p, chunk);
     if (m0 == 9 && m1 == 7) return run_fwd3_l1<dt3d::Fwd3L1Cfg<9, 7>>(p, chunk);
-    if (m0 == 5 && m1 == 3) return run_fwd3_l1<dt3d::Fwd3L1Cfg<5, 3>>(p, chunk);
+    if (m0 == 5 && m1 == 3) {       // as dtcwt_hip_fwd3_level1: centred zero-padded 7 taps
+        for (int k = 0; k < DT_MAXT; ++k) p.h1[k] = 0.f;
+        for (int k = 0; k < 3; ++k) p.h1[k + 2] = (float)h1[k];
+        return run_fwd3_l1<dt3d::Fwd3L1Cfg<5, 7>>(p, chunk);
+    }
     return -3;
 }
 
