@@ -64,9 +64,14 @@ __global__ void __launch_bounds__(DT_NT) k_fwd3_l2_planes(dt2d::Fwd2Params p, fl
 }
 
 // Level >= 2, pass B: axis-0 decimating filters + cube2c, one thread per output cell.
-template <int M>
-__global__ void __launch_bounds__(DT_NT) k_fwd3_l2_axis0(Fwd3L2Params p) {
-    f3l2_axis0_pack<M>(p, (int)(blockIdx.x * DT_NT + threadIdx.x));
+template <int M, int NT>
+__global__ void __launch_bounds__(NT) k_fwd3_l2_axis0(Fwd3L2Params p) {
+    __shared__ __attribute__((aligned(16))) float slab[(NT / 64) * 64 * 56];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int id = (int)(blockIdx.x * NT + threadIdx.x);
+    float *ws = slab + wave * 64 * 56;
+    f3l2_axis0_stage<M>(p, id, ws + lane * 56);
+    f3l2_axis0_flush(p, id - lane, lane, ws);
 }
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -78,9 +83,13 @@ int launch_l2_planes(dt2d::Fwd2Params &p, float *planes, int64_t pstride, hipStr
     return 0;
 }
 template <class C>
-int launch_l2_axis0(Fwd3L2Params &p, hipStream_t s) {
+int launch_l2_axis0(Fwd3L2Params &p, int cus, hipStream_t s) {
     int cells = (p.O0 / 2) * (p.O1 / 2) * (p.O2 / 2);
-    k_fwd3_l2_axis0<C::M><<<(unsigned)cdiv(cells, DT_NT), DT_NT, 0, s>>>(p);
+    // coarse levels: single-wavefront workgroups so that every CU gets work
+    if (cdiv(cells, DT_NT) < 4 * cus)
+        k_fwd3_l2_axis0<C::M, 64><<<(unsigned)cdiv(cells, 64), 64, 0, s>>>(p);
+    else
+        k_fwd3_l2_axis0<C::M, DT_NT><<<(unsigned)cdiv(cells, DT_NT), DT_NT, 0, s>>>(p);
     return 0;
 }
 
@@ -100,6 +109,7 @@ int launch_fwd3_l1(Fwd3L1Params &p, int cus, hipStream_t s) {
     k_fwd3_l1<C><<<(unsigned)(p.tilesJ * p.tilesK * p.chunks), C::NT, 0, s>>>(p);
     return 0;
 }
+
 
 void put_taps(float *dst, const double *src, int m) {
     for (int k = 0; k < DT_MAXT; ++k) dst[k] = k < m ? (float)src[k] : 0.f;
@@ -181,7 +191,7 @@ extern "C" int dtcwt_hip_fwd3_level2(dtcwt_hip_ctx *ctx, const float *X, int64_t
 #define X_(TR, TC, PS, M)                                                                   \
     if (m == M) {                                                                           \
         launch_l2_planes<dt2d::Fwd2DCfg<TR, TC, PS, M>>(a, (float *)planes, b.pstride, ctx->stream); \
-        launch_l2_axis0<dt2d::Fwd2DCfg<TR, TC, PS, M>>(b, ctx->stream);                     \
+        launch_l2_axis0<dt2d::Fwd2DCfg<TR, TC, PS, M>>(b, ctx->cus, ctx->stream);                     \
     }
     DT_FWD2_TABLE(X_)
 #undef X_

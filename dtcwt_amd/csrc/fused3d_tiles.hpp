@@ -328,8 +328,11 @@ struct Fwd3L2Params {
     float l_a[DT_MAXT], l_b[DT_MAXT], h_a[DT_MAXT], h_b[DT_MAXT];
 };
 
+// One thread per output cell; the 56-float record goes to the thread's slot of a
+// wave-private LDS slab (64 x 56 floats) and f3l2_axis0_flush writes the wavefront's 64
+// consecutive records (cell ids are record indices) as fourteen 1 KiB runs.
 template <int M>
-DT_HD void f3l2_axis0_pack(const Fwd3L2Params &p, int id) {
+DT_HD void f3l2_axis0_stage(const Fwd3L2Params &p, int id, float *rec) {
     using dt2d::dfilt_pair;
     const int e2 = p.O2 / 2, e1 = p.O1 / 2, e0 = p.O0 / 2;
     if (id >= e0 * e1 * e2) return;
@@ -345,7 +348,6 @@ DT_HD void f3l2_axis0_pack(const Fwd3L2Params &p, int id) {
         soff[j] = r * ss;
     }
     const int base = (2 * c1) * p.O2 + 2 * c2;
-    float *rec = p.Yh + (int64_t)id * 56;
 #pragma unroll 1
     for (int v = 0; v < 4; ++v) {
         const float *Pv = p.P + v * p.pstride + base;
@@ -375,6 +377,19 @@ DT_HD void f3l2_axis0_pack(const Fwd3L2Params &p, int id) {
             cube2c_record(rec + 8 * octant_slot(v), lev, lod);
         }
         cube2c_record(rec + 8 * octant_slot(4 + v), hev, hod);
+    }
+}
+
+// first: cell id of the wavefront's lane 0
+DT_HD void f3l2_axis0_flush(const Fwd3L2Params &p, int first, int lane, const float *slab) {
+    const int ncell = (p.O0 / 2) * (p.O1 / 2) * (p.O2 / 2);
+    const int n = ncell - first < 64 ? ncell - first : 64;
+    f4 *dst = reinterpret_cast<f4 *>(p.Yh + (int64_t)first * 56);
+    const f4 *src = reinterpret_cast<const f4 *>(slab);
+#pragma unroll
+    for (int it = 0; it < 14; ++it) {
+        int piece = it * 64 + lane;
+        if (piece < n * 14) dst[piece] = src[piece];
     }
 }
 

@@ -11,7 +11,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 run() {
   name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" -d "$OUT/$name" -o p --output-format csv -- python $R/bench.py $ARGS > "$OUT/$name.log" 2>&1
+  timeout 180 rocprofv3 --kernel-trace --pmc "$@" -d "$OUT/$name" -o p --output-format csv -- python $R/bench.py $ARGS > "$OUT/$name.log" 2>&1
   echo "$name rc=$?" >> "$OUT/status.txt"
 }
 run sq_a SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
@@ -19,7 +19,7 @@ run sq_b SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_
 run sq_c SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_INSTS_VALU_FMA_F32 SQ_THREAD_CYCLES_VALU
 run tcc_fetch FETCH_SIZE GRBM_GUI_ACTIVE
 run tcc_write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
-run tcp TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_READ_sum TCP_TOTAL_WRITE_sum
+# (a TCP_* pass aborted inside rocprofv3 on this image and then hung: not collected)
 cd $R
 python tools/pmc_summary.py "$OUT" > "$OUT/summary.txt" 2>&1
 cat "$OUT/status.txt"
