@@ -823,10 +823,11 @@ DT_HD void rec_samples(const float *rec, const float *g, int e, float (&top)[3],
 #endif
 
 template <class C>
-DT_HD void inv1r_fetch(const Inv1Params &p, float (&w0)[C::WN], int tid, int b, int r0, int c0) {
+DT_HD void inv1r_fetch_from(const Inv1Params &p, const float *Z, float (&w0)[C::WN], int tid, int b, int r0,
+                            int c0) {
     const ColTask t = inv_col_task<C>(tid);
     if (!t.valid) return;
-    const float *Zb = p.Z + (int64_t)b * p.R * p.C;
+    const float *Zb = Z + (int64_t)b * p.R * p.C;
     const int ro = r0 - C::HE, co = c0 - C::HE;
     const bool interior = ro >= 0 && ro + C::NR <= p.R && co >= 0 && co + C::NC <= p.C;
     const int cc = 2 * t.i + t.e;
@@ -840,6 +841,11 @@ DT_HD void inv1r_fetch(const Inv1Params &p, float (&w0)[C::WN], int tid, int b, 
         for (int j = 0; j < C::WN; ++j)
             w0[j] = Zb[(int64_t)reflect_i(ro + t.strip * C::RS + j, p.R) * p.C + gc];
     }
+}
+
+template <class C>
+DT_HD void inv1r_fetch(const Inv1Params &p, float (&w0)[C::WN], int tid, int b, int r0, int c0) {
+    inv1r_fetch_from<C>(p, p.Z, w0, tid, b, r0, c0);
 }
 
 template <class C, int E>
@@ -1059,10 +1065,11 @@ struct Inv2RCfg {
 };
 
 template <class C>
-DT_HD void inv2r_fetch(const Inv2Params &p, float (&w0)[C::WS], int tid, int b, int r0, int c0) {
+DT_HD void inv2r_fetch_from(const Inv2Params &p, const float *Z, float (&w0)[C::WS], int tid, int b, int r0,
+                            int c0) {
     const ColTask t = inv_col_task<C>(tid);
     if (!t.valid) return;
-    const float *Zb = p.Z + (int64_t)b * p.zr * p.zc;
+    const float *Zb = Z + (int64_t)b * p.zr * p.zc;
     const int ro = r0 + C::ORG, co = c0 + C::ORG;
     const bool interior = ro >= 0 && ro + C::NR <= p.zr && co >= 0 && co + C::NC <= p.zc;
     const int cc = 2 * t.i + t.e, rs = C::RS * t.strip;
@@ -1075,6 +1082,11 @@ DT_HD void inv2r_fetch(const Inv2Params &p, float (&w0)[C::WS], int tid, int b, 
 #pragma unroll
         for (int j = 0; j < C::WS; ++j) w0[j] = Zb[(int64_t)reflect_i(ro + rs + j, p.zr) * p.zc + gc];
     }
+}
+
+template <class C>
+DT_HD void inv2r_fetch(const Inv2Params &p, float (&w0)[C::WS], int tid, int b, int r0, int c0) {
+    inv2r_fetch_from<C>(p, p.Z, w0, tid, b, r0, c0);
 }
 
 template <class C, int E>

@@ -8,6 +8,7 @@
 #include "common.hpp"
 #include "fused2d_table.hpp"
 #include "fused3d_tiles.hpp"
+#include "fused3d_inv_tiles.hpp"
 
 using namespace dt3d;
 
@@ -198,5 +199,189 @@ extern "C" int dtcwt_hip_fwd3_level2(dtcwt_hip_ctx *ctx, const float *X, int64_t
     hipError_t e = hipGetLastError();
     dtcwt_hip_free(ctx, planes);        // stream-ordered reuse (common.hpp)
     if (e != hipSuccess) return dtcwt_set_error(-2, "3-D level launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+// ======================================================================== inverse
+namespace {
+
+// pass A: unpack + axis-0 merge, marching along axis 0 (fused3d_inv_tiles.hpp)
+template <class F>
+__global__ void __launch_bounds__(DT_NT) k_inv3_axis0(Inv3AParams p) {
+    __shared__ __attribute__((aligned(16))) float slab[2][I3_SLAB];
+    const int bid = blockIdx.x, tid = threadIdx.x;
+    const int tk = bid % p.tilesK, tj = (bid / p.tilesK) % p.tilesJ, ch = bid / (p.tilesK * p.tilesJ);
+    const int cj0 = tj * I3_CJ, ck0 = tk * I3_CK, c0 = ch * p.chunk;
+    const int c1 = min(c0 + p.chunk, p.n0 / 2);
+    const int cs = c0 - (2 * F::HP + 1);            // warm-up steps fill the rings
+    Inv3AState<F> st;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int t = 0; t < F::NS; ++t) { st.ra[q][t] = 0.f; st.rb[q][t] = 0.f; }
+    i3a_issue_rec<F>(p, st, tid, cj0, ck0, cs + F::HP + 1);
+    i3a_issue_low<F>(p, st, tid, cj0, ck0, cs + F::HP + 1);
+    i3a_slab_write<F>(st, slab[0], tid);
+    i3a_issue_rec<F>(p, st, tid, cj0, ck0, cs + F::HP + 2);
+    __syncthreads();
+    for (int c = cs; c < c1; ++c) {
+        const int buf = (c - cs) & 1;
+        float out[F::NOUT][4];
+        if (c >= c0) F::compute(p, st.ra, st.rb, out);
+        i3a_push<F>(p, st, slab[buf], tid, c + F::HP + 1);
+        i3a_slab_write<F>(st, slab[buf ^ 1], tid);
+        if (c + 1 < c1) {
+            i3a_issue_rec<F>(p, st, tid, cj0, ck0, c + F::HP + 3);
+            i3a_issue_low<F>(p, st, tid, cj0, ck0, c + F::HP + 2);
+        }
+        if (c >= c0) i3a_store<F>(p, out, tid, cj0, ck0, c);
+        __syncthreads();
+    }
+}
+
+// pass B, level 1: column + row pass of the 2-D level-1 inverse tile program per slice, the
+// four planes in place of the lowpass and the c2q quad planes
+template <class C>
+__global__ void __launch_bounds__(DT_NT) k_inv3_l1_planes(dt2d::Inv1Params p, const float *planes, int64_t ps) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * C::SY];
+    const int t = blockIdx.x;
+    const int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    float *y1 = smem, *y2 = y1 + C::SY;
+    const int r0 = tr * C::TR, c0 = tc * C::TC;
+    float wz[C::WN], w1[C::WN], w2[C::WN], w3[C::WN];
+    dt2d::inv1r_fetch_from<C>(p, planes, wz, threadIdx.x, b, r0, c0);            // a1 = 0, a2 = 0
+    dt2d::inv1r_fetch_from<C>(p, planes + 2 * ps, w1, threadIdx.x, b, r0, c0);   // a1 = 1, a2 = 0
+    dt2d::inv1r_fetch_from<C>(p, planes + ps, w2, threadIdx.x, b, r0, c0);       // a1 = 0, a2 = 1
+    dt2d::inv1r_fetch_from<C>(p, planes + 3 * ps, w3, threadIdx.x, b, r0, c0);   // a1 = 1, a2 = 1
+    dt2d::inv1r_fir<C>(p, wz, w1, w2, w3, y1, y2, threadIdx.x);
+    __syncthreads();
+    dt2d::inv1d_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0);
+}
+
+// pass B, level >= 2
+template <class C>
+__global__ void __launch_bounds__(DT_NT) k_inv3_l2_planes(dt2d::Inv2Params p, const float *planes, int64_t ps) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * C::SY];
+    const int t = blockIdx.x;
+    const int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    float *y1 = smem, *y2 = y1 + C::SY;
+    const int r0 = tr * C::TR, c0 = tc * C::TC;
+    float wz[C::WS], w1[C::WS], w2[C::WS], w3[C::WS];
+    dt2d::inv2r_fetch_from<C>(p, planes, wz, threadIdx.x, b, r0, c0);
+    dt2d::inv2r_fetch_from<C>(p, planes + 2 * ps, w1, threadIdx.x, b, r0, c0);
+    dt2d::inv2r_fetch_from<C>(p, planes + ps, w2, threadIdx.x, b, r0, c0);
+    dt2d::inv2r_fetch_from<C>(p, planes + 3 * ps, w3, threadIdx.x, b, r0, c0);
+    dt2d::inv2r_fir<C>(p, wz, w1, w2, w3, y1, y2, threadIdx.x);
+    __syncthreads();
+    dt2d::inv2_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0);
+}
+
+template <class F>
+void launch_inv3_axis0(Inv3AParams &p, int cus, hipStream_t s) {
+    p.tilesJ = cdiv(p.n1 / 2, I3_CJ); p.tilesK = cdiv(p.n2 / 2, I3_CK);
+    const int pairs = p.n0 / 2;
+    int chunk = 64;             // long marches amortise the 2 HP + 1 warm-up steps
+    while (chunk > 8 && (int64_t)p.tilesJ * p.tilesK * cdiv(pairs, chunk) < 4 * (int64_t)cus) chunk /= 2;
+    if (const char *e = getenv("DTCWT_HIP_CHUNK3D_INV")) {
+        int v = atoi(e);
+        if (v >= 1) chunk = v;
+    }
+    p.chunk = chunk; p.chunks = cdiv(pairs, chunk);
+    k_inv3_axis0<F><<<(unsigned)(p.tilesJ * p.tilesK * p.chunks), DT_NT, 0, s>>>(p);
+}
+
+int check_inv3_dims(int64_t n0, int64_t n1, int64_t n2, int64_t S) {
+    if (n0 < 8 || n1 < DT_MIN_FUSED_DIM || n2 < DT_MIN_FUSED_DIM || 4 * S * n1 * n2 >= ((int64_t)1 << 31) ||
+        2 * n1 >= (1 << 15) * (int64_t)4 || n0 * n1 * n2 >= ((int64_t)1 << 31))
+        return dtcwt_set_error(-3, "fused 3-D inverse needs n0 >= 8, slices of at least %d x %d and < 2^31 samples",
+                               DT_MIN_FUSED_DIM, DT_MIN_FUSED_DIM);
+    return 0;
+}
+
+}  // namespace
+
+#define DT_INV3_L1_TABLE(X) X(16, 120, 8, 7, 5) X(16, 120, 8, 7, 9) X(16, 124, 8, 3, 5)
+#define DT_INV3_L2_TABLE(X) X(16, 56, 2, 10) X(16, 52, 2, 14)
+
+extern "C" int dtcwt_hip_inv3_level1(dtcwt_hip_ctx *ctx, const float *LLL, const float *Yh, int64_t n0, int64_t n1,
+                                     int64_t n2, const double *g0o, int m0, const double *g1o, int m1, float *Z) {
+    DT_REQUIRE(ctx && LLL && Yh && g0o && g1o && Z, "NULL argument");
+    DT_REQUIRE(n0 > 0 && n1 > 0 && n2 > 0 && n0 % 2 == 0 && n1 % 2 == 0 && n2 % 2 == 0, "extents must be even");
+    DT_REQUIRE(m0 > 0 && m1 > 0 && m0 <= DT_MAXT && m1 <= DT_MAXT, "bad tap counts");
+    if (int rc = check_inv3_dims(n0, n1, n2, n0)) return rc;
+    bool have = false;
+#define X_(TR, TC, RS, A, B) if (m0 == A && m1 == B) have = true;
+    DT_INV3_L1_TABLE(X_)
+#undef X_
+    if (!have) return dtcwt_set_error(-3, "no fused 3-D level-1 inverse for %d/%d-tap biort filters", m0, m1);
+    Inv3AParams a{};
+    a.LLL = LLL; a.Yh = Yh; a.n0 = (int)n0; a.n1 = (int)n1; a.n2 = (int)n2; a.S = (int)n0; a.crop0 = 0;
+    a.pstride = n0 * n1 * n2;
+    put_taps(a.l_a, g0o, m0); put_taps(a.h_a, g1o, m1);
+    dt2d::Inv1Params b{};
+    b.X = Z; b.B = (int)n0; b.R = (int)n1; b.C = (int)n2;
+    put_taps(b.g0, g0o, m0); put_taps(b.g1, g1o, m1);
+    void *planes = nullptr;
+    if (int rc = dtcwt_hip_malloc(ctx, (size_t)(4 * a.pstride) * sizeof(float), &planes)) return rc;
+    a.P = (float *)planes;
+    DT_CHECK_HIP(hipSetDevice(ctx->device));
+#define X_(TR_, TC_, RS_, MA_, MB_)                                                         \
+    if (m0 == MA_ && m1 == MB_) {                                                           \
+        launch_inv3_axis0<Inv3L1<MA_, MB_>>(a, ctx->cus, ctx->stream);                      \
+        using Cf = dt2d::Inv1RCfg<TR_, TC_, RS_, MA_, MB_>;                                 \
+        b.tilesR = cdiv(b.R, Cf::TR); b.tilesC = cdiv(b.C, Cf::TC);                         \
+        k_inv3_l1_planes<Cf><<<(unsigned)(b.tilesR * b.tilesC * b.B), DT_NT, 0, ctx->stream>>>( \
+            b, (const float *)planes, a.pstride);                                           \
+    }
+    DT_INV3_L1_TABLE(X_)
+#undef X_
+    hipError_t e = hipGetLastError();
+    dtcwt_hip_free(ctx, planes);
+    if (e != hipSuccess) return dtcwt_set_error(-2, "3-D inverse launch failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int dtcwt_hip_inv3_level2(dtcwt_hip_ctx *ctx, const float *LLL, const float *Yh, int64_t n0, int64_t n1,
+                                     int64_t n2, int crop0, int crop1, int crop2, const double *g0b,
+                                     const double *g0a, const double *g1b, const double *g1a, int m, float *Z) {
+    DT_REQUIRE(ctx && LLL && Yh && g0b && g0a && g1b && g1a && Z, "NULL argument");
+    DT_REQUIRE(n0 > 0 && n1 > 0 && n2 > 0 && n0 % 2 == 0 && n1 % 2 == 0 && n2 % 2 == 0, "extents must be even");
+    DT_REQUIRE(m > 0 && m % 2 == 0 && m <= DT_MAXT, "q-shift filters must have even length <= %d", DT_MAXT);
+    DT_REQUIRE(crop0 >= 0 && crop1 >= 0 && crop2 >= 0 && crop0 <= 2 && crop1 <= 2 && crop2 <= 2, "bad crop");
+    const int64_t S = 2 * n0 - 2 * crop0;
+    if (int rc = check_inv3_dims(n0, n1, n2, S)) return rc;
+    bool have = false;
+#define X_(TR, TC, JS, M) if (m == M) have = true;
+    DT_INV3_L2_TABLE(X_)
+#undef X_
+    if (!have) return dtcwt_set_error(-3, "no fused 3-D level >= 2 inverse for %d-tap q-shift filters", m);
+    double dl = 0, dh = 0;
+    for (int k = 0; k < m; ++k) { dl += g0b[k] * g0a[k]; dh += g1b[k] * g1a[k]; }
+    Inv3AParams a{};
+    a.LLL = LLL; a.Yh = Yh; a.n0 = (int)n0; a.n1 = (int)n1; a.n2 = (int)n2; a.S = (int)S; a.crop0 = crop0;
+    a.pstride = S * n1 * n2;
+    a.lo_pos = dl > 0; a.hi_pos = dh > 0;
+    put_taps(a.l_a, g0b, m); put_taps(a.l_b, g0a, m); put_taps(a.h_a, g1b, m); put_taps(a.h_b, g1a, m);
+    dt2d::Inv2Params b{};
+    b.Out = Z; b.B = (int)S; b.zr = (int)n1; b.zc = (int)n2; b.cropR = crop1; b.cropC = crop2;
+    b.lo_pos = a.lo_pos; b.hi_pos = a.hi_pos;
+    put_taps(b.l_a, g0b, m); put_taps(b.l_b, g0a, m); put_taps(b.h_a, g1b, m); put_taps(b.h_b, g1a, m);
+    void *planes = nullptr;
+    if (int rc = dtcwt_hip_malloc(ctx, (size_t)(4 * a.pstride) * sizeof(float), &planes)) return rc;
+    a.P = (float *)planes;
+    DT_CHECK_HIP(hipSetDevice(ctx->device));
+#define X_(TR_, TC_, JS_, M_)                                                               \
+    if (m == M_) {                                                                          \
+        launch_inv3_axis0<Inv3L2<M_>>(a, ctx->cus, ctx->stream);                            \
+        using Cf = dt2d::Inv2RCfg<TR_, TC_, JS_, M_>;                                       \
+        b.tilesR = cdiv(b.zr, Cf::TR); b.tilesC = cdiv(b.zc, Cf::TC);                       \
+        k_inv3_l2_planes<Cf><<<(unsigned)(b.tilesR * b.tilesC * b.B), DT_NT, 0, ctx->stream>>>( \
+            b, (const float *)planes, a.pstride);                                           \
+    }
+    DT_INV3_L2_TABLE(X_)
+#undef X_
+    hipError_t e = hipGetLastError();
+    dtcwt_hip_free(ctx, planes);
+    if (e != hipSuccess) return dtcwt_set_error(-2, "3-D inverse launch failed: %s", hipGetErrorString(e));
     return 0;
 }

@@ -83,6 +83,8 @@ SIGNATURES = {
     'dtcwt_hip_c2q': (_i, [_vp, _i, _vp, _i64, _i64, _i64, _i, _i, _dbl, _dbl, _vp, _i64, _i64]),
     'dtcwt_hip_fwd3_level1': (_i, [_vp, _vp, _i64, _i64, _i64, _pd, _i, _pd, _i, _vp, _vp]),
     'dtcwt_hip_fwd3_level2': (_i, [_vp, _vp, _i64, _i64, _i64, _i, _i, _i, _pd, _pd, _pd, _pd, _i, _vp, _vp]),
+    'dtcwt_hip_inv3_level1': (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _pd, _i, _pd, _i, _vp]),
+    'dtcwt_hip_inv3_level2': (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _pd, _pd, _pd, _pd, _i, _vp]),
     'dtcwt_hip_cube2c': (_i, [_vp, _i, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i]),
     'dtcwt_hip_c2cube': (_i, [_vp, _i, _vp, _i64, _i64, _i64, _i, _vp, _i64, _i64]),
     'dtcwt_hip_pack1d': (_i, [_vp, _i, _vp, _i64, _i64, _vp]),

@@ -81,6 +81,43 @@ def _fused_level2(Xd, pads, h0b, h0a, h1b, h1a):
     return LLL, Yh
 
 
+def _fused_inverse_level1(Yl, Yh, g0o, g1o):
+    """Level-1 merge in two launches (dtcwt_hip_inv3_level1) -> Z, or None."""
+    if Yl.dtype != np.float32 or Yh.dtype != np.complex64:
+        return None
+    g0, g1 = flat_taps(g0o), flat_taps(g1o)
+    if g0.shape[0] % 2 == 0 or g1.shape[0] % 2 == 0:
+        return None
+    n0, n1, n2 = Yl.shape
+    Z = DeviceArray(Yl.ctx, (n0, n1, n2), np.float32)
+    pd = ctypes.POINTER(ctypes.c_double)
+    rc = _lib.lib().dtcwt_hip_inv3_level1(Yl.ctx.handle, Yl.ptr, Yh.ptr, n0, n1, n2, g0.ctypes.data_as(pd),
+                                          g0.shape[0], g1.ctypes.data_as(pd), g1.shape[0], Z.ptr)
+    if rc == -3:
+        return None
+    check(rc)
+    return Z
+
+
+def _fused_inverse_level2(Yl, Yh, crops, g0b, g0a, g1b, g1a):
+    """One level >= 2 merge in two launches (dtcwt_hip_inv3_level2) -> Z, or None."""
+    if Yl.dtype != np.float32 or Yh.dtype != np.complex64:
+        return None
+    taps = [flat_taps(h) for h in (g0b, g0a, g1b, g1a)]
+    m = taps[0].shape[0]
+    if any(t.shape[0] != m for t in taps) or m % 2:
+        return None
+    n = Yl.shape
+    Z = DeviceArray(Yl.ctx, tuple(2 * n[a] - 2 * crops[a][0] for a in range(3)), np.float32)
+    pd = ctypes.POINTER(ctypes.c_double)
+    rc = _lib.lib().dtcwt_hip_inv3_level2(Yl.ctx.handle, Yl.ptr, Yh.ptr, n[0], n[1], n[2], crops[0][0], crops[1][0],
+                                          crops[2][0], *[t.ctypes.data_as(pd) for t in taps], m, Z.ptr)
+    if rc == -3:
+        return None
+    check(rc)
+    return Z
+
+
 def _c2cube(Yh, octant):
     e0, e1, e2 = Yh.shape[:3]
     rdt = np.float32 if Yh.dtype == np.complex64 else np.float64
@@ -241,7 +278,9 @@ class Transform3d(object):
                 else:
                     if tuple(Yl.shape) != tuple(2 * s for s in cur.shape[:3]):
                         raise ValueError('Sizes of highpasses are not valid for the 3D inverse')
-                    Yl = self._merge(Yl, cur, ll.axis_colfilter_sum2, g0o, g1o, nocrop)
+                    fused = _fused_inverse_level1(Yl, cur, g0o, g1o) if self.fused else None
+                    Yl = fused if fused is not None else \
+                        self._merge(Yl, cur, ll.axis_colfilter_sum2, g0o, g1o, nocrop)
             else:                                              # :460-526
                 if tuple(Yl.shape) != tuple(2 * s for s in cur.shape[:3]):
                     raise ValueError('Sizes of highpasses are not valid for the 3D inverse')
@@ -249,5 +288,7 @@ class Transform3d(object):
                 prev = tuple(nxt.shape[:3]) if nxt is not None else tuple(2 * s for s in cur.shape[:3])
                 c = 1 if self.ext_mode == 4 else 2
                 crops = tuple((c, c) if cur.shape[a] * 2 != prev[a] else (0, 0) for a in range(3))
-                Yl = self._merge(Yl, cur, ll.axis_colifilt_sum2, (g0b, g0a), (g1b, g1a), crops)
+                fused = _fused_inverse_level2(Yl, cur, crops, g0b, g0a, g1b, g1a) if self.fused else None
+                Yl = fused if fused is not None else \
+                    self._merge(Yl, cur, ll.axis_colifilt_sum2, (g0b, g0a), (g1b, g1a), crops)
         return Yl if device_output else Yl.get()

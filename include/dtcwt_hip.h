@@ -163,6 +163,21 @@ int dtcwt_hip_fwd3_level1(dtcwt_hip_ctx *ctx, const float *X, int64_t n0, int64_
 int dtcwt_hip_fwd3_level2(dtcwt_hip_ctx *ctx, const float *X, int64_t n0, int64_t n1, int64_t n2,
                           int pad0, int pad1, int pad2, const double *h0b, const double *h0a,
                           const double *h1b, const double *h1a, int m, float *LLL, float *Yh);
+/* Fused float32 level 1 of the 3-D inverse transform: replaces `_level1_ifm`
+ * (dtcwt/numpy/transform3d.py:385-440) for odd-length biort filters -- c2cube of the seven
+ * octants and the three merges colfilter(lo, g0o) + colfilter(hi, g1o) -- in two launches
+ * (unpack + axis-0 merge marching along axis 0 into four pooled planes, then the 2-D
+ * column/row passes per slice).  LLL, Z: [n0][n1][n2] float32; Yh: [n0/2][n1/2][n2/2][28]
+ * complex64.  Returns -3 when no fused kernel exists for the tap lengths or n1/n2 < 40. */
+int dtcwt_hip_inv3_level1(dtcwt_hip_ctx *ctx, const float *LLL, const float *Yh, int64_t n0, int64_t n1,
+                          int64_t n2, const double *g0o, int m0, const double *g1o, int m1, float *Z);
+/* Fused float32 level >= 2 of the 3-D inverse transform: replaces `_level2_ifm`
+ * (dtcwt/numpy/transform3d.py:460-526): colifilt(., g0b, g0a) + colifilt(., g1b, g1a) merges
+ * and the cropping of ext_mode 4 / 8 (crop_a planes per side of the 2 n_a output, :505-524).
+ * LLL: [n0][n1][n2]; Yh: [n0/2][n1/2][n2/2][28]; Z: [2n0-2crop0][2n1-2crop1][2n2-2crop2]. */
+int dtcwt_hip_inv3_level2(dtcwt_hip_ctx *ctx, const float *LLL, const float *Yh, int64_t n0, int64_t n1,
+                          int64_t n2, int crop0, int crop1, int crop2, const double *g0b,
+                          const double *g0a, const double *g1b, const double *g1a, int m, float *Z);
 /* cube2c: replaces dtcwt/numpy/transform3d.py:532-579 for one octant.
  * y: real volume view [d0][d1][d2] with element strides (s0, s1, 1), d* even;
  * Yh: [d0/2][d1/2][d2/2][28] complex; writes components 4*octant .. 4*octant+3. */

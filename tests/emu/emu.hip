@@ -13,6 +13,7 @@
 #include "fused2d_tiles_v2.hpp"
 #include "fused2d_table.hpp"
 #include "fused3d_tiles.hpp"
+#include "fused3d_inv_tiles.hpp"
 
 using namespace dt2d;
 
@@ -172,6 +173,93 @@ static int run_fwd3_l2(Fwd2Params a, dt3d::Fwd3L2Params b, float *planes) {
     return 0;
 }
 
+// ---- 3-D inverse: pass A (march) and pass B (2-D tile passes over the four planes)
+template <class F>
+static void run_inv3_axis0(dt3d::Inv3AParams p, int chunk) {
+    using namespace dt3d;
+    p.tilesJ = cdiv(p.n1 / 2, I3_CJ); p.tilesK = cdiv(p.n2 / 2, I3_CK);
+    p.chunk = chunk; p.chunks = cdiv(p.n0 / 2, chunk);
+    std::vector<float> mem(2 * I3_SLAB + 4);
+    float *base = mem.data();
+    while (((uintptr_t)base) & 15) ++base;
+    float *slab[2] = {base, base + I3_SLAB};
+    static Inv3AState<F> st[DT_NT];
+    static float out[DT_NT][F::NOUT][4];
+    for (int ch = 0; ch < p.chunks; ++ch)
+        for (int tj = 0; tj < p.tilesJ; ++tj)
+            for (int tk = 0; tk < p.tilesK; ++tk) {
+                const int cj0 = tj * I3_CJ, ck0 = tk * I3_CK, c0 = ch * p.chunk;
+                const int c1 = c0 + p.chunk < p.n0 / 2 ? c0 + p.chunk : p.n0 / 2;
+                const int cs = c0 - (2 * F::HP + 1);
+                for (int t = 0; t < DT_NT; ++t) {
+                    memset(&st[t], 0, sizeof(st[t]));
+                    i3a_issue_rec<F>(p, st[t], t, cj0, ck0, cs + F::HP + 1);
+                    i3a_issue_low<F>(p, st[t], t, cj0, ck0, cs + F::HP + 1);
+                    i3a_slab_write<F>(st[t], slab[0], t);
+                    i3a_issue_rec<F>(p, st[t], t, cj0, ck0, cs + F::HP + 2);
+                }
+                for (int c = cs; c < c1; ++c) {
+                    const int buf = (c - cs) & 1;
+                    for (int t = 0; t < DT_NT; ++t) {
+                        if (c >= c0) F::compute(p, st[t].ra, st[t].rb, out[t]);
+                        i3a_push<F>(p, st[t], slab[buf], t, c + F::HP + 1);
+                        i3a_slab_write<F>(st[t], slab[buf ^ 1], t);
+                        if (c + 1 < c1) {
+                            i3a_issue_rec<F>(p, st[t], t, cj0, ck0, c + F::HP + 3);
+                            i3a_issue_low<F>(p, st[t], t, cj0, ck0, c + F::HP + 2);
+                        }
+                        if (c >= c0) i3a_store<F>(p, out[t], t, cj0, ck0, c);
+                    }
+                }
+            }
+}
+
+template <class C>
+static void run_inv3_l1_planes(Inv1Params p, const float *planes, int64_t ps) {
+    p.tilesR = cdiv(p.R, C::TR); p.tilesC = cdiv(p.C, C::TC);
+    std::vector<float> smem(2 * C::SY + 4);
+    float *base = smem.data();
+    while (((uintptr_t)base) & 15) ++base;
+    float *y1 = base, *y2 = y1 + C::SY;
+    static float wz[DT_NT][C::WN], w1[DT_NT][C::WN], w2[DT_NT][C::WN], w3[DT_NT][C::WN];
+    for (int b = 0; b < p.B; ++b)
+        for (int tr = 0; tr < p.tilesR; ++tr)
+            for (int tc = 0; tc < p.tilesC; ++tc) {
+                int r0 = tr * C::TR, c0 = tc * C::TC;
+                for (int t = 0; t < DT_NT; ++t) {
+                    inv1r_fetch_from<C>(p, planes, wz[t], t, b, r0, c0);
+                    inv1r_fetch_from<C>(p, planes + 2 * ps, w1[t], t, b, r0, c0);
+                    inv1r_fetch_from<C>(p, planes + ps, w2[t], t, b, r0, c0);
+                    inv1r_fetch_from<C>(p, planes + 3 * ps, w3[t], t, b, r0, c0);
+                    inv1r_fir<C>(p, wz[t], w1[t], w2[t], w3[t], y1, y2, t);
+                }
+                for (int t = 0; t < DT_NT; ++t) inv1d_rows<C>(p, y1, y2, t, b, r0, c0);
+            }
+}
+
+template <class C>
+static void run_inv3_l2_planes(Inv2Params p, const float *planes, int64_t ps) {
+    p.tilesR = cdiv(p.zr, C::TR); p.tilesC = cdiv(p.zc, C::TC);
+    std::vector<float> smem(2 * C::SY + 4);
+    float *base = smem.data();
+    while (((uintptr_t)base) & 15) ++base;
+    float *y1 = base, *y2 = y1 + C::SY;
+    static float wz[DT_NT][C::WS], w1[DT_NT][C::WS], w2[DT_NT][C::WS], w3[DT_NT][C::WS];
+    for (int b = 0; b < p.B; ++b)
+        for (int tr = 0; tr < p.tilesR; ++tr)
+            for (int tc = 0; tc < p.tilesC; ++tc) {
+                int r0 = tr * C::TR, c0 = tc * C::TC;
+                for (int t = 0; t < DT_NT; ++t) {
+                    inv2r_fetch_from<C>(p, planes, wz[t], t, b, r0, c0);
+                    inv2r_fetch_from<C>(p, planes + 2 * ps, w1[t], t, b, r0, c0);
+                    inv2r_fetch_from<C>(p, planes + ps, w2[t], t, b, r0, c0);
+                    inv2r_fetch_from<C>(p, planes + 3 * ps, w3[t], t, b, r0, c0);
+                    inv2r_fir<C>(p, wz[t], w1[t], w2[t], w3[t], y1, y2, t);
+                }
+                for (int t = 0; t < DT_NT; ++t) inv2_rows<C>(p, y1, y2, t, b, r0, c0);
+            }
+}
+
 #define EMU_FWD1(TR, TC, RS, A, B_) if (m0 == A && m1 == B_) return run_fwd1<Fwd1DCfg<TR, TC, RS, A, B_>>(p);
 #define EMU_INV1(TR, TC, RS, A, B_) if (m0 == A && m1 == B_) return run_inv1<Inv1RCfg<TR, TC, RS, A, B_>>(p);
 #define EMU_FWD2(TR, TC, PS, M) if (m == M) return run_fwd2<Fwd2DCfg<TR, TC, PS, M>>(p);
@@ -254,6 +342,38 @@ int emu_fwd3_l2(int m, const float *X, float *planes, float *LLL, float *Yh, int
     put_taps(b.l_a, h0b, m); put_taps(b.l_b, h0a, m); put_taps(b.h_a, h1b, m); put_taps(b.h_b, h1a, m);
 #define EMU_L2(TR, TC, PS, M) if (m == M) return run_fwd3_l2<Fwd2DCfg<TR, TC, PS, M>>(a, b, planes);
     DT_FWD2_TABLE(EMU_L2)
+    return -3;
+}
+
+int emu_inv3_l1(int m0, int m1, const float *LLL, const float *Yh, float *planes, float *Z, int n0, int n1,
+                int n2, int chunk, const double *g0, const double *g1) {
+    dt3d::Inv3AParams a{};
+    a.LLL = LLL; a.Yh = Yh; a.P = planes; a.n0 = n0; a.n1 = n1; a.n2 = n2; a.S = n0; a.crop0 = 0;
+    a.pstride = (int64_t)n0 * n1 * n2;
+    put_taps(a.l_a, g0, m0); put_taps(a.h_a, g1, m1);
+    Inv1Params b{};
+    b.X = Z; b.B = n0; b.R = n1; b.C = n2;
+    put_taps(b.g0, g0, m0); put_taps(b.g1, g1, m1);
+    if (m0 == 7 && m1 == 5) { run_inv3_axis0<dt3d::Inv3L1<7, 5>>(a, chunk); run_inv3_l1_planes<Inv1RCfg<16, 120, 8, 7, 5>>(b, planes, a.pstride); return 0; }
+    if (m0 == 7 && m1 == 9) { run_inv3_axis0<dt3d::Inv3L1<7, 9>>(a, chunk); run_inv3_l1_planes<Inv1RCfg<16, 120, 8, 7, 9>>(b, planes, a.pstride); return 0; }
+    if (m0 == 3 && m1 == 5) { run_inv3_axis0<dt3d::Inv3L1<3, 5>>(a, chunk); run_inv3_l1_planes<Inv1RCfg<16, 124, 8, 3, 5>>(b, planes, a.pstride); return 0; }
+    return -3;
+}
+
+int emu_inv3_l2(int m, const float *LLL, const float *Yh, float *planes, float *Z, int n0, int n1, int n2,
+                int crop0, int crop1, int crop2, int chunk, const double *g0b, const double *g0a,
+                const double *g1b, const double *g1a) {
+    dt3d::Inv3AParams a{};
+    a.LLL = LLL; a.Yh = Yh; a.P = planes; a.n0 = n0; a.n1 = n1; a.n2 = n2; a.S = 2 * n0 - 2 * crop0; a.crop0 = crop0;
+    a.pstride = (int64_t)a.S * n1 * n2;
+    a.lo_pos = dotd(g0b, g0a, m) > 0; a.hi_pos = dotd(g1b, g1a, m) > 0;
+    put_taps(a.l_a, g0b, m); put_taps(a.l_b, g0a, m); put_taps(a.h_a, g1b, m); put_taps(a.h_b, g1a, m);
+    Inv2Params b{};
+    b.Out = Z; b.B = a.S; b.zr = n1; b.zc = n2; b.cropR = crop1; b.cropC = crop2;
+    b.lo_pos = a.lo_pos; b.hi_pos = a.hi_pos;
+    put_taps(b.l_a, g0b, m); put_taps(b.l_b, g0a, m); put_taps(b.h_a, g1b, m); put_taps(b.h_b, g1a, m);
+    if (m == 10) { run_inv3_axis0<dt3d::Inv3L2<10>>(a, chunk); run_inv3_l2_planes<Inv2RCfg<16, 56, 2, 10>>(b, planes, a.pstride); return 0; }
+    if (m == 14) { run_inv3_axis0<dt3d::Inv3L2<14>>(a, chunk); run_inv3_l2_planes<Inv2RCfg<16, 52, 2, 14>>(b, planes, a.pstride); return 0; }
     return -3;
 }
 

@@ -26,7 +26,7 @@ TOL = 2e-6
 
 def _build():
     deps = [EMU_SRC] + [os.path.join(ROOT, 'dtcwt_amd', 'csrc', f) for f in
-                        ('fused2d_tiles.hpp', 'fused2d_tiles_v2.hpp', 'fused2d_table.hpp', 'fused3d_tiles.hpp')]
+                        ('fused2d_tiles.hpp', 'fused2d_tiles_v2.hpp', 'fused2d_table.hpp', 'fused3d_tiles.hpp', 'fused3d_inv_tiles.hpp')]
     if os.path.exists(EMU_LIB) and all(os.path.getmtime(EMU_LIB) >= os.path.getmtime(d) for d in deps):
         return
     if not os.path.exists(HIPCC):
@@ -218,3 +218,50 @@ def test_fwd3_level2_tiles(emu, shape, ext, qname):
     assert LLL.shape == lo.shape and rel(LLL, lo) < TOL
     Yc = Yh.view(np.complex64)
     assert Yc.shape == hi.shape and rel(Yc, hi) < TOL
+
+
+def _rand_level(shape, seed):
+    """(lowpass volume, highpass records) of one 3-D level with the lowpass *shape*."""
+    rs = np.random.RandomState(seed)
+    Yl = rs.standard_normal(shape).astype(np.float32)
+    hs = tuple(s // 2 for s in shape) + (28,)
+    Yh = (rs.standard_normal(hs) + 1j * rs.standard_normal(hs)).astype(np.complex64)
+    return Yl, Yh
+
+
+@pytest.mark.parametrize('shape,chunk', [((8, 40, 44), 4), ((12, 42, 70), 3), ((10, 40, 130), 64)])
+@pytest.mark.parametrize('bname', ['near_sym_a', 'antonini', 'legall'])
+def test_inv3_level1_tiles(emu, shape, chunk, bname):
+    Yl, Yh = _rand_level(shape, 21)
+    b = biort(bname)
+    g0, p0 = _d(b[1])
+    g1, p1 = _d(b[3])
+    planes = np.full((4,) + shape, np.nan, np.float32)
+    Z = np.full(shape, np.nan, np.float32)
+    rc = emu.emu_inv3_l1(len(g0), len(g1), _f(Yl), _f(Yh), _f(planes), _f(Z), shape[0], shape[1], shape[2], chunk,
+                         p0, p1)
+    assert rc == 0
+    want = o.Transform3d(b, qshift('qshift_a')).inverse(o.Pyramid(Yl.astype(np.float64), (Yh.astype(np.complex128),)))
+    assert Z.shape == want.shape and rel(Z, want) < TOL
+
+
+@pytest.mark.parametrize('shape,crops,chunk', [((8, 40, 44), (0, 0, 0), 4), ((12, 42, 70), (1, 1, 0), 3),
+                                               ((10, 40, 64), (2, 0, 2), 64), ((16, 44, 40), (1, 2, 1), 5)])
+@pytest.mark.parametrize('qname', ['qshift_a', 'qshift_b'])
+def test_inv3_level2_tiles(emu, shape, crops, chunk, qname):
+    Yl, Yh = _rand_level(shape, 22)
+    q = qshift(qname)
+    g0a, g0b, g1a, g1b = q[2], q[3], q[6], q[7]
+    t = [_d(h) for h in (g0b, g0a, g1b, g1a)]
+    S = 2 * shape[0] - 2 * crops[0]
+    oshape = tuple(2 * s - 2 * c for s, c in zip(shape, crops))
+    planes = np.full((4, S, shape[1], shape[2]), np.nan, np.float32)
+    Z = np.full(oshape, np.nan, np.float32)
+    rc = emu.emu_inv3_l2(len(t[0][0]), _f(Yl), _f(Yh), _f(planes), _f(Z), shape[0], shape[1], shape[2],
+                         crops[0], crops[1], crops[2], chunk, t[0][1], t[1][1], t[2][1], t[3][1])
+    assert rc == 0
+    full = o.Transform3d._merge(Yl.astype(np.float64), Yh.astype(np.complex128), o.colifilt,
+                                (np.asarray(g0b), np.asarray(g0a)), (np.asarray(g1b), np.asarray(g1a)))
+    sl = tuple(slice(c, full.shape[a] - c) for a, c in enumerate(crops))
+    want = full[sl]
+    assert Z.shape == want.shape and rel(Z, want) < TOL

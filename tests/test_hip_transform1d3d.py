@@ -161,6 +161,7 @@ def test_3d_fused_level1_matches_generic_and_oracle(shape, bname):
             assert_pyramids_close(p, want, XFM_TOL)
         z = t.inverse(p)
         assert_close(z, X, 2e-5, 'PR')
+        assert_close(z, g.inverse(p), 2e-5, 'fused vs generic inverse')
 
 
 @pytest.mark.parametrize('shape,ext', [((42, 46, 90), 4), ((44, 52, 84), 8), ((80, 80, 80), 4), ((48, 40, 200), 8)])
@@ -177,6 +178,7 @@ def test_3d_fused_level2_matches_generic_and_oracle(shape, ext, qname):
     want = o.Transform3d(biort('near_sym_a'), qshift(qname), ext_mode=ext).forward(X, nlevels=3, include_scale=True)
     assert_pyramids_close(p, want, XFM_TOL)
     assert_close(t.inverse(p), want_inverse(want, qname, ext), 2e-5, 'inverse')
+    assert_close(t.inverse(p), g.inverse(p), 2e-5, 'fused vs generic inverse')
 
 
 def want_inverse(pyr, qname, ext):
