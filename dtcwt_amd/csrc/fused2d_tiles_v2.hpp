@@ -787,6 +787,18 @@ DT_HD ColTask inv_col_task(int tid) {
     return t;
 }
 
+// Linear variant for plane inputs (3-D pass B): no records, so no reason to split the
+// columns by parity -- consecutive lanes take consecutive columns (coalesced plane reads).
+template <class C>
+DT_HD ColTask inv_col_task_lin(int tid) {
+    ColTask t;
+    t.strip = tid / C::NC;
+    const int cc = tid - t.strip * C::NC;
+    t.e = cc & 1; t.i = cc >> 1;
+    t.valid = tid < C::NS * C::NC;
+    return t;
+}
+
 // Samples (top, bottom) of the three planes at column parity e from one raw record
 // (A.4 with gains folded in): plane "lh" = subbands (0,5), "hl" = (2,3), "hh" = (1,4).
 template <int E>
@@ -822,10 +834,10 @@ DT_HD void rec_samples(const float *rec, const float *g, int e, float (&top)[3],
 #define DT_WAVE_UNIFORM(x) (x)
 #endif
 
-template <class C>
+template <class C, bool LIN = false>
 DT_HD void inv1r_fetch_from(const Inv1Params &p, const float *Z, float (&w0)[C::WN], int tid, int b, int r0,
                             int c0) {
-    const ColTask t = inv_col_task<C>(tid);
+    const ColTask t = LIN ? inv_col_task_lin<C>(tid) : inv_col_task<C>(tid);
     if (!t.valid) return;
     const float *Zb = Z + (int64_t)b * p.R * p.C;
     const int ro = r0 - C::HE, co = c0 - C::HE;
@@ -937,10 +949,10 @@ DT_HD void inv1r_gather(const Inv1Params &p, const float *srec, float (&w1)[C::W
     if (DT_WAVE_UNIFORM((tid >> 6) & 1)) inv1r_gather_e<C, 1>(p, srec, w1, w2, w3, tid, r0, c0);
     else inv1r_gather_e<C, 0>(p, srec, w1, w2, w3, tid, r0, c0);
 }
-template <class C>
+template <class C, bool LIN = false>
 DT_HD void inv1r_fir(const Inv1Params &p, const float (&w0)[C::WN], const float (&w1)[C::WN],
                      const float (&w2)[C::WN], const float (&w3)[C::WN], float *y1, float *y2, int tid) {
-    const ColTask t = inv_col_task<C>(tid);
+    const ColTask t = LIN ? inv_col_task_lin<C>(tid) : inv_col_task<C>(tid);
     if (!t.valid) return;
     const int cc = 2 * t.i + t.e;
 #pragma unroll
@@ -1064,10 +1076,10 @@ struct Inv2RCfg {
     static_assert(NS * QC <= 128, "column-pass tasks: two wavefronts per column parity");
 };
 
-template <class C>
+template <class C, bool LIN = false>
 DT_HD void inv2r_fetch_from(const Inv2Params &p, const float *Z, float (&w0)[C::WS], int tid, int b, int r0,
                             int c0) {
-    const ColTask t = inv_col_task<C>(tid);
+    const ColTask t = LIN ? inv_col_task_lin<C>(tid) : inv_col_task<C>(tid);
     if (!t.valid) return;
     const float *Zb = Z + (int64_t)b * p.zr * p.zc;
     const int ro = r0 + C::ORG, co = c0 + C::ORG;
@@ -1180,10 +1192,10 @@ DT_HD void inv2r_gather(const Inv2Params &p, const float *srec, float (&w1)[C::W
     if (DT_WAVE_UNIFORM((tid >> 6) & 1)) inv2r_gather_e<C, 1>(p, srec, w1, w2, w3, tid, r0, c0);
     else inv2r_gather_e<C, 0>(p, srec, w1, w2, w3, tid, r0, c0);
 }
-template <class C>
+template <class C, bool LIN = false>
 DT_HD void inv2r_fir(const Inv2Params &p, const float (&w0)[C::WS], const float (&w1)[C::WS],
                      const float (&w2)[C::WS], const float (&w3)[C::WS], float *y1, float *y2, int tid) {
-    const ColTask t = inv_col_task<C>(tid);
+    const ColTask t = LIN ? inv_col_task_lin<C>(tid) : inv_col_task<C>(tid);
     if (!t.valid) return;
     const int cc = 2 * t.i + t.e;
     float a[4], tt[4];

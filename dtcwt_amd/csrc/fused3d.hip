@@ -83,6 +83,22 @@ int launch_l2_planes(dt2d::Fwd2Params &p, float *planes, int64_t pstride, hipStr
     k_fwd3_l2_planes<C><<<(unsigned)(p.tilesR * p.tilesC * p.B), DT_NT, 0, s>>>(p, planes, pstride);
     return 0;
 }
+// Volume slices are narrow (64 .. 512 columns): when the wide tile of the 2-D table would
+// overhang the plane by more than a tenth, take the narrow one.
+inline int64_t padded(int n, int t) { return (int64_t)cdiv(n, t) * t; }
+inline bool narrow_wins(int n, int wide, int narrow) { return 10 * padded(n, narrow) < 9 * padded(n, wide); }
+
+template <int TR, int TC, int PS, int M>
+void launch_l2_planes_best(dt2d::Fwd2Params &p, float *planes, int64_t pstride, hipStream_t s) {
+    if constexpr (M == 10) {
+        if (narrow_wins(p.LC / 2, TC, 32)) {
+            launch_l2_planes<dt2d::Fwd2DCfg<16, 32, 4, 10>>(p, planes, pstride, s);
+            return;
+        }
+    }
+    launch_l2_planes<dt2d::Fwd2DCfg<TR, TC, PS, M>>(p, planes, pstride, s);
+}
+
 template <class C>
 int launch_l2_axis0(Fwd3L2Params &p, int cus, hipStream_t s) {
     int cells = (p.O0 / 2) * (p.O1 / 2) * (p.O2 / 2);
@@ -191,7 +207,7 @@ extern "C" int dtcwt_hip_fwd3_level2(dtcwt_hip_ctx *ctx, const float *X, int64_t
     DT_CHECK_HIP(hipSetDevice(ctx->device));
 #define X_(TR, TC, PS, M)                                                                   \
     if (m == M) {                                                                           \
-        launch_l2_planes<dt2d::Fwd2DCfg<TR, TC, PS, M>>(a, (float *)planes, b.pstride, ctx->stream); \
+        launch_l2_planes_best<TR, TC, PS, M>(a, (float *)planes, b.pstride, ctx->stream);   \
         launch_l2_axis0<dt2d::Fwd2DCfg<TR, TC, PS, M>>(b, ctx->cus, ctx->stream);                     \
     }
     DT_FWD2_TABLE(X_)
@@ -249,11 +265,11 @@ __global__ void __launch_bounds__(DT_NT) k_inv3_l1_planes(dt2d::Inv1Params p, co
     float *y1 = smem, *y2 = y1 + C::SY;
     const int r0 = tr * C::TR, c0 = tc * C::TC;
     float wz[C::WN], w1[C::WN], w2[C::WN], w3[C::WN];
-    dt2d::inv1r_fetch_from<C>(p, planes, wz, threadIdx.x, b, r0, c0);            // a1 = 0, a2 = 0
-    dt2d::inv1r_fetch_from<C>(p, planes + 2 * ps, w1, threadIdx.x, b, r0, c0);   // a1 = 1, a2 = 0
-    dt2d::inv1r_fetch_from<C>(p, planes + ps, w2, threadIdx.x, b, r0, c0);       // a1 = 0, a2 = 1
-    dt2d::inv1r_fetch_from<C>(p, planes + 3 * ps, w3, threadIdx.x, b, r0, c0);   // a1 = 1, a2 = 1
-    dt2d::inv1r_fir<C>(p, wz, w1, w2, w3, y1, y2, threadIdx.x);
+    dt2d::inv1r_fetch_from<C, true>(p, planes, wz, threadIdx.x, b, r0, c0);            // a1 = 0, a2 = 0
+    dt2d::inv1r_fetch_from<C, true>(p, planes + 2 * ps, w1, threadIdx.x, b, r0, c0);   // a1 = 1, a2 = 0
+    dt2d::inv1r_fetch_from<C, true>(p, planes + ps, w2, threadIdx.x, b, r0, c0);       // a1 = 0, a2 = 1
+    dt2d::inv1r_fetch_from<C, true>(p, planes + 3 * ps, w3, threadIdx.x, b, r0, c0);   // a1 = 1, a2 = 1
+    dt2d::inv1r_fir<C, true>(p, wz, w1, w2, w3, y1, y2, threadIdx.x);
     __syncthreads();
     dt2d::inv1d_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0);
 }
@@ -267,13 +283,24 @@ __global__ void __launch_bounds__(DT_NT) k_inv3_l2_planes(dt2d::Inv2Params p, co
     float *y1 = smem, *y2 = y1 + C::SY;
     const int r0 = tr * C::TR, c0 = tc * C::TC;
     float wz[C::WS], w1[C::WS], w2[C::WS], w3[C::WS];
-    dt2d::inv2r_fetch_from<C>(p, planes, wz, threadIdx.x, b, r0, c0);
-    dt2d::inv2r_fetch_from<C>(p, planes + 2 * ps, w1, threadIdx.x, b, r0, c0);
-    dt2d::inv2r_fetch_from<C>(p, planes + ps, w2, threadIdx.x, b, r0, c0);
-    dt2d::inv2r_fetch_from<C>(p, planes + 3 * ps, w3, threadIdx.x, b, r0, c0);
-    dt2d::inv2r_fir<C>(p, wz, w1, w2, w3, y1, y2, threadIdx.x);
+    dt2d::inv2r_fetch_from<C, true>(p, planes, wz, threadIdx.x, b, r0, c0);
+    dt2d::inv2r_fetch_from<C, true>(p, planes + 2 * ps, w1, threadIdx.x, b, r0, c0);
+    dt2d::inv2r_fetch_from<C, true>(p, planes + ps, w2, threadIdx.x, b, r0, c0);
+    dt2d::inv2r_fetch_from<C, true>(p, planes + 3 * ps, w3, threadIdx.x, b, r0, c0);
+    dt2d::inv2r_fir<C, true>(p, wz, w1, w2, w3, y1, y2, threadIdx.x);
     __syncthreads();
     dt2d::inv2_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0);
+}
+
+template <class C>
+void launch_inv3_l1_planes(dt2d::Inv1Params &b, const float *planes, int64_t ps, hipStream_t s) {
+    b.tilesR = cdiv(b.R, C::TR); b.tilesC = cdiv(b.C, C::TC);
+    k_inv3_l1_planes<C><<<(unsigned)(b.tilesR * b.tilesC * b.B), DT_NT, 0, s>>>(b, planes, ps);
+}
+template <class C>
+void launch_inv3_l2_planes(dt2d::Inv2Params &b, const float *planes, int64_t ps, hipStream_t s) {
+    b.tilesR = cdiv(b.zr, C::TR); b.tilesC = cdiv(b.zc, C::TC);
+    k_inv3_l2_planes<C><<<(unsigned)(b.tilesR * b.tilesC * b.B), DT_NT, 0, s>>>(b, planes, ps);
 }
 
 template <class F>
@@ -328,10 +355,10 @@ extern "C" int dtcwt_hip_inv3_level1(dtcwt_hip_ctx *ctx, const float *LLL, const
 #define X_(TR_, TC_, RS_, MA_, MB_)                                                         \
     if (m0 == MA_ && m1 == MB_) {                                                           \
         launch_inv3_axis0<Inv3L1<MA_, MB_>>(a, ctx->cus, ctx->stream);                      \
-        using Cf = dt2d::Inv1RCfg<TR_, TC_, RS_, MA_, MB_>;                                 \
-        b.tilesR = cdiv(b.R, Cf::TR); b.tilesC = cdiv(b.C, Cf::TC);                         \
-        k_inv3_l1_planes<Cf><<<(unsigned)(b.tilesR * b.tilesC * b.B), DT_NT, 0, ctx->stream>>>( \
-            b, (const float *)planes, a.pstride);                                           \
+        if (narrow_wins(b.C, TC_, 56))                                                      \
+            launch_inv3_l1_planes<dt2d::Inv1RCfg<32, 56, 8, MA_, MB_>>(b, (const float *)planes, a.pstride, ctx->stream); \
+        else                                                                                \
+            launch_inv3_l1_planes<dt2d::Inv1RCfg<TR_, TC_, RS_, MA_, MB_>>(b, (const float *)planes, a.pstride, ctx->stream); \
     }
     DT_INV3_L1_TABLE(X_)
 #undef X_
@@ -373,10 +400,7 @@ extern "C" int dtcwt_hip_inv3_level2(dtcwt_hip_ctx *ctx, const float *LLL, const
 #define X_(TR_, TC_, JS_, M_)                                                               \
     if (m == M_) {                                                                          \
         launch_inv3_axis0<Inv3L2<M_>>(a, ctx->cus, ctx->stream);                            \
-        using Cf = dt2d::Inv2RCfg<TR_, TC_, JS_, M_>;                                       \
-        b.tilesR = cdiv(b.zr, Cf::TR); b.tilesC = cdiv(b.zc, Cf::TC);                       \
-        k_inv3_l2_planes<Cf><<<(unsigned)(b.tilesR * b.tilesC * b.B), DT_NT, 0, ctx->stream>>>( \
-            b, (const float *)planes, a.pstride);                                           \
+        launch_inv3_l2_planes<dt2d::Inv2RCfg<TR_, TC_, JS_, M_>>(b, (const float *)planes, a.pstride, ctx->stream); \
     }
     DT_INV3_L2_TABLE(X_)
 #undef X_

@@ -227,11 +227,11 @@ static void run_inv3_l1_planes(Inv1Params p, const float *planes, int64_t ps) {
             for (int tc = 0; tc < p.tilesC; ++tc) {
                 int r0 = tr * C::TR, c0 = tc * C::TC;
                 for (int t = 0; t < DT_NT; ++t) {
-                    inv1r_fetch_from<C>(p, planes, wz[t], t, b, r0, c0);
-                    inv1r_fetch_from<C>(p, planes + 2 * ps, w1[t], t, b, r0, c0);
-                    inv1r_fetch_from<C>(p, planes + ps, w2[t], t, b, r0, c0);
-                    inv1r_fetch_from<C>(p, planes + 3 * ps, w3[t], t, b, r0, c0);
-                    inv1r_fir<C>(p, wz[t], w1[t], w2[t], w3[t], y1, y2, t);
+                    inv1r_fetch_from<C, true>(p, planes, wz[t], t, b, r0, c0);
+                    inv1r_fetch_from<C, true>(p, planes + 2 * ps, w1[t], t, b, r0, c0);
+                    inv1r_fetch_from<C, true>(p, planes + ps, w2[t], t, b, r0, c0);
+                    inv1r_fetch_from<C, true>(p, planes + 3 * ps, w3[t], t, b, r0, c0);
+                    inv1r_fir<C, true>(p, wz[t], w1[t], w2[t], w3[t], y1, y2, t);
                 }
                 for (int t = 0; t < DT_NT; ++t) inv1d_rows<C>(p, y1, y2, t, b, r0, c0);
             }
@@ -250,11 +250,11 @@ static void run_inv3_l2_planes(Inv2Params p, const float *planes, int64_t ps) {
             for (int tc = 0; tc < p.tilesC; ++tc) {
                 int r0 = tr * C::TR, c0 = tc * C::TC;
                 for (int t = 0; t < DT_NT; ++t) {
-                    inv2r_fetch_from<C>(p, planes, wz[t], t, b, r0, c0);
-                    inv2r_fetch_from<C>(p, planes + 2 * ps, w1[t], t, b, r0, c0);
-                    inv2r_fetch_from<C>(p, planes + ps, w2[t], t, b, r0, c0);
-                    inv2r_fetch_from<C>(p, planes + 3 * ps, w3[t], t, b, r0, c0);
-                    inv2r_fir<C>(p, wz[t], w1[t], w2[t], w3[t], y1, y2, t);
+                    inv2r_fetch_from<C, true>(p, planes, wz[t], t, b, r0, c0);
+                    inv2r_fetch_from<C, true>(p, planes + 2 * ps, w1[t], t, b, r0, c0);
+                    inv2r_fetch_from<C, true>(p, planes + ps, w2[t], t, b, r0, c0);
+                    inv2r_fetch_from<C, true>(p, planes + 3 * ps, w3[t], t, b, r0, c0);
+                    inv2r_fir<C, true>(p, wz[t], w1[t], w2[t], w3[t], y1, y2, t);
                 }
                 for (int t = 0; t < DT_NT; ++t) inv2_rows<C>(p, y1, y2, t, b, r0, c0);
             }
