@@ -179,9 +179,10 @@ extern "C" int dtcwt_hip_fwd3_level2(dtcwt_hip_ctx *ctx, const float *X, int64_t
     const int64_t L0 = n0 + 2 * pad0, L1 = n1 + 2 * pad1, L2 = n2 + 2 * pad2;
     DT_REQUIRE(n0 > 0 && n1 > 0 && n2 > 0 && L0 % 4 == 0 && L1 % 4 == 0 && L2 % 4 == 0,
                "padded extents must be multiples of 4 (transform3d.py:322-335)");
-    if (L1 < DT_MIN_FUSED_DIM || L2 < DT_MIN_FUSED_DIM || n0 * L1 * L2 >= ((int64_t)1 << 31))
-        return dtcwt_set_error(-3, "fused 3-D level >= 2 needs slices of at least %d x %d", DT_MIN_FUSED_DIM,
-                               DT_MIN_FUSED_DIM);
+    // one-bounce reflection in the tile programs: the window reach (< 2m) must not exceed the plane
+    const int minw = 2 * m > 16 ? 2 * m : 16;
+    if (L1 < minw || L2 < minw || n0 * L1 * L2 >= ((int64_t)1 << 31))
+        return dtcwt_set_error(-3, "fused 3-D level >= 2 needs slices of at least %d x %d", minw, minw);
     const int O0 = (int)(L0 / 2), O1 = (int)(L1 / 2), O2 = (int)(L2 / 2);
     dt2d::Fwd2Params a{};
     a.X = X; a.B = (int)n0; a.inR = (int)n1; a.inC = (int)n2; a.padR = pad1; a.padC = pad2;
@@ -317,11 +318,14 @@ void launch_inv3_axis0(Inv3AParams &p, int cus, hipStream_t s) {
     k_inv3_axis0<F><<<(unsigned)(p.tilesJ * p.tilesK * p.chunks), DT_NT, 0, s>>>(p);
 }
 
-int check_inv3_dims(int64_t n0, int64_t n1, int64_t n2, int64_t S) {
-    if (n0 < 8 || n1 < DT_MIN_FUSED_DIM || n2 < DT_MIN_FUSED_DIM || 4 * S * n1 * n2 >= ((int64_t)1 << 31) ||
-        2 * n1 >= (1 << 15) * (int64_t)4 || n0 * n1 * n2 >= ((int64_t)1 << 31))
-        return dtcwt_set_error(-3, "fused 3-D inverse needs n0 >= 8, slices of at least %d x %d and < 2^31 samples",
-                               DT_MIN_FUSED_DIM, DT_MIN_FUSED_DIM);
+// one-bounce reflection in the tile programs: the window reach (< 2 x taps) must not exceed
+// the plane, and the march needs a few records of run-in
+int check_inv3_dims(int64_t n0, int64_t n1, int64_t n2, int64_t S, int taps) {
+    const int minw = 2 * taps > 16 ? 2 * taps : 16;
+    if (n0 < 12 || n1 < minw || n2 < minw || 4 * S * n1 * n2 >= ((int64_t)1 << 31) ||
+        n0 * n1 * n2 >= ((int64_t)1 << 31))
+        return dtcwt_set_error(-3, "fused 3-D inverse needs n0 >= 12, slices of at least %d x %d and < 2^31 samples",
+                               minw, minw);
     return 0;
 }
 
@@ -335,7 +339,7 @@ extern "C" int dtcwt_hip_inv3_level1(dtcwt_hip_ctx *ctx, const float *LLL, const
     DT_REQUIRE(ctx && LLL && Yh && g0o && g1o && Z, "NULL argument");
     DT_REQUIRE(n0 > 0 && n1 > 0 && n2 > 0 && n0 % 2 == 0 && n1 % 2 == 0 && n2 % 2 == 0, "extents must be even");
     DT_REQUIRE(m0 > 0 && m1 > 0 && m0 <= DT_MAXT && m1 <= DT_MAXT, "bad tap counts");
-    if (int rc = check_inv3_dims(n0, n1, n2, n0)) return rc;
+    if (int rc = check_inv3_dims(n0, n1, n2, n0, m0 > m1 ? m0 : m1)) return rc;
     bool have = false;
 #define X_(TR, TC, RS, A, B) if (m0 == A && m1 == B) have = true;
     DT_INV3_L1_TABLE(X_)
@@ -376,7 +380,7 @@ extern "C" int dtcwt_hip_inv3_level2(dtcwt_hip_ctx *ctx, const float *LLL, const
     DT_REQUIRE(m > 0 && m % 2 == 0 && m <= DT_MAXT, "q-shift filters must have even length <= %d", DT_MAXT);
     DT_REQUIRE(crop0 >= 0 && crop1 >= 0 && crop2 >= 0 && crop0 <= 2 && crop1 <= 2 && crop2 <= 2, "bad crop");
     const int64_t S = 2 * n0 - 2 * crop0;
-    if (int rc = check_inv3_dims(n0, n1, n2, S)) return rc;
+    if (int rc = check_inv3_dims(n0, n1, n2, S, m)) return rc;
     bool have = false;
 #define X_(TR, TC, JS, M) if (m == M) have = true;
     DT_INV3_L2_TABLE(X_)

@@ -159,7 +159,7 @@ int dtcwt_hip_fwd3_level1(dtcwt_hip_ctx *ctx, const float *X, int64_t n0, int64_
  * X: [n0][n1][n2] float32 lowpass of the previous level; pad_a in {0, 1, 2}: planes replicated
  * per side on axis a (ext_mode 4 / 8, :322-335), n_a + 2 pad_a must be a multiple of 4.
  * LLL: [(n0+2pad0)/2][(n1+2pad1)/2][(n2+2pad2)/2]; Yh: the same extents halved, [28] complex64.
- * Returns -3 when no fused kernel exists for m-tap filters or slices are under 40 x 40. */
+ * Returns -3 when no fused kernel exists for m-tap filters or slices are under 2m x 2m. */
 int dtcwt_hip_fwd3_level2(dtcwt_hip_ctx *ctx, const float *X, int64_t n0, int64_t n1, int64_t n2,
                           int pad0, int pad1, int pad2, const double *h0b, const double *h0a,
                           const double *h1b, const double *h1a, int m, float *LLL, float *Yh);
@@ -168,7 +168,8 @@ int dtcwt_hip_fwd3_level2(dtcwt_hip_ctx *ctx, const float *X, int64_t n0, int64_
  * octants and the three merges colfilter(lo, g0o) + colfilter(hi, g1o) -- in two launches
  * (unpack + axis-0 merge marching along axis 0 into four pooled planes, then the 2-D
  * column/row passes per slice).  LLL, Z: [n0][n1][n2] float32; Yh: [n0/2][n1/2][n2/2][28]
- * complex64.  Returns -3 when no fused kernel exists for the tap lengths or n1/n2 < 40. */
+ * complex64.  Returns -3 when no fused kernel exists for the tap lengths or the volume is
+ * small (n0 < 12 or n1/n2 under twice the tap count). */
 int dtcwt_hip_inv3_level1(dtcwt_hip_ctx *ctx, const float *LLL, const float *Yh, int64_t n0, int64_t n1,
                           int64_t n2, const double *g0o, int m0, const double *g1o, int m1, float *Z);
 /* Fused float32 level >= 2 of the 3-D inverse transform: replaces `_level2_ifm`

@@ -196,7 +196,7 @@ def _oracle_level2(X, q, ext):
     return t._level2_xfm(X, h0a, h0b, h1a, h1b)
 
 
-@pytest.mark.parametrize('shape,ext', [((8, 40, 44), 4), ((14, 42, 50), 4), ((20, 44, 60), 8), ((4, 48, 40), 8)])
+@pytest.mark.parametrize('shape,ext', [((8, 40, 44), 4), ((14, 42, 50), 4), ((20, 44, 60), 8), ((4, 48, 40), 8), ((12, 36, 38), 4)])
 @pytest.mark.parametrize('qname', ['qshift_a', 'qshift_b', 'qshift_d'])
 def test_fwd3_level2_tiles(emu, shape, ext, qname):
     """Level >= 2 (two passes) against the oracle's level 2 given the same input volume."""
@@ -229,7 +229,7 @@ def _rand_level(shape, seed):
     return Yl, Yh
 
 
-@pytest.mark.parametrize('shape,chunk', [((8, 40, 44), 4), ((12, 42, 70), 3), ((10, 40, 130), 64)])
+@pytest.mark.parametrize('shape,chunk', [((12, 40, 44), 4), ((12, 42, 70), 3), ((14, 40, 130), 64), ((12, 18, 20), 2)])
 @pytest.mark.parametrize('bname', ['near_sym_a', 'antonini', 'legall'])
 def test_inv3_level1_tiles(emu, shape, chunk, bname):
     Yl, Yh = _rand_level(shape, 21)
@@ -245,8 +245,9 @@ def test_inv3_level1_tiles(emu, shape, chunk, bname):
     assert Z.shape == want.shape and rel(Z, want) < TOL
 
 
-@pytest.mark.parametrize('shape,crops,chunk', [((8, 40, 44), (0, 0, 0), 4), ((12, 42, 70), (1, 1, 0), 3),
-                                               ((10, 40, 64), (2, 0, 2), 64), ((16, 44, 40), (1, 2, 1), 5)])
+@pytest.mark.parametrize('shape,crops,chunk', [((12, 40, 44), (0, 0, 0), 4), ((12, 42, 70), (1, 1, 0), 3),
+                                               ((14, 40, 64), (2, 0, 2), 64), ((16, 44, 40), (1, 2, 1), 5),
+                                               ((12, 28, 30), (1, 0, 1), 2)])
 @pytest.mark.parametrize('qname', ['qshift_a', 'qshift_b'])
 def test_inv3_level2_tiles(emu, shape, crops, chunk, qname):
     Yl, Yh = _rand_level(shape, 22)
