@@ -42,10 +42,15 @@ plan_case(ctx, 1, 4096, 4096, 4, 'C2  1 x 4096^2 nl=4')
 plan_case(ctx, 64, 1024, 1024, 5, 'C3 64 x 1024^2 nl=5')
 plan_case(ctx, 64, 2048, 2048, 4, 'C5 64 x 2048^2 nl=4 (1/8 of 512)')
 plan_case(ctx, 8, 4096, 4096, 4, '    8 x 4096^2 nl=4')
-# C4: 3-D forward 256^3 nlevels=3 (generic device filters)
+# C4: 3-D 256^3 nlevels=3 (fused level kernels; the generic axis passes for comparison)
 rs = np.random.RandomState(2)
 V = ctx.to_device(rs.standard_normal((256, 256, 256)).astype(np.float32))
-t3 = Transform3d(ctx=ctx)
-tf = timeit(lambda: t3.forward(V, nlevels=3), ctx, reps=3, warm=1)
-print('%-34s fwd %8.3f ms %9.0f Mvox/s (%.3f of 8TB/s @36B/vox)' % ('C4 256^3 nl=3 (generic path)', tf * 1e3,
-                                                                      256 ** 3 / tf / 1e6, 36 * 256 ** 3 / tf / 8e12))
+for fused in (True, False):
+    t3 = Transform3d(ctx=ctx)
+    t3.fused = fused
+    tf = timeit(lambda: t3.forward(V, nlevels=3), ctx, reps=10, warm=3)
+    p3 = t3.forward(V, nlevels=3)
+    ti = timeit(lambda: t3.inverse(p3, device_output=True), ctx, reps=10, warm=3)
+    print('%-34s fwd %8.3f ms %9.0f Mvox/s (%.3f of 8TB/s @36B/vox) | inv %8.3f ms %9.0f Mvox/s' % (
+        'C4 256^3 nl=3 (%s)' % ('fused levels' if fused else 'generic axis passes'), tf * 1e3, 256 ** 3 / tf / 1e6,
+        36 * 256 ** 3 / tf / 8e12, ti * 1e3, 256 ** 3 / ti / 1e6))
