@@ -13,6 +13,7 @@
 
 #include "fused2d_tiles.hpp"
 #include "fused2d_tiles_v2.hpp"
+#include "tile_variants.hpp"
 
 using namespace dt2d;
 
