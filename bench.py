@@ -37,8 +37,8 @@ L1_BYTES_PER_PX = 20.0        # level-1 kernel: X 4 + LoLo 4 + Yh[0] 12 (inverse
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=500)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--rows', type=int, default=ROWS)
     ap.add_argument('--cols', type=int, default=COLS)
@@ -56,7 +56,13 @@ def main():
     use_dist = world > 1 or os.environ.get('DTCWT_BENCH_FORCE_DIST', '0') == '1'   # latter: exercise RCCL at N=1
     if use_dist or os.environ.get('DTCWT_BENCH_TORCH', '0') == '1':
         import torch
+    saved_stdout = None
     if use_dist:
+        # RCCL prints its own banner lines on stdout at initialisation: keep stdout for the one
+        # JSON line of the contract, send everything else to stderr
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
@@ -168,7 +174,12 @@ def main():
     elif rank == 0:
         out['cpu_baseline'] = None
     if rank == 0:
-        print(json.dumps(out))
+        if saved_stdout is not None:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
+        if saved_stdout is not None:
+            os.dup2(2, 1)           # teardown chatter of the collective library, if any
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
