@@ -67,11 +67,11 @@ __global__ void __launch_bounds__(DT_NT) k_fwd3_l2_planes(dt2d::Fwd2Params p, fl
 // Level >= 2, pass B: axis-0 decimating filters + cube2c, one thread per output cell.
 template <int M, int NT>
 __global__ void __launch_bounds__(NT) k_fwd3_l2_axis0(Fwd3L2Params p) {
-    __shared__ __attribute__((aligned(16))) float slab[(NT / 64) * 64 * 56];
+    __shared__ __attribute__((aligned(16))) float slab[(NT / 64) * 64 * REC_LDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int id = (int)(blockIdx.x * NT + threadIdx.x);
-    float *ws = slab + wave * 64 * 56;
-    f3l2_axis0_stage<M>(p, id, ws + lane * 56);
+    float *ws = slab + wave * 64 * REC_LDS;
+    f3l2_axis0_stage<M>(p, id, ws + lane * REC_LDS);
     f3l2_axis0_flush(p, id - lane, lane, ws);
 }
 

@@ -41,8 +41,8 @@ struct Inv3AParams {
 };
 
 constexpr int I3_CJ = 2, I3_CK = 32;                 // cells per workgroup tile
-constexpr int I3_SLAB = I3_CJ * I3_CK * 56;          // floats of one staged record tile
-constexpr int I3_NPIECE = I3_SLAB / 4;               // 16-byte pieces (896)
+constexpr int I3_SLAB = I3_CJ * I3_CK * REC_LDS;     // floats of one staged record tile
+constexpr int I3_NPIECE = I3_CJ * I3_CK * 14;        // 16-byte pieces (896)
 constexpr int I3_RP = (I3_NPIECE + DT_NT - 1) / DT_NT;
 
 // level 1: odd-length biort filters g0o (M0 taps) on the a0 = 0 branch, g1o (M1) on a0 = 1
@@ -151,7 +151,7 @@ DT_HD void i3a_slab_write(Inv3AState<F> &st, float *slab, int tid) {
     for (int s = 0; s < I3_RP; ++s) {
         int piece = tid + DT_NT * s;
         DT_PIN_HERE(st.R[s][0]);
-        if (piece < I3_NPIECE) dst[piece] = f4{st.R[s][0], st.R[s][1], st.R[s][2], st.R[s][3]};
+        if (piece < I3_NPIECE) dst[slab_f4(piece)] = f4{st.R[s][0], st.R[s][1], st.R[s][2], st.R[s][3]};
     }
 }
 
@@ -181,7 +181,7 @@ DT_HD void i3a_push(const Inv3AParams &p, Inv3AState<F> &st, const float *slab, 
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int t = 0; t < F::NS - 2; ++t) { st.ra[q][t] = st.ra[q][t + 2]; st.rb[q][t] = st.rb[q][t + 2]; }
-    const float *rec = slab + lane * 56;
+    const float *rec = slab + lane * REC_LDS;
     float ev[4], od[4];
     c2cube_piece(rec + 8 * octant_slot(4 + v), ev, od);
 #pragma unroll

@@ -42,6 +42,14 @@ using dt2d::f2;
 using dt2d::f4;
 using dt2d::reflect_i;
 
+// A 224-byte record is 56 floats; in the LDS slabs consecutive records are 60 floats apart.
+// 56 floats = 14 sixteen-byte slots makes lanes 4 apart (writes, 32 banks) or every second
+// lane (16-byte reads, 64 banks) share banks; with 15 slots the lanes of a bank group all
+// land on different banks (MI355X_MICROARCH.md, LDS lane groups).
+constexpr int REC_LDS = 60;
+// 16-byte piece `piece` (0 .. 14 n) of n consecutive records -> its float4 index in a slab
+DT_HD int slab_f4(int piece) { int r = piece / 14; return r * (REC_LDS / 4) + (piece - 14 * r); }
+
 struct Fwd3L1Params {
     const float *X;      // [n0][n1][n2]
     float *LLL;          // [n0][n1][n2]
@@ -64,7 +72,7 @@ struct Fwd3L1Cfg {
     static constexpr int NPOS = PJ * PK;
     static constexpr int NPT = (NPOS + NT - 1) / NT;      // ring positions per thread
     static constexpr int S0F = 2 * PJ * S0S, S1F = 4 * PJ * TK;
-    static constexpr int STAGE_W = 32 * 56;               // floats: 32 records per wavefront
+    static constexpr int STAGE_W = 32 * REC_LDS;          // floats: 32 records per wavefront
     static constexpr int LDS_FLOATS = S0F + S1F + (NT / 64) * STAGE_W;
     static constexpr int NT2 = 2 * PJ * (TK / 4);         // axis-2 tasks (4 outputs each)
     static constexpr int WK = 4 + 2 * H;                  // axis-2 window (<= 12)
@@ -240,7 +248,7 @@ template <class C>
 DT_HD void f3l1_pack_stage(const float (&ev)[8][4], const float (&od)[8][4], float *stage, int tid, int half) {
     const int lane = tid & 63, wave = tid >> 6;
     if ((lane >> 5) != half) return;
-    float *rec = stage + wave * C::STAGE_W + (lane & 31) * 56;
+    float *rec = stage + wave * C::STAGE_W + (lane & 31) * REC_LDS;
     // record slots in the reference's concatenation order (transform3d.py:278-289):
     // (a0,a1,a2) = 010, 100, 110, 001, 011, 101, 111
     cube2c_record(rec + 0, ev[2], od[2]);
@@ -264,7 +272,7 @@ DT_HD void f3l1_pack_flush(const Fwd3L1Params &p, const float *stage, int tid, i
 #pragma unroll
     for (int it = 0; it < 7; ++it) {
         int piece = it * 64 + lane;                      // 16-byte piece of the row's 32 records
-        if (piece < ncell * 14) row[piece] = slab[piece];
+        if (piece < ncell * 14) row[piece] = slab[slab_f4(piece)];
     }
 }
 
@@ -389,7 +397,7 @@ DT_HD void f3l2_axis0_flush(const Fwd3L2Params &p, int first, int lane, const fl
 #pragma unroll
     for (int it = 0; it < 14; ++it) {
         int piece = it * 64 + lane;
-        if (piece < n * 14) dst[piece] = src[piece];
+        if (piece < n * 14) dst[piece] = src[slab_f4(piece)];
     }
 }
 

@@ -163,11 +163,11 @@ static int run_fwd3_l2(Fwd2Params a, dt3d::Fwd3L2Params b, float *planes) {
                     for (int t = 0; t < DT_NT; ++t) dt3d::fwd2p_rows<C>(a, sLo, sHi, planes, b.pstride, t, q, s, r0, c0);
             }
     int cells = (b.O0 / 2) * (b.O1 / 2) * (b.O2 / 2);
-    std::vector<float> slab(64 * 56 + 4);
+    std::vector<float> slab(64 * dt3d::REC_LDS + 4);
     float *ws = slab.data();
     while (((uintptr_t)ws) & 15) ++ws;
     for (int first = 0; first < cells; first += 64) {
-        for (int l = 0; l < 64; ++l) dt3d::f3l2_axis0_stage<C::M>(b, first + l, ws + l * 56);
+        for (int l = 0; l < 64; ++l) dt3d::f3l2_axis0_stage<C::M>(b, first + l, ws + l * dt3d::REC_LDS);
         for (int l = 0; l < 64; ++l) dt3d::f3l2_axis0_flush(b, first, l, ws);
     }
     return 0;
