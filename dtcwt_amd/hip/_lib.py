@@ -85,6 +85,11 @@ SIGNATURES = {
     'dtcwt_hip_fwd3_level2': (_i, [_vp, _vp, _i64, _i64, _i64, _i, _i, _i, _pd, _pd, _pd, _pd, _i, _vp, _vp]),
     'dtcwt_hip_inv3_level1': (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _pd, _i, _pd, _i, _vp]),
     'dtcwt_hip_inv3_level2': (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _pd, _pd, _pd, _pd, _i, _vp]),
+    'dtcwt_hip_sample': (_i, [_vp, _i, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i, _vp]),
+    'dtcwt_hip_rescale': (_i, [_vp, _i, _vp, _i64, _i64, _i64, _i64, _i64, _i, _vp]),
+    'dtcwt_hip_upsample2': (_i, [_vp, _i, _vp, _i64, _i64, _i64, _i, ctypes.POINTER(ctypes.c_int), _pd, _pd, _vp]),
+    'dtcwt_hip_phase_roll_grid': (_i, [_vp, _i, _vp, _i64, _i64, _i64, _i, ctypes.POINTER(ctypes.c_int), _pd, _pd, _dbl, _dbl, _dbl, _vp]),
+    'dtcwt_hip_phase_roll_points': (_i, [_vp, _i, _vp, _i64, _i64, _i, ctypes.POINTER(ctypes.c_int), _pd, _pd, _vp, _vp, _dbl, _vp]),
     'dtcwt_hip_cube2c': (_i, [_vp, _i, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i]),
     'dtcwt_hip_c2cube': (_i, [_vp, _i, _vp, _i64, _i64, _i64, _i, _vp, _i64, _i64]),
     'dtcwt_hip_pack1d': (_i, [_vp, _i, _vp, _i64, _i64, _vp]),

@@ -238,6 +238,39 @@ int dtcwt_hip_plan2d_inverse(dtcwt_hip_plan2d *plan, const float *Yl, const void
 int dtcwt_hip_plan2d_set_profiling(dtcwt_hip_plan2d *plan, int enable);
 int dtcwt_hip_plan2d_kernel_ms(dtcwt_hip_plan2d *plan, float *fwd_ms, float *inv_ms);
 
+/* ---------------------------------------------------------------- re-sampling ------ */
+/* Replaces dtcwt/sampling.py.  An image is [H][W][ncomp] of the real
+ * dtype (channels; complex data counts two components per channel).  Coordinates are DEVICE
+ * arrays of double; (x, y) is the centre of im[y][x]; outside the image the half-sample
+ * symmetric extension applies (sampling.py:36-40).  method: */
+#define DTCWT_HIP_SAMPLE_NEAREST 0     /* sampling.py:42-43 */
+#define DTCWT_HIP_SAMPLE_BILINEAR 1    /* sampling.py:45-66 */
+#define DTCWT_HIP_SAMPLE_LANCZOS 2     /* sampling.py:68-103, window radius 3 */
+/* sample: dtcwt/sampling.py:105-129.  out: [npts][ncomp]. */
+int dtcwt_hip_sample(dtcwt_hip_ctx *ctx, int dtype, const void *im, int64_t H, int64_t W, int64_t ncomp,
+                     const double *xs, const double *ys, int64_t npts, int method, void *out);
+/* rescale: dtcwt/sampling.py:131-165 (the sample grid is computed in the kernel).
+ * out: [out_h][out_w][ncomp]. */
+int dtcwt_hip_rescale(dtcwt_hip_ctx *ctx, int dtype, const void *im, int64_t H, int64_t W, int64_t ncomp,
+                      int64_t out_h, int64_t out_w, int method, void *out);
+/* upsample by two along both axes: dtcwt/sampling.py:280-367.  offsets / w_even / w_odd are
+ * HOST arrays of the per-axis taps (outputs 2i and 2i+1 sit at i - 1/4 and i + 1/4).
+ * out: [2H][2W][ncomp]. */
+int dtcwt_hip_upsample2(dtcwt_hip_ctx *ctx, int dtype, const void *im, int64_t H, int64_t W, int64_t ncomp,
+                        int ntaps, const int *offsets, const double *w_even, const double *w_odd, void *out);
+/* Phase rolling of complex subbands: dtcwt/sampling.py:167-190 (`_phase_image`) fused with
+ * the subband selection `im[:, :, sbs]` (:213, :270).
+ *   out[p][k] = in[p][src[k]] * exp(sign * j * (dtheta_dx[k] * x_p + dtheta_dy[k] * y_p))
+ * in: [..][nin] complex, out: [..][nch] complex (nch <= 6; src, dtheta_* are HOST arrays).
+ * _grid: p runs over an H x W array whose pixel (py, px) sits at
+ * (xscale (px + 1/2) - 1/2, yscale (py + 1/2) - 1/2); _points: x_p, y_p from device arrays. */
+int dtcwt_hip_phase_roll_grid(dtcwt_hip_ctx *ctx, int dtype, const void *in, int64_t H, int64_t W, int64_t nin,
+                              int nch, const int *src, const double *dtheta_dx, const double *dtheta_dy,
+                              double xscale, double yscale, double sign, void *out);
+int dtcwt_hip_phase_roll_points(dtcwt_hip_ctx *ctx, int dtype, const void *in, int64_t npts, int64_t nin, int nch,
+                                const int *src, const double *dtheta_dx, const double *dtheta_dy,
+                                const double *xs, const double *ys, double sign, void *out);
+
 #ifdef __cplusplus
 }
 #endif
