@@ -183,3 +183,26 @@ def test_3d_fused_level2_matches_generic_and_oracle(shape, ext, qname):
 
 def want_inverse(pyr, qname, ext):
     return o.Transform3d(biort('near_sym_a'), qshift(qname), ext_mode=ext).inverse(pyr)
+
+
+def test_3d_fused_vs_generic_random_sweep():
+    """Seeded random shapes / wavelets / ext_modes: every fused level kernel (or its fallback
+    decision) against the generic axis passes, forward and inverse."""
+    rs = np.random.RandomState(2024)
+    biorts = ['near_sym_a', 'antonini', 'legall', 'near_sym_b']
+    qshifts = ['qshift_a', 'qshift_b', 'qshift_06', 'qshift_c']
+    for trial in range(24):
+        ext = int(rs.choice([4, 8]))
+        mult = 2 if ext == 4 else 4
+        shape = tuple(int(mult * rs.randint(12 // mult, 72 // mult + 1)) for _ in range(3))
+        bn, qn = biorts[rs.randint(len(biorts))], qshifts[rs.randint(len(qshifts))]
+        nl = int(rs.randint(1, 4))
+        X = rs.standard_normal(shape).astype(np.float32)
+        t, g = Transform3d(bn, qn, ext_mode=ext), Transform3d(bn, qn, ext_mode=ext)
+        g.fused = False
+        p, q = t.forward(X, nlevels=nl, include_scale=True), g.forward(X, nlevels=nl, include_scale=True)
+        assert_pyramids_close(p, q, XFM_TOL)
+        zt, zg = t.inverse(p), g.inverse(p)
+        assert zt.shape == zg.shape == X.shape
+        assert_close(zt, zg, 2e-5, 'inverse %s %s %s ext%d nl%d' % (shape, bn, qn, ext, nl))
+        assert_close(zt, X, 3e-5, 'PR')
