@@ -1,0 +1,286 @@
+// Inner loops of the DT-CWT image registration on the device: the kernels behind
+// dtcwt_hip_qtilde / _solve6 / _boxfilter / _colsum / _affine_velocity / _warp_coords /
+// _axpy / _fill_rows (include/dtcwt_hip.h).
+//
+// Replaces the per-pixel work of dtcwt/registration.py of the reference (SURVEY.md section
+// 8(f) row 2): `qtildematrices` with its `confidence` and `phasegradient` (:31-214),
+// `solvetransform` (:216-250), `_boxfilter` (:417-446) and the coordinate arithmetic of
+// `velocityfield` / `warp` / `warphighpass` (:374-415).  Pyramids stay in HBM: the kernels
+// read the complex subband records [H][W][6] the transform kernels wrote.  All arithmetic is
+// float64 whatever the pyramid's precision (the reference accumulates Q-tilde in float64,
+// :190); the data are tiny next to the transforms (levels >= 2 of a pyramid).
+#include "common.hpp"
+
+namespace {
+
+struct c2 { double re, im; };
+__device__ inline c2 mk(double r, double i) { c2 z; z.re = r; z.im = i; return z; }
+__device__ inline c2 operator+(c2 a, c2 b) { return mk(a.re + b.re, a.im + b.im); }
+__device__ inline c2 mul(c2 a, c2 b) { return mk(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+__device__ inline c2 mulconj(c2 a, c2 b) { return mk(a.re * b.re + a.im * b.im, a.im * b.re - a.re * b.im); }   // a conj(b)
+__device__ inline double ang(c2 z) { return atan2(z.im, z.re); }
+
+template <typename T>
+__device__ inline c2 ld(const T *__restrict__ Yh, int W, int y, int x, int sb) {
+    const T *p = Yh + (((int64_t)y * W + x) * 6 + sb) * 2;
+    return mk((double)p[0], (double)p[1]);
+}
+
+// registration.py:29
+__constant__ double c_shift[6][2] = {{-1, -3}, {-3, -3}, {-3, -1}, {-3, 1}, {-3, 3}, {-1, 3}};
+
+// One pixel of one level of `qtildematrices` (registration.py:166-212):
+//   out[y][x][0..26] = sum over the six subbands of C^2 * (t_r t_c over triu(6x6), then t_r t_6)
+template <typename T>
+__global__ void __launch_bounds__(256) k_qtilde(const T *__restrict__ A, const T *__restrict__ B, int H, int W,
+                                                double eps, double *__restrict__ out) {
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (int64_t)H * W) return;
+    const int y = (int)(id / W), x = (int)(id - (int64_t)y * W);
+    const double xs = x * (1.0 / W), ys = y * (1.0 / H);          // np.arange(0, 1, 1/W)  (:168-169)
+    double q[27];
+#pragma unroll
+    for (int e = 0; e < 27; ++e) q[e] = 0.0;
+    for (int sb = 0; sb < 6; ++sb) {
+        const double wx = c_shift[sb][0] * (3.14159265358979323846 / 2.15);
+        const double wy = c_shift[sb][1] * (3.14159265358979323846 / 2.15);
+        // confidence (:83-137): the four diagonal neighbours, edges replicated
+        c2 num = mk(0, 0);
+        double den = eps;
+#pragma unroll
+        for (int oy = -1; oy <= 1; oy += 2)
+#pragma unroll
+            for (int ox = -1; ox <= 1; ox += 2) {
+                const int yy = min(max(y + oy, 0), H - 1), xx = min(max(x + ox, 0), W - 1);
+                const c2 u = ld(A, W, yy, xx, sb), v = ld(B, W, yy, xx, sb);
+                num = num + mulconj(v, u);                         // conj(u) v
+                const double au = hypot(u.re, u.im), av = hypot(v.re, v.im);
+                den += au * au * au + av * av * av;
+            }
+        const double an = hypot(num.re, num.im);
+        const double C = an * an / den;
+        // phase gradients (:31-75)
+        const c2 a0 = ld(A, W, y, x, sb), b0 = ld(B, W, y, x, sb);
+        const c2 ex = mk(cos(wx), -sin(wx)), ey = mk(cos(wy), -sin(wy));
+        // S(i) = (a[i+1] conj a[i] + b[i+1] conj b[i]) exp(-j w) between samples i and i+1
+        c2 Sx;
+        {
+            const int xl = x > 0 ? x - 1 : 0, xr = x < W - 1 ? x : W - 2;    // pairs (xl, xl+1), (xr, xr+1)
+            const c2 s1 = mul(mulconj(ld(A, W, y, xl + 1, sb), ld(A, W, y, xl, sb)) +
+                              mulconj(ld(B, W, y, xl + 1, sb), ld(B, W, y, xl, sb)), ex);
+            const c2 s2 = mul(mulconj(ld(A, W, y, xr + 1, sb), ld(A, W, y, xr, sb)) +
+                              mulconj(ld(B, W, y, xr + 1, sb), ld(B, W, y, xr, sb)), ex);
+            Sx = (x == 0) ? s1 : (x == W - 1 ? s2 : mk(0.5 * (s1.re + s2.re), 0.5 * (s1.im + s2.im)));
+        }
+        c2 Sy;
+        {
+            const int yl = y > 0 ? y - 1 : 0, yr = y < H - 1 ? y : H - 2;
+            const c2 s1 = mul(mulconj(ld(A, W, yl + 1, x, sb), ld(A, W, yl, x, sb)) +
+                              mulconj(ld(B, W, yl + 1, x, sb), ld(B, W, yl, x, sb)), ey);
+            const c2 s2 = mul(mulconj(ld(A, W, yr + 1, x, sb), ld(A, W, yr, x, sb)) +
+                              mulconj(ld(B, W, yr + 1, x, sb), ld(B, W, yr, x, sb)), ey);
+            Sy = (y == 0) ? s1 : (y == H - 1 ? s2 : mk(0.5 * (s1.re + s2.re), 0.5 * (s1.im + s2.im)));
+        }
+        const double dx = (ang(Sx) + wx) * W, dy = (ang(Sy) + wy) * H;
+        const double dt = ang(mulconj(b0, a0));                     // angle(b conj a)
+        const double t[7] = {dx, dy, xs * dx, xs * dy, ys * dx, ys * dy, -dt};
+        const double c2w = C * C;
+        int e = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = r; c < 6; ++c) q[e++] += c2w * (t[r] * t[c]);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) q[21 + r] += c2w * (t[r] * t[6]);
+    }
+    double *o = out + id * 27;
+#pragma unroll
+    for (int e = 0; e < 27; ++e) o[e] = q[e];
+}
+
+// a = -Q^{-1} q with the Q the reference builds -- upper triangle only (registration.py:231-232),
+// so the solve is a back substitution.  Qt: [n][27], a: [n][6].
+__global__ void __launch_bounds__(256) k_solve6(const double *__restrict__ Qt, int64_t n, double *__restrict__ a) {
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= n) return;
+    const double *q = Qt + id * 27;
+    double U[6][6], s[6];
+    int e = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = r; c < 6; ++c) U[r][c] = q[e++];
+#pragma unroll
+    for (int r = 5; r >= 0; --r) {
+        double acc = -q[21 + r];
+#pragma unroll
+        for (int c = r + 1; c < 6; ++c) acc -= U[r][c] * s[c];
+        s[r] = acc / U[r][r];
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) a[id * 6 + r] = s[r];
+}
+
+__device__ inline int refl_i(int u, int n) { return (int)dt_reflect(u, n); }
+
+// box filter of odd size k over the first two axes with symmetric extension (registration.py:417-446)
+__global__ void __launch_bounds__(256) k_boxfilter(const double *__restrict__ in, int H, int W, int K, int half,
+                                                   double *__restrict__ out) {
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (int64_t)H * W * K) return;
+    const int c = (int)(id % K);
+    const int64_t p = id / K;
+    const int y = (int)(p / W), x = (int)(p - (int64_t)y * W);
+    const double inv = 1.0 / (2 * half + 1);
+    double acc = 0.0;
+    for (int dy = -half; dy <= half; ++dy) {
+        const double *row = in + (int64_t)refl_i(y + dy, H) * W * K + c;
+        double r = 0.0;
+        for (int dx = -half; dx <= half; ++dx) r += row[(int64_t)refl_i(x + dx, W) * K];
+        acc += r * inv;
+    }
+    out[id] = acc * inv;
+}
+
+// out[c] += sum_p in[p][c]   (out zeroed by the caller)
+__global__ void __launch_bounds__(256) k_colsum(const double *__restrict__ in, int64_t n, int K, double *__restrict__ out) {
+    __shared__ double part[256];
+    const int c = blockIdx.y;
+    double acc = 0.0;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n; p += (int64_t)gridDim.x * 256) acc += in[p * K + c];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(out + c, part[0]);
+}
+
+// velocity of the affine parameters at their own grid (registration.py:385-390): pixel
+// coordinates are float32 quotients, as np.arange(dtype=float32) / w gives them
+__global__ void __launch_bounds__(256) k_affine_velocity(const double *__restrict__ av, int h, int w,
+                                                         double *__restrict__ vx, double *__restrict__ vy) {
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (int64_t)h * w) return;
+    const int y = (int)(id / w), x = (int)(id - (int64_t)y * w);
+    const double px = (double)((float)x / (float)w), py = (double)((float)y / (float)h);
+    const double *a = av + id * 6;
+    vx[id] = a[0] + a[2] * px + a[4] * py;
+    vy[id] = a[1] + a[3] * px + a[5] * py;
+}
+
+// sample positions of a warp (registration.py:401-415): ((x/W)_f32 + vx) W, ((y/H)_f32 + vy) H
+__global__ void __launch_bounds__(256) k_warp_coords(const double *__restrict__ vx, const double *__restrict__ vy,
+                                                     int H, int W, double *__restrict__ xs, double *__restrict__ ys) {
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (int64_t)H * W) return;
+    const int y = (int)(id / W), x = (int)(id - (int64_t)y * W);
+    xs[id] = ((double)((float)x / (float)W) + vx[id]) * W;
+    ys[id] = ((double)((float)y / (float)H) + vy[id]) * H;
+}
+
+__global__ void __launch_bounds__(256) k_axpy(int64_t n, double alpha, const double *__restrict__ x, double *__restrict__ y) {
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id < n) y[id] += alpha * x[id];
+}
+
+struct Row8 { double v[8]; };
+__global__ void __launch_bounds__(256) k_fill_rows(int64_t n, int K, Row8 row, double *__restrict__ out) {
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id < n * K) out[id] = row.v[id % K];
+}
+
+inline unsigned blocks_for(int64_t total) { return (unsigned)((total + 255) / 256); }
+
+}  // namespace
+
+#define DT_LAUNCH_CHECK() DT_CHECK_HIP(hipGetLastError())
+
+extern "C" {
+
+int dtcwt_hip_qtilde(dtcwt_hip_ctx *ctx, int dtype, const void *Yh_ref, const void *Yh_target, int64_t H, int64_t W,
+                     double epsilon, double *out) {
+    DT_REQUIRE(ctx && Yh_ref && Yh_target && out, "NULL argument");
+    DT_REQUIRE(H >= 2 && W >= 2 && H * W < ((int64_t)1 << 31), "subbands must be at least 2 x 2");
+    DT_CHECK_HIP(hipSetDevice(ctx->device));
+    if (dtype == DTCWT_HIP_F32)
+        k_qtilde<float><<<blocks_for(H * W), 256, 0, ctx->stream>>>((const float *)Yh_ref, (const float *)Yh_target, (int)H, (int)W, epsilon, out);
+    else if (dtype == DTCWT_HIP_F64)
+        k_qtilde<double><<<blocks_for(H * W), 256, 0, ctx->stream>>>((const double *)Yh_ref, (const double *)Yh_target, (int)H, (int)W, epsilon, out);
+    else
+        return dtcwt_set_error(-1, "bad dtype %d", dtype);
+    DT_LAUNCH_CHECK();
+    return 0;
+}
+
+int dtcwt_hip_solve6(dtcwt_hip_ctx *ctx, const double *Qt, int64_t n, double *a) {
+    DT_REQUIRE(ctx && Qt && a && n >= 0, "bad argument");
+    if (n == 0) return 0;
+    DT_CHECK_HIP(hipSetDevice(ctx->device));
+    k_solve6<<<blocks_for(n), 256, 0, ctx->stream>>>(Qt, n, a);
+    DT_LAUNCH_CHECK();
+    return 0;
+}
+
+int dtcwt_hip_boxfilter(dtcwt_hip_ctx *ctx, const double *in, int64_t H, int64_t W, int64_t K, int kernel_size,
+                        double *out) {
+    DT_REQUIRE(ctx && in && out, "NULL argument");
+    DT_REQUIRE(kernel_size > 0 && kernel_size % 2 == 1, "Kernel size must be odd");
+    DT_REQUIRE(H > 0 && W > 0 && K > 0 && H * W < ((int64_t)1 << 31) && K < (1 << 20), "bad extents");
+    DT_CHECK_HIP(hipSetDevice(ctx->device));
+    k_boxfilter<<<blocks_for(H * W * K), 256, 0, ctx->stream>>>(in, (int)H, (int)W, (int)K, kernel_size / 2, out);
+    DT_LAUNCH_CHECK();
+    return 0;
+}
+
+int dtcwt_hip_colsum(dtcwt_hip_ctx *ctx, const double *in, int64_t n, int64_t K, double *out) {
+    DT_REQUIRE(ctx && in && out && n >= 0 && K > 0 && K < 65536, "bad argument");
+    DT_CHECK_HIP(hipSetDevice(ctx->device));
+    DT_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)K * sizeof(double), ctx->stream));
+    if (n == 0) return 0;
+    int64_t nb = (n + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    k_colsum<<<dim3((unsigned)nb, (unsigned)K), 256, 0, ctx->stream>>>(in, n, (int)K, out);
+    DT_LAUNCH_CHECK();
+    return 0;
+}
+
+int dtcwt_hip_affine_velocity(dtcwt_hip_ctx *ctx, const double *avecs, int64_t h, int64_t w, double *vx, double *vy) {
+    DT_REQUIRE(ctx && avecs && vx && vy && h > 0 && w > 0 && h * w < ((int64_t)1 << 31), "bad argument");
+    DT_CHECK_HIP(hipSetDevice(ctx->device));
+    k_affine_velocity<<<blocks_for(h * w), 256, 0, ctx->stream>>>(avecs, (int)h, (int)w, vx, vy);
+    DT_LAUNCH_CHECK();
+    return 0;
+}
+
+int dtcwt_hip_warp_coords(dtcwt_hip_ctx *ctx, const double *vx, const double *vy, int64_t H, int64_t W, double *xs,
+                          double *ys) {
+    DT_REQUIRE(ctx && vx && vy && xs && ys && H > 0 && W > 0 && H * W < ((int64_t)1 << 31), "bad argument");
+    DT_CHECK_HIP(hipSetDevice(ctx->device));
+    k_warp_coords<<<blocks_for(H * W), 256, 0, ctx->stream>>>(vx, vy, (int)H, (int)W, xs, ys);
+    DT_LAUNCH_CHECK();
+    return 0;
+}
+
+int dtcwt_hip_axpy(dtcwt_hip_ctx *ctx, int64_t n, double alpha, const double *x, double *y) {
+    DT_REQUIRE(ctx && x && y && n >= 0, "bad argument");
+    if (n == 0) return 0;
+    DT_CHECK_HIP(hipSetDevice(ctx->device));
+    k_axpy<<<blocks_for(n), 256, 0, ctx->stream>>>(n, alpha, x, y);
+    DT_LAUNCH_CHECK();
+    return 0;
+}
+
+int dtcwt_hip_fill_rows(dtcwt_hip_ctx *ctx, int64_t n, int K, const double *row, double *out) {
+    DT_REQUIRE(ctx && row && out && n >= 0 && K >= 1 && K <= 8, "rows of 1..8 values");
+    if (n == 0) return 0;
+    Row8 r{};
+    for (int k = 0; k < K; ++k) r.v[k] = row[k];
+    DT_CHECK_HIP(hipSetDevice(ctx->device));
+    k_fill_rows<<<blocks_for(n * K), 256, 0, ctx->stream>>>(n, K, r, out);
+    DT_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -90,6 +90,14 @@ SIGNATURES = {
     'dtcwt_hip_upsample2': (_i, [_vp, _i, _vp, _i64, _i64, _i64, _i, ctypes.POINTER(ctypes.c_int), _pd, _pd, _vp]),
     'dtcwt_hip_phase_roll_grid': (_i, [_vp, _i, _vp, _i64, _i64, _i64, _i, ctypes.POINTER(ctypes.c_int), _pd, _pd, _dbl, _dbl, _dbl, _vp]),
     'dtcwt_hip_phase_roll_points': (_i, [_vp, _i, _vp, _i64, _i64, _i, ctypes.POINTER(ctypes.c_int), _pd, _pd, _vp, _vp, _dbl, _vp]),
+    'dtcwt_hip_qtilde': (_i, [_vp, _i, _vp, _vp, _i64, _i64, _dbl, _vp]),
+    'dtcwt_hip_solve6': (_i, [_vp, _vp, _i64, _vp]),
+    'dtcwt_hip_boxfilter': (_i, [_vp, _vp, _i64, _i64, _i64, _i, _vp]),
+    'dtcwt_hip_colsum': (_i, [_vp, _vp, _i64, _i64, _vp]),
+    'dtcwt_hip_affine_velocity': (_i, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    'dtcwt_hip_warp_coords': (_i, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
+    'dtcwt_hip_axpy': (_i, [_vp, _i64, _dbl, _vp, _vp]),
+    'dtcwt_hip_fill_rows': (_i, [_vp, _i64, _i, _pd, _vp]),
     'dtcwt_hip_cube2c': (_i, [_vp, _i, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i]),
     'dtcwt_hip_c2cube': (_i, [_vp, _i, _vp, _i64, _i64, _i64, _i, _vp, _i64, _i64]),
     'dtcwt_hip_pack1d': (_i, [_vp, _i, _vp, _i64, _i64, _vp]),

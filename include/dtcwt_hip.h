@@ -271,6 +271,33 @@ int dtcwt_hip_phase_roll_points(dtcwt_hip_ctx *ctx, int dtype, const void *in, i
                                 const int *src, const double *dtheta_dx, const double *dtheta_dy,
                                 const double *xs, const double *ys, double sign, void *out);
 
+/* ---------------------------------------------------------------- registration ----- */
+/* Replaces the per-pixel loops of dtcwt/registration.py.  All results
+ * are float64; Yh_* are the [H][W][6] complex subband records of one pyramid level (dtype =
+ * their real type). */
+/* One level of `qtildematrices` (registration.py:140-214) with `confidence` (:83-137) and
+ * `phasegradient` (:31-75) folded in.  out: [H][W][27]. */
+int dtcwt_hip_qtilde(dtcwt_hip_ctx *ctx, int dtype, const void *Yh_ref, const void *Yh_target, int64_t H, int64_t W,
+                     double epsilon, double *out);
+/* `solvetransform` (registration.py:216-250): a = -Q^{-1} q per row of Qt [n][27] -> a [n][6]
+ * (the reference fills only the upper triangle of Q, :231-232: a back substitution). */
+int dtcwt_hip_solve6(dtcwt_hip_ctx *ctx, const double *Qt, int64_t n, double *a);
+/* `_boxfilter` (registration.py:417-446): odd kernel_size, first two axes of in [H][W][K]. */
+int dtcwt_hip_boxfilter(dtcwt_hip_ctx *ctx, const double *in, int64_t H, int64_t W, int64_t K, int kernel_size,
+                        double *out);
+/* out[c] = sum_p in[p][c]: the `np.sum(np.sum(x, axis=0), axis=0)` of registration.py:341-344. */
+int dtcwt_hip_colsum(dtcwt_hip_ctx *ctx, const double *in, int64_t n, int64_t K, double *out);
+/* `velocityfield` before its rescale (registration.py:385-390): avecs [h][w][6] -> vx, vy [h][w]. */
+int dtcwt_hip_affine_velocity(dtcwt_hip_ctx *ctx, const double *avecs, int64_t h, int64_t w, double *vx, double *vy);
+/* sample positions of `warp` / `warphighpass` (registration.py:401-415) in pixels:
+ * xs = ((x / W)_float32 + vx) W, ys likewise. */
+int dtcwt_hip_warp_coords(dtcwt_hip_ctx *ctx, const double *vx, const double *vy, int64_t H, int64_t W, double *xs,
+                          double *ys);
+/* y += alpha x (the `qts +=` / `avecs +=` of registration.py:368-370); out[p][k] = row[k] (HOST
+ * row of K <= 8 values: the broadcast of the global estimate, :347-348). */
+int dtcwt_hip_axpy(dtcwt_hip_ctx *ctx, int64_t n, double alpha, const double *x, double *y);
+int dtcwt_hip_fill_rows(dtcwt_hip_ctx *ctx, int64_t n, int K, const double *row, double *out);
+
 #ifdef __cplusplus
 }
 #endif
