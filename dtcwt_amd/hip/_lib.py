@@ -277,9 +277,9 @@ class Event(object):
 
     def __del__(self):
         try:
-            if getattr(self, '_h', None):
+            if getattr(self, '_h', None) and getattr(self.ctx, '_h', None):
                 self.ctx._lib.dtcwt_hip_event_destroy(self._h)
-                self._h = None
+            self._h = None
         except Exception:
             pass
 

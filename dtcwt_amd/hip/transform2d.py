@@ -101,10 +101,13 @@ class _Plan2d(object):
         return list(f), list(i)
 
     def __del__(self):
+        # The plan dereferences its context when it is destroyed.  When both die in one garbage
+        # cycle (typically at interpreter exit) the finalisers run in arbitrary order: if the
+        # context went first, leave the plan's workspaces to the process teardown.
         try:
-            if getattr(self, '_h', None):
+            if getattr(self, '_h', None) and getattr(self.ctx, '_h', None):
                 self._lib.dtcwt_hip_plan2d_destroy(self._h)
-                self._h = None
+            self._h = None
         except Exception:
             pass
 
