@@ -9,6 +9,8 @@
 // read the complex subband records [H][W][6] the transform kernels wrote.  All arithmetic is
 // float64 whatever the pyramid's precision (the reference accumulates Q-tilde in float64,
 // :190); the data are tiny next to the transforms (levels >= 2 of a pyramid).
+#include <vector>
+
 #include "common.hpp"
 
 namespace {
@@ -191,7 +193,29 @@ __global__ void __launch_bounds__(256) k_fill_rows(int64_t n, int K, Row8 row, d
     if (id < n * K) out[id] = row.v[id % K];
 }
 
+// out[p][k] = row[k] with the row on the device (no host round trip inside estimatereg)
+__global__ void __launch_bounds__(256) k_broadcast_rows(int64_t n, int K, const double *__restrict__ row,
+                                                        double *__restrict__ out) {
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id < n * K) out[id] = row[id % K];
+}
+
 inline unsigned blocks_for(int64_t total) { return (unsigned)((total + 255) / 256); }
+
+// pooled scratch buffers of one estimatereg call, released (stream-ordered) on every exit path
+struct Scratch {
+    dtcwt_hip_ctx *ctx;
+    std::vector<void *> bufs;
+    explicit Scratch(dtcwt_hip_ctx *c) : ctx(c) {}
+    ~Scratch() { for (void *b : bufs) dtcwt_hip_free(ctx, b); }
+    template <typename T>
+    T *get(int64_t count) {
+        void *p = nullptr;
+        if (dtcwt_hip_malloc(ctx, (size_t)count * sizeof(T), &p)) return nullptr;
+        bufs.push_back(p);
+        return (T *)p;
+    }
+};
 
 }  // namespace
 
@@ -280,6 +304,90 @@ int dtcwt_hip_fill_rows(dtcwt_hip_ctx *ctx, int64_t n, int K, const double *row,
     DT_CHECK_HIP(hipSetDevice(ctx->device));
     k_fill_rows<<<blocks_for(n * K), 256, 0, ctx->stream>>>(n, K, r, out);
     DT_LAUNCH_CHECK();
+    return 0;
+}
+
+#define DT_TRY(expr)              \
+    do {                          \
+        int rc__ = (expr);        \
+        if (rc__) return rc__;    \
+    } while (0)
+
+// The whole of `estimatereg` (dtcwt/registration.py:301-372) sequenced natively: the same kernels
+// the host-side sequence of dtcwt_amd/hip/registration.py launches one by one, without the
+// per-launch interpreter and ctypes latency that dominates at these sizes.
+//   Yh_src / Yh_ref: per level, [H_l][W_l][6] complex records (dtype = their real type);
+//   shapes: [nlevels][2] = (H_l, W_l);  groups: `ngroups` level lists, group g holds
+//   group_sizes[g] consecutive entries of group_levels (0-based); the first group gives the
+//   global estimate, the others refine it (:339-370);  avecs: [reg_h][reg_w][6] float64 out.
+int dtcwt_hip_estimatereg(dtcwt_hip_ctx *ctx, int dtype, int nlevels, const void *const *Yh_src,
+                          const void *const *Yh_ref, const int64_t *shapes, int64_t reg_h, int64_t reg_w,
+                          int ngroups, const int *group_sizes, const int *group_levels, double *avecs) {
+    DT_REQUIRE(ctx && Yh_src && Yh_ref && shapes && group_sizes && group_levels && avecs, "NULL argument");
+    DT_REQUIRE(nlevels > 0 && ngroups > 0 && reg_h > 0 && reg_w > 0, "bad extents");
+    DT_REQUIRE(dtype == DTCWT_HIP_F32 || dtype == DTCWT_HIP_F64, "bad dtype");
+    int total = 0;
+    for (int g = 0; g < ngroups; ++g) total += group_sizes[g];
+    for (int k = 0; k < total; ++k)
+        DT_REQUIRE(group_levels[k] >= 0 && group_levels[k] < nlevels && Yh_src[group_levels[k]] && Yh_ref[group_levels[k]],
+                   "level index out of range");
+    DT_CHECK_HIP(hipSetDevice(ctx->device));
+    Scratch sc(ctx);
+    const double W0 = -3 * 3.14159265358979323846 / 2.15, W1 = -3.14159265358979323846 / 2.15;
+    const double tdx[6] = {W1, W0, W0, W0, W0, W1}, tdy[6] = {W0, W0, W1, -W1, -W0, -W0};   // sampling.py:26-33
+    const int ident[6] = {0, 1, 2, 3, 4, 5};
+    const size_t esz = dtype == DTCWT_HIP_F32 ? sizeof(float) : sizeof(double);
+    const int64_t nreg = reg_h * reg_w;
+
+    // global estimate: Q-tilde summed over every pixel of the first group's levels
+    double *Qt = sc.get<double>(27), *part = sc.get<double>(27), *a0 = sc.get<double>(6);
+    DT_REQUIRE(Qt && part && a0, "out of device memory");
+    DT_CHECK_HIP(hipMemsetAsync(Qt, 0, 27 * sizeof(double), ctx->stream));
+    const int *lv = group_levels;
+    for (int k = 0; k < group_sizes[0]; ++k) {
+        const int l = lv[k];
+        const int64_t H = shapes[2 * l], W = shapes[2 * l + 1];
+        double *q = sc.get<double>(H * W * 27);
+        DT_REQUIRE(q, "out of device memory");
+        DT_TRY(dtcwt_hip_qtilde(ctx, dtype, Yh_src[l], Yh_ref[l], H, W, 1e-6, q));
+        DT_TRY(dtcwt_hip_colsum(ctx, q, H * W, 27, part));
+        DT_TRY(dtcwt_hip_axpy(ctx, 27, 1.0, part, Qt));
+    }
+    DT_TRY(dtcwt_hip_solve6(ctx, Qt, 1, a0));
+    k_broadcast_rows<<<blocks_for(nreg * 6), 256, 0, ctx->stream>>>(nreg, 6, a0, avecs);
+    DT_LAUNCH_CHECK();
+    lv += group_sizes[0];
+
+    double *vx = sc.get<double>(nreg), *vy = sc.get<double>(nreg);
+    double *qts = sc.get<double>(nreg * 27), *qr = sc.get<double>(nreg * 27), *da = sc.get<double>(nreg * 6);
+    DT_REQUIRE(vx && vy && qts && qr && da, "out of device memory");
+    for (int g = 1; g < ngroups; lv += group_sizes[g], ++g) {
+        if (group_sizes[g] < 1) continue;
+        for (int k = 0; k < group_sizes[g]; ++k) {
+            const int l = lv[k];
+            const int64_t H = shapes[2 * l], W = shapes[2 * l + 1], n = H * W;
+            double *vxs = sc.get<double>(n), *vys = sc.get<double>(n), *xs = sc.get<double>(n), *ys = sc.get<double>(n);
+            void *un = sc.get<char>(n * 12 * esz), *smp = sc.get<char>(n * 12 * esz), *wrp = sc.get<char>(n * 12 * esz);
+            double *q = sc.get<double>(n * 27), *qb = sc.get<double>(n * 27);
+            DT_REQUIRE(vxs && vys && xs && ys && un && smp && wrp && q && qb, "out of device memory");
+            // warphighpass(Yh_src[l], avecs, 'bilinear')   (:397-408)
+            DT_TRY(dtcwt_hip_affine_velocity(ctx, avecs, reg_h, reg_w, vx, vy));
+            DT_TRY(dtcwt_hip_rescale(ctx, DTCWT_HIP_F64, vx, reg_h, reg_w, 1, H, W, DTCWT_HIP_SAMPLE_BILINEAR, vxs));
+            DT_TRY(dtcwt_hip_rescale(ctx, DTCWT_HIP_F64, vy, reg_h, reg_w, 1, H, W, DTCWT_HIP_SAMPLE_BILINEAR, vys));
+            DT_TRY(dtcwt_hip_warp_coords(ctx, vxs, vys, H, W, xs, ys));
+            DT_TRY(dtcwt_hip_phase_roll_grid(ctx, dtype, Yh_src[l], H, W, 6, 6, ident, tdx, tdy, 1.0, 1.0, -1.0, un));
+            DT_TRY(dtcwt_hip_sample(ctx, dtype, un, H, W, 12, xs, ys, n, DTCWT_HIP_SAMPLE_BILINEAR, smp));
+            DT_TRY(dtcwt_hip_phase_roll_points(ctx, dtype, smp, n, 6, 6, ident, tdx, tdy, xs, ys, 1.0, wrp));
+            // Q-tilde of the warped level, box filtered and resampled onto the block grid (:362-368)
+            DT_TRY(dtcwt_hip_qtilde(ctx, dtype, wrp, Yh_ref[l], H, W, 1e-6, q));
+            DT_TRY(dtcwt_hip_boxfilter(ctx, q, H, W, 27, 3, qb));
+            DT_TRY(dtcwt_hip_rescale(ctx, DTCWT_HIP_F64, qb, H, W, 27, reg_h, reg_w, DTCWT_HIP_SAMPLE_BILINEAR,
+                                     k == 0 ? qts : qr));
+            if (k > 0) DT_TRY(dtcwt_hip_axpy(ctx, nreg * 27, 1.0, qr, qts));
+        }
+        DT_TRY(dtcwt_hip_solve6(ctx, qts, nreg, da));
+        DT_TRY(dtcwt_hip_axpy(ctx, nreg * 6, 1.0, da, avecs));
+    }
     return 0;
 }
 

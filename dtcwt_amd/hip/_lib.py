@@ -98,6 +98,8 @@ SIGNATURES = {
     'dtcwt_hip_warp_coords': (_i, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     'dtcwt_hip_axpy': (_i, [_vp, _i64, _dbl, _vp, _vp]),
     'dtcwt_hip_fill_rows': (_i, [_vp, _i64, _i, _pd, _vp]),
+    'dtcwt_hip_estimatereg': (_i, [_vp, _i, _i, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_i64), _i64, _i64,
+                                   _i, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), _vp]),
     'dtcwt_hip_cube2c': (_i, [_vp, _i, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i]),
     'dtcwt_hip_c2cube': (_i, [_vp, _i, _vp, _i64, _i64, _i64, _i, _vp, _i64, _i64]),
     'dtcwt_hip_pack1d': (_i, [_vp, _i, _vp, _i64, _i64, _vp]),

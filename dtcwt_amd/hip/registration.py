@@ -206,14 +206,46 @@ def _boxfilter_dev(X, kernel_size):
     return out
 
 
-def estimatereg(source, reference, regshape=None, levels=None, device_output=False):
+def _estimatereg_native(ctx, source, reference, nlevels, shp, levels, device_output):
+    used = sorted(set(l for g in levels for l in g))
+    if any(l < 0 or l >= nlevels for l in used):
+        raise IndexError('level index out of range')
+    src = {l: _dev_highpass(source, l, ctx) for l in used}
+    ref = {l: _dev_highpass(reference, l, ctx) for l in used}
+    dt = src[used[0]].dtype
+    for l in used:
+        if src[l].shape != ref[l].shape:
+            raise ValueError('Subbands should have identical size')
+        if src[l].dtype != dt:
+            src[l] = ctx.to_device(src[l].get().astype(dt))
+        if ref[l].dtype != dt:
+            ref[l] = ctx.to_device(ref[l].get().astype(dt))
+    vp = ctypes.c_void_p
+    ps = (vp * nlevels)(*[src[l].ptr if l in src else None for l in range(nlevels)])
+    pr = (vp * nlevels)(*[ref[l].ptr if l in ref else None for l in range(nlevels)])
+    shapes = (ctypes.c_int64 * (2 * nlevels))()
+    for l in used:
+        shapes[2 * l], shapes[2 * l + 1] = src[l].shape[0], src[l].shape[1]
+    sizes = (ctypes.c_int * len(levels))(*[len(g) for g in levels])
+    flat = [l for g in levels for l in g]
+    lv = (ctypes.c_int * max(len(flat), 1))(*flat)
+    avecs = DeviceArray(ctx, shp + (6,), np.float64)
+    check(_lib.lib().dtcwt_hip_estimatereg(ctx.handle, _real_code(src[used[0]]), nlevels, ps, pr, shapes, shp[0], shp[1],
+                                           len(levels), sizes, lv, avecs.ptr))
+    return avecs if device_output else avecs.get()
+
+
+def estimatereg(source, reference, regshape=None, levels=None, device_output=False, native=True):
     """Estimate the registration which will map *source* to *reference* (transformed images
     with the ``dtcwt.Pyramid`` API).  The local affine distortion is estimated at 8x8 pixel
     scales: returns a NxMx6 array whose 6-vector at (N, M) holds the affine distortion
     parameters of that block (default shape: that of the level-4 subbands, or *regshape*).
     *levels*, if not None, is a sequence of sequences of 0-based level indices to use
     (dtcwt/registration.py:301-372).  Use :py:func:`velocityfield` to turn the result into a
-    velocity field."""
+    velocity field.
+
+    *native* (default): the whole kernel sequence is issued by one library call
+    (``dtcwt_hip_estimatereg``); ``native=False`` issues the same kernels one by one from here."""
     ctx = _ctx_of(source, reference)
     nlevels = len(source.highpasses)
     if regshape is None:
@@ -229,6 +261,10 @@ def estimatereg(source, reference, regshape=None, levels=None, device_output=Fal
             if len(refine) >= 2:
                 levels.append(refine)
 
+    if native:
+        return _estimatereg_native(ctx, source, reference, nlevels, shp, levels, device_output)
+
+    # the same sequence launch by launch (kept for inspection of the intermediate results)
     # initial global transform: Q-tilde summed over every pixel of the coarsest levels
     Qt = ctx.zeros((27,), np.float64)
     for l in levels[0]:

@@ -297,6 +297,16 @@ int dtcwt_hip_warp_coords(dtcwt_hip_ctx *ctx, const double *vx, const double *vy
  * row of K <= 8 values: the broadcast of the global estimate, :347-348). */
 int dtcwt_hip_axpy(dtcwt_hip_ctx *ctx, int64_t n, double alpha, const double *x, double *y);
 int dtcwt_hip_fill_rows(dtcwt_hip_ctx *ctx, int64_t n, int K, const double *row, double *out);
+/* The whole of `estimatereg` (registration.py:301-372) in one call: the sequence of the kernels
+ * above and of the re-sampling ones, without a host round trip per launch.
+ * Yh_src / Yh_ref: HOST arrays of `nlevels` device pointers to the [H_l][W_l][6] complex records
+ * of the two pyramids (entries of unused levels may be NULL); shapes: HOST [nlevels][2] = (H_l, W_l);
+ * the level schedule is `ngroups` lists, group g = group_sizes[g] consecutive entries of
+ * group_levels (0-based level indices): group 0 gives the global estimate, the others refine it.
+ * avecs: DEVICE [reg_h][reg_w][6] float64 out. */
+int dtcwt_hip_estimatereg(dtcwt_hip_ctx *ctx, int dtype, int nlevels, const void *const *Yh_src,
+                          const void *const *Yh_ref, const int64_t *shapes, int64_t reg_h, int64_t reg_w,
+                          int ngroups, const int *group_sizes, const int *group_levels, double *avecs);
 
 #ifdef __cplusplus
 }

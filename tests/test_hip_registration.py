@@ -38,6 +38,9 @@ def test_estimatereg_vs_reference_vectors():
     assert av.shape == g['estimatereg'].shape and av.dtype == np.float64
     assert rel(av, g['estimatereg']) < 1e-6
     assert rel(reg.estimatereg(p1, p2, regshape=(5, 7), levels=[[4, 3], [3, 2]]), g['estimatereg_custom']) < 1e-6
+    # one native call and the launch-by-launch sequence are the same kernels
+    assert rel(reg.estimatereg(p1, p2, native=False), av) < 1e-12
+    assert rel(reg.estimatereg(p1, p2, regshape=(5, 7), levels=[[4, 3], [3, 2]], native=False), g['estimatereg_custom']) < 1e-6
     # host pyramids (uploaded) give the same answer as device-resident ones
     o1, o2 = pyramids(g)
     assert rel(reg.estimatereg(o1, o2), av) < 1e-9
