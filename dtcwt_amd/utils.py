@@ -46,3 +46,24 @@ def reflect(x, minx, maxx):
 def flat_taps(h):
     """Filter as a flat float64 vector."""
     return np.ascontiguousarray(np.asarray(h, dtype=np.float64).reshape(-1))
+
+
+def unpack(pyramid, backend='numpy'):
+    """Unpack a pyramid into its constituent parts: a generator of ``Yl, Yh[, Yscale]`` (the
+    third only if the pyramid was created with ``include_scale``), as dtcwt/utils.py:9-42.
+    ``backend='numpy'`` gives NumPy arrays whatever backend produced the pyramid;
+    ``backend='hip'`` gives the device-resident buffers (``hip_lowpass`` ...), the analogue of
+    the reference's ``'opencl'`` / ``'tf'`` selections."""
+    backend = backend.lower()
+    if backend == 'numpy':
+        yield pyramid.lowpass
+        yield pyramid.highpasses
+        if pyramid.scales is not None:
+            yield pyramid.scales
+    elif backend == 'hip':
+        yield pyramid.hip_lowpass
+        yield pyramid.hip_highpasses
+        if pyramid.hip_scales is not None:
+            yield pyramid.hip_scales
+    else:
+        raise ValueError('unknown backend "%s": use "numpy" or "hip"' % backend)

@@ -92,3 +92,18 @@ def test_coeffs_interface():
         biort('qshift_a')
     with pytest.raises(ValueError):
         qshift('near_sym_a')
+
+
+def test_unpack_numpy_pyramid_parts():
+    """utils.unpack (dtcwt/utils.py:9-42) on a host-constructed pyramid: no device needed."""
+    import numpy as np
+    from dtcwt_amd.utils import unpack
+    from dtcwt_amd.hip import Pyramid
+    lo, hi = np.zeros((4, 4)), (np.zeros((2, 2, 6), complex),)
+    assert len(list(unpack(Pyramid(lo, hi)))) == 2
+    yl, yh, ys = unpack(Pyramid(lo, hi, (lo,)))
+    assert yl is not None and len(yh) == 1 and len(ys) == 1
+    assert list(unpack(Pyramid(lo, hi), 'hip'))[0] is None      # host arrays: no device handles
+    import pytest
+    with pytest.raises(ValueError):
+        list(unpack(Pyramid(lo, hi), 'tf'))
