@@ -284,3 +284,33 @@ def test_batched_config_c3_shape():
     single = t.forward(Xb[37], nlevels=5)
     assert np.array_equal(pb.highpasses[0][37], single.highpasses[0])
     assert np.array_equal(pb.lowpass[37], single.lowpass)
+
+
+def test_two_contexts_from_two_threads():
+    """a context is single-threaded, distinct contexts may be driven
+    from distinct host threads (ctypes releases the GIL during the calls)."""
+    import threading
+    from dtcwt_amd.hip import Context
+    rs = np.random.RandomState(21)
+    images = [rs.standard_normal((384, 512)).astype(np.float32) for _ in range(2)]
+    want = [o.Transform2d(biort('near_sym_a'), qshift('qshift_a')).forward(x.astype(np.float64), nlevels=3) for x in images]
+    errors = []
+
+    def work(k):
+        try:
+            ctx = Context(0)
+            t = Transform2d(ctx=ctx)
+            for _ in range(20):
+                p = t.forward(images[k], nlevels=3)
+                z = t.inverse(p)
+            assert_pyramids_close(p, want[k], XFM_TOL, same_dtype=False)
+            assert_close(z, images[k], INV_TOL, 'PR')
+        except Exception as e:           # surfaced in the main thread below
+            errors.append(e)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    assert not errors, errors
