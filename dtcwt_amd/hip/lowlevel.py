@@ -152,8 +152,9 @@ def axis_coldfilt2(X, pair0, pair1, axis=0, pad=(0, 0), crop=(0, 0)):
     axis = axis % X.ndim
     ka, pa0, pb0, m = _pair_args(*pair0)
     kb, pa1, pb1, m1 = _pair_args(*pair1)
-    if m != m1:
-        raise ValueError('Shapes of the two filter pairs must be the same')
+    if m != m1:             # pairs of different lengths: two single launches
+        return (axis_coldfilt(X, pair0[0], pair0[1], axis=axis, pad=pad, crop=crop),
+                axis_coldfilt(X, pair1[0], pair1[1], axis=axis, pad=pad, crop=crop))
     L = X.shape[axis] + pad[0] + pad[1]
     if L % 4 != 0:
         raise ValueError('No. of rows in X must be a multiple of 4')
@@ -170,10 +171,11 @@ def axis_colifilt_sum2(X0, X1, pair0, pair1, axis=0, crop=(0, 0)):
     axis = axis % X0.ndim
     ka, pa0, pb0, m = _pair_args(*pair0)
     kb, pa1, pb1, m1 = _pair_args(*pair1)
-    if m != m1:
-        raise ValueError('Shapes of the two filter pairs must be the same')
     if X0.shape != X1.shape or X0.dtype != X1.dtype:
         raise ValueError('operands of a fused sum must have equal shape and dtype')
+    if m != m1:             # pairs of different lengths: two single launches
+        Y = axis_colifilt(X0, pair0[0], pair0[1], axis=axis, crop=crop)
+        return axis_colifilt(X1, pair1[0], pair1[1], axis=axis, crop=crop, out=Y, accumulate=True)
     L = X0.shape[axis]
     if L % 2 != 0:
         raise ValueError('No. of rows in X must be a multiple of 2')

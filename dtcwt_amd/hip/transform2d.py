@@ -232,18 +232,21 @@ class Transform2d(object):
         for level in range(max(start_level, 1), nlevels):        # :132-160
             g = lv[level]
             pr, pc = (g['padR'],) * 2, (g['padC'],) * 2
-            Lo = ll.axis_coldfilt(LoLo, h0b, h0a, axis=1, pad=pr)
-            Hi = ll.axis_coldfilt(LoLo, h1b, h1a, axis=1, pad=pr)
-            if bp2:
-                Ba = ll.axis_coldfilt(LoLo, qshift[9], qshift[8], axis=1, pad=pr)
-            LoLo = ll.axis_coldfilt(Lo, h0b, h0a, axis=2, pad=pc)
+            # lo and hi filter of one pass in one launch (dtcwt_hip_coldfilt2)
+            lo, hi = (h0b, h0a), (h1b, h1a)
+            prev = LoLo
+            Lo, Hi = ll.axis_coldfilt2(prev, lo, hi, axis=1, pad=pr)
+            LoLo, LoHi = ll.axis_coldfilt2(Lo, lo, hi, axis=2, pad=pc)
             y = DeviceArray(ctx, (B, LoLo.shape[1] >> 1, LoLo.shape[2] >> 1, 6), cdt)
-            ll.q2c(ll.axis_coldfilt(Hi, h0b, h0a, axis=2, pad=pc), y, 0, 5)
-            ll.q2c(ll.axis_coldfilt(Lo, h1b, h1a, axis=2, pad=pc), y, 2, 3)
+            ll.q2c(LoHi, y, 2, 3)
             if bp2:
+                ll.q2c(ll.axis_coldfilt(Hi, h0b, h0a, axis=2, pad=pc), y, 0, 5)
+                Ba = ll.axis_coldfilt(prev, qshift[9], qshift[8], axis=1, pad=pr)
                 ll.q2c(ll.axis_coldfilt(Ba, qshift[9], qshift[8], axis=2, pad=pc), y, 1, 4)
             else:
-                ll.q2c(ll.axis_coldfilt(Hi, h1b, h1a, axis=2, pad=pc), y, 1, 4)
+                HiLo, HiHi = ll.axis_coldfilt2(Hi, lo, hi, axis=2, pad=pc)
+                ll.q2c(HiLo, y, 0, 5)
+                ll.q2c(HiHi, y, 1, 4)
             Yh.append(y)
             Ys.append(LoLo)
         return LoLo, Yh, (Ys if include_scale else None)
@@ -255,17 +258,18 @@ class Transform2d(object):
         B = Xd.shape[0]
         # level 1 (transform2d.py:112-130); odd sizes extended by index math (:86-94)
         pr, pc = (0, lv[0]['padR']), (0, lv[0]['padC'])
-        Lo = ll.axis_colfilter(Xd, h0o, axis=1, pad=pr)
-        Hi = ll.axis_colfilter(Xd, h1o, axis=1, pad=pr)
-        LoLo = ll.axis_colfilter(Lo, h0o, axis=2, pad=pc)
+        Lo, Hi = ll.axis_colfilter2(Xd, h0o, h1o, axis=1, pad=pr)
+        LoLo, LoHi = ll.axis_colfilter2(Lo, h0o, h1o, axis=2, pad=pc)
         y = DeviceArray(Xd.ctx, (B, LoLo.shape[1] >> 1, LoLo.shape[2] >> 1, 6), cdt)
-        ll.q2c(ll.axis_colfilter(Hi, h0o, axis=2, pad=pc), y, 0, 5)
-        ll.q2c(ll.axis_colfilter(Lo, h1o, axis=2, pad=pc), y, 2, 3)
+        ll.q2c(LoHi, y, 2, 3)
         if bp1:
+            ll.q2c(ll.axis_colfilter(Hi, h0o, axis=2, pad=pc), y, 0, 5)
             Ba = ll.axis_colfilter(Xd, biort[4], axis=1, pad=pr)
             ll.q2c(ll.axis_colfilter(Ba, biort[4], axis=2, pad=pc), y, 1, 4)
         else:
-            ll.q2c(ll.axis_colfilter(Hi, h1o, axis=2, pad=pc), y, 1, 4)
+            HiLo, HiHi = ll.axis_colfilter2(Hi, h0o, h1o, axis=2, pad=pc)
+            ll.q2c(HiLo, y, 0, 5)
+            ll.q2c(HiHi, y, 1, 4)
         Yh.append(y)
         Ys.append(LoLo)
         return LoLo
@@ -387,15 +391,15 @@ class Transform2d(object):
             lh = ll.c2q(w, 0, 5, g[0], g[5])
             hl = ll.c2q(w, 2, 3, g[2], g[3])
             hh = ll.c2q(w, 1, 4, g[1], g[4])
-            y1 = ll.axis_colifilt(Z, g0b, g0a, axis=1, crop=(cr, cr))
-            ll.axis_colifilt(lh, g1b, g1a, axis=1, crop=(cr, cr), out=y1, accumulate=True)
-            y2 = ll.axis_colifilt(hl, g0b, g0a, axis=1, crop=(cr, cr))
+            # filter(lo branch) + filter(hi branch) of one pass in one launch (dtcwt_hip_colifilt_sum2)
+            lo, hi = (g0b, g0a), (g1b, g1a)
+            y1 = ll.axis_colifilt_sum2(Z, lh, lo, hi, axis=1, crop=(cr, cr))
             if bp2:
+                y2 = ll.axis_colifilt(hl, g0b, g0a, axis=1, crop=(cr, cr))
                 y2bp = ll.axis_colifilt(hh, qshift[11], qshift[10], axis=1, crop=(cr, cr))
             else:
-                ll.axis_colifilt(hh, g1b, g1a, axis=1, crop=(cr, cr), out=y2, accumulate=True)
-            Z = ll.axis_colifilt(y1, g0b, g0a, axis=2, crop=(cc, cc))
-            ll.axis_colifilt(y2, g1b, g1a, axis=2, crop=(cc, cc), out=Z, accumulate=True)
+                y2 = ll.axis_colifilt_sum2(hl, hh, lo, hi, axis=1, crop=(cr, cr))
+            Z = ll.axis_colifilt_sum2(y1, y2, lo, hi, axis=2, crop=(cc, cc))
             if bp2:
                 ll.axis_colifilt(y2bp, qshift[11], qshift[10], axis=2, crop=(cc, cc), out=Z, accumulate=True)
             level -= 1
@@ -404,15 +408,13 @@ class Transform2d(object):
             lh = ll.c2q(w, 0, 5, g[0], g[5])
             hl = ll.c2q(w, 2, 3, g[2], g[3])
             hh = ll.c2q(w, 1, 4, g[1], g[4])
-            y1 = ll.axis_colfilter(Z, g0o, axis=1)
-            ll.axis_colfilter(lh, g1o, axis=1, out=y1, accumulate=True)
-            y2 = ll.axis_colfilter(hl, g0o, axis=1)
+            y1 = ll.axis_colfilter_sum2(Z, lh, g0o, g1o, axis=1)
             if bp1:
+                y2 = ll.axis_colfilter(hl, g0o, axis=1)
                 y2bp = ll.axis_colfilter(hh, biort[5], axis=1)
             else:
-                ll.axis_colfilter(hh, g1o, axis=1, out=y2, accumulate=True)
-            Z = ll.axis_colfilter(y1, g0o, axis=2)
-            ll.axis_colfilter(y2, g1o, axis=2, out=Z, accumulate=True)
+                y2 = ll.axis_colfilter_sum2(hl, hh, g0o, g1o, axis=1)
+            Z = ll.axis_colfilter_sum2(y1, y2, g0o, g1o, axis=2)
             if bp1:
                 ll.axis_colfilter(y2bp, biort[5], axis=2, out=Z, accumulate=True)
         return Z
