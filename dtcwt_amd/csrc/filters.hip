@@ -104,6 +104,122 @@ __global__ void __launch_bounds__(256) k_colfilter(const T *__restrict__ X, T *_
     put(g, Yb, lo, acc);
 }
 
+// ---- marching variants ----------------------------------------------------------------
+// When the lanes run along a contiguous inner dimension and the filter axis is strided
+// (the orientation of the public colfilter / coldfilt: "down the columns"), one thread
+// produces G consecutive outputs from a sliding register window: (G + MB - 1) / G loads
+// per output instead of m, every load a coalesced row.  MB is the compile-time tap bucket
+// (taps zero padded to it); the reflection is the branch-free one-bounce form, valid
+// because the launcher only takes this path when the window reach is shorter than the
+// signal (anything else: the one-output-per-thread kernels above).
+__device__ inline int64_t src_index1(const Geo &g, int u) {
+    const int L = (int)g.L;
+    u = u < 0 ? -1 - u : u;
+    u = u >= L ? 2 * L - 1 - u : u;
+    u -= g.pad_lo;
+    const int n1 = (int)g.n - 1;
+    return u < 0 ? 0 : (u > n1 ? n1 : u);
+}
+
+// colfilter: Y[lo] = sum_k h[k] X[rho(lo + c - k)], c = (m-1) - m/2
+template <typename T, int G, int MB>
+__global__ void __launch_bounds__(256) k_colfilter_march(const T *__restrict__ X, T *__restrict__ Y, Geo g,
+                                                         Taps<T> taps, int m) {
+    int64_t o, i, grp;
+    if (!decode(g, o, grp, i)) return;
+    const T *Xb = X + o * g.xso + i * g.xsi;
+    T *Yb = Y + o * g.yso + i * g.ysi;
+    const int lo0 = (int)grp * G + g.crop_lo;
+    const int u0 = lo0 + (m - 1) - (m / 2) - (MB - 1);
+    T w[G + MB - 1];
+#pragma unroll
+    for (int j = 0; j < G + MB - 1; ++j) w[j] = Xb[src_index1(g, u0 + j) * g.xsn];
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+        T acc = 0;
+#pragma unroll
+        for (int k = 0; k < MB; ++k) acc += taps.a[k] * w[q + MB - 1 - k];
+        put(g, Yb, lo0 + q, acc);
+    }
+}
+
+// coldfilt: pair i reads the window starting at 4i - m + 2; taps.a/b hold ha/hb FRONT padded
+// to MB (the launcher shifts them), which keeps the register indices compile-time:
+//   A = sum_k a[2k] w[4q + 2MB-2-4k] + a[2k+1] w[4q + 2MB-4-4k],  B: +1 on both indices
+template <typename T, int GP, int MB>
+__global__ void __launch_bounds__(256) k_coldfilt_march(const T *__restrict__ X, T *__restrict__ Y, Geo g,
+                                                        Taps<T> taps, int m, int a_first) {
+    int64_t o, i, grp;
+    if (!decode(g, o, grp, i)) return;
+    const T *Xb = X + o * g.xso + i * g.xsi;
+    T *Yb = Y + o * g.yso + i * g.ysi;
+    const int i0 = (int)grp * GP;
+    const int u0 = 4 * i0 - m + 2;
+    constexpr int WN = 4 * (GP - 1) + 2 * MB;
+    T w[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) w[j] = Xb[src_index1(g, u0 + j) * g.xsn];
+#pragma unroll
+    for (int q = 0; q < GP; ++q) {
+        T A = 0, B = 0;
+#pragma unroll
+        for (int k = 0; k < MB / 2; ++k) {
+            A += taps.a[2 * k] * w[4 * q + 2 * MB - 2 - 4 * k];
+            A += taps.a[2 * k + 1] * w[4 * q + 2 * MB - 4 - 4 * k];
+            B += taps.b[2 * k] * w[4 * q + 2 * MB - 1 - 4 * k];
+            B += taps.b[2 * k + 1] * w[4 * q + 2 * MB - 3 - 4 * k];
+        }
+        put(g, Yb, 2 * (i0 + q), a_first ? A : B);
+        put(g, Yb, 2 * (i0 + q) + 1, a_first ? B : A);
+    }
+}
+
+// colifilt: input pair j (samples 2j, 2j+1) gives outputs 4j .. 4j+3 from the window starting
+// at 2j + ORG (ORG = 1 - m/2 for odd m/2, -m/2 for even).  Zero padding ha / hb by the same
+// EVEN number of taps on both sides leaves every output unchanged (all indices of the
+// polyphase sums shift together), so m is padded to the bucket MB of its m/2 parity and the
+// register indices stay compile-time.  GJ input pairs per thread.
+template <typename T, int GJ, int MB>
+__global__ void __launch_bounds__(256) k_colifilt_march(const T *__restrict__ X, T *__restrict__ Y, Geo g,
+                                                        Taps<T> taps, int pos) {
+    constexpr int M2 = MB / 2;
+    constexpr bool ODD = (M2 % 2) == 1;
+    constexpr int WN = ODD ? MB : MB + 2;
+    constexpr int ORG = ODD ? 1 - M2 : -M2;
+    int64_t o, i, grp;
+    if (!decode(g, o, grp, i)) return;
+    const T *Xb = X + o * g.xso + i * g.xsi;
+    T *Yb = Y + o * g.yso + i * g.ysi;
+    const int j0 = (int)grp * GJ;
+    T w[WN + 2 * (GJ - 1)];
+#pragma unroll
+    for (int j = 0; j < WN + 2 * (GJ - 1); ++j) w[j] = Xb[src_index1(g, 2 * j0 + ORG + j) * g.xsn];
+#pragma unroll
+    for (int q = 0; q < GJ; ++q) {
+        const T *v = w + 2 * q;
+        T y0 = 0, y1 = 0, y2 = 0, y3 = 0;
+        if (ODD) {
+#pragma unroll
+            for (int k = 0; k < M2; ++k) {
+                const T hi = v[MB - 1 - 2 * k], lo = v[MB - 2 - 2 * k];
+                const T xa = pos ? hi : lo, xb = pos ? lo : hi;
+                y0 += taps.a[2 * k] * xb; y1 += taps.b[2 * k] * xa;
+                y2 += taps.a[2 * k + 1] * xb; y3 += taps.b[2 * k + 1] * xa;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < M2; ++k) {
+                const T t0 = v[MB + 1 - 2 * k], t1 = v[MB - 2 * k], t2 = v[MB - 1 - 2 * k], t3 = v[MB - 2 - 2 * k];
+                const T xa = pos ? t0 : t1, xb = pos ? t1 : t0, xa2 = pos ? t2 : t3, xb2 = pos ? t3 : t2;
+                y0 += taps.a[2 * k + 1] * xb2; y1 += taps.b[2 * k + 1] * xa2;
+                y2 += taps.a[2 * k] * xb; y3 += taps.b[2 * k] * xa;
+            }
+        }
+        put(g, Yb, 4 * (j0 + q), y0); put(g, Yb, 4 * (j0 + q) + 1, y1);
+        put(g, Yb, 4 * (j0 + q) + 2, y2); put(g, Yb, 4 * (j0 + q) + 3, y3);
+    }
+}
+
 // Two undecimated filters of the same length parity applied to the same input in one pass
 // (the 3-D level loops always filter a volume with the lo AND the hi filter,
 // dtcwt/numpy/transform3d.py:256-273): every input sample is loaded once and feeds both.
@@ -421,6 +537,32 @@ void load_taps(Taps<T> &t, const double *a, const double *b, int m) {
 
 inline unsigned blocks_for(int64_t total) { return (unsigned)((total + 255) / 256); }
 
+// The marching kernels: lanes along a contiguous inner dimension of at least a wavefront,
+// 32-bit decode, and a signal longer than the window reach (one-bounce reflection).
+bool march_ok(const Geo &g, int reach) {
+    return g.inner_fast && g.inner >= 64 && g.idx32 && g.L >= reach && g.nwrite >= 16;
+}
+
+// taps FRONT padded to mb entries (k_coldfilt_march)
+template <typename T>
+void load_taps_front(Taps<T> &t, const double *a, const double *b, int m, int mb) {
+    for (int k = 0; k < DTCWT_HIP_MAX_TAPS; ++k) {
+        const int s = k - (mb - m);
+        t.a[k] = (s >= 0 && s < m) ? (T)a[s] : (T)0;
+        t.b[k] = (s >= 0 && s < m) ? (T)b[s] : (T)0;
+    }
+}
+
+// taps padded to mb entries, (mb - m) / 2 zeros on each side (k_colifilt_march)
+template <typename T>
+void load_taps_centred(Taps<T> &t, const double *a, const double *b, int m, int mb) {
+    for (int k = 0; k < DTCWT_HIP_MAX_TAPS; ++k) {
+        const int s = k - (mb - m) / 2;
+        t.a[k] = (s >= 0 && s < m) ? (T)a[s] : (T)0;
+        t.b[k] = (s >= 0 && s < m) ? (T)b[s] : (T)0;
+    }
+}
+
 int64_t nout_colfilter(int64_t L, int m) { return (m & 1) ? L : L + 1; }
 int64_t nout_coldfilt(int64_t L, int) { return L / 2; }
 int64_t nout_colifilt(int64_t L, int) { return 2 * L; }
@@ -450,6 +592,22 @@ int dtcwt_hip_colfilter(dtcwt_hip_ctx *ctx, int dtype, const void *X, void *Y,
     if (total == 0) return 0;
     DT_REQUIRE(total < ((int64_t)1 << 39), "problem too large");
     DT_CHECK_HIP(hipSetDevice(ctx->device));
+    if (march_ok(g, 8 + 20) && m <= 20) {
+        // lanes along the contiguous inner dimension: 8 outputs per thread from a register window
+        g.ngroups = (g.nwrite + 7) / 8;
+        const int64_t tot = g.outer * g.ngroups * g.inner;
+        if (dtype == DTCWT_HIP_F32) {
+            Taps<float> t; load_taps(t, h, nullptr, m);
+            if (m <= 8) k_colfilter_march<float, 8, 8><<<blocks_for(tot), 256, 0, ctx->stream>>>((const float *)X, (float *)Y, g, t, m);
+            else k_colfilter_march<float, 8, 20><<<blocks_for(tot), 256, 0, ctx->stream>>>((const float *)X, (float *)Y, g, t, m);
+        } else {
+            Taps<double> t; load_taps(t, h, nullptr, m);
+            if (m <= 8) k_colfilter_march<double, 8, 8><<<blocks_for(tot), 256, 0, ctx->stream>>>((const double *)X, (double *)Y, g, t, m);
+            else k_colfilter_march<double, 8, 20><<<blocks_for(tot), 256, 0, ctx->stream>>>((const double *)X, (double *)Y, g, t, m);
+        }
+        DT_LAUNCH_CHECK();
+        return 0;
+    }
     if (dtype == DTCWT_HIP_F32) {
         Taps<float> t; load_taps(t, h, nullptr, m);
         k_colfilter<float><<<blocks_for(total), 256, 0, ctx->stream>>>((const float *)X, (float *)Y, g, t, m);
@@ -477,6 +635,23 @@ int dtcwt_hip_coldfilt(dtcwt_hip_ctx *ctx, int dtype, const void *X, void *Y,
     DT_REQUIRE(total < ((int64_t)1 << 39), "problem too large");
     int a_first = dot(ha, hb, m) > 0 ? 1 : 0;
     DT_CHECK_HIP(hipSetDevice(ctx->device));
+    if (march_ok(g, 12 + 40) && m <= 20) {
+        // 4 (A, B) pairs per thread from a register window, taps front padded to the bucket
+        const int mb = m <= 10 ? 10 : 20;
+        g.ngroups = (g.ngroups + 3) / 4;
+        const int64_t tot = g.outer * g.ngroups * g.inner;
+        if (dtype == DTCWT_HIP_F32) {
+            Taps<float> t; load_taps_front(t, ha, hb, m, mb);
+            if (mb == 10) k_coldfilt_march<float, 4, 10><<<blocks_for(tot), 256, 0, ctx->stream>>>((const float *)X, (float *)Y, g, t, m, a_first);
+            else k_coldfilt_march<float, 4, 20><<<blocks_for(tot), 256, 0, ctx->stream>>>((const float *)X, (float *)Y, g, t, m, a_first);
+        } else {
+            Taps<double> t; load_taps_front(t, ha, hb, m, mb);
+            if (mb == 10) k_coldfilt_march<double, 4, 10><<<blocks_for(tot), 256, 0, ctx->stream>>>((const double *)X, (double *)Y, g, t, m, a_first);
+            else k_coldfilt_march<double, 4, 20><<<blocks_for(tot), 256, 0, ctx->stream>>>((const double *)X, (double *)Y, g, t, m, a_first);
+        }
+        DT_LAUNCH_CHECK();
+        return 0;
+    }
     if (dtype == DTCWT_HIP_F32) {
         Taps<float> t; load_taps(t, ha, hb, m);
         k_coldfilt<float><<<blocks_for(total), 256, 0, ctx->stream>>>((const float *)X, (float *)Y, g, t, m, a_first);
@@ -504,6 +679,24 @@ int dtcwt_hip_colifilt(dtcwt_hip_ctx *ctx, int dtype, const void *X, void *Y,
     DT_REQUIRE(total < ((int64_t)1 << 39), "problem too large");
     int pos = dot(ha, hb, m) > 0 ? 1 : 0;
     DT_CHECK_HIP(hipSetDevice(ctx->device));
+    // bucket of the same m/2 parity (zero padding must be even per side): 10 / 18 odd, 8 / 16 even
+    const int mb = ((m / 2) & 1) ? (m <= 10 ? 10 : (m <= 18 ? 18 : 0)) : (m <= 8 ? 8 : (m <= 16 ? 16 : 0));
+    if (mb && march_ok(g, mb + 4)) {
+        g.ngroups = (g.ngroups + 1) / 2;            // two input pairs (eight outputs) per thread
+        const int64_t tot = g.outer * g.ngroups * g.inner;
+#define DT_IFILT_MARCH(T_)                                                                              \
+        do {                                                                                            \
+            Taps<T_> t; load_taps_centred(t, ha, hb, m, mb);                                            \
+            if (mb == 10) k_colifilt_march<T_, 2, 10><<<blocks_for(tot), 256, 0, ctx->stream>>>((const T_ *)X, (T_ *)Y, g, t, pos); \
+            else if (mb == 18) k_colifilt_march<T_, 2, 18><<<blocks_for(tot), 256, 0, ctx->stream>>>((const T_ *)X, (T_ *)Y, g, t, pos); \
+            else if (mb == 8) k_colifilt_march<T_, 2, 8><<<blocks_for(tot), 256, 0, ctx->stream>>>((const T_ *)X, (T_ *)Y, g, t, pos); \
+            else k_colifilt_march<T_, 2, 16><<<blocks_for(tot), 256, 0, ctx->stream>>>((const T_ *)X, (T_ *)Y, g, t, pos); \
+        } while (0)
+        if (dtype == DTCWT_HIP_F32) DT_IFILT_MARCH(float); else DT_IFILT_MARCH(double);
+#undef DT_IFILT_MARCH
+        DT_LAUNCH_CHECK();
+        return 0;
+    }
     if (dtype == DTCWT_HIP_F32) {
         Taps<float> t; load_taps(t, ha, hb, m);
         k_colifilt<float><<<blocks_for(total), 256, 0, ctx->stream>>>((const float *)X, (float *)Y, g, t, m, pos);

@@ -125,3 +125,24 @@ def test_device_array_in_device_array_out():
     y = colfilter(d, biort('near_sym_a')[0])
     assert isinstance(y, DeviceArray)
     assert_close(y.get(), o.colfilter(m, biort('near_sym_a')[0]), LOW_TOL)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rows', [24, 40, 132, 256])
+def test_marching_kernels_all_tap_buckets(rows):
+    """The register-window variants (lanes along a contiguous inner dimension of >= 64, window
+    reach shorter than the signal) and the fall-back to one output per thread, for every tap
+    bucket and for lengths outside them, float32 and float64."""
+    rs = np.random.RandomState(rows)
+    for dt, tol in ((np.float32, LOW_TOL), (np.float64, F64_TOL)):
+        X = rs.standard_normal((rows, 192)).astype(dt)
+        for m in (1, 3, 5, 7, 8, 9, 13, 19, 20, 21, 32):
+            h = rs.standard_normal(m)
+            assert_close(colfilter(X, h), o.colfilter(X, h), tol, 'colfilter m=%d' % m)
+        for m in (2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 32):
+            ha, hb = rs.standard_normal(m), rs.standard_normal(m)
+            if rows % 4 == 0:
+                assert_close(coldfilt(X, ha, hb), o.coldfilt(X, ha, hb), tol, 'coldfilt m=%d' % m)
+                assert_close(coldfilt(X, ha, -hb), o.coldfilt(X, ha, -hb), tol, 'coldfilt m=%d flipped' % m)
+            assert_close(colifilt(X, ha, hb), o.colifilt(X, ha, hb), tol, 'colifilt m=%d' % m)
+            assert_close(colifilt(X, ha, -hb), o.colifilt(X, ha, -hb), tol, 'colifilt m=%d flipped' % m)
