@@ -27,13 +27,13 @@ __global__ void __launch_bounds__(DT_NT) k_fwd1(Fwd1Params p) {
     int t = tile_of(blockIdx.x, ntile, p.xcd_order);
     if (t >= ntile) return;
     int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
-    float *sLo = smem, *sHi = sLo + C::SL, *stage = sHi + C::SL;
+    float *sLo = smem, *sHi = sLo + C::SL, *sBa = sHi + C::SL, *stage = smem + C::LDS_FLOATS;
     int r0 = tr * C::TR, c0 = tc * C::TC;
-    fwd1d_cols<C>(p, sLo, sHi, threadIdx.x, b, r0, c0);
+    fwd1d_cols<C>(p, sLo, sHi, threadIdx.x, b, r0, c0, sBa);
     __syncthreads();
     constexpr int NQ = (C::TR / 2) * (C::TC / 2);
     for (int base = 0; base < NQ; base += DT_NT) {
-        fwd1s_rows_compute<C>(p, sLo, sHi, stage, threadIdx.x, base, b, r0, c0);
+        fwd1s_rows_compute<C>(p, sLo, sHi, stage, threadIdx.x, base, b, r0, c0, sBa);
         fwd1s_rows_flush<C>(p, stage, threadIdx.x, base, b, r0, c0);
     }
 }
@@ -46,12 +46,12 @@ __global__ void __launch_bounds__(DT_NT) k_fwd2(Fwd2Params p) {
     int t = tile_of(blockIdx.x, ntile, p.xcd_order);
     if (t >= ntile) return;
     int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
-    float *sLo = smem, *sHi = sLo + C::SL, *stage = sHi + C::SL;
+    float *sLo = smem, *sHi = sLo + C::SL, *sBa = sHi + C::SL, *stage = smem + C::LDS_FLOATS;
     int r0 = tr * C::TR, c0 = tc * C::TC;
-    fwd2d_cols<C>(p, sLo, sHi, threadIdx.x, b, r0, c0);
+    fwd2d_cols<C>(p, sLo, sHi, threadIdx.x, b, r0, c0, sBa);
     __syncthreads();
     for (int base = 0; base < C::TI * C::TJ; base += DT_NT) {
-        fwd2s_rows_compute<C>(p, sLo, sHi, stage, threadIdx.x, base, b, r0, c0);
+        fwd2s_rows_compute<C>(p, sLo, sHi, stage, threadIdx.x, base, b, r0, c0, sBa);
         fwd2s_rows_flush<C>(p, stage, threadIdx.x, base, b, r0, c0);
     }
 }
@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(DT_NT) k_inv1(Inv1Params p) {
     int t = tile_of(blockIdx.x, ntile, p.xcd_order);
     if (t >= ntile) return;
     int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
-    float *srec = smem, *y1 = smem, *y2 = y1 + C::SY;
+    float *srec = smem, *y1 = smem, *y2 = y1 + C::SY, *y3 = y2 + C::SY;     // y3: band-pass variant only
     int r0 = tr * C::TR, c0 = tc * C::TC;
     const float *Yhb = p.Yh + (int64_t)b * (p.R / 2) * (p.C / 2) * 12;
     float wz[C::WN], w1[C::WN], w2[C::WN], w3[C::WN];
@@ -76,9 +76,9 @@ __global__ void __launch_bounds__(DT_NT) k_inv1(Inv1Params p) {
     __syncthreads();
     inv1r_gather<C>(p, srec, w1, w2, w3, threadIdx.x, r0, c0);
     __syncthreads();
-    inv1r_fir<C>(p, wz, w1, w2, w3, y1, y2, threadIdx.x);
+    inv1r_fir<C>(p, wz, w1, w2, w3, y1, y2, threadIdx.x, y3);
     __syncthreads();
-    inv1d_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0);
+    inv1d_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0, y3);
 }
 
 // Level >= 2 inverse: same structure with the polyphase interpolating filters.
@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(DT_NT) k_inv2(Inv2Params p) {
     int t = tile_of(blockIdx.x, ntile, p.xcd_order);
     if (t >= ntile) return;
     int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
-    float *srec = smem, *y1 = smem, *y2 = y1 + C::SY;
+    float *srec = smem, *y1 = smem, *y2 = y1 + C::SY, *y3 = y2 + C::SY;     // y3: band-pass variant only
     int r0 = tr * C::TR, c0 = tc * C::TC;
     const float *Yhb = p.Yh + (int64_t)b * (p.zr / 2) * (p.zc / 2) * 12;
     float wz[C::WS], w1[C::WS], w2[C::WS], w3[C::WS];
@@ -98,9 +98,9 @@ __global__ void __launch_bounds__(DT_NT) k_inv2(Inv2Params p) {
     __syncthreads();
     inv2r_gather<C>(p, srec, w1, w2, w3, threadIdx.x, r0, c0);
     __syncthreads();
-    inv2r_fir<C>(p, wz, w1, w2, w3, y1, y2, threadIdx.x);
+    inv2r_fir<C>(p, wz, w1, w2, w3, y1, y2, threadIdx.x, y3);
     __syncthreads();
-    inv2_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0);
+    inv2_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0, y3);
 }
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -138,16 +138,34 @@ int launch_inv2(Inv2Params &p, hipStream_t s) {
 #define DT_CASE_INV1(TR, TC, RS, A, B) if (m0 == A && m1 == B) return launch_inv1<Inv1RCfg<TR, TC, RS, A, B>>(p, s);
 #define DT_CASE_FWD2(TR, TC, PS, M) if (m == M) return launch_fwd2<Fwd2DCfg<TR, TC, PS, M>>(p, s);
 #define DT_CASE_INV2(TR, TC, JS, M) if (m == M) return launch_inv2<Inv2RCfg<TR, TC, JS, M>>(p, s);
-int dispatch_fwd1(int m0, int m1, Fwd1Params &p, hipStream_t s) { DT_FWD1_TABLE(DT_CASE_FWD1) return -3; }
-int dispatch_inv1(int m0, int m1, Inv1Params &p, hipStream_t s) { DT_INV1_TABLE(DT_CASE_INV1) return -3; }
-int dispatch_fwd2(int m, Fwd2Params &p, hipStream_t s, bool small) {
+#define DT_CASE_FWD1_BP(TR, TC, RS, A, B, C2) if (m0 == A && m1 == B && m2 == C2) return launch_fwd1<Fwd1DCfg<TR, TC, RS, A, B, C2>>(p, s);
+#define DT_CASE_INV1_BP(TR, TC, RS, A, B, C2) if (m0 == A && m1 == B && m2 == C2) return launch_inv1<Inv1RCfg<TR, TC, RS, A, B, C2>>(p, s);
+#define DT_CASE_FWD2_BP(TR, TC, PS, M) if (m == M) return launch_fwd2<Fwd2DCfg<TR, TC, PS, M, true>>(p, s);
+#define DT_CASE_INV2_BP(TR, TC, JS, M) if (m == M) return launch_inv2<Inv2RCfg<TR, TC, JS, M, true>>(p, s);
+// m2 / bp: length of the band-pass filter of a 6-vector biort set / a 12-vector q-shift set (0 / false: none)
+int dispatch_fwd1(int m0, int m1, int m2, Fwd1Params &p, hipStream_t s) {
+    if (m2) { DT_FWD1_BP_TABLE(DT_CASE_FWD1_BP) return -3; }
+    DT_FWD1_TABLE(DT_CASE_FWD1) return -3;
+}
+int dispatch_inv1(int m0, int m1, int m2, Inv1Params &p, hipStream_t s) {
+    if (m2) { DT_INV1_BP_TABLE(DT_CASE_INV1_BP) return -3; }
+    DT_INV1_TABLE(DT_CASE_INV1) return -3;
+}
+int dispatch_fwd2(int m, bool bp, Fwd2Params &p, hipStream_t s, bool small) {
+    if (bp) { DT_FWD2_BP_TABLE(DT_CASE_FWD2_BP) return -3; }
     if (small) { DT_FWD2_SMALL_TABLE(DT_CASE_FWD2) }
     DT_FWD2_TABLE(DT_CASE_FWD2) return -3;
 }
-int dispatch_inv2(int m, Inv2Params &p, hipStream_t s, bool small) {
+int dispatch_inv2(int m, bool bp, Inv2Params &p, hipStream_t s, bool small) {
+    if (bp) { DT_INV2_BP_TABLE(DT_CASE_INV2_BP) return -3; }
     if (small) { DT_INV2_SMALL_TABLE(DT_CASE_INV2) }
     DT_INV2_TABLE(DT_CASE_INV2) return -3;
 }
+#define DT_HAS3(TR, TC, RS, A, B, C2) if (m0 == A && m1 == B && m2 == C2) return true;
+bool fwd1_bp_supported(int m0, int m1, int m2) { DT_FWD1_BP_TABLE(DT_HAS3) return false; }
+bool inv1_bp_supported(int m0, int m1, int m2) { DT_INV1_BP_TABLE(DT_HAS3) return false; }
+#define DT_HAS1B(TR, TC, JS, M) if (m == M) return true;
+bool q_bp_supported(int m) { DT_INV2_BP_TABLE(DT_HAS1B) return false; }
 
 #define DT_HAS2(TR, TC, A, B) if (m0 == A && m1 == B) return true;
 #define DT_HAS2F(TR, TC, RS, A, B) if (m0 == A && m1 == B) return true;
@@ -182,6 +200,8 @@ struct dtcwt_hip_plan2d {
     std::vector<Level> lv;
     std::vector<double> biort[4];     // h0o g0o h1o g1o
     std::vector<double> qshift[8];    // h0a h0b g0a g0b h1a h1b g1a g1b
+    std::vector<double> bp1[2];       // h2o g2o   (band-pass biort, dtcwt_hip_plan2d_set_bandpass)
+    std::vector<double> bp2[4];       // h2a h2b g2a g2b
     std::vector<float *> work;        // LoLo / Z per level (level nlevels-1 unused on fwd)
     bool profiling = false;           // record an event pair around every level kernel
     std::vector<hipEvent_t> ev;       // [fwd: 2 per level][inv: 2 per level]
@@ -257,6 +277,29 @@ int dtcwt_hip_plan2d_destroy(dtcwt_hip_plan2d *p) {
     return 0;
 }
 
+int dtcwt_hip_plan2d_set_bandpass(dtcwt_hip_plan2d *p, const double *h2o, const double *g2o, int m_biort,
+                                  const double *h2a, const double *h2b, const double *g2a, const double *g2b,
+                                  int m_qshift) {
+    DT_REQUIRE(p, "NULL plan");
+    const bool b1 = m_biort > 0, b2 = m_qshift > 0;
+    DT_REQUIRE(!b1 || (h2o && g2o && m_biort <= DT_MAXT), "band-pass biort pair missing or too long");
+    DT_REQUIRE(!b2 || (h2a && h2b && g2a && g2b && m_qshift <= DT_MAXT), "band-pass q-shift vectors missing or too long");
+    if (b1 && (!fwd1_bp_supported((int)p->biort[0].size(), (int)p->biort[2].size(), m_biort) ||
+               !inv1_bp_supported((int)p->biort[1].size(), (int)p->biort[3].size(), m_biort)))
+        return dtcwt_set_error(-3, "no fused band-pass level-1 kernel for biort lengths (%d,%d,%d)",
+                               (int)p->biort[0].size(), (int)p->biort[2].size(), m_biort);
+    if (b2 && p->nlevels >= 2 && (m_qshift != (int)p->qshift[0].size() || !q_bp_supported(m_qshift)))
+        return dtcwt_set_error(-3, "no fused band-pass level >= 2 kernel for %d-tap q-shift filters", m_qshift);
+    for (auto &v : p->bp1) v.clear();
+    for (auto &v : p->bp2) v.clear();
+    if (b1) { p->bp1[0].assign(h2o, h2o + m_biort); p->bp1[1].assign(g2o, g2o + m_biort); }
+    if (b2) {
+        p->bp2[0].assign(h2a, h2a + m_qshift); p->bp2[1].assign(h2b, h2b + m_qshift);
+        p->bp2[2].assign(g2a, g2a + m_qshift); p->bp2[3].assign(g2b, g2b + m_qshift);
+    }
+    return 0;
+}
+
 int dtcwt_hip_plan2d_set_profiling(dtcwt_hip_plan2d *p, int enable) {
     DT_REQUIRE(p, "NULL plan");
     if (enable && p->ev.empty()) {
@@ -308,8 +351,8 @@ int dtcwt_hip_plan2d_forward(dtcwt_hip_plan2d *p, const float *X, float *Yl, voi
             q.X = in; q.LoLo = lo; q.Yh = (float *)Yh[l];
             q.B = p->batch; q.inR = L.inR; q.inC = L.inC; q.LR = L.LR; q.LC = L.LC;
             q.xcd_order = p->xcd_order < 0 ? 0 : p->xcd_order;      // write-heavy: linear order
-            put_taps(q.h0, p->biort[0]); put_taps(q.h1, p->biort[2]);
-            rc = dispatch_fwd1((int)p->biort[0].size(), (int)p->biort[2].size(), q, s);
+            put_taps(q.h0, p->biort[0]); put_taps(q.h1, p->biort[2]); put_taps(q.h2, p->bp1[0]);
+            rc = dispatch_fwd1((int)p->biort[0].size(), (int)p->biort[2].size(), (int)p->bp1[0].size(), q, s);
         } else {
             Fwd2Params q{};
             q.X = in; q.LoLo = lo; q.Yh = (float *)Yh[l];
@@ -320,10 +363,15 @@ int dtcwt_hip_plan2d_forward(dtcwt_hip_plan2d *p, const float *X, float *Yl, voi
             put_taps(q.h_a, p->qshift[5]); put_taps(q.h_b, p->qshift[4]);
             q.lo_a_first = dotd(p->qshift[1], p->qshift[0]) > 0;
             q.hi_a_first = dotd(p->qshift[5], p->qshift[4]) > 0;
+            const bool bp = !p->bp2[0].empty();     // coldfilt(X, h2b, h2a) for the diagonal subbands
+            if (bp) {
+                put_taps(q.b_a, p->bp2[1]); put_taps(q.b_b, p->bp2[0]);
+                q.bp_a_first = dotd(p->bp2[1], p->bp2[0]) > 0;
+            }
             // default tile 16 x ~56: use the small shape when that gives too few workgroups
             bool small = p->small_tiles >= 0 ? p->small_tiles != 0
                                              : (int64_t)cdiv(L.loR, 16) * cdiv(L.loC, 56) * p->batch < DT_SMALL_TILE_THRESHOLD;
-            rc = dispatch_fwd2((int)p->qshift[0].size(), q, s, small);
+            rc = dispatch_fwd2((int)p->qshift[0].size(), bp, q, s, small);
         }
         if (rc) return dtcwt_set_error(rc, "no fused forward kernel at level %d", l);
         DT_CHECK_HIP(hipGetLastError());
@@ -358,8 +406,8 @@ int dtcwt_hip_plan2d_inverse(dtcwt_hip_plan2d *p, const float *Yl, const void *c
             q.Z = in; q.Yh = (const float *)Yh[0]; q.X = Z;
             q.B = p->batch; q.R = L.LR; q.C = L.LC; q.xcd_order = p->xcd_order < 0 ? 1 : p->xcd_order;
             for (int d = 0; d < 6; ++d) q.g[d] = g[d];
-            put_taps(q.g0, p->biort[1]); put_taps(q.g1, p->biort[3]);
-            rc = dispatch_inv1((int)p->biort[1].size(), (int)p->biort[3].size(), q, s);
+            put_taps(q.g0, p->biort[1]); put_taps(q.g1, p->biort[3]); put_taps(q.g2, p->bp1[1]);
+            rc = dispatch_inv1((int)p->biort[1].size(), (int)p->biort[3].size(), (int)p->bp1[1].size(), q, s);
         } else {
             Inv2Params q{};
             float *out = p->work[l - 1];          // size of LoLo_{l-1} = this level's input
@@ -372,9 +420,14 @@ int dtcwt_hip_plan2d_inverse(dtcwt_hip_plan2d *p, const float *Yl, const void *c
             put_taps(q.h_a, p->qshift[7]); put_taps(q.h_b, p->qshift[6]);
             q.lo_pos = dotd(p->qshift[3], p->qshift[2]) > 0;
             q.hi_pos = dotd(p->qshift[7], p->qshift[6]) > 0;
+            const bool bp = !p->bp2[2].empty();     // colifilt(., g2b, g2a) on the diagonal plane
+            if (bp) {
+                put_taps(q.b_a, p->bp2[3]); put_taps(q.b_b, p->bp2[2]);
+                q.bp_pos = dotd(p->bp2[3], p->bp2[2]) > 0;
+            }
             bool small = p->small_tiles >= 0 ? p->small_tiles != 0
                                              : (int64_t)cdiv(L.loR, 16) * cdiv(L.loC, 56) * p->batch < DT_SMALL_TILE_THRESHOLD;
-            rc = dispatch_inv2((int)p->qshift[0].size(), q, s, small);
+            rc = dispatch_inv2((int)p->qshift[0].size(), bp, q, s, small);
             in = out;
         }
         if (rc) return dtcwt_set_error(rc, "no fused inverse kernel at level %d", l);

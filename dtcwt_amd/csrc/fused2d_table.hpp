@@ -35,6 +35,18 @@
     X(16, 48, 2, 18) \
     X(16, 32, 2, 32)
 
+/* Band-pass variants (6-vector biort / 12-vector q-shift sets: a third filter for the diagonal
+ * subbands, dtcwt/numpy/transform2d.py:116-129, :145-155, :250-271, :283-291).
+ * level 1: X(tile rows, tile cols, strip, len lo, len hi, len band-pass) */
+#define DT_FWD1_BP_TABLE(X) \
+    X(32, 64, 8, 13, 19, 19)     /* near_sym_b_bp: h0o h1o h2o */
+#define DT_INV1_BP_TABLE(X) \
+    X(16, 108, 8, 19, 13, 19)    /* near_sym_b_bp: g0o g1o g2o */
+#define DT_FWD2_BP_TABLE(X) \
+    X(16, 52, 4, 14)             /* qshift_b_bp */
+#define DT_INV2_BP_TABLE(X) \
+    X(16, 52, 2, 14)
+
 /* Smaller tiles for coarse levels (more workgroups).  Measured on MI355X (4096^2, levels 3-4):
  * no gain -- those launches sit at a ~6-9 us floor either way -- so they are only used when
  * forced with DTCWT_HIP_SMALL_TILES=1 (threshold 0 = never automatically). */

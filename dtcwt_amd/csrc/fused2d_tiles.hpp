@@ -63,6 +63,7 @@ struct Fwd1Params {
     int tilesR, tilesC;
     int xcd_order;        // 1: XCD-contiguous tile runs, 0: linear order
     float h0[DT_MAXT], h1[DT_MAXT];
+    float h2[DT_MAXT];    // band-pass biort (6-vector sets): the diagonal subbands (transform2d.py:116-129)
 };
 
 // q2c of quad (a b / c d): z0 = s((a-d) + j(b+c)), z1 = s((a+d) + j(b-c))   (A.4)
@@ -103,6 +104,9 @@ struct Fwd2Params {
     // coldfilt(X, ha, hb) is called as (h0b, h0a) and (h1b, h1a): "a" arrays hold the
     // first argument, "b" the second.
     float l_a[DT_MAXT], l_b[DT_MAXT], h_a[DT_MAXT], h_b[DT_MAXT];
+    // band-pass q-shift (12-vector sets): coldfilt(X, h2b, h2a) for the diagonal subbands (:145-155)
+    int bp_a_first;
+    float b_a[DT_MAXT], b_b[DT_MAXT];
 };
 
 // One (A, B) pair from a 2M window w[0..2M) whose element j is logical sample
@@ -135,6 +139,7 @@ struct Inv1Params {
     int xcd_order;        // 1: XCD-contiguous tile runs, 0: linear order
     float g[6];           // gain_mask column * sqrt(1/2)
     float g0[DT_MAXT], g1[DT_MAXT];
+    float g2[DT_MAXT];    // band-pass biort: y2bp = colfilter(hh, g2), third row filter (:283-291)
 };
 
 // ======================================================================================
@@ -156,6 +161,9 @@ struct Inv2Params {
     float g[6];
     // colifilt(X, ha, hb) is called as (g0b, g0a) and (g1b, g1a)
     float l_a[DT_MAXT], l_b[DT_MAXT], h_a[DT_MAXT], h_b[DT_MAXT];
+    // band-pass q-shift: colifilt(., g2b, g2a) on the diagonal plane and as third row filter (:250-271)
+    int bp_pos;
+    float b_a[DT_MAXT], b_b[DT_MAXT];
 };
 
 // Four output phases 4j..4j+3 from window w (element j' = sample 2j + ORG + j')   (A.3)
@@ -194,7 +202,7 @@ DT_HD void ifilt4(const float *w, const float *ha, const float *hb, int pos, flo
 
 template <class C>
 DT_HD void inv2_rows(const Inv2Params &p, const float *y1, const float *y2, int tid, int b,
-                     int r0, int c0) {
+                     int r0, int c0, const float *y3 = nullptr) {
     constexpr int NJ = C::TC / 2;
     const int OR = 2 * p.zr - 2 * p.cropR, OC = 2 * p.zc - 2 * p.cropC;
     for (int task = tid; task < 2 * C::TR * NJ; task += DT_NT) {
@@ -214,6 +222,14 @@ DT_HD void inv2_rows(const Inv2Params &p, const float *y1, const float *y2, int 
 #pragma unroll
         for (int j = 0; j < C::WN / 2; ++j) { f2 v = pb[j]; w[2 * j] = v.x; w[2 * j + 1] = v.y; }
         ifilt4<C>(w, p.h_a, p.h_b, p.hi_pos, t);
+        if (C::BP) {            // third row filter on the band-pass plane
+            const f2 *pc = reinterpret_cast<const f2 *>(y3 + r * C::NC + 2 * jl);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += t[e];
+#pragma unroll
+            for (int j = 0; j < C::WN / 2; ++j) { f2 v = pc[j]; w[2 * j] = v.x; w[2 * j + 1] = v.y; }
+            ifilt4<C>(w, p.b_a, p.b_b, p.bp_pos, t);
+        }
         float *O = p.Out + ((int64_t)b * OR + Rw) * OC;
         if (p.cropC == 0 && (OC & 3) == 0) {
             *reinterpret_cast<f4 *>(O + Cl) = f4{a[0] + t[0], a[1] + t[1], a[2] + t[2], a[3] + t[3]};

@@ -15,22 +15,27 @@ namespace dt2d {
 // ======================================================================================
 // Level 1 forward, direct column pass.
 // ======================================================================================
-template <int TR_, int TC_, int RS_, int M0_, int M1_>
+// M2_ > 0: band-pass variant (6-vector biort): a third plane Ba = colfilter(X, h2) feeds the
+// diagonal subbands through h2 along the rows as well (transform2d.py:116-129).
+template <int TR_, int TC_, int RS_, int M0_, int M1_, int M2_ = 0>
 struct Fwd1DCfg {
-    static constexpr int TR = TR_, TC = TC_, RS = RS_, M0 = M0_, M1 = M1_;
-    static constexpr int H0 = M0 / 2, H1 = M1 / 2, HH = cmax(H0, H1);
+    static constexpr int TR = TR_, TC = TC_, RS = RS_, M0 = M0_, M1 = M1_, M2 = M2_;
+    static constexpr bool BP = M2 > 0;
+    static constexpr int H0 = M0 / 2, H1 = M1 / 2, H2 = M2 / 2, HH = cmax(cmax(H0, H1), H2);
     static constexpr int HC = (HH + 1) & ~1;
     static constexpr int W = TC + 2 * HC;
     static constexpr int NS = TR / RS;
     static constexpr int WN = RS + 2 * HH;            // register window per task
     static constexpr int SL = TR * W;
-    static constexpr int LDS_FLOATS = 2 * SL;
+    static constexpr int LDS_FLOATS = (BP ? 3 : 2) * SL;
     static_assert(TR % RS == 0 && TR % 2 == 0 && TC % 2 == 0, "tile shape");
-    static_assert(M0 % 2 == 1 && M1 % 2 == 1, "biort filters must have odd length");
+    static_assert(M0 % 2 == 1 && M1 % 2 == 1 && (!BP || M2 % 2 == 1), "biort filters must have odd length");
 };
 
+// sBa: third LDS plane of the band-pass variant (ignored otherwise)
 template <class C>
-DT_HD void fwd1d_cols(const Fwd1Params &p, float *sLo, float *sHi, int tid, int b, int r0, int c0) {
+DT_HD void fwd1d_cols(const Fwd1Params &p, float *sLo, float *sHi, int tid, int b, int r0, int c0,
+                      float *sBa = nullptr) {
     const float *Xb = p.X + (int64_t)b * p.inR * p.inC;
     const int ro = r0 - C::HH, co = c0 - C::HC;
     const bool interior = ro >= 0 && ro + C::TR + 2 * C::HH <= p.inR && co >= 0 && co + C::W <= p.inC;
@@ -58,6 +63,12 @@ DT_HD void fwd1d_cols(const Fwd1Params &p, float *sLo, float *sHi, int tid, int 
             for (int k = 0; k < C::M1; ++k) hi += p.h1[k] * w[q + C::HH + C::H1 - k];
             sLo[(strip * C::RS + q) * C::W + cc] = lo;
             sHi[(strip * C::RS + q) * C::W + cc] = hi;
+            if (C::BP) {
+                float ba = 0.f;
+#pragma unroll
+                for (int k = 0; k < C::M2; ++k) ba += p.h2[k] * w[q + C::HH + C::H2 - k];
+                sBa[(strip * C::RS + q) * C::W + cc] = ba;
+            }
         }
     }
 }
@@ -74,7 +85,7 @@ constexpr int STAGE_FLOATS_PER_WAVE = 64 * 12;
 
 template <class C>
 DT_HD void fwd1s_rows_compute(const Fwd1Params &p, const float *sLo, const float *sHi, float *stage,
-                              int tid, int base, int b, int r0, int c0) {
+                              int tid, int base, int b, int r0, int c0, const float *sBa = nullptr) {
     constexpr int NV = C::TC / 2, NU = C::TR / 2;
     constexpr int WL = 2 * C::HC + 2;
     const int lane = tid & 63, wave = tid >> 6;
@@ -106,9 +117,22 @@ DT_HD void fwd1s_rows_compute(const Fwd1Params &p, const float *sLo, const float
 #pragma unroll
             for (int k = 0; k < C::M1; ++k) {
                 s_lh += p.h1[k] * wl[ec + C::HC + C::H1 - k];
-                s_hh += p.h1[k] * wh[ec + C::HC + C::H1 - k];
+                if (!C::BP) s_hh += p.h1[k] * wh[ec + C::HC + C::H1 - k];
             }
             ll[er][ec] = s_ll; hl[er][ec] = s_hl; lh[er][ec] = s_lh; hh[er][ec] = s_hh;
+        }
+        if (C::BP) {            // diagonal subbands: Ba rows through h2
+            float wb[WL];
+            const f2 *pb = reinterpret_cast<const f2 *>(sBa + (2 * u + er) * C::W + 2 * v);
+#pragma unroll
+            for (int j = 0; j < WL / 2; ++j) { f2 a = pb[j]; wb[2 * j] = a.x; wb[2 * j + 1] = a.y; }
+#pragma unroll
+            for (int ec = 0; ec < 2; ++ec) {
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < C::M2; ++k) s += p.h2[k] * wb[ec + C::HC + C::H2 - k];
+                hh[er][ec] = s;
+            }
         }
     }
     float *L = p.LoLo + ((int64_t)b * p.LR + R) * p.LC + Cc;
@@ -141,20 +165,24 @@ DT_HD void fwd1s_rows_flush(const Fwd1Params &p, const float *stage, int tid, in
 // ======================================================================================
 // Level >= 2 forward, direct column pass + staged record stores.
 // ======================================================================================
-template <int TR_, int TC_, int PS_, int M_>
+// BP_: band-pass variant (12-vector q-shift): third plane Ba = coldfilt(X, h2b, h2a) for the
+// diagonal subbands (transform2d.py:145-155)
+template <int TR_, int TC_, int PS_, int M_, bool BP_ = false>
 struct Fwd2DCfg {
+    static constexpr bool BP = BP_;
     static constexpr int TR = TR_, TC = TC_, PS = PS_, M = M_;     // TR x TC outputs of LoLo'
     static constexpr int TI = TR / 2, TJ = TC / 2;                 // (A,B) pairs per axis
     static constexpr int NS = TI / PS;                             // strips of PS pairs
     static constexpr int WN = 4 * PS + 2 * M - 4;                  // register window per task
     static constexpr int NCI = 2 * TC + 2 * M - 4;                 // input window cols (% 4 == 0)
     static constexpr int SL = TR * NCI;
-    static constexpr int LDS_FLOATS = 2 * SL;
+    static constexpr int LDS_FLOATS = (BP ? 3 : 2) * SL;
     static_assert(M % 2 == 0 && TR % 2 == 0 && TC % 2 == 0 && TI % PS == 0, "even taps / tile");
 };
 
 template <class C>
-DT_HD void fwd2d_cols(const Fwd2Params &p, float *sLo, float *sHi, int tid, int b, int r0, int c0) {
+DT_HD void fwd2d_cols(const Fwd2Params &p, float *sLo, float *sHi, int tid, int b, int r0, int c0,
+                      float *sBa = nullptr) {
     const float *Xb = p.X + (int64_t)b * p.inR * p.inC;
     const int ro = 2 * r0 - C::M + 2, co = 2 * c0 - C::M + 2;      // logical origin of the window
     const int NRI = 2 * C::TR + 2 * C::M - 4;
@@ -186,13 +214,18 @@ DT_HD void fwd2d_cols(const Fwd2Params &p, float *sLo, float *sHi, int tid, int 
             dfilt_pair<C::M>(w + 4 * q, p.h_a, p.h_b, A, Bv);
             sHi[row * C::NCI + cc] = p.hi_a_first ? A : Bv;
             sHi[(row + 1) * C::NCI + cc] = p.hi_a_first ? Bv : A;
+            if (C::BP) {
+                dfilt_pair<C::M>(w + 4 * q, p.b_a, p.b_b, A, Bv);
+                sBa[row * C::NCI + cc] = p.bp_a_first ? A : Bv;
+                sBa[(row + 1) * C::NCI + cc] = p.bp_a_first ? Bv : A;
+            }
         }
     }
 }
 
 template <class C>
 DT_HD void fwd2s_rows_compute(const Fwd2Params &p, const float *sLo, const float *sHi, float *stage,
-                              int tid, int base, int b, int r0, int c0) {
+                              int tid, int base, int b, int r0, int c0, const float *sBa = nullptr) {
     const int OR = p.LR / 2, OC = p.LC / 2;
     const int lane = tid & 63, wave = tid >> 6;
     float *slab = stage + wave * STAGE_FLOATS_PER_WAVE + lane * 12;
@@ -219,8 +252,19 @@ DT_HD void fwd2s_rows_compute(const Fwd2Params &p, const float *sLo, const float
         hl[er][0] = p.lo_a_first ? A : Bv; hl[er][1] = p.lo_a_first ? Bv : A;
         dfilt_pair<C::M>(wl, p.h_a, p.h_b, A, Bv);
         lh[er][0] = p.hi_a_first ? A : Bv; lh[er][1] = p.hi_a_first ? Bv : A;
-        dfilt_pair<C::M>(wh, p.h_a, p.h_b, A, Bv);
-        hh[er][0] = p.hi_a_first ? A : Bv; hh[er][1] = p.hi_a_first ? Bv : A;
+        if (C::BP) {            // diagonal subbands: Ba rows through the band-pass pair
+            const f4 *pb = reinterpret_cast<const f4 *>(sBa + (2 * il + er) * C::NCI + 4 * jl);
+#pragma unroll
+            for (int j = 0; j < C::M / 2; ++j) {
+                f4 a = pb[j];
+                wh[4 * j] = a.x; wh[4 * j + 1] = a.y; wh[4 * j + 2] = a.z; wh[4 * j + 3] = a.w;
+            }
+            dfilt_pair<C::M>(wh, p.b_a, p.b_b, A, Bv);
+            hh[er][0] = p.bp_a_first ? A : Bv; hh[er][1] = p.bp_a_first ? Bv : A;
+        } else {
+            dfilt_pair<C::M>(wh, p.h_a, p.h_b, A, Bv);
+            hh[er][0] = p.hi_a_first ? A : Bv; hh[er][1] = p.hi_a_first ? Bv : A;
+        }
     }
     float *L = p.LoLo + ((int64_t)b * OR + R) * OC + Cc;
     *reinterpret_cast<f2 *>(L) = f2{ll[0][0], ll[0][1]};
@@ -255,7 +299,7 @@ DT_HD void fwd2s_rows_flush(const Fwd2Params &p, const float *stage, int tid, in
 // level-1 inverse row pass: y1 (*) g0 + y2 (*) g1 along the columns, 16-byte stores
 template <class C>
 DT_HD void inv1d_rows(const Inv1Params &p, const float *y1, const float *y2, int tid, int b, int r0,
-                      int c0) {
+                      int c0, const float *y3 = nullptr) {
     constexpr int NQ = C::TC / 4;
     constexpr int WL = 4 + 2 * C::HE;
     for (int task = tid; task < C::TR * NQ; task += DT_NT) {
@@ -281,6 +325,18 @@ DT_HD void inv1d_rows(const Inv1Params &p, const float *y1, const float *y2, int
             for (int k = 0; k < C::M1; ++k) s += p.g1[k] * wb[e + C::HE + C::H1 - k];
             o[e] = s;
         }
+        if (C::BP) {
+            const f2 *pc = reinterpret_cast<const f2 *>(y3 + r * C::NC + 4 * q);
+#pragma unroll
+            for (int j = 0; j < WL / 2; ++j) { f2 a = pc[j]; wa[2 * j] = a.x; wa[2 * j + 1] = a.y; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < C::M2; ++k) s += p.g2[k] * wa[e + C::HE + C::H2 - k];
+                o[e] += s;
+            }
+        }
         float *X = p.X + ((int64_t)b * p.R + R) * p.C + Cc;
         if (Cc + 3 < p.C && (p.C & 3) == 0) {
             *reinterpret_cast<f4 *>(X) = f4{o[0], o[1], o[2], o[3]};
@@ -303,10 +359,14 @@ DT_HD void inv1d_rows(const Inv1Params &p, const float *y1, const float *y2, int
 // "bottom" sample of each of the three planes = 2 multiplies + 2 FMAs per plane.  Tasks
 // are dealt so that the column parity is uniform per wavefront (no divergence, no
 // selects); border tiles, where reflection can flip a quad, take a generic path.
-template <int TR_, int TC_, int RS_, int M0_, int M1_>
+// M2_ > 0: band-pass variant: the diagonal plane goes through g2 into a third plane y3, which
+// the row pass filters with g2 as well (transform2d.py:283-291).
+template <int TR_, int TC_, int RS_, int M0_, int M1_, int M2_ = 0>
 struct Inv1RCfg {
-    static constexpr int TR = TR_, TC = TC_, RS = RS_, M0 = M0_, M1 = M1_;
-    static constexpr int H0 = M0 / 2, H1 = M1 / 2, HH = cmax(H0, H1);
+    static constexpr int TR = TR_, TC = TC_, RS = RS_, M0 = M0_, M1 = M1_, M2 = M2_;
+    static constexpr bool BP = M2 > 0;
+    static constexpr int NY = BP ? 3 : 2;             // column-pass planes
+    static constexpr int H0 = M0 / 2, H1 = M1 / 2, H2 = M2 / 2, HH = cmax(cmax(H0, H1), H2);
     static constexpr int HE = (HH + 1) & ~1;
     static constexpr int NR = TR + 2 * HE, NC = TC + 2 * HE;
     static constexpr int QR = NR / 2, QC = NC / 2, NREC = QR * QC;
@@ -314,11 +374,11 @@ struct Inv1RCfg {
     static constexpr int WN = RS + 2 * HE;
     static constexpr int SREC = NREC * 12;
     static constexpr int SY = TR * NC;
-    static constexpr int LDS_FLOATS = SREC + 2 * SY;
-    static constexpr int LDS_ALIASED = SREC > 2 * SY ? SREC : 2 * SY;   // y planes over the records
+    static constexpr int LDS_FLOATS = SREC + NY * SY;
+    static constexpr int LDS_ALIASED = SREC > NY * SY ? SREC : NY * SY;   // y planes over the records
     static_assert(TR % RS == 0 && RS % 2 == 0 && TC % 4 == 0, "tile shape");
     static_assert(NS * QC <= 128, "column-pass tasks: two wavefronts per column parity");
-    static_assert(M0 % 2 == 1 && M1 % 2 == 1, "biort filters must have odd length");
+    static_assert(M0 % 2 == 1 && M1 % 2 == 1 && (!BP || M2 % 2 == 1), "biort filters must have odd length");
 };
 
 // stage the window's records verbatim: srec[uw][vw][12], source record reflected.  All of a
@@ -478,7 +538,8 @@ DT_HD void inv1r_gather(const Inv1Params &p, const float *srec, float (&w1)[C::W
 }
 template <class C, bool LIN = false>
 DT_HD void inv1r_fir(const Inv1Params &p, const float (&w0)[C::WN], const float (&w1)[C::WN],
-                     const float (&w2)[C::WN], const float (&w3)[C::WN], float *y1, float *y2, int tid) {
+                     const float (&w2)[C::WN], const float (&w3)[C::WN], float *y1, float *y2, int tid,
+                     float *y3 = nullptr) {
     const ColTask t = LIN ? inv_col_task_lin<C>(tid) : inv_col_task<C>(tid);
     if (!t.valid) return;
     const int cc = 2 * t.i + t.e;
@@ -493,16 +554,24 @@ DT_HD void inv1r_fir(const Inv1Params &p, const float (&w0)[C::WN], const float 
 #pragma unroll
         for (int k = 0; k < C::M1; ++k) {
             a += p.g1[k] * w1[q + C::HE + C::H1 - k];
-            bq += p.g1[k] * w3[q + C::HE + C::H1 - k];
+            if (!C::BP) bq += p.g1[k] * w3[q + C::HE + C::H1 - k];
         }
         y1[(t.strip * C::RS + q) * C::NC + cc] = a;
         y2[(t.strip * C::RS + q) * C::NC + cc] = bq;
+        if (C::BP) {
+            float c = 0.f;
+#pragma unroll
+            for (int k = 0; k < C::M2; ++k) c += p.g2[k] * w3[q + C::HE + C::H2 - k];
+            y3[(t.strip * C::RS + q) * C::NC + cc] = c;
+        }
     }
 }
 
 // ---- level >= 2 inverse with raw records (c2q folded into the column pass) --------------
-template <int TR_, int TC_, int JS_, int M_>
+template <int TR_, int TC_, int JS_, int M_, bool BP_ = false>
 struct Inv2RCfg {
+    static constexpr bool BP = BP_;                                // band-pass q-shift (12 vectors)
+    static constexpr int NY = BP ? 3 : 2;
     static constexpr int TR = TR_, TC = TC_, JS = JS_, M = M_;     // TR x TC INPUT samples per tile
     static constexpr int M2 = M / 2;
     static constexpr bool ODD = (M2 % 2) == 1;
@@ -516,8 +585,8 @@ struct Inv2RCfg {
     static constexpr int RS = 2 * JS;                              // window rows advanced per strip
     static constexpr int SREC = NREC * 12;
     static constexpr int SY = 2 * TR * NC;
-    static constexpr int LDS_FLOATS = SREC + 2 * SY;
-    static constexpr int LDS_ALIASED = SREC > 2 * SY ? SREC : 2 * SY;
+    static constexpr int LDS_FLOATS = SREC + NY * SY;
+    static constexpr int LDS_ALIASED = SREC > NY * SY ? SREC : NY * SY;
     static_assert(M % 2 == 0 && TR % 2 == 0 && TC % 2 == 0 && NJ % JS == 0, "even taps / tile");
     static_assert(NS * QC <= 128, "column-pass tasks: two wavefronts per column parity");
 };
@@ -588,7 +657,8 @@ DT_HD void inv2r_gather(const Inv2Params &p, const float *srec, float (&w1)[C::W
 }
 template <class C, bool LIN = false>
 DT_HD void inv2r_fir(const Inv2Params &p, const float (&w0)[C::WS], const float (&w1)[C::WS],
-                     const float (&w2)[C::WS], const float (&w3)[C::WS], float *y1, float *y2, int tid) {
+                     const float (&w2)[C::WS], const float (&w3)[C::WS], float *y1, float *y2, int tid,
+                     float *y3 = nullptr) {
     const ColTask t = LIN ? inv_col_task_lin<C>(tid) : inv_col_task<C>(tid);
     if (!t.valid) return;
     const int cc = 2 * t.i + t.e;
@@ -600,9 +670,17 @@ DT_HD void inv2r_fir(const Inv2Params &p, const float (&w0)[C::WS], const float 
 #pragma unroll
         for (int e = 0; e < 4; ++e) y1[(4 * (t.strip * C::JS + q) + e) * C::NC + cc] = a[e] + tt[e];
         ifilt4<C>(w2 + 2 * q, p.l_a, p.l_b, p.lo_pos, a);
-        ifilt4<C>(w3 + 2 * q, p.h_a, p.h_b, p.hi_pos, tt);
+        if (C::BP) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y2[(4 * (t.strip * C::JS + q) + e) * C::NC + cc] = a[e] + tt[e];
+            for (int e = 0; e < 4; ++e) y2[(4 * (t.strip * C::JS + q) + e) * C::NC + cc] = a[e];
+            ifilt4<C>(w3 + 2 * q, p.b_a, p.b_b, p.bp_pos, tt);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y3[(4 * (t.strip * C::JS + q) + e) * C::NC + cc] = tt[e];
+        } else {
+            ifilt4<C>(w3 + 2 * q, p.h_a, p.h_b, p.hi_pos, tt);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y2[(4 * (t.strip * C::JS + q) + e) * C::NC + cc] = a[e] + tt[e];
+        }
     }
 }
 

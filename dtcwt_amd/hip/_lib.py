@@ -105,6 +105,7 @@ SIGNATURES = {
     'dtcwt_hip_pack1d': (_i, [_vp, _i, _vp, _i64, _i64, _vp]),
     'dtcwt_hip_unpack1d': (_i, [_vp, _i, _vp, _i64, _i64, _dbl, _vp]),
     'dtcwt_hip_scale': (_i, [_vp, _i, _vp, _i64, _dbl]),
+    'dtcwt_hip_plan2d_set_bandpass': (_i, [_vp, _pd, _pd, _i, _pd, _pd, _pd, _pd, _i]),
     'dtcwt_hip_plan2d_create': (_i, [_vp, _i, _i, _i, _i, ctypes.POINTER(_pd), ctypes.POINTER(_i),
                                      ctypes.POINTER(_pd), ctypes.POINTER(_i), ctypes.POINTER(_vp)]),
     'dtcwt_hip_plan2d_destroy': (_i, [_vp]),

@@ -3,10 +3,11 @@
 Same constructor, ``forward`` / ``inverse`` signatures, shapes, dtypes, exceptions and
 log messages as dtcwt/numpy/transform2d.py:18-295.  The level loop runs on the device:
 
-* float32 images with the shipped 4-vector biort / 8-vector q-shift sets go through the
-  fused plan (``dtcwt_hip_plan2d_*``): one gfx950 kernel per level and direction;
-* everything else (float64, the band-pass ``_bp`` sets, unusual tap lengths) goes through
-  the generic device filters (``dtcwt_hip_colfilter/coldfilt/colifilt/q2c/c2q``).
+* float32 images with the shipped biort / q-shift sets -- the band-pass ``_bp`` ones (6 / 12
+  vectors) included -- go through the fused plan (``dtcwt_hip_plan2d_*``): one gfx950 kernel
+  per level and direction;
+* everything else (float64, unusual tap lengths) goes through the generic device filters
+  (``dtcwt_hip_colfilter/coldfilt/colifilt/q2c/c2q``).
 
 There is no host fallback: without the library or a GPU the first use raises
 ``NoHIPPresentError``.  Batches of equally-sized images are transformed in one go by
@@ -50,6 +51,25 @@ class _Plan2d(object):
         check(rc)
         self._h = h
         self._lib = L
+        if len(biort) >= 6 or len(qshift) >= 12:
+            # band-pass sets: third filter of the diagonal subbands (transform2d.py:116-129, :145-155)
+            b = [flat_taps(h) for h in biort[4:6]] if len(biort) >= 6 else []
+            q = [flat_taps(h) for h in qshift[8:12]] if len(qshift) >= 12 else []
+            self._keep += b + q
+            nb = b[0].shape[0] if b else 0
+            nq = q[0].shape[0] if q else 0
+            if (b and b[1].shape[0] != nb) or any(v.shape[0] != nq for v in q):
+                rc = -3
+            else:
+                pb = [v.ctypes.data_as(_pd) for v in b] or [None, None]
+                pq = [v.ctypes.data_as(_pd) for v in q] or [None] * 4
+                rc = L.dtcwt_hip_plan2d_set_bandpass(h, pb[0], pb[1], nb, pq[0], pq[1], pq[2], pq[3], nq)
+            if rc:
+                self._h = None                      # not ours any more: __del__ must not destroy it again
+                L.dtcwt_hip_plan2d_destroy(h)
+                if rc == -3:
+                    raise NotImplementedError('no fused band-pass kernels for these tap lengths')
+                check(rc)
         self.batch, self.rows, self.cols, self.nlevels = batch, rows, cols, nlevels
         s = (ctypes.c_int * (4 + 4 * nlevels))()
         check(L.dtcwt_hip_plan2d_shapes(h, s))
@@ -177,7 +197,7 @@ class Transform2d(object):
 
     def _plan(self, batch, rows, cols, nlevels):
         """Fused plan or None when the wavelets have no fused kernels."""
-        if len(self.biort) != 4 or len(self.qshift) != 8:
+        if len(self.biort) not in (4, 6) or len(self.qshift) not in (8, 12):
             return None
         key = (batch, rows, cols, nlevels)
         if key not in self._plans:

@@ -231,6 +231,14 @@ int dtcwt_hip_plan2d_forward(dtcwt_hip_plan2d *plan, const float *X, float *Yl,
 int dtcwt_hip_plan2d_inverse(dtcwt_hip_plan2d *plan, const float *Yl, const void *const *Yh,
                              const double *gain_mask_host, float *Z);
 
+/* Band-pass ("_bp") wavelet sets: the third filter of a 6-vector biort (h2o, g2o; m_biort taps, 0:
+ * none) and of a 12-vector q-shift (h2a, h2b, g2a, g2b; m_qshift taps, 0: none), used for the diagonal
+ * subbands (dtcwt/numpy/transform2d.py:116-129, :145-155, :250-271, :283-291).  Call once after
+ * dtcwt_hip_plan2d_create; HOST pointers.  Returns -3 when no fused band-pass kernel exists for
+ * these lengths (the caller then uses the generic filters). */
+int dtcwt_hip_plan2d_set_bandpass(dtcwt_hip_plan2d *plan, const double *h2o, const double *g2o, int m_biort,
+                                  const double *h2a, const double *h2b, const double *g2a, const double *g2b,
+                                  int m_qshift);
 /* Per-kernel timing for the benchmark's roofline report: when enabled, every level kernel
  * of forward/inverse is bracketed by a hipEvent pair on the plan's stream;
  * kernel_ms() synchronises and returns the durations of the LAST forward (fwd_ms[l]) and

@@ -33,15 +33,15 @@ static int run_fwd1(Fwd1Params p) {
     std::vector<float> smem(C::LDS_FLOATS + 4 * STAGE_FLOATS_PER_WAVE + 4);
     float *base = smem.data();
     while (((uintptr_t)base) & 15) ++base;
-    float *sLo = base, *sHi = sLo + C::SL, *stage = sHi + C::SL;
+    float *sLo = base, *sHi = sLo + C::SL, *sBa = sHi + C::SL, *stage = base + C::LDS_FLOATS;
     constexpr int NQ = (C::TR / 2) * (C::TC / 2);
     for (int b = 0; b < p.B; ++b)
         for (int tr = 0; tr < p.tilesR; ++tr)
             for (int tc = 0; tc < p.tilesC; ++tc) {
                 int r0 = tr * C::TR, c0 = tc * C::TC;
-                for (int t = 0; t < DT_NT; ++t) fwd1d_cols<C>(p, sLo, sHi, t, b, r0, c0);
+                for (int t = 0; t < DT_NT; ++t) fwd1d_cols<C>(p, sLo, sHi, t, b, r0, c0, sBa);
                 for (int q = 0; q < NQ; q += DT_NT) {      // a wave's two halves run as two passes
-                    for (int t = 0; t < DT_NT; ++t) fwd1s_rows_compute<C>(p, sLo, sHi, stage, t, q, b, r0, c0);
+                    for (int t = 0; t < DT_NT; ++t) fwd1s_rows_compute<C>(p, sLo, sHi, stage, t, q, b, r0, c0, sBa);
                     for (int t = 0; t < DT_NT; ++t) fwd1s_rows_flush<C>(p, stage, t, q, b, r0, c0);
                 }
             }
@@ -54,14 +54,14 @@ static int run_fwd2(Fwd2Params p) {
     std::vector<float> smem(C::LDS_FLOATS + 4 * STAGE_FLOATS_PER_WAVE + 4);
     float *base = smem.data();
     while (((uintptr_t)base) & 15) ++base;
-    float *sLo = base, *sHi = sLo + C::SL, *stage = sHi + C::SL;
+    float *sLo = base, *sHi = sLo + C::SL, *sBa = sHi + C::SL, *stage = base + C::LDS_FLOATS;
     for (int b = 0; b < p.B; ++b)
         for (int tr = 0; tr < p.tilesR; ++tr)
             for (int tc = 0; tc < p.tilesC; ++tc) {
                 int r0 = tr * C::TR, c0 = tc * C::TC;
-                for (int t = 0; t < DT_NT; ++t) fwd2d_cols<C>(p, sLo, sHi, t, b, r0, c0);
+                for (int t = 0; t < DT_NT; ++t) fwd2d_cols<C>(p, sLo, sHi, t, b, r0, c0, sBa);
                 for (int q = 0; q < C::TI * C::TJ; q += DT_NT) {
-                    for (int t = 0; t < DT_NT; ++t) fwd2s_rows_compute<C>(p, sLo, sHi, stage, t, q, b, r0, c0);
+                    for (int t = 0; t < DT_NT; ++t) fwd2s_rows_compute<C>(p, sLo, sHi, stage, t, q, b, r0, c0, sBa);
                     for (int t = 0; t < DT_NT; ++t) fwd2s_rows_flush<C>(p, stage, t, q, b, r0, c0);
                 }
             }
@@ -74,7 +74,7 @@ static int run_inv1(Inv1Params p) {
     std::vector<float> smem(C::LDS_ALIASED + 4);
     float *base = smem.data();
     while (((uintptr_t)base) & 15) ++base;
-    float *srec = base, *y1 = base, *y2 = y1 + C::SY;          // y planes alias the records
+    float *srec = base, *y1 = base, *y2 = y1 + C::SY, *y3 = y2 + C::SY;    // y planes alias the records
     static float wz[DT_NT][C::WN], w1[DT_NT][C::WN], w2[DT_NT][C::WN], w3[DT_NT][C::WN];
     for (int b = 0; b < p.B; ++b)
         for (int tr = 0; tr < p.tilesR; ++tr)
@@ -85,8 +85,8 @@ static int run_inv1(Inv1Params p) {
                 for (int t = 0; t < DT_NT; ++t)
                     inv_rec_stage<C::QR, C::QC>(Yhb, p.R, p.C, srec, r0 - C::HE, c0 - C::HE, t);
                 for (int t = 0; t < DT_NT; ++t) inv1r_gather<C>(p, srec, w1[t], w2[t], w3[t], t, r0, c0);
-                for (int t = 0; t < DT_NT; ++t) inv1r_fir<C>(p, wz[t], w1[t], w2[t], w3[t], y1, y2, t);
-                for (int t = 0; t < DT_NT; ++t) inv1d_rows<C>(p, y1, y2, t, b, r0, c0);
+                for (int t = 0; t < DT_NT; ++t) inv1r_fir<C>(p, wz[t], w1[t], w2[t], w3[t], y1, y2, t, y3);
+                for (int t = 0; t < DT_NT; ++t) inv1d_rows<C>(p, y1, y2, t, b, r0, c0, y3);
             }
     return 0;
 }
@@ -97,7 +97,7 @@ static int run_inv2(Inv2Params p) {
     std::vector<float> smem(C::LDS_ALIASED + 4);
     float *base = smem.data();
     while (((uintptr_t)base) & 15) ++base;
-    float *srec = base, *y1 = base, *y2 = y1 + C::SY;
+    float *srec = base, *y1 = base, *y2 = y1 + C::SY, *y3 = y2 + C::SY;
     static float wz[DT_NT][C::WS], w1[DT_NT][C::WS], w2[DT_NT][C::WS], w3[DT_NT][C::WS];
     for (int b = 0; b < p.B; ++b)
         for (int tr = 0; tr < p.tilesR; ++tr)
@@ -108,8 +108,8 @@ static int run_inv2(Inv2Params p) {
                 for (int t = 0; t < DT_NT; ++t)
                     inv_rec_stage<C::QR, C::QC>(Yhb, p.zr, p.zc, srec, r0 + C::ORG, c0 + C::ORG, t);
                 for (int t = 0; t < DT_NT; ++t) inv2r_gather<C>(p, srec, w1[t], w2[t], w3[t], t, r0, c0);
-                for (int t = 0; t < DT_NT; ++t) inv2r_fir<C>(p, wz[t], w1[t], w2[t], w3[t], y1, y2, t);
-                for (int t = 0; t < DT_NT; ++t) inv2_rows<C>(p, y1, y2, t, b, r0, c0);
+                for (int t = 0; t < DT_NT; ++t) inv2r_fir<C>(p, wz[t], w1[t], w2[t], w3[t], y1, y2, t, y3);
+                for (int t = 0; t < DT_NT; ++t) inv2_rows<C>(p, y1, y2, t, b, r0, c0, y3);
             }
     return 0;
 }
@@ -309,6 +309,57 @@ int emu_inv2(int m, const float *Z, const float *Yh, float *Out, int B, int zr, 
     put_taps(p.l_a, la, m); put_taps(p.l_b, lb, m); put_taps(p.h_a, ha, m); put_taps(p.h_b, hb, m);
     p.lo_pos = dotd(la, lb, m) > 0; p.hi_pos = dotd(ha, hb, m) > 0;
     DT_INV2_TABLE(EMU_INV2)
+    return -3;
+}
+
+// band-pass variants: h2 / g2 (level 1) and the (b, a) band-pass q-shift pairs (level >= 2)
+int emu_fwd1_bp(int m0, int m1, int m2, const float *X, float *LoLo, float *Yh, int B, int inR, int inC,
+                const double *h0, const double *h1, const double *h2) {
+    Fwd1Params p{};
+    p.X = X; p.LoLo = LoLo; p.Yh = Yh; p.B = B; p.inR = inR; p.inC = inC;
+    p.LR = inR + (inR & 1); p.LC = inC + (inC & 1);
+    put_taps(p.h0, h0, m0); put_taps(p.h1, h1, m1); put_taps(p.h2, h2, m2);
+#define EMU_FWD1_BP(TR, TC, RS, A, B_, C2) if (m0 == A && m1 == B_ && m2 == C2) return run_fwd1<Fwd1DCfg<TR, TC, RS, A, B_, C2>>(p);
+    DT_FWD1_BP_TABLE(EMU_FWD1_BP)
+    return -3;
+}
+
+int emu_fwd2_bp(int m, const float *X, float *LoLo, float *Yh, int B, int inR, int inC, const double *la,
+                const double *lb, const double *ha, const double *hb, const double *ba, const double *bb) {
+    Fwd2Params p{};
+    p.X = X; p.LoLo = LoLo; p.Yh = Yh; p.B = B; p.inR = inR; p.inC = inC;
+    p.padR = (inR % 4) ? 1 : 0; p.padC = (inC % 4) ? 1 : 0;
+    p.LR = inR + 2 * p.padR; p.LC = inC + 2 * p.padC;
+    put_taps(p.l_a, la, m); put_taps(p.l_b, lb, m); put_taps(p.h_a, ha, m); put_taps(p.h_b, hb, m);
+    put_taps(p.b_a, ba, m); put_taps(p.b_b, bb, m);
+    p.lo_a_first = dotd(la, lb, m) > 0; p.hi_a_first = dotd(ha, hb, m) > 0; p.bp_a_first = dotd(ba, bb, m) > 0;
+#define EMU_FWD2_BP(TR, TC, PS, M) if (m == M) return run_fwd2<Fwd2DCfg<TR, TC, PS, M, true>>(p);
+    DT_FWD2_BP_TABLE(EMU_FWD2_BP)
+    return -3;
+}
+
+int emu_inv1_bp(int m0, int m1, int m2, const float *Z, const float *Yh, float *X, int B, int R, int C,
+                const double *gain6, const double *g0, const double *g1, const double *g2) {
+    Inv1Params p{};
+    p.Z = Z; p.Yh = Yh; p.X = X; p.B = B; p.R = R; p.C = C;
+    for (int d = 0; d < 6; ++d) p.g[d] = (float)(0.70710678118654752440 * gain6[d]);
+    put_taps(p.g0, g0, m0); put_taps(p.g1, g1, m1); put_taps(p.g2, g2, m2);
+#define EMU_INV1_BP(TR, TC, RS, A, B_, C2) if (m0 == A && m1 == B_ && m2 == C2) return run_inv1<Inv1RCfg<TR, TC, RS, A, B_, C2>>(p);
+    DT_INV1_BP_TABLE(EMU_INV1_BP)
+    return -3;
+}
+
+int emu_inv2_bp(int m, const float *Z, const float *Yh, float *Out, int B, int zr, int zc, int cropR, int cropC,
+                const double *gain6, const double *la, const double *lb, const double *ha, const double *hb,
+                const double *ba, const double *bb) {
+    Inv2Params p{};
+    p.Z = Z; p.Yh = Yh; p.Out = Out; p.B = B; p.zr = zr; p.zc = zc; p.cropR = cropR; p.cropC = cropC;
+    for (int d = 0; d < 6; ++d) p.g[d] = (float)(0.70710678118654752440 * gain6[d]);
+    put_taps(p.l_a, la, m); put_taps(p.l_b, lb, m); put_taps(p.h_a, ha, m); put_taps(p.h_b, hb, m);
+    put_taps(p.b_a, ba, m); put_taps(p.b_b, bb, m);
+    p.lo_pos = dotd(la, lb, m) > 0; p.hi_pos = dotd(ha, hb, m) > 0; p.bp_pos = dotd(ba, bb, m) > 0;
+#define EMU_INV2_BP(TR, TC, JS, M) if (m == M) return run_inv2<Inv2RCfg<TR, TC, JS, M, true>>(p);
+    DT_INV2_BP_TABLE(EMU_INV2_BP)
     return -3;
 }
 

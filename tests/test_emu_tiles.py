@@ -166,6 +166,46 @@ def test_emu_level2_forward_inverse(emu, qn, shape):
         assert rel(Zi[i], Z) < 4 * TOL
 
 
+# ------------------------------------------------------------------------------ band-pass sets
+@pytest.mark.parametrize('shape', [(64, 128), (41, 47), (70, 40), (44, 52)])
+def test_emu_bandpass_levels(emu, shape):
+    """near_sym_b_bp / qshift_b_bp: the third filter of the diagonal subbands in all four tile
+    programs, against the oracle's two-level transform of the same wavelets."""
+    rs = np.random.RandomState(8)
+    X = rs.standard_normal((2,) + shape).astype(np.float32)
+    b, q = biort('near_sym_b_bp'), qshift('qshift_b_bp')
+    t = o.Transform2d(b, q)
+    B, r, c = X.shape
+    R, C = r + (r & 1), c + (c & 1)
+    lolo = np.full((B, R, C), np.nan, np.float32)
+    yh0 = np.full((B, R // 2, C // 2, 12), np.nan, np.float32)
+    d = lambda a: _d(a)
+    (h0, p0), (h1, p1), (h2, p2) = d(b[0]), d(b[2]), d(b[4])
+    assert emu.emu_fwd1_bp(len(h0), len(h1), len(h2), _f(X), _f(lolo), _f(yh0), B, r, c, p0, p1, p2) == 0
+    LR, LC = R + (2 if R % 4 else 0), C + (2 if C % 4 else 0)
+    lolo2 = np.full((B, LR // 2, LC // 2), np.nan, np.float32)
+    yh1 = np.full((B, LR // 4, LC // 4, 12), np.nan, np.float32)
+    taps = [d(q[1]), d(q[0]), d(q[5]), d(q[4]), d(q[9]), d(q[8])]       # (h0b,h0a) (h1b,h1a) (h2b,h2a)
+    assert emu.emu_fwd2_bp(len(taps[0][0]), _f(lolo), _f(lolo2), _f(yh1), B, R, C, *[x[1] for x in taps]) == 0
+    gain = np.array([[1.0, 0.8], [0.5, 1.2], [0.0, 1.0], [2.0, 0.3], [1.5, 1.0], [0.7, 0.9]])
+    gtaps = [d(q[3]), d(q[2]), d(q[7]), d(q[6]), d(q[11]), d(q[10])]    # (g0b,g0a) (g1b,g1a) (g2b,g2a)
+    padR, padC = int(R % 4 != 0), int(C % 4 != 0)
+    z1 = np.full((B, R, C), np.nan, np.float32)
+    g1, pg1 = _d(gain[:, 1])
+    assert emu.emu_inv2_bp(len(gtaps[0][0]), _f(lolo2), _f(yh1), _f(z1), B, LR // 2, LC // 2, padR, padC, pg1,
+                           *[x[1] for x in gtaps]) == 0
+    z0 = np.full((B, R, C), np.nan, np.float32)
+    (g0o, q0), (g1o, q1), (g2o, q2) = d(b[1]), d(b[3]), d(b[5])
+    g0, pg0 = _d(gain[:, 0])
+    assert emu.emu_inv1_bp(len(g0o), len(g1o), len(g2o), _f(z1), _f(yh0), _f(z0), B, R, C, pg0, q0, q1, q2) == 0
+    for i in range(2):
+        p = t.forward(X[i], nlevels=2, include_scale=True)
+        assert rel(lolo[i], p.scales[0]) < TOL and rel(yh0[i].view(np.complex64), p.highpasses[0]) < TOL
+        assert rel(lolo2[i], p.lowpass) < TOL and rel(yh1[i].view(np.complex64), p.highpasses[1]) < 2 * TOL
+        want = t.inverse(o.Pyramid(lolo2[i], (yh0[i].view(np.complex64), yh1[i].view(np.complex64))), gain)
+        assert want.shape == z0[i].shape and rel(z0[i], want) < 4 * TOL
+
+
 # ------------------------------------------------------------------------------ 3-D
 def emu_fwd3_l1(emu, X, h0o, h1o, chunk):
     n0, n1, n2 = X.shape

@@ -28,8 +28,9 @@ def _mandrill():
 def test_plan_is_used_for_float32():
     t = Transform2d()
     assert t.plan(1, 256, 256, 3) is not None
-    with pytest.raises(NotImplementedError):
-        Transform2d('near_sym_b_bp', 'qshift_b_bp').plan(1, 256, 256, 3)
+    assert Transform2d('near_sym_b_bp', 'qshift_b_bp').plan(1, 256, 256, 3) is not None
+    with pytest.raises(NotImplementedError):          # band-pass pair of another length than the q-shift set
+        Transform2d('near_sym_a', (np.ones(10),) * 8 + (np.ones(12),) * 4).plan(1, 256, 256, 3)
     with pytest.raises(NotImplementedError):          # levels narrower than 40 samples: generic kernels
         t.plan(1, 64, 64, 3)
 
@@ -314,3 +315,21 @@ def test_two_contexts_from_two_threads():
     for t_ in th:
         t_.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize('bn,qn', [('near_sym_b_bp', 'qshift_b_bp'), ('near_sym_b_bp', 'qshift_a'),
+                                   ('near_sym_a', 'qshift_b_bp'), ('near_sym_b_bp', 'qshift_d')])
+def test_bandpass_sets_use_the_fused_plan(bn, qn):
+    """6-vector biort / 12-vector q-shift sets (third filter for the diagonal subbands,
+    transform2d.py:116-129, :145-155, :250-271, :283-291): fused kernels, any mix with the
+    ordinary sets, against the oracle."""
+    rs = np.random.RandomState(31)
+    X = rs.standard_normal((200, 264)).astype(np.float32)
+    t = Transform2d(bn, qn)
+    assert t.plan(1, 200, 264, 3) is not None
+    to = o.Transform2d(biort(bn), qshift(qn))
+    p = t.forward(X, nlevels=3, include_scale=True)
+    want = to.forward(X.astype(np.float64), nlevels=3, include_scale=True)
+    assert_pyramids_close(p, want, XFM_TOL, same_dtype=False)
+    gain = rs.uniform(0.2, 1.5, (6, 3))
+    assert_close(t.inverse(p, gain), to.inverse(want, gain), INV_TOL, 'inverse with gains')
