@@ -542,6 +542,12 @@ inline unsigned blocks_for(int64_t total) { return (unsigned)((total + 255) / 25
 bool march_ok(const Geo &g, int reach) {
     return g.inner_fast && g.inner >= 64 && g.idx32 && g.L >= reach && g.nwrite >= 16;
 }
+// Lanes along the filter axis itself (a contiguous axis): one output group per thread as in the
+// generic kernels, but with the compile-time tap bucket -- unrolled taps, all loads of a
+// thread issued up front, branch-free reflection.
+bool unrolled_ok(const Geo &g, int reach) {
+    return !(g.inner_fast && g.inner > 1) && g.idx32 && g.L >= reach && g.nwrite >= 16;
+}
 
 // taps FRONT padded to mb entries (k_coldfilt_march)
 template <typename T>
@@ -608,6 +614,19 @@ int dtcwt_hip_colfilter(dtcwt_hip_ctx *ctx, int dtype, const void *X, void *Y,
         DT_LAUNCH_CHECK();
         return 0;
     }
+    if (unrolled_ok(g, 20) && m <= 20) {
+        if (dtype == DTCWT_HIP_F32) {
+            Taps<float> t; load_taps(t, h, nullptr, m);
+            if (m <= 8) k_colfilter_march<float, 1, 8><<<blocks_for(total), 256, 0, ctx->stream>>>((const float *)X, (float *)Y, g, t, m);
+            else k_colfilter_march<float, 1, 20><<<blocks_for(total), 256, 0, ctx->stream>>>((const float *)X, (float *)Y, g, t, m);
+        } else {
+            Taps<double> t; load_taps(t, h, nullptr, m);
+            if (m <= 8) k_colfilter_march<double, 1, 8><<<blocks_for(total), 256, 0, ctx->stream>>>((const double *)X, (double *)Y, g, t, m);
+            else k_colfilter_march<double, 1, 20><<<blocks_for(total), 256, 0, ctx->stream>>>((const double *)X, (double *)Y, g, t, m);
+        }
+        DT_LAUNCH_CHECK();
+        return 0;
+    }
     if (dtype == DTCWT_HIP_F32) {
         Taps<float> t; load_taps(t, h, nullptr, m);
         k_colfilter<float><<<blocks_for(total), 256, 0, ctx->stream>>>((const float *)X, (float *)Y, g, t, m);
@@ -648,6 +667,20 @@ int dtcwt_hip_coldfilt(dtcwt_hip_ctx *ctx, int dtype, const void *X, void *Y,
             Taps<double> t; load_taps_front(t, ha, hb, m, mb);
             if (mb == 10) k_coldfilt_march<double, 4, 10><<<blocks_for(tot), 256, 0, ctx->stream>>>((const double *)X, (double *)Y, g, t, m, a_first);
             else k_coldfilt_march<double, 4, 20><<<blocks_for(tot), 256, 0, ctx->stream>>>((const double *)X, (double *)Y, g, t, m, a_first);
+        }
+        DT_LAUNCH_CHECK();
+        return 0;
+    }
+    if (unrolled_ok(g, 40) && m <= 20) {
+        const int mb = m <= 10 ? 10 : 20;
+        if (dtype == DTCWT_HIP_F32) {
+            Taps<float> t; load_taps_front(t, ha, hb, m, mb);
+            if (mb == 10) k_coldfilt_march<float, 1, 10><<<blocks_for(total), 256, 0, ctx->stream>>>((const float *)X, (float *)Y, g, t, m, a_first);
+            else k_coldfilt_march<float, 1, 20><<<blocks_for(total), 256, 0, ctx->stream>>>((const float *)X, (float *)Y, g, t, m, a_first);
+        } else {
+            Taps<double> t; load_taps_front(t, ha, hb, m, mb);
+            if (mb == 10) k_coldfilt_march<double, 1, 10><<<blocks_for(total), 256, 0, ctx->stream>>>((const double *)X, (double *)Y, g, t, m, a_first);
+            else k_coldfilt_march<double, 1, 20><<<blocks_for(total), 256, 0, ctx->stream>>>((const double *)X, (double *)Y, g, t, m, a_first);
         }
         DT_LAUNCH_CHECK();
         return 0;
@@ -694,6 +727,20 @@ int dtcwt_hip_colifilt(dtcwt_hip_ctx *ctx, int dtype, const void *X, void *Y,
         } while (0)
         if (dtype == DTCWT_HIP_F32) DT_IFILT_MARCH(float); else DT_IFILT_MARCH(double);
 #undef DT_IFILT_MARCH
+        DT_LAUNCH_CHECK();
+        return 0;
+    }
+    if (mb && unrolled_ok(g, mb + 2)) {
+#define DT_IFILT_UNROLLED(T_)                                                                           \
+        do {                                                                                            \
+            Taps<T_> t; load_taps_centred(t, ha, hb, m, mb);                                            \
+            if (mb == 10) k_colifilt_march<T_, 1, 10><<<blocks_for(total), 256, 0, ctx->stream>>>((const T_ *)X, (T_ *)Y, g, t, pos); \
+            else if (mb == 18) k_colifilt_march<T_, 1, 18><<<blocks_for(total), 256, 0, ctx->stream>>>((const T_ *)X, (T_ *)Y, g, t, pos); \
+            else if (mb == 8) k_colifilt_march<T_, 1, 8><<<blocks_for(total), 256, 0, ctx->stream>>>((const T_ *)X, (T_ *)Y, g, t, pos); \
+            else k_colifilt_march<T_, 1, 16><<<blocks_for(total), 256, 0, ctx->stream>>>((const T_ *)X, (T_ *)Y, g, t, pos); \
+        } while (0)
+        if (dtype == DTCWT_HIP_F32) DT_IFILT_UNROLLED(float); else DT_IFILT_UNROLLED(double);
+#undef DT_IFILT_UNROLLED
         DT_LAUNCH_CHECK();
         return 0;
     }
