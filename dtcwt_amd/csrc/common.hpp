@@ -22,7 +22,7 @@ struct dtcwt_hip_ctx {
     std::unordered_map<size_t, std::vector<void *>> pool;   // size -> free buffers
     std::unordered_map<void *, size_t> live;                // buffer -> size
     size_t pooled_bytes = 0;
-    size_t pool_limit = (size_t)16 << 30;                   // DTCWT_HIP_POOL_MB overrides
+    size_t pool_limit = (size_t)16 << 30;                   // raised to HBM/2 at creation; DTCWT_HIP_POOL_MB overrides
 };
 
 struct dtcwt_hip_event {

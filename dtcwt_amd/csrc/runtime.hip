@@ -62,8 +62,14 @@ int dtcwt_hip_ctx_create(int device, void *stream, dtcwt_hip_ctx **out) {
         }
     }
     hipDeviceProp_t p;
-    if (hipGetDeviceProperties(&p, device) == hipSuccess) c->cus = p.multiProcessorCount;
-    else c->cus = 256;
+    if (hipGetDeviceProperties(&p, device) == hipSuccess) {
+        c->cus = p.multiProcessorCount;
+        // cache of freed buffers: up to half of the HBM (288 GB on MI355X) -- pyramids of large
+        // volumes are several GB per buffer, and every hipFree / hipMalloc is a device-wide sync
+        if (p.totalGlobalMem / 2 > c->pool_limit) c->pool_limit = p.totalGlobalMem / 2;
+    } else {
+        c->cus = 256;
+    }
     if (const char *e = getenv("DTCWT_HIP_POOL_MB")) c->pool_limit = (size_t)atoll(e) << 20;
     *out = c;
     return 0;

@@ -13,11 +13,18 @@ import numpy as np
 from dtcwt_amd.utils import asfarray
 from dtcwt_amd.hip._lib import DeviceArray
 
-__all__ = ['Pyramid']
+__all__ = ['Pyramid', 'nlevels_of']
 
 
 def _is_dev(x):
     return isinstance(x, DeviceArray)
+
+
+def nlevels_of(pyramid):
+    """len(pyramid.highpasses) that does not make a device-resident pyramid copy its levels
+    to the host (the ``highpasses`` property of the hip Pyramid materialises them)."""
+    n = getattr(pyramid, 'nlevels', None)
+    return n if isinstance(n, int) else len(pyramid.highpasses)
 
 
 class Pyramid(object):
@@ -41,6 +48,11 @@ class Pyramid(object):
         if self._scales is None:
             return None
         return tuple(x if _is_dev(x) else None for x in self._scales)
+
+    @property
+    def nlevels(self):
+        """Number of highpass levels -- without touching (copying to the host) any of them."""
+        return len(self._high)
 
     # ---- NumPy-compatible attributes, memoised --------------------------------
     def _get(self, key, x):

@@ -19,7 +19,7 @@ import numpy as np
 from dtcwt_amd.hip import _lib
 from dtcwt_amd.hip import sampling as _s
 from dtcwt_amd.hip._lib import DeviceArray, check, dtype_code
-from dtcwt_amd.hip.common import Pyramid
+from dtcwt_amd.hip.common import Pyramid, nlevels_of
 
 __all__ = ['estimatereg', 'velocityfield', 'warp', 'warptransform',
            'qtildematrices', 'solvetransform', 'warphighpass', 'normsample', 'normsamplehighpass']
@@ -175,13 +175,13 @@ def warptransform(t, avecs, levels, method=None):
     (dtcwt/registration.py:274-299)."""
     ctx = _ctx_of(t, avecs)
     av = _f64(ctx, avecs)
-    hip = getattr(t, 'hip_highpasses', None)
-    hp = [hip[i] if hip is not None and hip[i] is not None else h for i, h in enumerate(t.highpasses)] \
-        if hip is not None else list(t.highpasses)
+    if isinstance(t, Pyramid):          # raw entries: nothing is copied to the host
+        hp, low, scales = list(t._high), t._low, t._scales
+    else:
+        hp, low, scales = list(t.highpasses), t.lowpass, getattr(t, 'scales', None)
     for l in levels:
         hp[l] = _warphighpass_dev(_dev_highpass(t, l, ctx), av, method)
-    low = getattr(t, 'hip_lowpass', None)
-    return Pyramid(low if low is not None else t.lowpass, tuple(hp), getattr(t, 'scales', None))
+    return Pyramid(low, tuple(hp), scales)
 
 
 def _colsum(Q):
@@ -247,7 +247,7 @@ def estimatereg(source, reference, regshape=None, levels=None, device_output=Fal
     *native* (default): the whole kernel sequence is issued by one library call
     (``dtcwt_hip_estimatereg``); ``native=False`` issues the same kernels one by one from here."""
     ctx = _ctx_of(source, reference)
-    nlevels = len(source.highpasses)
+    nlevels = nlevels_of(source)
     if regshape is None:
         h3 = getattr(source, 'hip_highpasses', None)
         shp = (h3[3].shape if h3 is not None and h3[3] is not None else source.highpasses[3].shape)[:2]

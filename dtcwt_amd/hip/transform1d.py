@@ -12,7 +12,7 @@ from dtcwt_amd.defaults import DEFAULT_BIORT, DEFAULT_QSHIFT
 from dtcwt_amd.utils import asfarray
 from dtcwt_amd.hip import _lib
 from dtcwt_amd.hip._lib import DeviceArray, check, dtype_code
-from dtcwt_amd.hip.common import Pyramid
+from dtcwt_amd.hip.common import Pyramid, nlevels_of
 from dtcwt_amd.hip import lowlevel as ll
 
 __all__ = ['Transform1d']
@@ -104,7 +104,7 @@ class Transform1d(object):
         """Perform an *n*-level dual-tree complex wavelet (DTCWT) 1D reconstruction.
         ``gain_mask[l]`` is the gain of level *l* (default ones)."""
         (h0o, g0o, h1o, g1o), (h0a, h0b, g0a, g0b, h1a, h1b, g1a, g1b) = self._taps()
-        a = len(pyramid.highpasses)
+        a = nlevels_of(pyramid)
         if a == 0:
             return pyramid.lowpass
         gain_mask = np.ones(a) if gain_mask is None else np.asarray(gain_mask, dtype=np.float64)

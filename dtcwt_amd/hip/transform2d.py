@@ -24,7 +24,7 @@ from dtcwt_amd.defaults import DEFAULT_BIORT, DEFAULT_QSHIFT
 from dtcwt_amd.utils import asfarray, flat_taps
 from dtcwt_amd.hip import _lib
 from dtcwt_amd.hip._lib import DeviceArray, check
-from dtcwt_amd.hip.common import Pyramid
+from dtcwt_amd.hip.common import Pyramid, nlevels_of
 from dtcwt_amd.hip import lowlevel as ll
 
 __all__ = ['Transform2d', 'dtwavexfm2', 'dtwaveifm2']
@@ -449,7 +449,7 @@ class Transform2d(object):
         :returns: the reconstruction, shape of the (even-extended) input.
         """
         self._taps()
-        nl = len(pyramid.highpasses)
+        nl = nlevels_of(pyramid)
         if nl == 0:
             return pyramid.lowpass
         if gain_mask is not None:
@@ -550,7 +550,7 @@ class Transform2d(object):
         data_format = data_format.lower()
         if data_format not in self._FORMATS:
             raise ValueError('The data format must be one of: {}'.format(self._FORMATS))
-        nl = len(pyramid.highpasses)
+        nl = nlevels_of(pyramid)
         native = data_format in ('nhw', 'chw')
         if nl == 0:
             return pyramid.lowpass

@@ -22,7 +22,7 @@ from dtcwt_amd.defaults import DEFAULT_BIORT, DEFAULT_QSHIFT
 from dtcwt_amd.utils import asfarray, flat_taps
 from dtcwt_amd.hip import _lib
 from dtcwt_amd.hip._lib import DeviceArray, check, dtype_code
-from dtcwt_amd.hip.common import Pyramid
+from dtcwt_amd.hip.common import Pyramid, nlevels_of
 from dtcwt_amd.hip import lowlevel as ll
 
 __all__ = ['Transform3d']
@@ -248,7 +248,7 @@ class Transform3d(object):
         """Perform an *n*-level dual-tree complex wavelet (DTCWT) 3D reconstruction
         (dtcwt/numpy/transform3d.py:133-206); ``highpasses[0]`` may be ``None``."""
         (h0o, g0o, h1o, g1o), (h0a, h0b, g0a, g0b, h1a, h1b, g1a, g1b) = self._taps()
-        nlevels = len(pyramid.highpasses)
+        nlevels = nlevels_of(pyramid)
         if hasattr(pyramid, 'device_parts'):
             probe = pyramid.hip_lowpass if pyramid.hip_lowpass is not None else pyramid.lowpass
             rdt = np.float32 if probe.dtype in (np.float32, np.complex64) else np.float64

@@ -333,3 +333,31 @@ def test_bandpass_sets_use_the_fused_plan(bn, qn):
     assert_pyramids_close(p, want, XFM_TOL, same_dtype=False)
     gain = rs.uniform(0.2, 1.5, (6, 3))
     assert_close(t.inverse(p, gain), to.inverse(want, gain), INV_TOL, 'inverse with gains')
+
+
+def test_inverse_of_a_device_pyramid_never_touches_the_host():
+    """A device-resident pyramid goes back through the inverse (and through registration /
+    re-sampling) without any of its levels being copied to the host: the NumPy attributes are
+    only materialised when somebody reads them."""
+    from dtcwt_amd.hip import Transform1d, Transform3d
+    from dtcwt_amd import registration
+    rs = np.random.RandomState(3)
+    X = rs.standard_normal((256, 320)).astype(np.float32)
+    t = Transform2d()
+    p = t.forward(X, nlevels=5)
+    z = t.inverse(p, device_output=True)
+    assert isinstance(z, DeviceArray) and p._host == {} and p.nlevels == 5
+    q = t.forward(np.roll(X, 1, axis=0), nlevels=5)
+    registration.estimatereg(p, q, device_output=True)
+    w = registration.warptransform(p, np.zeros((16, 20, 6)), [2, 3])
+    assert p._host == {} and q._host == {} and w._host == {}
+    V = rs.standard_normal((48, 40, 56)).astype(np.float32)
+    t3 = Transform3d()
+    p3 = t3.forward(V, nlevels=2)
+    t3.inverse(p3, device_output=True)
+    assert p3._host == {}
+    t1 = Transform1d()
+    p1 = t1.forward(rs.standard_normal(128).astype(np.float32), nlevels=3)
+    t1.inverse(p1, device_output=True)
+    assert p1._host == {}
+    assert_close(z.get(), X, INV_TOL, 'PR')
