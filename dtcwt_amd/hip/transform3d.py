@@ -273,7 +273,10 @@ class Transform3d(object):
                     # even-length taps (:394-398, :437-438): first N samples of the lowpass
                     # block, N -> N+1 per axis, then drop sample 0 of every axis.
                     n0, n1, n2 = (2 * s for s in cur.shape[:3])
-                    low = self.ctx.to_device(np.ascontiguousarray(Yl.get()[:n0, :n1, :n2]))
+                    low = Yl            # leading block on the device: identity filter + crop per axis
+                    for axis, n in enumerate((n0, n1, n2)):
+                        if low.shape[axis] != n:
+                            low = ll.axis_colfilter(low, np.ones(1), axis=axis, crop=(0, low.shape[axis] - n))
                     Yl = self._merge(low, cur, ll.axis_colfilter_sum2, g0o, g1o, ((1, 0),) * 3)
                 else:
                     if tuple(Yl.shape) != tuple(2 * s for s in cur.shape[:3]):
