@@ -1,0 +1,748 @@
+// One 2-D DT-CWT level in two launches for ANY wavelet length and float32 / float64: the path
+// of every (dtype, wavelet) combination that has no fused tile program in fused2d.hip --
+// above all float64, which is what the reference computes in for non-float32 input
+// (dtcwt/utils.py:104-134 asfarray).  It replaces the seven-to-nine launches of the
+// filter-by-filter level (colfilter2 / coldfilt2 x3 + q2c x3, c2q x3 + *_sum2 x3) with
+//
+//   forward   pass 1  (Lo, Hi)  = filter pair down the image columns        (marching)
+//             pass 2  LoLo + the six q2c-packed subbands from (Lo, Hi)      (LDS rows)
+//   inverse   pass 1  (y1, y2)  = column filters of LoLo + c2q(subbands)    (marching)
+//             pass 2  Z         = row filters of y1 + y2                    (LDS rows)
+//
+// so the quad <-> complex packings (dtcwt/numpy/transform2d.py:301-350) never make a trip
+// through HBM of their own.  KIND 0 is level 1 (odd-length biorthogonal pair, colfilter
+// algebra, transform2d.py:112-130 / :275-293), KIND 1 levels >= 2 (q-shift pairs, coldfilt /
+// colifilt algebra, :132-160 / :242-273).
+//
+// "Marching" kernels: lanes along the contiguous image axis, every thread slides a register
+// window down the rows.  "LDS rows" kernels filter ALONG the contiguous axis: a block stages
+// line segments (with the reflected halo) into LDS with coalesced loads, threads read their
+// windows back as 16-byte vectors and write 16-byte lane-contiguous results; the interleaved
+// subband records of forward pass 2 are staged through LDS once more so that they leave as
+// contiguous 16-byte stores rather than 16 bytes every 48 / 96.
+//
+// Taps arrive zero padded to a compile-time bucket MB so that every register index is a
+// constant (same device as the marching kernels of filters.hip).  Index algebra: SURVEY.md
+// Appendix A.
+#include "common.hpp"
+
+#include <type_traits>
+
+namespace {
+
+constexpr int G2_MAXB = 20;
+
+template <typename T>
+struct QTaps {          // KIND 0: a = lo filter, b = hi filter.  KIND 1: (a, b) lo pair, (c, d) hi pair
+    T a[G2_MAXB], b[G2_MAXB], c[G2_MAXB], d[G2_MAXB];
+};
+
+// logical sample u -> real sample of a line of n samples replicated by (pad_lo, L-n-pad_lo)
+// and reflected about its ends; u further out than one period is clamped first (such window
+// entries only feed outputs that are never written).
+__device__ inline int g2_src(int u, int L, int pad_lo, int n) {
+    u = u < -L ? -L : (u > 2 * L - 1 ? 2 * L - 1 : u);
+    u = u < 0 ? -1 - u : u;
+    u = u >= L ? 2 * L - 1 - u : u;
+    u -= pad_lo;
+    return u < 0 ? 0 : (u > n - 1 ? n - 1 : u);
+}
+
+template <typename T> struct Vec16;
+template <> struct Vec16<float> { using type = float4; static constexpr int N = 4; };
+template <> struct Vec16<double> { using type = double2; static constexpr int N = 2; };
+
+template <typename T, int N>
+__device__ inline void lds_window(const T *p, T (&w)[N]) {        // p 16-byte aligned
+    using V = typename Vec16<T>::type;
+    constexpr int VN = Vec16<T>::N;
+    static_assert(N % VN == 0, "window not a whole number of vectors");
+#pragma unroll
+    for (int j = 0; j < N / VN; ++j) {
+        V v = reinterpret_cast<const V *>(p)[j];
+        const T *e = reinterpret_cast<const T *>(&v);
+#pragma unroll
+        for (int t = 0; t < VN; ++t) w[j * VN + t] = e[t];
+    }
+}
+
+// ---- window algebra ------------------------------------------------------------------------
+// colfilter, taps end padded to MB: out[q] = sum_k h[k] w[q + MB-1-k]
+template <typename T, int G, int MB, int WN>
+__device__ inline void fir_colfilter(const T (&w)[WN], const T *h, T (&acc)[G]) {
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+#pragma unroll
+        for (int k = 0; k < MB; ++k) acc[q] += h[k] * w[q + MB - 1 - k];
+    }
+}
+
+// coldfilt, taps FRONT padded to MB (cf. k_coldfilt_march): pair q -> outputs 2q, 2q+1
+template <typename T, int GP, int MB, int WN>
+__device__ inline void fir_coldfilt(const T (&w)[WN], const T *ha, const T *hb, int a_first, T (&out)[2 * GP]) {
+#pragma unroll
+    for (int q = 0; q < GP; ++q) {
+        T A = 0, B = 0;
+#pragma unroll
+        for (int k = 0; k < MB / 2; ++k) {
+            A += ha[2 * k] * w[4 * q + 2 * MB - 2 - 4 * k];
+            A += ha[2 * k + 1] * w[4 * q + 2 * MB - 4 - 4 * k];
+            B += hb[2 * k] * w[4 * q + 2 * MB - 1 - 4 * k];
+            B += hb[2 * k + 1] * w[4 * q + 2 * MB - 3 - 4 * k];
+        }
+        out[2 * q] = a_first ? A : B;
+        out[2 * q + 1] = a_first ? B : A;
+    }
+}
+
+// colifilt, taps centre padded to MB (cf. k_colifilt_march): input pair q -> outputs 4q..4q+3,
+// ACCUMULATED into acc
+template <int MB> struct IfiltGeo {
+    static constexpr int M2 = MB / 2;
+    static constexpr bool ODD = (M2 % 2) == 1;
+    static constexpr int WN = ODD ? MB : MB + 2;
+    static constexpr int ORG = ODD ? 1 - M2 : -M2;
+};
+template <typename T, int GJ, int MB, int WN>
+__device__ inline void fir_colifilt(const T (&w)[WN], const T *ha, const T *hb, int pos, T (&acc)[4 * GJ]) {
+    using IG = IfiltGeo<MB>;
+    constexpr int M2 = IG::M2;
+#pragma unroll
+    for (int q = 0; q < GJ; ++q) {
+        T y0 = 0, y1 = 0, y2 = 0, y3 = 0;
+        if constexpr (IG::ODD) {
+#pragma unroll
+            for (int k = 0; k < M2; ++k) {
+                const T hi = w[2 * q + MB - 1 - 2 * k], lo = w[2 * q + MB - 2 - 2 * k];
+                const T xa = pos ? hi : lo, xb = pos ? lo : hi;
+                y0 += ha[2 * k] * xb; y1 += hb[2 * k] * xa;
+                y2 += ha[2 * k + 1] * xb; y3 += hb[2 * k + 1] * xa;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < M2; ++k) {
+                const T t0 = w[2 * q + MB + 1 - 2 * k], t1 = w[2 * q + MB - 2 * k];
+                const T t2 = w[2 * q + MB - 1 - 2 * k], t3 = w[2 * q + MB - 2 - 2 * k];
+                const T xa = pos ? t0 : t1, xb = pos ? t1 : t0, xa2 = pos ? t2 : t3, xb2 = pos ? t3 : t2;
+                y0 += ha[2 * k + 1] * xb2; y1 += hb[2 * k + 1] * xa2;
+                y2 += ha[2 * k] * xb; y3 += hb[2 * k] * xa;
+            }
+        }
+        acc[4 * q] += y0; acc[4 * q + 1] += y1; acc[4 * q + 2] += y2; acc[4 * q + 3] += y3;
+    }
+}
+
+// ---- forward pass 1: (Lo, Hi) down the columns -------------------------------------------
+struct P1Geo {
+    int B, R, C;        // input [B][R][C]
+    int pad_lo, L;      // logical rows L = R + pad_lo + pad_hi
+    int nout;           // output rows
+    int ngroups;        // thread groups along the rows
+    int u_shift;        // window start = group origin + u_shift
+    int af0, af1;       // KIND 1: (A, B) order of the lo / hi pair
+};
+
+template <typename T, int KIND, int MB>
+__global__ void __launch_bounds__(256) k_g2_fwd_p1(const T *__restrict__ X, T *__restrict__ Lo,
+                                                   T *__restrict__ Hi, P1Geo g, QTaps<T> tp) {
+    const unsigned id = blockIdx.x * 256u + threadIdx.x;
+    const unsigned total = (unsigned)g.B * g.ngroups * g.C;
+    if (id >= total) return;
+    const unsigned t = id / g.C, c = id - t * g.C;
+    const unsigned b = t / g.ngroups, grp = t - b * g.ngroups;
+    const T *Xb = X + (size_t)b * g.R * g.C + c;
+    T *Lb = Lo + (size_t)b * g.nout * g.C + c, *Hb = Hi + (size_t)b * g.nout * g.C + c;
+    if constexpr (KIND == 0) {
+        constexpr int G = 8, WN = G + MB - 1;
+        const int lo0 = grp * G, u0 = lo0 + g.u_shift;
+        T w[WN];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) w[j] = Xb[(size_t)g2_src(u0 + j, g.L, g.pad_lo, g.R) * g.C];
+        T l[G], h[G];
+#pragma unroll
+        for (int q = 0; q < G; ++q) l[q] = h[q] = 0;
+        fir_colfilter<T, G, MB>(w, tp.a, l);
+        fir_colfilter<T, G, MB>(w, tp.b, h);
+#pragma unroll
+        for (int q = 0; q < G; ++q)
+            if (lo0 + q < g.nout) {
+                Lb[(size_t)(lo0 + q) * g.C] = l[q];
+                Hb[(size_t)(lo0 + q) * g.C] = h[q];
+            }
+    } else {
+        constexpr int GP = 4, WN = 4 * (GP - 1) + 2 * MB;
+        const int i0 = grp * GP, u0 = 4 * i0 + g.u_shift;
+        T w[WN];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) w[j] = Xb[(size_t)g2_src(u0 + j, g.L, g.pad_lo, g.R) * g.C];
+        T l[2 * GP], h[2 * GP];
+        fir_coldfilt<T, GP, MB>(w, tp.a, tp.b, g.af0, l);
+        fir_coldfilt<T, GP, MB>(w, tp.c, tp.d, g.af1, h);
+#pragma unroll
+        for (int q = 0; q < 2 * GP; ++q)
+            if (2 * i0 + q < g.nout) {
+                Lb[(size_t)(2 * i0 + q) * g.C] = l[q];
+                Hb[(size_t)(2 * i0 + q) * g.C] = h[q];
+            }
+    }
+}
+
+// ---- LDS row kernels: common geometry -----------------------------------------------------
+// A block of 256 threads = (256 / tpl) lines (or row pairs) x tpl threads per line; a thread
+// owns IN_STEP input samples of its line and the WIN-sample window that starts there.
+template <int KIND, int MB, bool INVERSE> struct RowGeo;
+template <int MB> struct RowGeo<0, MB, false> {      // colfilter, 4 outputs per thread
+    static constexpr int IN_STEP = 4, WIN = (4 + MB - 1 + 3) / 4 * 4, OUTS = 4;
+};
+template <int MB> struct RowGeo<1, MB, false> {      // coldfilt, 2 (A, B) pairs per thread
+    static constexpr int IN_STEP = 8, WIN = 4 + 2 * MB, OUTS = 4;
+};
+template <int MB> struct RowGeo<0, MB, true> {       // colfilter
+    static constexpr int IN_STEP = 4, WIN = (4 + MB - 1 + 3) / 4 * 4, OUTS = 4;
+};
+template <int MB> struct RowGeo<1, MB, true> {       // colifilt, 2 input pairs -> 8 outputs
+    static constexpr int IN_STEP = 4, WIN = IfiltGeo<MB>::WN + 2, OUTS = 8;
+};
+
+struct P2Geo {
+    int nlines;         // lines (inverse) or row pairs (forward) in the whole problem
+    int R1;             // forward: rows of Lo / Hi per image
+    int Cin;            // samples per input line
+    int pad_lo, L;      // logical line length L = Cin + pads
+    int Cout;           // written samples per output line
+    int crop;           // inverse: logical output samples dropped at the start
+    int tpl, tpl_log2;  // threads per line (power of two, 16..256)
+    int nseg;           // blocks per line
+    int span, stride;   // staged samples per line, LDS line stride (elements)
+    int region;         // LDS elements per line / row pair
+    int u_shift;
+    int f0, f1;         // a_first (forward KIND 1) or pos (inverse KIND 1) of the lo / hi pair
+};
+
+template <typename T>
+__device__ inline void stage_line(T *sm, const T *line, int q, int tpl, int span, int ublk, int L,
+                                  int pad_lo, int n) {
+    for (int s = q; s < span; s += tpl) sm[s] = line[g2_src(ublk + s, L, pad_lo, n)];
+}
+
+// 4 consecutive outputs of one row for the lo and the hi filter (forward pass 2)
+template <typename T, int KIND, int MB, int WIN>
+__device__ inline void fwd_row_fir(const T *wp, const QTaps<T> &tp, const P2Geo &g, T (&lo)[4], T (&hi)[4]) {
+    T w[WIN];
+    lds_window<T, WIN>(wp, w);
+    if constexpr (KIND == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lo[q] = hi[q] = 0;
+        fir_colfilter<T, 4, MB>(w, tp.a, lo);
+        fir_colfilter<T, 4, MB>(w, tp.b, hi);
+    } else {
+        fir_coldfilt<T, 2, MB>(w, tp.a, tp.b, g.f0, lo);
+        fir_coldfilt<T, 2, MB>(w, tp.c, tp.d, g.f1, hi);
+    }
+}
+
+// q2c of the two quads held as rows r0 / r1 of four columns into slots (s0, s1) of the two
+// pixel records rec[0], rec[1]  (dtcwt/numpy/transform2d.py:301-322)
+template <typename T>
+__device__ inline void q2c_pair(const T (&r0)[4], const T (&r1)[4], T (&rec)[2][12], int s0, int s1) {
+    const T s = (T)0.70710678118654752440;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const T a = r0[2 * t], b = r0[2 * t + 1], c = r1[2 * t], d = r1[2 * t + 1];
+        rec[t][2 * s0] = s * (a - d);
+        rec[t][2 * s0 + 1] = s * (b + c);
+        rec[t][2 * s1] = s * (a + d);
+        rec[t][2 * s1 + 1] = s * (b - c);
+    }
+}
+
+template <typename T>
+__device__ inline void store4(T *p, const T (&v)[4], int valid, bool vec_ok) {
+    using V = typename Vec16<T>::type;
+    constexpr int VN = Vec16<T>::N;
+    if (valid >= 4 && vec_ok) {
+#pragma unroll
+        for (int j = 0; j < 4 / VN; ++j) {
+            V x;
+            T *e = reinterpret_cast<T *>(&x);
+#pragma unroll
+            for (int t = 0; t < VN; ++t) e[t] = v[j * VN + t];
+            reinterpret_cast<V *>(p)[j] = x;
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (t < valid) p[t] = v[t];
+    }
+}
+
+// forward pass 2: Lo, Hi [B][R1][Cin] -> LoLo [B][R1][Cout], Yh [B][R1/2][Cout/2][6] complex
+template <typename T, int KIND, int MB>
+__global__ void __launch_bounds__(256) k_g2_fwd_p2(const T *__restrict__ Lo, const T *__restrict__ Hi,
+                                                   T *__restrict__ LoLo, T *__restrict__ Yh, P2Geo g,
+                                                   QTaps<T> tp) {
+    using RG = RowGeo<KIND, MB, false>;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int tid = threadIdx.x, q = tid & (g.tpl - 1), rp = tid >> g.tpl_log2;
+    const int seg = blockIdx.x % g.nseg, rpg = (blockIdx.x / g.nseg) * (256 >> g.tpl_log2) + rp;
+    const bool live = rpg < g.nlines;
+    T *sm = reinterpret_cast<T *>(smem_raw) + (size_t)rp * g.region;
+    const int ublk = seg * g.tpl * RG::IN_STEP + g.u_shift;
+    const size_t in0 = (size_t)rpg * 2 * g.Cin;               // rows 2 rpg, 2 rpg + 1 (all images stacked)
+    const int col0 = (seg * g.tpl + q) * 4;
+    const int valid = g.Cout - col0;                          // outputs of this thread that exist
+    const T *wp = sm + q * RG::IN_STEP;
+    const int C2 = g.Cout >> 1;
+    T rec[2][12];
+
+    if (live) {
+        stage_line(sm, Lo + in0, q, g.tpl, g.span, ublk, g.L, g.pad_lo, g.Cin);
+        stage_line(sm + g.stride, Lo + in0 + g.Cin, q, g.tpl, g.span, ublk, g.L, g.pad_lo, g.Cin);
+    }
+    __syncthreads();
+    if (live && valid > 0) {
+        T ll0[4], lh0[4], ll1[4], lh1[4];
+        fwd_row_fir<T, KIND, MB, RG::WIN>(wp, tp, g, ll0, lh0);
+        fwd_row_fir<T, KIND, MB, RG::WIN>(wp + g.stride, tp, g, ll1, lh1);
+        T *o = LoLo + (size_t)rpg * 2 * g.Cout + col0;
+        const bool vec_ok = ((g.Cout * sizeof(T)) & 15) == 0;
+        store4(o, ll0, valid, vec_ok);
+        store4(o + g.Cout, ll1, valid, vec_ok);
+        q2c_pair(lh0, lh1, rec, 2, 3);
+    }
+    __syncthreads();
+    if (live) {
+        stage_line(sm, Hi + in0, q, g.tpl, g.span, ublk, g.L, g.pad_lo, g.Cin);
+        stage_line(sm + g.stride, Hi + in0 + g.Cin, q, g.tpl, g.span, ublk, g.L, g.pad_lo, g.Cin);
+    }
+    __syncthreads();
+    if (live && valid > 0) {
+        T hl0[4], hh0[4], hl1[4], hh1[4];
+        fwd_row_fir<T, KIND, MB, RG::WIN>(wp, tp, g, hl0, hh0);
+        fwd_row_fir<T, KIND, MB, RG::WIN>(wp + g.stride, tp, g, hl1, hh1);
+        q2c_pair(hl0, hl1, rec, 0, 5);
+        q2c_pair(hh0, hh1, rec, 1, 4);
+    }
+    __syncthreads();
+    // records -> LDS -> contiguous 16-byte stores
+    using V = typename Vec16<T>::type;
+    constexpr int VN = Vec16<T>::N;
+    if (live && valid > 0) {
+        V *dst = reinterpret_cast<V *>(sm + q * 24);
+        const T *src = &rec[0][0];
+#pragma unroll
+        for (int j = 0; j < 24 / VN; ++j) {
+            V x;
+            T *e = reinterpret_cast<T *>(&x);
+#pragma unroll
+            for (int t = 0; t < VN; ++t) e[t] = src[j * VN + t];
+            dst[j] = x;
+        }
+    }
+    __syncthreads();
+    if (live) {
+        const int pix0 = seg * g.tpl * 2;
+        int npix = C2 - pix0;
+        npix = npix > 2 * g.tpl ? 2 * g.tpl : npix;
+        const int nvec = npix > 0 ? npix * 12 / VN : 0;
+        V *dst = reinterpret_cast<V *>(Yh + ((size_t)rpg * C2 + pix0) * 12);
+        const V *src = reinterpret_cast<const V *>(sm);
+        for (int e = q; e < nvec; e += g.tpl) dst[e] = src[e];
+    }
+}
+
+// inverse pass 2: Z = filter(y1, lo) + filter(y2, hi) along the contiguous axis
+template <typename T, int KIND, int MB>
+__global__ void __launch_bounds__(256) k_g2_inv_p2(const T *__restrict__ Y1, const T *__restrict__ Y2,
+                                                   T *__restrict__ Z, P2Geo g, QTaps<T> tp) {
+    using RG = RowGeo<KIND, MB, true>;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int tid = threadIdx.x, q = tid & (g.tpl - 1), ln = tid >> g.tpl_log2;
+    const int seg = blockIdx.x % g.nseg, line = (blockIdx.x / g.nseg) * (256 >> g.tpl_log2) + ln;
+    const bool live = line < g.nlines;
+    T *sm = reinterpret_cast<T *>(smem_raw) + (size_t)ln * g.region;
+    const int ublk = seg * g.tpl * RG::IN_STEP + g.u_shift;
+    if (live) {
+        stage_line(sm, Y1 + (size_t)line * g.Cin, q, g.tpl, g.span, ublk, g.L, 0, g.Cin);
+        stage_line(sm + g.stride, Y2 + (size_t)line * g.Cin, q, g.tpl, g.span, ublk, g.L, 0, g.Cin);
+    }
+    __syncthreads();
+    if (!live) return;
+    const T *wp = sm + q * RG::IN_STEP;
+    T acc[RG::OUTS];
+#pragma unroll
+    for (int k = 0; k < RG::OUTS; ++k) acc[k] = 0;
+    {
+        T w[RG::WIN];
+        lds_window<T, RG::WIN>(wp, w);
+        if constexpr (KIND == 0) fir_colfilter<T, 4, MB>(w, tp.a, acc);
+        else fir_colifilt<T, 2, MB>(w, tp.a, tp.b, g.f0, acc);
+    }
+    {
+        T w[RG::WIN];
+        lds_window<T, RG::WIN>(wp + g.stride, w);
+        if constexpr (KIND == 0) fir_colfilter<T, 4, MB>(w, tp.b, acc);
+        else fir_colifilt<T, 2, MB>(w, tp.c, tp.d, g.f1, acc);
+    }
+    const int lo0 = (seg * g.tpl + q) * RG::OUTS - g.crop;    // first written index of this thread
+    T *o = Z + (size_t)line * g.Cout;
+    const bool vec_ok = g.crop == 0 && ((g.Cout * sizeof(T)) & 15) == 0;
+#pragma unroll
+    for (int h = 0; h < RG::OUTS / 4; ++h) {
+        const int w0 = lo0 + 4 * h;
+        T v[4] = {acc[4 * h], acc[4 * h + 1], acc[4 * h + 2], acc[4 * h + 3]};
+        if (w0 >= 0 && w0 + 4 <= g.Cout && vec_ok) store4(o + w0, v, 4, true);
+        else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (w0 + t >= 0 && w0 + t < g.Cout) o[w0 + t] = v[t];
+        }
+    }
+}
+
+// ---- inverse pass 1: (y1, y2) down the columns, c2q on load --------------------------------
+struct I1Geo {
+    int B, Rl, C;       // lowpass input [B][Rl][C]; subbands [B][Rl/2][C/2][6]
+    int Rout;           // written rows of y1 / y2
+    int crop;           // logical output rows dropped at the start
+    int ngroups;
+    int u_shift;
+    int f0, f1;         // KIND 1: pos of the lo / hi pair
+};
+
+template <typename T, int WR>
+__device__ inline void load_plane_window(const T *__restrict__ Zb, const I1Geo &g, int u0, T (&w0)[WR], T (&w1)[WR]) {
+    using V2 = typename std::conditional<sizeof(T) == 4, float2, double2>::type;
+#pragma unroll
+    for (int j = 0; j < WR; ++j) {
+        const int r = g2_src(u0 + j, g.Rl, 0, g.Rl);
+        V2 v = *reinterpret_cast<const V2 *>(Zb + (size_t)r * g.C);
+        w0[j] = v.x; w1[j] = v.y;
+    }
+}
+
+// rows u0 .. u0+WR-1 (u0 even) of the plane c2q(w, s0, s1) at this thread's two columns
+// (dtcwt/numpy/transform2d.py:324-350); a reflected row pair is the same record, rows swapped
+template <typename T, int WR>
+__device__ inline void load_c2q_window(const T *__restrict__ Yb, const I1Geo &g, int u0, int s0, int s1,
+                                       T g0, T g1, T (&w0)[WR], T (&w1)[WR]) {
+    using V2 = typename std::conditional<sizeof(T) == 4, float2, double2>::type;
+    const size_t rstride = (size_t)(g.C >> 1) * 12;
+#pragma unroll
+    for (int p = 0; p < WR / 2; ++p) {
+        const int r = g2_src(u0 + 2 * p, g.Rl, 0, g.Rl);
+        const T *rec = Yb + (size_t)(r >> 1) * rstride;
+        const V2 z0 = *reinterpret_cast<const V2 *>(rec + 2 * s0);
+        const V2 z1 = *reinterpret_cast<const V2 *>(rec + 2 * s1);
+        const T w0r = z0.x * g0, w0i = z0.y * g0, w1r = z1.x * g1, w1i = z1.y * g1;
+        const T a = w0r + w1r, b = w0i + w1i, c = w0i - w1i, d = -(w0r - w1r);
+        const bool sw = r & 1;
+        w0[2 * p] = sw ? c : a; w1[2 * p] = sw ? d : b;
+        w0[2 * p + 1] = sw ? a : c; w1[2 * p + 1] = sw ? b : d;
+    }
+}
+
+template <typename T>
+struct Gains { T g[6]; };
+
+template <typename T, int KIND, int MB>
+__global__ void __launch_bounds__(256) k_g2_inv_p1(const T *__restrict__ Zl, const T *__restrict__ Yh,
+                                                   T *__restrict__ Y1, T *__restrict__ Y2, I1Geo g,
+                                                   QTaps<T> tp, Gains<T> gn) {
+    constexpr int OUTS = 8;
+    constexpr int WR = KIND == 0 ? 8 + MB : IfiltGeo<MB>::WN + 2;       // even, MB even
+    const unsigned C2 = g.C >> 1;
+    const unsigned id = blockIdx.x * 256u + threadIdx.x;
+    const unsigned total = (unsigned)g.B * g.ngroups * C2;
+    if (id >= total) return;
+    const unsigned t = id / C2, jc = id - t * C2;
+    const unsigned b = t / g.ngroups, grp = t - b * g.ngroups;
+    const T *Zb = Zl + (size_t)b * g.Rl * g.C + 2 * jc;
+    const T *Yb = Yh + ((size_t)b * (g.Rl >> 1) * C2 + jc) * 12;
+    const int u0 = (KIND == 0 ? grp * 8 : grp * 4) + g.u_shift;
+    using V2 = typename std::conditional<sizeof(T) == 4, float2, double2>::type;
+
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        T a0[OUTS], a1[OUTS];
+#pragma unroll
+        for (int k = 0; k < OUTS; ++k) a0[k] = a1[k] = 0;
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            T w0[WR], w1[WR];
+            if (half == 0 && part == 0) load_plane_window<T, WR>(Zb, g, u0, w0, w1);
+            else if (half == 0) load_c2q_window<T, WR>(Yb, g, u0, 0, 5, gn.g[0], gn.g[5], w0, w1);
+            else if (part == 0) load_c2q_window<T, WR>(Yb, g, u0, 2, 3, gn.g[2], gn.g[3], w0, w1);
+            else load_c2q_window<T, WR>(Yb, g, u0, 1, 4, gn.g[1], gn.g[4], w0, w1);
+            if constexpr (KIND == 0) {
+                fir_colfilter<T, 8, MB>(w0, part ? tp.b : tp.a, a0);
+                fir_colfilter<T, 8, MB>(w1, part ? tp.b : tp.a, a1);
+            } else {
+                fir_colifilt<T, 2, MB>(w0, part ? tp.c : tp.a, part ? tp.d : tp.b, part ? g.f1 : g.f0, a0);
+                fir_colifilt<T, 2, MB>(w1, part ? tp.c : tp.a, part ? tp.d : tp.b, part ? g.f1 : g.f0, a1);
+            }
+        }
+        T *Ob = (half ? Y2 : Y1) + (size_t)b * g.Rout * g.C + 2 * jc;
+        const int lo0 = (int)grp * 8 - g.crop;
+#pragma unroll
+        for (int k = 0; k < OUTS; ++k) {
+            const int r = lo0 + k;
+            if (r >= 0 && r < g.Rout) {
+                V2 v; v.x = a0[k]; v.y = a1[k];
+                *reinterpret_cast<V2 *>(Ob + (size_t)r * g.C) = v;
+            }
+        }
+    }
+}
+
+// ---- host side -----------------------------------------------------------------------------
+struct TapPrep {
+    double a[G2_MAXB], b[G2_MAXB], c[G2_MAXB], d[G2_MAXB];
+    int mb = 0, u_shift = 0, f0 = 0, f1 = 0;
+};
+
+double dotp(const double *x, const double *y, int m) {
+    double s = 0;
+    for (int k = 0; k < m; ++k) s += x[k] * y[k];
+    return s;
+}
+
+// level-1 pair of odd lengths: both symmetric padded to the longer, `front` zeros in front,
+// end padded to the bucket.  Window start of the output group at lo0: lo0 + u_shift.
+bool prep_level1(const double *h0, int m0, const double *h1, int m1, bool even_start, TapPrep &p) {
+    if (!(m0 & 1) || !(m1 & 1)) return false;
+    const int mm = m0 > m1 ? m0 : m1, cc = (mm - 1) / 2;
+    int mb = mm <= 7 ? 8 : 20;
+    int front = 0;
+    if (even_start && ((cc - (mb - 1)) & 1)) front = 1;
+    if (mm + front > mb) { if (mb == 8) { mb = 20; front = even_start && ((cc - 19) & 1) ? 1 : 0; } }
+    if (mm + front > mb) return false;
+    for (int k = 0; k < G2_MAXB; ++k) p.a[k] = p.b[k] = p.c[k] = p.d[k] = 0;
+    for (int k = 0; k < m0; ++k) p.a[front + (mm - m0) / 2 + k] = h0[k];
+    for (int k = 0; k < m1; ++k) p.b[front + (mm - m1) / 2 + k] = h1[k];
+    p.mb = mb;
+    p.u_shift = cc + front - (mb - 1);
+    return true;
+}
+
+// q-shift pairs for coldfilt: front padded to 10 / 20
+bool prep_dfilt(const double *ha0, const double *hb0, const double *ha1, const double *hb1, int m, TapPrep &p) {
+    if (m < 2 || (m & 1) || m > 20) return false;
+    const int mb = m <= 10 ? 10 : 20;
+    for (int k = 0; k < G2_MAXB; ++k) p.a[k] = p.b[k] = p.c[k] = p.d[k] = 0;
+    for (int k = 0; k < m; ++k) {
+        p.a[mb - m + k] = ha0[k]; p.b[mb - m + k] = hb0[k];
+        p.c[mb - m + k] = ha1[k]; p.d[mb - m + k] = hb1[k];
+    }
+    p.mb = mb;
+    p.u_shift = -m + 2;
+    p.f0 = dotp(ha0, hb0, m) > 0 ? 1 : 0;
+    p.f1 = dotp(ha1, hb1, m) > 0 ? 1 : 0;
+    return true;
+}
+
+// q-shift pairs for colifilt: centre padded (an even number of zeros per side) to the bucket of
+// the same m/2 parity: 10 / 18 (odd), 8 / 16 (even)
+bool prep_ifilt(const double *ha0, const double *hb0, const double *ha1, const double *hb1, int m, TapPrep &p) {
+    if (m < 2 || (m & 1)) return false;
+    const int mb = ((m / 2) & 1) ? (m <= 10 ? 10 : (m <= 18 ? 18 : 0)) : (m <= 8 ? 8 : (m <= 16 ? 16 : 0));
+    if (!mb) return false;
+    const int s = (mb - m) / 2;
+    for (int k = 0; k < G2_MAXB; ++k) p.a[k] = p.b[k] = p.c[k] = p.d[k] = 0;
+    for (int k = 0; k < m; ++k) {
+        p.a[s + k] = ha0[k]; p.b[s + k] = hb0[k];
+        p.c[s + k] = ha1[k]; p.d[s + k] = hb1[k];
+    }
+    p.mb = mb;
+    const int m2 = mb / 2;
+    p.u_shift = (m2 & 1) ? 1 - m2 : -m2;
+    p.f0 = dotp(ha0, hb0, m) > 0 ? 1 : 0;
+    p.f1 = dotp(ha1, hb1, m) > 0 ? 1 : 0;
+    return true;
+}
+
+template <typename T>
+QTaps<T> to_device_taps(const TapPrep &p) {
+    QTaps<T> t;
+    for (int k = 0; k < G2_MAXB; ++k) {
+        t.a[k] = (T)p.a[k]; t.b[k] = (T)p.b[k]; t.c[k] = (T)p.c[k]; t.d[k] = (T)p.d[k];
+    }
+    return t;
+}
+
+// threads per line: the power of two in [16, 256] that covers `need` threads with least waste
+void choose_tpl(int need, int &tpl, int &lg) {
+    lg = 4;
+    while (lg < 8 && (1 << lg) < need) ++lg;
+    tpl = 1 << lg;
+}
+
+// fill the LDS-row geometry; returns the dynamic LDS bytes
+template <typename T>
+size_t finish_rows(P2Geo &g, int in_step, int win, int threads_per_line, int rec_elems_per_thread) {
+    choose_tpl(threads_per_line, g.tpl, g.tpl_log2);
+    g.nseg = (threads_per_line + g.tpl - 1) / g.tpl;
+    g.span = g.tpl * in_step + win - in_step;
+    g.stride = g.span + 4;
+    const int a = 2 * g.stride, b = g.tpl * rec_elems_per_thread;
+    g.region = a > b ? a : b;
+    return (size_t)(256 / g.tpl) * g.region * sizeof(T);
+}
+
+constexpr int G2_NA = -3;       // "use the filter-by-filter path"
+
+}  // namespace
+
+#define G2_LAUNCH_CHECK() DT_CHECK_HIP(hipGetLastError())
+
+// KIND 0 buckets 8 / 20; coldfilt buckets 10 / 20; colifilt buckets 8 / 10 / 16 / 18
+#define G2_SWITCH_FWD(KERNEL, T_, ...)                                                     \
+    do {                                                                                   \
+        if (kind == 0) {                                                                   \
+            if (p.mb == 8) KERNEL<T_, 0, 8> __VA_ARGS__;                                    \
+            else KERNEL<T_, 0, 20> __VA_ARGS__;                                             \
+        } else {                                                                           \
+            if (p.mb == 10) KERNEL<T_, 1, 10> __VA_ARGS__;                                  \
+            else KERNEL<T_, 1, 20> __VA_ARGS__;                                             \
+        }                                                                                  \
+    } while (0)
+
+#define G2_SWITCH_INV(KERNEL, T_, ...)                                                     \
+    do {                                                                                   \
+        if (kind == 0) {                                                                   \
+            if (p.mb == 8) KERNEL<T_, 0, 8> __VA_ARGS__;                                    \
+            else KERNEL<T_, 0, 20> __VA_ARGS__;                                             \
+        } else {                                                                           \
+            if (p.mb == 8) KERNEL<T_, 1, 8> __VA_ARGS__;                                    \
+            else if (p.mb == 10) KERNEL<T_, 1, 10> __VA_ARGS__;                             \
+            else if (p.mb == 16) KERNEL<T_, 1, 16> __VA_ARGS__;                             \
+            else KERNEL<T_, 1, 18> __VA_ARGS__;                                             \
+        }                                                                                  \
+    } while (0)
+
+extern "C" {
+
+int dtcwt_hip_level2d_forward(dtcwt_hip_ctx *ctx, int dtype, int kind, const void *X, int64_t B,
+                              int64_t R, int64_t C, int pad_r_lo, int pad_r_hi, int pad_c_lo,
+                              int pad_c_hi, const double *lo_a, const double *lo_b,
+                              const double *hi_a, const double *hi_b, int m_lo, int m_hi,
+                              void *Lo, void *Hi, void *LoLo, void *Yh) {
+    DT_REQUIRE(ctx && X && Lo && Hi && LoLo && Yh && lo_a && hi_a, "NULL argument");
+    DT_REQUIRE(dtype == DTCWT_HIP_F32 || dtype == DTCWT_HIP_F64, "bad dtype %d", dtype);
+    DT_REQUIRE(kind == 0 || kind == 1, "bad kind %d", kind);
+    DT_REQUIRE(B >= 1 && R >= 1 && C >= 1, "bad extents");
+    TapPrep p;
+    if (kind == 0) {
+        if (!prep_level1(lo_a, m_lo, hi_a, m_hi, false, p)) return G2_NA;
+    } else {
+        DT_REQUIRE(lo_b && hi_b, "NULL argument");
+        if (m_lo != m_hi || !prep_dfilt(lo_a, lo_b, hi_a, hi_b, m_lo, p)) return G2_NA;
+    }
+    const int64_t LR = R + pad_r_lo + pad_r_hi, LC = C + pad_c_lo + pad_c_hi;
+    const int64_t R1 = kind == 0 ? LR : LR / 2, C1 = kind == 0 ? LC : LC / 2;
+    if (kind == 1 && ((LR & 3) || (LC & 3))) return G2_NA;
+    if ((R1 & 1) || (C1 & 1)) return G2_NA;
+    const int reach = p.mb + 4;      // every sample a written output needs is one bounce away
+    if (LR < reach || LC < reach) return G2_NA;
+    if (B * LR * LC >= ((int64_t)1 << 31) || B * R1 * C1 * 6 >= ((int64_t)1 << 31)) return G2_NA;
+    DT_CHECK_HIP(hipSetDevice(ctx->device));
+
+    P1Geo g1;
+    g1.B = (int)B; g1.R = (int)R; g1.C = (int)C;
+    g1.pad_lo = pad_r_lo; g1.L = (int)LR; g1.nout = (int)R1;
+    g1.ngroups = kind == 0 ? (int)((R1 + 7) / 8) : (int)((R1 / 2 + 3) / 4);
+    g1.u_shift = p.u_shift; g1.af0 = p.f0; g1.af1 = p.f1;
+    const unsigned blocks1 = (unsigned)(((int64_t)g1.B * g1.ngroups * g1.C + 255) / 256);
+
+    P2Geo g2;
+    g2.nlines = (int)(B * R1 / 2); g2.R1 = (int)R1; g2.Cin = (int)C;
+    g2.pad_lo = pad_c_lo; g2.L = (int)LC; g2.Cout = (int)C1; g2.crop = 0;
+    g2.u_shift = p.u_shift; g2.f0 = p.f0; g2.f1 = p.f1;
+    const int in_step = kind == 0 ? 4 : 8;
+    const int win = kind == 0 ? (4 + p.mb - 1 + 3) / 4 * 4 : 4 + 2 * p.mb;
+    size_t lds;
+    if (dtype == DTCWT_HIP_F32) lds = finish_rows<float>(g2, in_step, win, (int)((C1 + 3) / 4), 24);
+    else lds = finish_rows<double>(g2, in_step, win, (int)((C1 + 3) / 4), 24);
+    const int rpb = 256 / g2.tpl;
+    const unsigned blocks2 = (unsigned)(((g2.nlines + rpb - 1) / rpb) * g2.nseg);
+
+    if (dtype == DTCWT_HIP_F32) {
+        QTaps<float> t = to_device_taps<float>(p);
+        G2_SWITCH_FWD(k_g2_fwd_p1, float, <<<blocks1, 256, 0, ctx->stream>>>((const float *)X, (float *)Lo, (float *)Hi, g1, t));
+        G2_LAUNCH_CHECK();
+        G2_SWITCH_FWD(k_g2_fwd_p2, float, <<<blocks2, 256, lds, ctx->stream>>>((const float *)Lo, (const float *)Hi, (float *)LoLo, (float *)Yh, g2, t));
+    } else {
+        QTaps<double> t = to_device_taps<double>(p);
+        G2_SWITCH_FWD(k_g2_fwd_p1, double, <<<blocks1, 256, 0, ctx->stream>>>((const double *)X, (double *)Lo, (double *)Hi, g1, t));
+        G2_LAUNCH_CHECK();
+        G2_SWITCH_FWD(k_g2_fwd_p2, double, <<<blocks2, 256, lds, ctx->stream>>>((const double *)Lo, (const double *)Hi, (double *)LoLo, (double *)Yh, g2, t));
+    }
+    G2_LAUNCH_CHECK();
+    return 0;
+}
+
+int dtcwt_hip_level2d_inverse(dtcwt_hip_ctx *ctx, int dtype, int kind, const void *Zl, const void *Yh,
+                              int64_t B, int64_t Rl, int64_t Cl, const double *gains6,
+                              int crop_r, int crop_c, const double *lo_a, const double *lo_b,
+                              const double *hi_a, const double *hi_b, int m_lo, int m_hi,
+                              void *Y1, void *Y2, void *Z) {
+    DT_REQUIRE(ctx && Zl && Yh && Y1 && Y2 && Z && lo_a && hi_a && gains6, "NULL argument");
+    DT_REQUIRE(dtype == DTCWT_HIP_F32 || dtype == DTCWT_HIP_F64, "bad dtype %d", dtype);
+    DT_REQUIRE(kind == 0 || kind == 1, "bad kind %d", kind);
+    DT_REQUIRE(B >= 1 && Rl >= 2 && Cl >= 2 && crop_r >= 0 && crop_c >= 0, "bad extents");
+    if ((Rl & 1) || (Cl & 1)) return G2_NA;
+    TapPrep p;
+    if (kind == 0) {
+        if (crop_r || crop_c) return G2_NA;
+        if (!prep_level1(lo_a, m_lo, hi_a, m_hi, true, p)) return G2_NA;
+    } else {
+        DT_REQUIRE(lo_b && hi_b, "NULL argument");
+        if (m_lo != m_hi || !prep_ifilt(lo_a, lo_b, hi_a, hi_b, m_lo, p)) return G2_NA;
+    }
+    const int reach = p.mb + 4;      // every sample a written output needs is one bounce away
+    if (Rl < reach || Cl < reach) return G2_NA;
+    const int64_t Rout = (kind == 0 ? Rl : 2 * Rl) - 2 * crop_r, Cout = (kind == 0 ? Cl : 2 * Cl) - 2 * crop_c;
+    if (B * Rout * Cout >= ((int64_t)1 << 31) || B * Rl * Cl * 3 >= ((int64_t)1 << 31)) return G2_NA;
+    DT_CHECK_HIP(hipSetDevice(ctx->device));
+
+    I1Geo g1;
+    g1.B = (int)B; g1.Rl = (int)Rl; g1.C = (int)Cl;
+    g1.Rout = (int)Rout; g1.crop = crop_r;
+    g1.ngroups = kind == 0 ? (int)((Rl + 7) / 8) : (int)((Rl / 2 + 1) / 2);
+    g1.u_shift = p.u_shift; g1.f0 = p.f0; g1.f1 = p.f1;
+    const unsigned blocks1 = (unsigned)(((int64_t)g1.B * g1.ngroups * (Cl / 2) + 255) / 256);
+
+    P2Geo g2;
+    g2.nlines = (int)(B * Rout); g2.R1 = 0; g2.Cin = (int)Cl; g2.pad_lo = 0; g2.L = (int)Cl;
+    g2.Cout = (int)Cout; g2.crop = crop_c;
+    // pass 2 has no parity constraint on its window start: level 1 reuses the pass-1 padding
+    g2.u_shift = p.u_shift; g2.f0 = p.f0; g2.f1 = p.f1;
+    const int win = kind == 0 ? (4 + p.mb - 1 + 3) / 4 * 4 : ((((p.mb / 2) & 1) ? p.mb : p.mb + 2) + 2);
+    const int tpl_need = kind == 0 ? (int)((Cl + 3) / 4) : (int)((Cl / 2 + 1) / 2);
+    size_t lds;
+    if (dtype == DTCWT_HIP_F32) lds = finish_rows<float>(g2, 4, win, tpl_need, 0);
+    else lds = finish_rows<double>(g2, 4, win, tpl_need, 0);
+    const int lpb = 256 / g2.tpl;
+    const unsigned blocks2 = (unsigned)(((g2.nlines + lpb - 1) / lpb) * g2.nseg);
+    const double s = 0.70710678118654752440;
+
+    if (dtype == DTCWT_HIP_F32) {
+        QTaps<float> t = to_device_taps<float>(p);
+        Gains<float> gn;
+        for (int k = 0; k < 6; ++k) gn.g[k] = (float)(s * gains6[k]);
+        G2_SWITCH_INV(k_g2_inv_p1, float, <<<blocks1, 256, 0, ctx->stream>>>((const float *)Zl, (const float *)Yh, (float *)Y1, (float *)Y2, g1, t, gn));
+        G2_LAUNCH_CHECK();
+        G2_SWITCH_INV(k_g2_inv_p2, float, <<<blocks2, 256, lds, ctx->stream>>>((const float *)Y1, (const float *)Y2, (float *)Z, g2, t));
+    } else {
+        QTaps<double> t = to_device_taps<double>(p);
+        Gains<double> gn;
+        for (int k = 0; k < 6; ++k) gn.g[k] = s * gains6[k];
+        G2_SWITCH_INV(k_g2_inv_p1, double, <<<blocks1, 256, 0, ctx->stream>>>((const double *)Zl, (const double *)Yh, (double *)Y1, (double *)Y2, g1, t, gn));
+        G2_LAUNCH_CHECK();
+        G2_SWITCH_INV(k_g2_inv_p2, double, <<<blocks2, 256, lds, ctx->stream>>>((const double *)Y1, (const double *)Y2, (double *)Z, g2, t));
+    }
+    G2_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -20,7 +20,7 @@ from dtcwt_amd.hip._lib import DeviceArray, View, check, dtype_code, taps_arg
 
 __all__ = ['colfilter', 'coldfilt', 'colifilt', 'axis_colfilter', 'axis_coldfilt',
            'axis_colifilt', 'axis_colfilter2', 'axis_colfilter_sum2', 'axis_coldfilt2',
-           'axis_colifilt_sum2', 'q2c', 'c2q']
+           'axis_colifilt_sum2', 'q2c', 'c2q', 'level2d_forward', 'level2d_inverse']
 
 
 def _prod(t):
@@ -208,6 +208,72 @@ def c2q(Yh, slot0, slot1, gain0, gain1, out=None):
     check(_lib.lib().dtcwt_hip_c2q(Yh.ctx.handle, dtype_code(Yh.dtype), Yh.ptr, batch, R, C, slot0, slot1,
                                    float(gain0), float(gain1), out.ptr, 4 * R * C, 2 * C))
     return out
+
+
+def _check_na(rc):
+    """-3 = "not applicable, use the filter-by-filter kernels"; anything else non-zero raises."""
+    if rc == -3:
+        return False
+    check(rc)
+    return True
+
+
+def level2d_forward(X, kind, pad_r, pad_c, lo, hi):
+    """One whole forward level of the 2-D transform on X [B, R, C] in two launches
+    (dtcwt_hip_level2d_forward): kind 0 = level 1 with the odd-length pair lo = h0o, hi = h1o
+    (dtcwt/numpy/transform2d.py:112-130); kind 1 = a level >= 2 with the q-shift pairs
+    lo = (h0b, h0a), hi = (h1b, h1a) in coldfilt's argument order (:132-160).  Returns
+    (LoLo, Yh) or None when the library has no such kernel for these filters / sizes."""
+    B, R, C = X.shape
+    LR, LC = R + pad_r[0] + pad_r[1], C + pad_c[0] + pad_c[1]
+    if kind == 0:
+        (k0, pa0, m0), (k1, pa1, m1) = taps_arg(lo), taps_arg(hi)
+        pb0 = pb1 = None
+        R1, C1 = LR, LC
+    else:
+        k0, pa0, pb0, m0 = _pair_args(*lo)
+        k1, pa1, pb1, m1 = _pair_args(*hi)
+        R1, C1 = LR // 2, LC // 2
+    if R1 % 2 or C1 % 2 or (kind == 1 and (LR % 4 or LC % 4)):
+        return None
+    cdt = np.complex64 if X.dtype == np.float32 else np.complex128
+    Lo = DeviceArray(X.ctx, (B, R1, C), X.dtype)
+    Hi = DeviceArray(X.ctx, (B, R1, C), X.dtype)
+    LoLo = DeviceArray(X.ctx, (B, R1, C1), X.dtype)
+    Yh = DeviceArray(X.ctx, (B, R1 // 2, C1 // 2, 6), cdt)
+    rc = _lib.lib().dtcwt_hip_level2d_forward(
+        X.ctx.handle, dtype_code(X.dtype), kind, X.ptr, B, R, C, int(pad_r[0]), int(pad_r[1]),
+        int(pad_c[0]), int(pad_c[1]), pa0, pb0, pa1, pb1, m0, m1, Lo.ptr, Hi.ptr, LoLo.ptr, Yh.ptr)
+    return (LoLo, Yh) if _check_na(rc) else None
+
+
+def level2d_inverse(Zl, Yh, kind, gains, crop_r, crop_c, lo, hi):
+    """One whole inverse level in two launches (dtcwt_hip_level2d_inverse): Zl [B, Rl, Cl]
+    lowpass, Yh [B, Rl/2, Cl/2, 6] subbands with per-subband *gains*; kind 0 = level 1 with
+    lo = g0o, hi = g1o (dtcwt/numpy/transform2d.py:275-293), kind 1 = a level >= 2 with
+    lo = (g0b, g0a), hi = (g1b, g1a) in colifilt's argument order and crop_r / crop_c output
+    samples dropped from both ends (:242-273).  Returns Z or None (no kernel for this case)."""
+    B, Rl, Cl = Zl.shape
+    if Yh.shape != (B, Rl // 2, Cl // 2, 6) or Rl % 2 or Cl % 2:
+        return None
+    if kind == 0:
+        (k0, pa0, m0), (k1, pa1, m1) = taps_arg(lo), taps_arg(hi)
+        pb0 = pb1 = None
+        Rz, Cz = Rl, Cl
+    else:
+        k0, pa0, pb0, m0 = _pair_args(*lo)
+        k1, pa1, pb1, m1 = _pair_args(*hi)
+        Rz, Cz = 2 * Rl - 2 * crop_r, 2 * Cl - 2 * crop_c
+    if Rz < 1 or Cz < 1:
+        return None
+    g = (ctypes.c_double * 6)(*[float(v) for v in gains])
+    Y1 = DeviceArray(Zl.ctx, (B, Rz, Cl), Zl.dtype)
+    Y2 = DeviceArray(Zl.ctx, (B, Rz, Cl), Zl.dtype)
+    Z = DeviceArray(Zl.ctx, (B, Rz, Cz), Zl.dtype)
+    rc = _lib.lib().dtcwt_hip_level2d_inverse(
+        Zl.ctx.handle, dtype_code(Zl.dtype), kind, Zl.ptr, Yh.ptr, B, Rl, Cl, g, int(crop_r), int(crop_c),
+        pa0, pb0, pa1, pb1, m0, m1, Y1.ptr, Y2.ptr, Z.ptr)
+    return Z if _check_na(rc) else None
 
 
 # ------------------------------------------------------------------ public functions

@@ -255,6 +255,12 @@ class Transform2d(object):
             # lo and hi filter of one pass in one launch (dtcwt_hip_coldfilt2)
             lo, hi = (h0b, h0a), (h1b, h1a)
             prev = LoLo
+            whole = None if bp2 else ll.level2d_forward(prev, 1, pr, pc, lo, hi)
+            if whole is not None:       # the level in two launches (dtcwt_hip_level2d_forward)
+                LoLo, y = whole
+                Yh.append(y)
+                Ys.append(LoLo)
+                continue
             Lo, Hi = ll.axis_coldfilt2(prev, lo, hi, axis=1, pad=pr)
             LoLo, LoHi = ll.axis_coldfilt2(Lo, lo, hi, axis=2, pad=pc)
             y = DeviceArray(ctx, (B, LoLo.shape[1] >> 1, LoLo.shape[2] >> 1, 6), cdt)
@@ -278,6 +284,11 @@ class Transform2d(object):
         B = Xd.shape[0]
         # level 1 (transform2d.py:112-130); odd sizes extended by index math (:86-94)
         pr, pc = (0, lv[0]['padR']), (0, lv[0]['padC'])
+        whole = None if bp1 else ll.level2d_forward(Xd, 0, pr, pc, h0o, h1o)
+        if whole is not None:           # the level in two launches (dtcwt_hip_level2d_forward)
+            Yh.append(whole[1])
+            Ys.append(whole[0])
+            return whole[0]
         Lo, Hi = ll.axis_colfilter2(Xd, h0o, h1o, axis=1, pad=pr)
         LoLo, LoHi = ll.axis_colfilter2(Lo, h0o, h1o, axis=2, pad=pc)
         y = DeviceArray(Xd.ctx, (B, LoLo.shape[1] >> 1, LoLo.shape[2] >> 1, 6), cdt)
@@ -408,6 +419,12 @@ class Transform2d(object):
         while level >= 2 and level > stop_level:             # transform2d.py:242-273
             w, g = Yh[level - 1], gm[:, level - 1]
             cr, cc = crops[level - 1]
+            lo, hi = (g0b, g0a), (g1b, g1a)
+            whole = None if bp2 else ll.level2d_inverse(Z, w, 1, g, cr, cc, lo, hi)
+            if whole is not None:       # the level in two launches (dtcwt_hip_level2d_inverse)
+                Z = whole
+                level -= 1
+                continue
             lh = ll.c2q(w, 0, 5, g[0], g[5])
             hl = ll.c2q(w, 2, 3, g[2], g[3])
             hh = ll.c2q(w, 1, 4, g[1], g[4])
@@ -425,6 +442,9 @@ class Transform2d(object):
             level -= 1
         if level == 1 and stop_level == 0:                   # :275-293
             w, g = Yh[0], gm[:, 0]
+            whole = None if bp1 else ll.level2d_inverse(Z, w, 0, g, 0, 0, g0o, g1o)
+            if whole is not None:
+                return whole
             lh = ll.c2q(w, 0, 5, g[0], g[5])
             hl = ll.c2q(w, 2, 3, g[2], g[3])
             hh = ll.c2q(w, 1, 4, g[1], g[4])

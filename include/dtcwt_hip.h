@@ -143,6 +143,38 @@ int dtcwt_hip_q2c(dtcwt_hip_ctx *ctx, int dtype, const void *y, int64_t batch, i
 int dtcwt_hip_c2q(dtcwt_hip_ctx *ctx, int dtype, const void *Yh, int64_t batch, int64_t rows,
                   int64_t cols, int slot0, int slot1, double gain0, double gain1, void *x,
                   int64_t x_sb, int64_t x_sr);
+/* One whole 2-D level, any wavelet length, float32 or float64, in two launches (the path of
+ * every dtype / wavelet without a fused float32 tile program; float64 is what the reference
+ * computes in for non-float32 input, dtcwt/utils.py:104-134).
+ *
+ * level2d_forward replaces one iteration of dtcwt/numpy/transform2d.py:112-130 (kind 0,
+ * level 1: Lo/Hi = colfilter(X, lo_a / hi_a) down the columns, then along the rows, then the
+ * three q2c, :301-322) or of :132-160 (kind 1, levels >= 2: coldfilt with the pairs
+ * (lo_a, lo_b) / (hi_a, hi_b) in the argument order of coldfilt).  X: [B][R][C]; rows / columns
+ * are logically replicated by (pad_r_lo, pad_r_hi) / (pad_c_lo, pad_c_hi) (the odd-size and
+ * multiple-of-4 extensions of :86-94, :134-143).  R1 x C1 = padded size (kind 0) or half of it
+ * (kind 1).  Lo, Hi: scratch [B][R1][C]; LoLo: [B][R1][C1]; Yh: [B][R1/2][C1/2][6] complex.
+ *
+ * level2d_inverse replaces one iteration of :275-293 (kind 0) or :242-273 (kind 1): the three
+ * c2q (:324-350, gains6[k] = gain of subband k) and the column / row synthesis filters with
+ * their sums.  Zl: [B][Rl][Cl] lowpass; Yh: [B][Rl/2][Cl/2][6]; kind 1 drops crop_r / crop_c
+ * output samples from both ends of the rows / columns (the size fix-up of :246-252).  With
+ * (Rz, Cz) = (Rl, Cl) for kind 0, (2 Rl - 2 crop_r, 2 Cl - 2 crop_c) for kind 1:
+ * Y1, Y2: scratch [B][Rz][Cl]; Z: [B][Rz][Cz].
+ *
+ * Both return -3 (caller uses the filter-by-filter entry points above) for even-length
+ * level-1 filters, pairs of unequal length, wavelets longer than the largest compile-time
+ * bucket, and planes narrower than the filter bucket + 4. */
+int dtcwt_hip_level2d_forward(dtcwt_hip_ctx *ctx, int dtype, int kind, const void *X, int64_t B,
+                              int64_t R, int64_t C, int pad_r_lo, int pad_r_hi, int pad_c_lo,
+                              int pad_c_hi, const double *lo_a, const double *lo_b,
+                              const double *hi_a, const double *hi_b, int m_lo, int m_hi,
+                              void *Lo, void *Hi, void *LoLo, void *Yh);
+int dtcwt_hip_level2d_inverse(dtcwt_hip_ctx *ctx, int dtype, int kind, const void *Zl, const void *Yh,
+                              int64_t B, int64_t Rl, int64_t Cl, const double *gains6,
+                              int crop_r, int crop_c, const double *lo_a, const double *lo_b,
+                              const double *hi_a, const double *hi_b, int m_lo, int m_hi,
+                              void *Y1, void *Y2, void *Z);
 /* Fused float32 level 1 of the 3-D forward transform: replaces `_level1_xfm`
  * (dtcwt/numpy/transform3d.py:208-289) for odd-length biort filters -- the three axis
  * passes (h0o/h1o along axes 2, 1, 0) and the seven cube2c packings in ONE launch.

@@ -361,3 +361,89 @@ def test_inverse_of_a_device_pyramid_never_touches_the_host():
     t1.inverse(p1, device_output=True)
     assert p1._host == {}
     assert_close(z.get(), X, INV_TOL, 'PR')
+
+
+# ---- the two-launch levels of generic2d.hip (every dtype / wavelet without a fused plan) ----
+GENERIC_WAVES = [w for w in WAVES if 'bp' not in w[0]]
+
+
+@pytest.mark.parametrize('bn,qn', GENERIC_WAVES)
+@pytest.mark.parametrize('shape', [(96, 128), (97, 123), (130, 70), (200, 88)])
+def test_float64_levels_vs_oracle(bn, qn, shape):
+    rs = np.random.RandomState(23)
+    X = rs.standard_normal(shape)
+    t, to = Transform2d(bn, qn), o.Transform2d(biort(bn), qshift(qn))
+    for nl in (1, 2, 4):
+        want = to.forward(X, nlevels=nl, include_scale=True)
+        p = t.forward(X, nlevels=nl, include_scale=True)
+        assert p.lowpass.dtype == np.float64 and p.highpasses[0].dtype == np.complex128
+        assert_pyramids_close(p, want, F64_TOL)
+        gm = rs.uniform(0.3, 1.4, size=(6, nl)) * (rs.uniform(size=(6, nl)) > 0.25)
+        for g in (None, gm):
+            assert_close(t.inverse(want, g), to.inverse(want, g), 1e-11, 'inverse f64 nl=%d' % nl)
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+@pytest.mark.parametrize('bn,qn', [('near_sym_a', 'qshift_a'), ('near_sym_b', 'qshift_d'), ('antonini', 'qshift_06'),
+                                   ('legall', 'qshift_c'), ('near_sym_b', 'qshift_b')])
+def test_two_launch_level_matches_filter_by_filter(dtype, bn, qn):
+    """dtcwt_hip_level2d_forward / _inverse against the same level built from the public
+    colfilter / coldfilt / colifilt + q2c / c2q launches, batch of 3, padded and cropped."""
+    from dtcwt_amd.hip import lowlevel as ll
+    ctx = default_context()
+    rs = np.random.RandomState(5)
+    h0o, g0o, h1o, g1o = biort(bn)[:4]
+    h0a, h0b, g0a, g0b, h1a, h1b, g1a, g1b = qshift(qn)[:8]
+    tol = 2e-6 if dtype == np.float32 else 1e-13
+    cdt = np.complex64 if dtype == np.float32 else np.complex128
+    X = ctx.to_device(rs.standard_normal((3, 91, 118)).astype(dtype))
+    # level 1, odd rows extended by one (pad (0, 1))
+    got = ll.level2d_forward(X, 0, (0, 1), (0, 0), h0o, h1o)
+    assert got is not None
+    Lo, Hi = ll.axis_colfilter2(X, h0o, h1o, axis=1, pad=(0, 1))
+    LoLo, LoHi = ll.axis_colfilter2(Lo, h0o, h1o, axis=2)
+    HiLo, HiHi = ll.axis_colfilter2(Hi, h0o, h1o, axis=2)
+    y = DeviceArray(ctx, (3, 46, 59, 6), cdt)
+    ll.q2c(LoHi, y, 2, 3); ll.q2c(HiLo, y, 0, 5); ll.q2c(HiHi, y, 1, 4)
+    assert_close(got[0].get(), LoLo.get(), tol, 'LoLo level 1')
+    assert_close(got[1].get(), y.get(), tol, 'Yh level 1')
+    # level 2 on the 92 x 118 lowpass: columns padded by one each side to a multiple of 4
+    lo, hi = (h0b, h0a), (h1b, h1a)
+    got2 = ll.level2d_forward(LoLo, 1, (0, 0), (1, 1), lo, hi)
+    assert got2 is not None
+    Lo, Hi = ll.axis_coldfilt2(LoLo, lo, hi, axis=1)
+    L2, LH = ll.axis_coldfilt2(Lo, lo, hi, axis=2, pad=(1, 1))
+    HL, HH = ll.axis_coldfilt2(Hi, lo, hi, axis=2, pad=(1, 1))
+    y2 = DeviceArray(ctx, (3, 23, 30, 6), cdt)
+    ll.q2c(LH, y2, 2, 3); ll.q2c(HL, y2, 0, 5); ll.q2c(HH, y2, 1, 4)
+    assert_close(got2[0].get(), L2.get(), tol, 'LoLo level 2')
+    assert_close(got2[1].get(), y2.get(), tol, 'Yh level 2')
+    # inverse of level 2 with gains and the column crop that undoes the padding
+    g = rs.uniform(0.4, 1.3, size=6)
+    lo, hi = (g0b, g0a), (g1b, g1a)
+    Z = ll.level2d_inverse(L2, y2, 1, g, 0, 1, lo, hi)
+    assert Z is not None and Z.shape == (3, 92, 118)
+    lh, hl, hh = ll.c2q(y2, 0, 5, g[0], g[5]), ll.c2q(y2, 2, 3, g[2], g[3]), ll.c2q(y2, 1, 4, g[1], g[4])
+    y1 = ll.axis_colifilt_sum2(L2, lh, lo, hi, axis=1)
+    yb = ll.axis_colifilt_sum2(hl, hh, lo, hi, axis=1)
+    want = ll.axis_colifilt_sum2(y1, yb, lo, hi, axis=2, crop=(1, 1))
+    assert_close(Z.get(), want.get(), tol, 'inverse level 2')
+    # inverse of level 1
+    Z1 = ll.level2d_inverse(Z, y, 0, g, 0, 0, g0o, g1o)
+    assert Z1 is not None
+    lh, hl, hh = ll.c2q(y, 0, 5, g[0], g[5]), ll.c2q(y, 2, 3, g[2], g[3]), ll.c2q(y, 1, 4, g[1], g[4])
+    y1 = ll.axis_colfilter_sum2(Z, lh, g0o, g1o, axis=1)
+    yb = ll.axis_colfilter_sum2(hl, hh, g0o, g1o, axis=1)
+    want = ll.axis_colfilter_sum2(y1, yb, g0o, g1o, axis=2)
+    assert_close(Z1.get(), want.get(), tol, 'inverse level 1')
+
+
+def test_two_launch_level_declines_what_it_cannot_do():
+    from dtcwt_amd.hip import lowlevel as ll
+    ctx = default_context()
+    X = ctx.to_device(np.zeros((1, 8, 8)))
+    h0o, g0o, h1o, g1o = biort('near_sym_a')[:4]
+    assert ll.level2d_forward(X, 0, (0, 0), (0, 0), h0o, h1o) is None            # plane too small
+    X = ctx.to_device(np.zeros((1, 128, 128)))
+    assert ll.level2d_forward(X, 0, (0, 0), (0, 0), np.ones(4) / 4, np.ones(4) / 4) is None   # even-length level 1
+    assert ll.level2d_forward(X, 0, (0, 0), (0, 0), np.ones(23) / 23, h1o) is None          # longer than the buckets
