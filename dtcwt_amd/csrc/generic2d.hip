@@ -295,9 +295,16 @@ __global__ void __launch_bounds__(256) k_g2_fwd_p2(const T *__restrict__ Lo, con
     const int C2 = g.Cout >> 1;
     T rec[2][12];
 
+    // KIND 0 stages the Lo and the Hi rows together (they fit the LDS the records need anyway);
+    // KIND 1 (twice the input per thread) one image after the other.
+    constexpr bool BOTH = KIND == 0;
     if (live) {
         stage_line(sm, Lo + in0, q, g.tpl, g.span, ublk, g.L, g.pad_lo, g.Cin);
         stage_line(sm + g.stride, Lo + in0 + g.Cin, q, g.tpl, g.span, ublk, g.L, g.pad_lo, g.Cin);
+        if (BOTH) {
+            stage_line(sm + 2 * g.stride, Hi + in0, q, g.tpl, g.span, ublk, g.L, g.pad_lo, g.Cin);
+            stage_line(sm + 3 * g.stride, Hi + in0 + g.Cin, q, g.tpl, g.span, ublk, g.L, g.pad_lo, g.Cin);
+        }
     }
     __syncthreads();
     if (live && valid > 0) {
@@ -310,16 +317,19 @@ __global__ void __launch_bounds__(256) k_g2_fwd_p2(const T *__restrict__ Lo, con
         store4(o + g.Cout, ll1, valid, vec_ok);
         q2c_pair(lh0, lh1, rec, 2, 3);
     }
-    __syncthreads();
-    if (live) {
-        stage_line(sm, Hi + in0, q, g.tpl, g.span, ublk, g.L, g.pad_lo, g.Cin);
-        stage_line(sm + g.stride, Hi + in0 + g.Cin, q, g.tpl, g.span, ublk, g.L, g.pad_lo, g.Cin);
+    if (!BOTH) {
+        __syncthreads();
+        if (live) {
+            stage_line(sm, Hi + in0, q, g.tpl, g.span, ublk, g.L, g.pad_lo, g.Cin);
+            stage_line(sm + g.stride, Hi + in0 + g.Cin, q, g.tpl, g.span, ublk, g.L, g.pad_lo, g.Cin);
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (live && valid > 0) {
+        const T *hp = wp + (BOTH ? 2 * g.stride : 0);
         T hl0[4], hh0[4], hl1[4], hh1[4];
-        fwd_row_fir<T, KIND, MB, RG::WIN>(wp, tp, g, hl0, hh0);
-        fwd_row_fir<T, KIND, MB, RG::WIN>(wp + g.stride, tp, g, hl1, hh1);
+        fwd_row_fir<T, KIND, MB, RG::WIN>(hp, tp, g, hl0, hh0);
+        fwd_row_fir<T, KIND, MB, RG::WIN>(hp + g.stride, tp, g, hl1, hh1);
         q2c_pair(hl0, hl1, rec, 0, 5);
         q2c_pair(hh0, hh1, rec, 1, 4);
     }
@@ -401,44 +411,59 @@ __global__ void __launch_bounds__(256) k_g2_inv_p2(const T *__restrict__ Y1, con
 }
 
 // ---- inverse pass 1: (y1, y2) down the columns, c2q on load --------------------------------
+// A block is 256 adjacent column pairs x one group of 8 output rows.  The window is consumed
+// one subband-record row (= two image rows) at a time: the block copies the 256 records of that
+// row into LDS with contiguous 16-byte loads (a record is 48 / 96 bytes, so per-lane record
+// loads would touch every cache line six times), every thread takes its own record back, undoes
+// the q2c packing of all three planes at once and SCATTERS the two rows into the output
+// accumulators (tap index = output row - input row, a compile-time constant once the loops
+// are unrolled) -- no register window, every record read once per row group.  The next row's
+// records and lowpass samples are in flight while the current one is consumed.
 struct I1Geo {
     int B, Rl, C;       // lowpass input [B][Rl][C]; subbands [B][Rl/2][C/2][6]
     int Rout;           // written rows of y1 / y2
     int crop;           // logical output rows dropped at the start
-    int ngroups;
+    int ngroups;        // groups of 8 output rows
+    int bpr;            // blocks per row of column pairs
     int u_shift;
     int f0, f1;         // KIND 1: pos of the lo / hi pair
 };
 
-template <typename T, int WR>
-__device__ inline void load_plane_window(const T *__restrict__ Zb, const I1Geo &g, int u0, T (&w0)[WR], T (&w1)[WR]) {
-    using V2 = typename std::conditional<sizeof(T) == 4, float2, double2>::type;
+// colfilter, rows (2P, 2P+1) of the window: acc[q] += h[q + MB-1 - j] w[j]
+template <typename T, int MB, int P>
+__device__ inline void scatter_colfilter(const T *h, T e, T o, T (&acc)[8]) {
 #pragma unroll
-    for (int j = 0; j < WR; ++j) {
-        const int r = g2_src(u0 + j, g.Rl, 0, g.Rl);
-        V2 v = *reinterpret_cast<const V2 *>(Zb + (size_t)r * g.C);
-        w0[j] = v.x; w1[j] = v.y;
+    for (int q = 0; q < 8; ++q) {
+        constexpr int base = MB - 1 - 2 * P;
+        const int k = q + base;
+        if (k >= 0 && k < MB) acc[q] += h[k] * e;
+        if (k - 1 >= 0 && k - 1 < MB) acc[q] += h[k - 1] * o;
     }
 }
 
-// rows u0 .. u0+WR-1 (u0 even) of the plane c2q(w, s0, s1) at this thread's two columns
-// (dtcwt/numpy/transform2d.py:324-350); a reflected row pair is the same record, rows swapped
-template <typename T, int WR>
-__device__ inline void load_c2q_window(const T *__restrict__ Yb, const I1Geo &g, int u0, int s0, int s1,
-                                       T g0, T g1, T (&w0)[WR], T (&w1)[WR]) {
-    using V2 = typename std::conditional<sizeof(T) == 4, float2, double2>::type;
-    const size_t rstride = (size_t)(g.C >> 1) * 12;
+// colifilt, input pair P of the window (cf. fir_colifilt): the pair feeds output pair q with
+// tap pair k = q + M2-1-P (and, for even M2, k = q + M2-P on the other two phases)
+template <typename T, int MB, int P>
+__device__ inline void scatter_colifilt(const T *ha, const T *hb, int pos, T e, T o, T (&acc)[8]) {
+    using IG = IfiltGeo<MB>;
+    constexpr int M2 = IG::M2;
+    const T xa = pos ? o : e, xb = pos ? e : o;
 #pragma unroll
-    for (int p = 0; p < WR / 2; ++p) {
-        const int r = g2_src(u0 + 2 * p, g.Rl, 0, g.Rl);
-        const T *rec = Yb + (size_t)(r >> 1) * rstride;
-        const V2 z0 = *reinterpret_cast<const V2 *>(rec + 2 * s0);
-        const V2 z1 = *reinterpret_cast<const V2 *>(rec + 2 * s1);
-        const T w0r = z0.x * g0, w0i = z0.y * g0, w1r = z1.x * g1, w1i = z1.y * g1;
-        const T a = w0r + w1r, b = w0i + w1i, c = w0i - w1i, d = -(w0r - w1r);
-        const bool sw = r & 1;
-        w0[2 * p] = sw ? c : a; w1[2 * p] = sw ? d : b;
-        w0[2 * p + 1] = sw ? a : c; w1[2 * p + 1] = sw ? b : d;
+    for (int q = 0; q < 2; ++q) {
+        const int k = q + M2 - 1 - P;
+        if constexpr (IG::ODD) {
+            if (k >= 0 && k < M2) {
+                acc[4 * q] += ha[2 * k] * xb; acc[4 * q + 1] += hb[2 * k] * xa;
+                acc[4 * q + 2] += ha[2 * k + 1] * xb; acc[4 * q + 3] += hb[2 * k + 1] * xa;
+            }
+        } else {
+            if (k >= 0 && k < M2) {
+                acc[4 * q] += ha[2 * k + 1] * xb; acc[4 * q + 1] += hb[2 * k + 1] * xa;
+            }
+            if (k + 1 >= 0 && k + 1 < M2) {
+                acc[4 * q + 2] += ha[2 * (k + 1)] * xb; acc[4 * q + 3] += hb[2 * (k + 1)] * xa;
+            }
+        }
     }
 }
 
@@ -446,51 +471,135 @@ template <typename T>
 struct Gains { T g[6]; };
 
 template <typename T, int KIND, int MB>
+struct InvP1 {
+    using V = typename Vec16<T>::type;
+    using V2 = typename std::conditional<sizeof(T) == 4, float2, double2>::type;
+    static constexpr int VN = Vec16<T>::N, NV = 12 / VN;
+    static constexpr int NP = (KIND == 0 ? 8 + MB : IfiltGeo<MB>::WN + 2) / 2;   // record rows per window
+
+    const T *Zb, *Yrow0;
+    T *O1, *O2;
+    int tid, nvec, u0, Rl, C;
+    size_t rstride;
+    bool live, swn;
+    T y1a[8], y1b[8], y2a[8], y2b[8];       // (column 0, column 1) of y1, y2
+    V rg[NV];
+    V2 z0, z1;
+
+    __device__ inline void issue(int p) {
+        int u = u0 + 2 * p;
+        asm volatile("" : "+v"(u));         // addresses of row p are computed here, not all up front
+        const int r = g2_src(u, Rl, 0, Rl);
+        swn = r & 1;
+        const V *src = reinterpret_cast<const V *>(Yrow0 + (size_t)(r >> 1) * rstride);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < nvec) rg[i] = src[idx];
+        }
+        if (live) {
+            z0 = *reinterpret_cast<const V2 *>(Zb + (size_t)r * C);
+            z1 = *reinterpret_cast<const V2 *>(Zb + (size_t)g2_src(u + 1, Rl, 0, Rl) * C);
+        }
+    }
+
+    template <int P>
+    __device__ inline void step(V *buf, const QTaps<T> &tp, const Gains<T> &gn, int f0, int f1) {
+        V *bw = buf + (P & 1) * 256 * NV;
+        asm volatile("" ::: "memory");      // keep the loads of later rows from being hoisted up here
+#pragma unroll
+        for (int i = 0; i < NV; ++i) bw[tid + 256 * i] = rg[i];
+        const V2 c0 = z0, c1 = z1;
+        const bool sw = swn;
+        if (P + 1 < NP) issue(P + 1);
+        __syncthreads();
+        T rec[12];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            V v = bw[tid * NV + i];
+            const T *e = reinterpret_cast<const T *>(&v);
+#pragma unroll
+            for (int t = 0; t < VN; ++t) rec[i * VN + t] = e[t];
+        }
+        // lowpass rows
+        acc<P, 0>(tp, f0, c0.x, c1.x, y1a);
+        acc<P, 0>(tp, f0, c0.y, c1.y, y1b);
+        // the three planes of c2q (dtcwt/numpy/transform2d.py:324-350)
+        plane<P, 1>(rec, 0, 5, gn, sw, tp, f1, y1a, y1b);
+        plane<P, 0>(rec, 2, 3, gn, sw, tp, f0, y2a, y2b);
+        plane<P, 1>(rec, 1, 4, gn, sw, tp, f1, y2a, y2b);
+        // the row is consumed HERE: without this the scheduler runs every load / barrier of the
+        // window first and keeps all the records live until one big block of arithmetic
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            asm volatile("" : "+v"(y1a[k]), "+v"(y1b[k]), "+v"(y2a[k]), "+v"(y2b[k]));
+    }
+
+    template <int P, int HI>
+    __device__ inline void acc(const QTaps<T> &tp, int pos, T e, T o, T (&a)[8]) {
+        if constexpr (KIND == 0) scatter_colfilter<T, MB, P>(HI ? tp.b : tp.a, e, o, a);
+        else scatter_colifilt<T, MB, P>(HI ? tp.c : tp.a, HI ? tp.d : tp.b, pos, e, o, a);
+    }
+
+    template <int P, int HI>
+    __device__ inline void plane(const T (&rec)[12], int s0, int s1, const Gains<T> &gn, bool sw,
+                                 const QTaps<T> &tp, int pos, T (&ya)[8], T (&yb)[8]) {
+        const T w0r = rec[2 * s0] * gn.g[s0], w0i = rec[2 * s0 + 1] * gn.g[s0];
+        const T w1r = rec[2 * s1] * gn.g[s1], w1i = rec[2 * s1 + 1] * gn.g[s1];
+        const T a = w0r + w1r, b = w0i + w1i, c = w0i - w1i, d = -(w0r - w1r);
+        // image rows (a b) / (c d); a reflected row pair is the same record, rows exchanged
+        acc<P, HI>(tp, pos, sw ? c : a, sw ? a : c, ya);
+        acc<P, HI>(tp, pos, sw ? d : b, sw ? b : d, yb);
+    }
+
+    template <int P>
+    __device__ inline void run(V *buf, const QTaps<T> &tp, const Gains<T> &gn, int f0, int f1) {
+        if constexpr (P < NP) {
+            step<P>(buf, tp, gn, f0, f1);
+            run<P + 1>(buf, tp, gn, f0, f1);
+        }
+    }
+};
+
+template <typename T, int KIND, int MB>
 __global__ void __launch_bounds__(256) k_g2_inv_p1(const T *__restrict__ Zl, const T *__restrict__ Yh,
                                                    T *__restrict__ Y1, T *__restrict__ Y2, I1Geo g,
                                                    QTaps<T> tp, Gains<T> gn) {
-    constexpr int OUTS = 8;
-    constexpr int WR = KIND == 0 ? 8 + MB : IfiltGeo<MB>::WN + 2;       // even, MB even
-    const unsigned C2 = g.C >> 1;
-    const unsigned id = blockIdx.x * 256u + threadIdx.x;
-    const unsigned total = (unsigned)g.B * g.ngroups * C2;
-    if (id >= total) return;
-    const unsigned t = id / C2, jc = id - t * C2;
-    const unsigned b = t / g.ngroups, grp = t - b * g.ngroups;
-    const T *Zb = Zl + (size_t)b * g.Rl * g.C + 2 * jc;
-    const T *Yb = Yh + ((size_t)b * (g.Rl >> 1) * C2 + jc) * 12;
-    const int u0 = (KIND == 0 ? grp * 8 : grp * 4) + g.u_shift;
-    using V2 = typename std::conditional<sizeof(T) == 4, float2, double2>::type;
-
+    using S = InvP1<T, KIND, MB>;
+    __shared__ typename S::V buf[2 * 256 * S::NV];
+    const int C2 = g.C >> 1;
+    const int bx = blockIdx.x % g.bpr, t = blockIdx.x / g.bpr;
+    const int grp = t % g.ngroups, b = t / g.ngroups;
+    const int jc0 = bx * 256;
+    S st;
+    st.tid = threadIdx.x;
+    st.live = jc0 + st.tid < C2;
+    const int nrec = C2 - jc0 < 256 ? C2 - jc0 : 256;
+    st.nvec = nrec * S::NV;
+    st.u0 = (KIND == 0 ? grp * 8 : grp * 4) + g.u_shift;
+    st.Rl = g.Rl; st.C = g.C;
+    st.rstride = (size_t)C2 * 12;
+    st.Zb = Zl + (size_t)b * g.Rl * g.C + 2 * (jc0 + st.tid);
+    st.Yrow0 = Yh + ((size_t)b * (g.Rl >> 1) * C2 + jc0) * 12;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        T a0[OUTS], a1[OUTS];
+    for (int k = 0; k < 8; ++k) st.y1a[k] = st.y1b[k] = st.y2a[k] = st.y2b[k] = 0;
 #pragma unroll
-        for (int k = 0; k < OUTS; ++k) a0[k] = a1[k] = 0;
+    for (int i = 0; i < S::NV; ++i) st.rg[i] = typename S::V{};
+    st.z0 = st.z1 = typename S::V2{};
+    st.issue(0);
+    st.template run<0>(buf, tp, gn, g.f0, g.f1);
+    if (!st.live) return;
+    const size_t ob = (size_t)b * g.Rout * g.C + 2 * (jc0 + st.tid);
+    const int lo0 = grp * 8 - g.crop;
 #pragma unroll
-        for (int part = 0; part < 2; ++part) {
-            T w0[WR], w1[WR];
-            if (half == 0 && part == 0) load_plane_window<T, WR>(Zb, g, u0, w0, w1);
-            else if (half == 0) load_c2q_window<T, WR>(Yb, g, u0, 0, 5, gn.g[0], gn.g[5], w0, w1);
-            else if (part == 0) load_c2q_window<T, WR>(Yb, g, u0, 2, 3, gn.g[2], gn.g[3], w0, w1);
-            else load_c2q_window<T, WR>(Yb, g, u0, 1, 4, gn.g[1], gn.g[4], w0, w1);
-            if constexpr (KIND == 0) {
-                fir_colfilter<T, 8, MB>(w0, part ? tp.b : tp.a, a0);
-                fir_colfilter<T, 8, MB>(w1, part ? tp.b : tp.a, a1);
-            } else {
-                fir_colifilt<T, 2, MB>(w0, part ? tp.c : tp.a, part ? tp.d : tp.b, part ? g.f1 : g.f0, a0);
-                fir_colifilt<T, 2, MB>(w1, part ? tp.c : tp.a, part ? tp.d : tp.b, part ? g.f1 : g.f0, a1);
-            }
-        }
-        T *Ob = (half ? Y2 : Y1) + (size_t)b * g.Rout * g.C + 2 * jc;
-        const int lo0 = (int)grp * 8 - g.crop;
-#pragma unroll
-        for (int k = 0; k < OUTS; ++k) {
-            const int r = lo0 + k;
-            if (r >= 0 && r < g.Rout) {
-                V2 v; v.x = a0[k]; v.y = a1[k];
-                *reinterpret_cast<V2 *>(Ob + (size_t)r * g.C) = v;
-            }
+    for (int k = 0; k < 8; ++k) {
+        const int r = lo0 + k;
+        if (r >= 0 && r < g.Rout) {
+            typename S::V2 v1, v2;
+            v1.x = st.y1a[k]; v1.y = st.y1b[k];
+            v2.x = st.y2a[k]; v2.y = st.y2b[k];
+            *reinterpret_cast<typename S::V2 *>(Y1 + ob + (size_t)r * g.C) = v1;
+            *reinterpret_cast<typename S::V2 *>(Y2 + ob + (size_t)r * g.C) = v2;
         }
     }
 }
@@ -579,12 +688,12 @@ void choose_tpl(int need, int &tpl, int &lg) {
 
 // fill the LDS-row geometry; returns the dynamic LDS bytes
 template <typename T>
-size_t finish_rows(P2Geo &g, int in_step, int win, int threads_per_line, int rec_elems_per_thread) {
+size_t finish_rows(P2Geo &g, int in_step, int win, int threads_per_line, int rec_elems_per_thread, int lines = 2) {
     choose_tpl(threads_per_line, g.tpl, g.tpl_log2);
     g.nseg = (threads_per_line + g.tpl - 1) / g.tpl;
     g.span = g.tpl * in_step + win - in_step;
     g.stride = g.span + 4;
-    const int a = 2 * g.stride, b = g.tpl * rec_elems_per_thread;
+    const int a = lines * g.stride, b = g.tpl * rec_elems_per_thread;
     g.region = a > b ? a : b;
     return (size_t)(256 / g.tpl) * g.region * sizeof(T);
 }
@@ -661,8 +770,9 @@ int dtcwt_hip_level2d_forward(dtcwt_hip_ctx *ctx, int dtype, int kind, const voi
     const int in_step = kind == 0 ? 4 : 8;
     const int win = kind == 0 ? (4 + p.mb - 1 + 3) / 4 * 4 : 4 + 2 * p.mb;
     size_t lds;
-    if (dtype == DTCWT_HIP_F32) lds = finish_rows<float>(g2, in_step, win, (int)((C1 + 3) / 4), 24);
-    else lds = finish_rows<double>(g2, in_step, win, (int)((C1 + 3) / 4), 24);
+    const int lines = kind == 0 ? 4 : 2;        // rows staged at once (k_g2_fwd_p2 BOTH)
+    if (dtype == DTCWT_HIP_F32) lds = finish_rows<float>(g2, in_step, win, (int)((C1 + 3) / 4), 24, lines);
+    else lds = finish_rows<double>(g2, in_step, win, (int)((C1 + 3) / 4), 24, lines);
     const int rpb = 256 / g2.tpl;
     const unsigned blocks2 = (unsigned)(((g2.nlines + rpb - 1) / rpb) * g2.nseg);
 
@@ -710,7 +820,8 @@ int dtcwt_hip_level2d_inverse(dtcwt_hip_ctx *ctx, int dtype, int kind, const voi
     g1.Rout = (int)Rout; g1.crop = crop_r;
     g1.ngroups = kind == 0 ? (int)((Rl + 7) / 8) : (int)((Rl / 2 + 1) / 2);
     g1.u_shift = p.u_shift; g1.f0 = p.f0; g1.f1 = p.f1;
-    const unsigned blocks1 = (unsigned)(((int64_t)g1.B * g1.ngroups * (Cl / 2) + 255) / 256);
+    g1.bpr = (int)((Cl / 2 + 255) / 256);
+    const unsigned blocks1 = (unsigned)((int64_t)g1.B * g1.ngroups * g1.bpr);
 
     P2Geo g2;
     g2.nlines = (int)(B * Rout); g2.R1 = 0; g2.Cin = (int)Cl; g2.pad_lo = 0; g2.L = (int)Cl;

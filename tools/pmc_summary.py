@@ -15,7 +15,9 @@ for f in sorted(glob.glob(os.path.join(out, '*', '**', '*counter_collection.csv'
         for r in csv.DictReader(fh):
             k = r.get('Kernel_Name', '')
             m = re.search(r'(k_\w+)<.*?<([\d, ]+)>(.*?)>\(', k)
-            short = (m.group(1) + '<' + m.group(2).replace(' ', '') + '>' + m.group(3).replace(' ', '')) if m else k[:40]
+            if not m:
+                m2 = re.search(r'(k_\w+)<([^>]*)>', k)
+            short = (m.group(1) + '<' + m.group(2).replace(' ', '') + '>' + m.group(3).replace(' ', '')) if m else (m2.group(0).replace(' ', '') if m2 else k[:40])
             g = int(r.get('Grid_Size', r.get('Grid_Size_X', 0)) or 0)
             key = (short, g)
             rows[key][r['Counter_Name']].append(float(r['Counter_Value']))
