@@ -219,10 +219,31 @@ struct P2Geo {
     int f0, f1;         // a_first (forward KIND 1) or pos (inverse KIND 1) of the lo / hi pair
 };
 
-template <typename T>
-__device__ inline void stage_line(T *sm, const T *line, int q, int tpl, int span, int ublk, int L,
-                                  int pad_lo, int n) {
-    for (int s = q; s < span; s += tpl) sm[s] = line[g2_src(ublk + s, L, pad_lo, n)];
+// Stage NL lines into LDS: all loads of a thread are issued before the first LDS write (a loop
+// with a run-time trip count compiles to load -> wait -> write per sample, one memory latency
+// each).  NLD = compile-time bound on samples per thread and line (tpl >= 16); every address is
+// in bounds whatever s is, so the loads need no guard.
+template <int IN_STEP, int WIN> struct StageGeo {
+    static constexpr int NLD = IN_STEP + (WIN - IN_STEP + 15) / 16;
+};
+template <typename T, int NLD, int NL>
+__device__ inline void stage_lines(T *sm, int stride, const T *const (&line)[NL], int q, int tpl,
+                                   int span, int ublk, int L, int pad_lo, int n) {
+    T v[NL][NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int src = g2_src(ublk + q + i * tpl, L, pad_lo, n);
+#pragma unroll
+        for (int l = 0; l < NL; ++l) v[l][i] = line[l][src];
+    }
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int s = q + i * tpl;
+        if (s < span) {
+#pragma unroll
+            for (int l = 0; l < NL; ++l) sm[l * stride + s] = v[l][i];
+        }
+    }
 }
 
 // 4 consecutive outputs of one row for the lo and the hi filter (forward pass 2)
@@ -288,23 +309,24 @@ __global__ void __launch_bounds__(256) k_g2_fwd_p2(const T *__restrict__ Lo, con
     const bool live = rpg < g.nlines;
     T *sm = reinterpret_cast<T *>(smem_raw) + (size_t)rp * g.region;
     const int ublk = seg * g.tpl * RG::IN_STEP + g.u_shift;
-    const size_t in0 = (size_t)rpg * 2 * g.Cin;               // rows 2 rpg, 2 rpg + 1 (all images stacked)
+    // rows 2 rpg, 2 rpg + 1 (all images stacked); idle threads stage the last row pair again
+    const size_t in0 = (size_t)(live ? rpg : g.nlines - 1) * 2 * g.Cin;
     const int col0 = (seg * g.tpl + q) * 4;
     const int valid = g.Cout - col0;                          // outputs of this thread that exist
     const T *wp = sm + q * RG::IN_STEP;
     const int C2 = g.Cout >> 1;
+    constexpr int NLD = StageGeo<RG::IN_STEP, RG::WIN>::NLD;
     T rec[2][12];
 
     // KIND 0 stages the Lo and the Hi rows together (they fit the LDS the records need anyway);
     // KIND 1 (twice the input per thread) one image after the other.
     constexpr bool BOTH = KIND == 0;
-    if (live) {
-        stage_line(sm, Lo + in0, q, g.tpl, g.span, ublk, g.L, g.pad_lo, g.Cin);
-        stage_line(sm + g.stride, Lo + in0 + g.Cin, q, g.tpl, g.span, ublk, g.L, g.pad_lo, g.Cin);
-        if (BOTH) {
-            stage_line(sm + 2 * g.stride, Hi + in0, q, g.tpl, g.span, ublk, g.L, g.pad_lo, g.Cin);
-            stage_line(sm + 3 * g.stride, Hi + in0 + g.Cin, q, g.tpl, g.span, ublk, g.L, g.pad_lo, g.Cin);
-        }
+    if constexpr (BOTH) {
+        const T *const lines[4] = {Lo + in0, Lo + in0 + g.Cin, Hi + in0, Hi + in0 + g.Cin};
+        stage_lines<T, NLD, 4>(sm, g.stride, lines, q, g.tpl, g.span, ublk, g.L, g.pad_lo, g.Cin);
+    } else {
+        const T *const lines[2] = {Lo + in0, Lo + in0 + g.Cin};
+        stage_lines<T, NLD, 2>(sm, g.stride, lines, q, g.tpl, g.span, ublk, g.L, g.pad_lo, g.Cin);
     }
     __syncthreads();
     if (live && valid > 0) {
@@ -317,12 +339,10 @@ __global__ void __launch_bounds__(256) k_g2_fwd_p2(const T *__restrict__ Lo, con
         store4(o + g.Cout, ll1, valid, vec_ok);
         q2c_pair(lh0, lh1, rec, 2, 3);
     }
-    if (!BOTH) {
+    if constexpr (!BOTH) {
         __syncthreads();
-        if (live) {
-            stage_line(sm, Hi + in0, q, g.tpl, g.span, ublk, g.L, g.pad_lo, g.Cin);
-            stage_line(sm + g.stride, Hi + in0 + g.Cin, q, g.tpl, g.span, ublk, g.L, g.pad_lo, g.Cin);
-        }
+        const T *const lines[2] = {Hi + in0, Hi + in0 + g.Cin};
+        stage_lines<T, NLD, 2>(sm, g.stride, lines, q, g.tpl, g.span, ublk, g.L, g.pad_lo, g.Cin);
         __syncthreads();
     }
     if (live && valid > 0) {
@@ -372,9 +392,10 @@ __global__ void __launch_bounds__(256) k_g2_inv_p2(const T *__restrict__ Y1, con
     const bool live = line < g.nlines;
     T *sm = reinterpret_cast<T *>(smem_raw) + (size_t)ln * g.region;
     const int ublk = seg * g.tpl * RG::IN_STEP + g.u_shift;
-    if (live) {
-        stage_line(sm, Y1 + (size_t)line * g.Cin, q, g.tpl, g.span, ublk, g.L, 0, g.Cin);
-        stage_line(sm + g.stride, Y2 + (size_t)line * g.Cin, q, g.tpl, g.span, ublk, g.L, 0, g.Cin);
+    {
+        const size_t in0 = (size_t)(live ? line : g.nlines - 1) * g.Cin;
+        const T *const lines[2] = {Y1 + in0, Y2 + in0};
+        stage_lines<T, StageGeo<RG::IN_STEP, RG::WIN>::NLD, 2>(sm, g.stride, lines, q, g.tpl, g.span, ublk, g.L, 0, g.Cin);
     }
     __syncthreads();
     if (!live) return;
@@ -423,17 +444,17 @@ struct I1Geo {
     int B, Rl, C;       // lowpass input [B][Rl][C]; subbands [B][Rl/2][C/2][6]
     int Rout;           // written rows of y1 / y2
     int crop;           // logical output rows dropped at the start
-    int ngroups;        // groups of 8 output rows
+    int ngroups;        // groups of InvP1Outs output rows
     int bpr;            // blocks per row of column pairs
     int u_shift;
     int f0, f1;         // KIND 1: pos of the lo / hi pair
 };
 
 // colfilter, rows (2P, 2P+1) of the window: acc[q] += h[q + MB-1 - j] w[j]
-template <typename T, int MB, int P>
-__device__ inline void scatter_colfilter(const T *h, T e, T o, T (&acc)[8]) {
+template <typename T, int MB, int P, int OUTS>
+__device__ inline void scatter_colfilter(const T *h, T e, T o, T (&acc)[OUTS]) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < OUTS; ++q) {
         constexpr int base = MB - 1 - 2 * P;
         const int k = q + base;
         if (k >= 0 && k < MB) acc[q] += h[k] * e;
@@ -443,13 +464,13 @@ __device__ inline void scatter_colfilter(const T *h, T e, T o, T (&acc)[8]) {
 
 // colifilt, input pair P of the window (cf. fir_colifilt): the pair feeds output pair q with
 // tap pair k = q + M2-1-P (and, for even M2, k = q + M2-P on the other two phases)
-template <typename T, int MB, int P>
-__device__ inline void scatter_colifilt(const T *ha, const T *hb, int pos, T e, T o, T (&acc)[8]) {
+template <typename T, int MB, int P, int OUTS>
+__device__ inline void scatter_colifilt(const T *ha, const T *hb, int pos, T e, T o, T (&acc)[OUTS]) {
     using IG = IfiltGeo<MB>;
     constexpr int M2 = IG::M2;
     const T xa = pos ? o : e, xb = pos ? e : o;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < OUTS / 4; ++q) {
         const int k = q + M2 - 1 - P;
         if constexpr (IG::ODD) {
             if (k >= 0 && k < M2) {
@@ -470,19 +491,24 @@ __device__ inline void scatter_colifilt(const T *ha, const T *hb, int pos, T e, 
 template <typename T>
 struct Gains { T g[6]; };
 
+// OUTS output rows per workgroup: the window is OUTS + MB (KIND 0) or OUTS / 2 + MB or so (KIND 1)
+// rows, so more rows per group = fewer re-reads, more accumulators.
+template <typename T, int KIND> struct InvP1Outs { static constexpr int N = KIND == 0 ? 8 : 16; };
+
 template <typename T, int KIND, int MB>
 struct InvP1 {
+    static constexpr int OUTS = InvP1Outs<T, KIND>::N;
     using V = typename Vec16<T>::type;
     using V2 = typename std::conditional<sizeof(T) == 4, float2, double2>::type;
     static constexpr int VN = Vec16<T>::N, NV = 12 / VN;
-    static constexpr int NP = (KIND == 0 ? 8 + MB : IfiltGeo<MB>::WN + 2) / 2;   // record rows per window
+    static constexpr int NP = (KIND == 0 ? OUTS + MB : IfiltGeo<MB>::WN + 2 * (OUTS / 4 - 1)) / 2;   // record rows per window
 
     const T *Zb, *Yrow0;
     T *O1, *O2;
     int tid, nvec, u0, Rl, C;
     size_t rstride;
     bool live, swn;
-    T y1a[8], y1b[8], y2a[8], y2b[8];       // (column 0, column 1) of y1, y2
+    T y1a[OUTS], y1b[OUTS], y2a[OUTS], y2b[OUTS];       // (column 0, column 1) of y1, y2
     V rg[NV];
     V2 z0, z1;
 
@@ -503,15 +529,21 @@ struct InvP1 {
         }
     }
 
-    template <int P>
+    // S = position in the sequence; the record row consumed is P = S (top-down) or NP-1-S
+    // (REV, bottom-up).  Odd row groups run bottom-up so that the rows two vertically adjacent
+    // workgroups share are wanted by both at the same time (one of them finds them in L2):
+    // without this the 2x window overlap went to the fabric twice (FETCH 1.92x algorithmic).
+    template <int S, bool REV>
     __device__ inline void step(V *buf, const QTaps<T> &tp, const Gains<T> &gn, int f0, int f1) {
-        V *bw = buf + (P & 1) * 256 * NV;
+        constexpr int P = REV ? NP - 1 - S : S;
+        constexpr int PN = REV ? P - 1 : P + 1;
+        V *bw = buf + (S & 1) * 256 * NV;
         asm volatile("" ::: "memory");      // keep the loads of later rows from being hoisted up here
 #pragma unroll
         for (int i = 0; i < NV; ++i) bw[tid + 256 * i] = rg[i];
         const V2 c0 = z0, c1 = z1;
         const bool sw = swn;
-        if (P + 1 < NP) issue(P + 1);
+        if (S + 1 < NP) issue(PN);
         __syncthreads();
         T rec[12];
 #pragma unroll
@@ -531,19 +563,19 @@ struct InvP1 {
         // the row is consumed HERE: without this the scheduler runs every load / barrier of the
         // window first and keeps all the records live until one big block of arithmetic
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
+        for (int k = 0; k < OUTS; ++k)
             asm volatile("" : "+v"(y1a[k]), "+v"(y1b[k]), "+v"(y2a[k]), "+v"(y2b[k]));
     }
 
     template <int P, int HI>
-    __device__ inline void acc(const QTaps<T> &tp, int pos, T e, T o, T (&a)[8]) {
-        if constexpr (KIND == 0) scatter_colfilter<T, MB, P>(HI ? tp.b : tp.a, e, o, a);
-        else scatter_colifilt<T, MB, P>(HI ? tp.c : tp.a, HI ? tp.d : tp.b, pos, e, o, a);
+    __device__ inline void acc(const QTaps<T> &tp, int pos, T e, T o, T (&a)[OUTS]) {
+        if constexpr (KIND == 0) scatter_colfilter<T, MB, P, OUTS>(HI ? tp.b : tp.a, e, o, a);
+        else scatter_colifilt<T, MB, P, OUTS>(HI ? tp.c : tp.a, HI ? tp.d : tp.b, pos, e, o, a);
     }
 
     template <int P, int HI>
     __device__ inline void plane(const T (&rec)[12], int s0, int s1, const Gains<T> &gn, bool sw,
-                                 const QTaps<T> &tp, int pos, T (&ya)[8], T (&yb)[8]) {
+                                 const QTaps<T> &tp, int pos, T (&ya)[OUTS], T (&yb)[OUTS]) {
         const T w0r = rec[2 * s0] * gn.g[s0], w0i = rec[2 * s0 + 1] * gn.g[s0];
         const T w1r = rec[2 * s1] * gn.g[s1], w1i = rec[2 * s1 + 1] * gn.g[s1];
         const T a = w0r + w1r, b = w0i + w1i, c = w0i - w1i, d = -(w0r - w1r);
@@ -552,11 +584,11 @@ struct InvP1 {
         acc<P, HI>(tp, pos, sw ? d : b, sw ? b : d, yb);
     }
 
-    template <int P>
+    template <int S, bool REV>
     __device__ inline void run(V *buf, const QTaps<T> &tp, const Gains<T> &gn, int f0, int f1) {
-        if constexpr (P < NP) {
-            step<P>(buf, tp, gn, f0, f1);
-            run<P + 1>(buf, tp, gn, f0, f1);
+        if constexpr (S < NP) {
+            step<S, REV>(buf, tp, gn, f0, f1);
+            run<S + 1, REV>(buf, tp, gn, f0, f1);
         }
     }
 };
@@ -576,23 +608,28 @@ __global__ void __launch_bounds__(256) k_g2_inv_p1(const T *__restrict__ Zl, con
     st.live = jc0 + st.tid < C2;
     const int nrec = C2 - jc0 < 256 ? C2 - jc0 : 256;
     st.nvec = nrec * S::NV;
-    st.u0 = (KIND == 0 ? grp * 8 : grp * 4) + g.u_shift;
+    st.u0 = grp * (KIND == 0 ? S::OUTS : S::OUTS / 2) + g.u_shift;
     st.Rl = g.Rl; st.C = g.C;
     st.rstride = (size_t)C2 * 12;
     st.Zb = Zl + (size_t)b * g.Rl * g.C + 2 * (jc0 + st.tid);
     st.Yrow0 = Yh + ((size_t)b * (g.Rl >> 1) * C2 + jc0) * 12;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) st.y1a[k] = st.y1b[k] = st.y2a[k] = st.y2b[k] = 0;
+    for (int k = 0; k < S::OUTS; ++k) st.y1a[k] = st.y1b[k] = st.y2a[k] = st.y2b[k] = 0;
 #pragma unroll
     for (int i = 0; i < S::NV; ++i) st.rg[i] = typename S::V{};
     st.z0 = st.z1 = typename S::V2{};
-    st.issue(0);
-    st.template run<0>(buf, tp, gn, g.f0, g.f1);
+    if (grp & 1) {
+        st.issue(S::NP - 1);
+        st.template run<0, true>(buf, tp, gn, g.f0, g.f1);
+    } else {
+        st.issue(0);
+        st.template run<0, false>(buf, tp, gn, g.f0, g.f1);
+    }
     if (!st.live) return;
     const size_t ob = (size_t)b * g.Rout * g.C + 2 * (jc0 + st.tid);
-    const int lo0 = grp * 8 - g.crop;
+    const int lo0 = grp * S::OUTS - g.crop;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < S::OUTS; ++k) {
         const int r = lo0 + k;
         if (r >= 0 && r < g.Rout) {
             typename S::V2 v1, v2;
@@ -818,7 +855,7 @@ int dtcwt_hip_level2d_inverse(dtcwt_hip_ctx *ctx, int dtype, int kind, const voi
     I1Geo g1;
     g1.B = (int)B; g1.Rl = (int)Rl; g1.C = (int)Cl;
     g1.Rout = (int)Rout; g1.crop = crop_r;
-    g1.ngroups = kind == 0 ? (int)((Rl + 7) / 8) : (int)((Rl / 2 + 1) / 2);
+    g1.ngroups = kind == 0 ? (int)((Rl + 7) / 8) : (int)((2 * Rl + 15) / 16);      // InvP1Outs rows per group
     g1.u_shift = p.u_shift; g1.f0 = p.f0; g1.f1 = p.f1;
     g1.bpr = (int)((Cl / 2 + 255) / 256);
     const unsigned blocks1 = (unsigned)((int64_t)g1.B * g1.ngroups * g1.bpr);
