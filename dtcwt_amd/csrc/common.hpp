@@ -64,3 +64,15 @@ __device__ inline int dt_reflect1(int u, int n) {
 __host__ __device__ inline int64_t dt_clamp(int64_t u, int64_t lo, int64_t hi) {
     return u < lo ? lo : (u > hi ? hi : u);
 }
+
+// Dense single-axis fast paths of generic2d.hip on [outer][n][inner] arrays (inner >= 32: marching
+// kernels, inner == 1: LDS-row kernels).  kind 0 = colfilter algebra (odd lengths), kind 1 =
+// coldfilt (pair) / colifilt (sum).  Return 1 = launched, 0 = not applicable, < 0 = error.
+int dtcwt_g2_pair(dtcwt_hip_ctx *ctx, int dtype, int kind, const void *X, void *Y0, void *Y1,
+                  int64_t outer, int64_t n, int64_t inner, int pad_lo, int pad_hi,
+                  const double *lo_a, const double *lo_b, const double *hi_a, const double *hi_b,
+                  int m_lo, int m_hi, int pack_hi);
+int dtcwt_g2_sum(dtcwt_hip_ctx *ctx, int dtype, int kind, const void *X0, const void *X1, void *Y,
+                 int64_t outer, int64_t n, int64_t inner, int crop, const double *lo_a,
+                 const double *lo_b, const double *hi_a, const double *hi_b, int m_lo, int m_hi,
+                 int packed_x1, double gain1);

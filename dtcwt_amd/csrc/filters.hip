@@ -583,6 +583,13 @@ double dot(const double *a, const double *b, int m) {
 
 #define DT_LAUNCH_CHECK() DT_CHECK_HIP(hipGetLastError())
 
+// A view that is a dense [outer][n][inner] array on both sides (what the transforms pass): the
+// pair / sum entry points try the marching and LDS-row kernels of generic2d.hip first.
+static bool dense_view(const dtcwt_hip_view *v, int64_t nwrite) {
+    return v->xsi == 1 && v->xsn == v->inner && v->xso == v->n * v->inner && v->ysi == 1 &&
+           v->ysn == v->inner && v->yso == nwrite * v->inner;
+}
+
 extern "C" {
 
 int dtcwt_hip_colfilter(dtcwt_hip_ctx *ctx, int dtype, const void *X, void *Y,
@@ -773,6 +780,11 @@ int dtcwt_hip_colfilter2(dtcwt_hip_ctx *ctx, int dtype, const void *X, void *Y0,
     int64_t total = g.outer * g.ngroups * g.inner;
     if (total == 0) return 0;
     DT_CHECK_HIP(hipSetDevice(ctx->device));
+    if (!v->crop_lo && !v->crop_hi && dense_view(v, g.nwrite)) {
+        rc = dtcwt_g2_pair(ctx, dtype, 0, X, Y0, Y1, v->outer, v->n, v->inner, v->pad_lo, v->pad_hi, h0, nullptr,
+                           h1, nullptr, m0, m1, 0);
+        if (rc) return rc < 0 ? rc : 0;
+    }
     Taps<float> tf; Taps<double> td;
     load_taps(tf, h0, nullptr, m0); load_taps(td, h0, nullptr, m0);
     for (int k = 0; k < DTCWT_HIP_MAX_TAPS; ++k) { tf.b[k] = k < m1 ? (float)h1[k] : 0.f; td.b[k] = k < m1 ? h1[k] : 0.0; }
@@ -793,6 +805,11 @@ int dtcwt_hip_colfilter_sum2(dtcwt_hip_ctx *ctx, int dtype, const void *X0, cons
     int64_t total = g.outer * g.ngroups * g.inner;
     if (total == 0) return 0;
     DT_CHECK_HIP(hipSetDevice(ctx->device));
+    if (!v->pad_lo && !v->pad_hi && !v->crop_lo && !v->crop_hi && dense_view(v, g.nwrite)) {
+        rc = dtcwt_g2_sum(ctx, dtype, 0, X0, X1, Y, v->outer, v->n, v->inner, 0, h0, nullptr, h1, nullptr, m0, m1,
+                          0, 1.0);
+        if (rc) return rc < 0 ? rc : 0;
+    }
     Taps<float> tf; Taps<double> td;
     load_taps(tf, h0, nullptr, m0); load_taps(td, h0, nullptr, m0);
     for (int k = 0; k < DTCWT_HIP_MAX_TAPS; ++k) { tf.b[k] = k < m1 ? (float)h1[k] : 0.f; td.b[k] = k < m1 ? h1[k] : 0.0; }
@@ -815,6 +832,11 @@ int dtcwt_hip_coldfilt2(dtcwt_hip_ctx *ctx, int dtype, const void *X, void *Y0, 
     if (total == 0) return 0;
     int f0 = dot(ha0, hb0, m) > 0, f1 = dot(ha1, hb1, m) > 0;
     DT_CHECK_HIP(hipSetDevice(ctx->device));
+    if (!v->crop_lo && !v->crop_hi && dense_view(v, g.nwrite)) {
+        rc = dtcwt_g2_pair(ctx, dtype, 1, X, Y0, Y1, v->outer, v->n, v->inner, v->pad_lo, v->pad_hi, ha0, hb0,
+                           ha1, hb1, m, m, 0);
+        if (rc) return rc < 0 ? rc : 0;
+    }
     if (dtype == DTCWT_HIP_F32) {
         Taps<float> t0, t1; load_taps(t0, ha0, hb0, m); load_taps(t1, ha1, hb1, m);
         k_coldfilt2<float><<<blocks_for(total), 256, 0, ctx->stream>>>((const float *)X, (float *)Y0, (float *)Y1, g, t0, t1, m, f0, f1);
@@ -840,6 +862,11 @@ int dtcwt_hip_colifilt_sum2(dtcwt_hip_ctx *ctx, int dtype, const void *X0, const
     if (total == 0) return 0;
     int p0 = dot(ha0, hb0, m) > 0, p1 = dot(ha1, hb1, m) > 0;
     DT_CHECK_HIP(hipSetDevice(ctx->device));
+    if (!v->pad_lo && !v->pad_hi && v->crop_lo == v->crop_hi && dense_view(v, g.nwrite)) {
+        rc = dtcwt_g2_sum(ctx, dtype, 1, X0, X1, Y, v->outer, v->n, v->inner, v->crop_lo, ha0, hb0, ha1, hb1, m, m,
+                          0, 1.0);
+        if (rc) return rc < 0 ? rc : 0;
+    }
     if (dtype == DTCWT_HIP_F32) {
         Taps<float> t0, t1; load_taps(t0, ha0, hb0, m); load_taps(t1, ha1, hb1, m);
         k_colifilt_sum2<float><<<blocks_for(total), 256, 0, ctx->stream>>>((const float *)X0, (const float *)X1, (float *)Y, g, t0, t1, m, p0, p1);

@@ -140,7 +140,31 @@ struct P1Geo {
     int ngroups;        // thread groups along the rows
     int u_shift;        // window start = group origin + u_shift
     int af0, af1;       // KIND 1: (A, B) order of the lo / hi pair
+    int pack;           // Hi rows (2j, 2j+1) stored interleaved as complex [nout/2][C] (1-D highpass)
 };
+
+// rows row0 .. row0+N-1 (row0 even, N even) of the lo and hi outputs of one thread
+template <typename T, int N>
+__device__ inline void store_p1(T *Lb, T *Hb, T *Hi, const T (&l)[N], const T (&h)[N], int row0,
+                                unsigned b, unsigned c, const P1Geo &g) {
+    using V2 = typename std::conditional<sizeof(T) == 4, float2, double2>::type;
+#pragma unroll
+    for (int q = 0; q < N; ++q)
+        if (row0 + q < g.nout) Lb[(size_t)(row0 + q) * g.C] = l[q];
+    if (g.pack) {       // Yh[j][c] = Hi[2j][c] + i Hi[2j+1][c]   (dtcwt/numpy/transform1d.py:88,100)
+        T *Pb = Hi + ((size_t)b * (g.nout >> 1) * g.C + c) * 2;
+#pragma unroll
+        for (int q = 0; q < N; q += 2)
+            if (row0 + q < g.nout) {
+                V2 v; v.x = h[q]; v.y = h[q + 1];
+                *reinterpret_cast<V2 *>(Pb + (size_t)((row0 + q) >> 1) * g.C * 2) = v;
+            }
+    } else {
+#pragma unroll
+        for (int q = 0; q < N; ++q)
+            if (row0 + q < g.nout) Hb[(size_t)(row0 + q) * g.C] = h[q];
+    }
+}
 
 template <typename T, int KIND, int MB>
 __global__ void __launch_bounds__(256) k_g2_fwd_p1(const T *__restrict__ X, T *__restrict__ Lo,
@@ -163,12 +187,7 @@ __global__ void __launch_bounds__(256) k_g2_fwd_p1(const T *__restrict__ X, T *_
         for (int q = 0; q < G; ++q) l[q] = h[q] = 0;
         fir_colfilter<T, G, MB>(w, tp.a, l);
         fir_colfilter<T, G, MB>(w, tp.b, h);
-#pragma unroll
-        for (int q = 0; q < G; ++q)
-            if (lo0 + q < g.nout) {
-                Lb[(size_t)(lo0 + q) * g.C] = l[q];
-                Hb[(size_t)(lo0 + q) * g.C] = h[q];
-            }
+        store_p1<T, G>(Lb, Hb, Hi, l, h, lo0, b, c, g);
     } else {
         constexpr int GP = 4, WN = 4 * (GP - 1) + 2 * MB;
         const int i0 = grp * GP, u0 = 4 * i0 + g.u_shift;
@@ -178,12 +197,7 @@ __global__ void __launch_bounds__(256) k_g2_fwd_p1(const T *__restrict__ X, T *_
         T l[2 * GP], h[2 * GP];
         fir_coldfilt<T, GP, MB>(w, tp.a, tp.b, g.af0, l);
         fir_coldfilt<T, GP, MB>(w, tp.c, tp.d, g.af1, h);
-#pragma unroll
-        for (int q = 0; q < 2 * GP; ++q)
-            if (2 * i0 + q < g.nout) {
-                Lb[(size_t)(2 * i0 + q) * g.C] = l[q];
-                Hb[(size_t)(2 * i0 + q) * g.C] = h[q];
-            }
+        store_p1<T, 2 * GP>(Lb, Hb, Hi, l, h, 2 * i0, b, c, g);
     }
 }
 
@@ -641,6 +655,85 @@ __global__ void __launch_bounds__(256) k_g2_inv_p1(const T *__restrict__ Zl, con
     }
 }
 
+// ---- single-axis building blocks on dense [B][n][C] arrays (1-D transform, 3-D axis passes) ----
+// lo / hi filter pair ALONG the contiguous axis of [nlines][Cin] lines -> Y0, Y1 [nlines][Cout]
+template <typename T, int KIND, int MB>
+__global__ void __launch_bounds__(256) k_g2_rows_pair(const T *__restrict__ X, T *__restrict__ Y0,
+                                                      T *__restrict__ Y1, P2Geo g, QTaps<T> tp) {
+    using RG = RowGeo<KIND, MB, false>;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int tid = threadIdx.x, q = tid & (g.tpl - 1), ln = tid >> g.tpl_log2;
+    const int seg = blockIdx.x % g.nseg, line = (blockIdx.x / g.nseg) * (256 >> g.tpl_log2) + ln;
+    const bool live = line < g.nlines;
+    T *sm = reinterpret_cast<T *>(smem_raw) + (size_t)ln * g.region;
+    const int ublk = seg * g.tpl * RG::IN_STEP + g.u_shift;
+    {
+        const T *const lines[1] = {X + (size_t)(live ? line : g.nlines - 1) * g.Cin};
+        stage_lines<T, StageGeo<RG::IN_STEP, RG::WIN>::NLD, 1>(sm, g.stride, lines, q, g.tpl, g.span, ublk, g.L, g.pad_lo, g.Cin);
+    }
+    __syncthreads();
+    const int col0 = (seg * g.tpl + q) * 4;
+    const int valid = g.Cout - col0;
+    if (!live || valid <= 0) return;
+    T lo[4], hi[4];
+    fwd_row_fir<T, KIND, MB, RG::WIN>(sm + q * RG::IN_STEP, tp, g, lo, hi);
+    const bool vec_ok = ((g.Cout * sizeof(T)) & 15) == 0;
+    store4(Y0 + (size_t)line * g.Cout + col0, lo, valid, vec_ok);
+    store4(Y1 + (size_t)line * g.Cout + col0, hi, valid, vec_ok);
+}
+
+// Y = filter(X0, lo) + filter(X1, hi) down the rows of [B][R][C] arrays (lanes along C); X1 may be
+// the interleaved complex form [B][R/2][C] of forward pass 1 (PACK).  8 output rows per thread.
+struct S1Geo {
+    int B, R, C;
+    int Rout, crop, ngroups, u_shift, f0, f1, packed;
+};
+
+template <typename T, int KIND, int MB>
+__global__ void __launch_bounds__(256) k_g2_sum_march(const T *__restrict__ X0, const T *__restrict__ X1,
+                                                      T *__restrict__ Y, S1Geo g, QTaps<T> tp) {
+    constexpr int WN = KIND == 0 ? 8 + MB - 1 : IfiltGeo<MB>::WN + 2;
+    const unsigned id = blockIdx.x * 256u + threadIdx.x;
+    const unsigned total = (unsigned)g.B * g.ngroups * g.C;
+    if (id >= total) return;
+    const unsigned t = id / g.C, c = id - t * g.C;
+    const unsigned b = t / g.ngroups, grp = t - b * g.ngroups;
+    const int u0 = (KIND == 0 ? grp * 8 : grp * 4) + g.u_shift;
+    const T *P0 = X0 + (size_t)b * g.R * g.C + c;
+    T acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0;
+    {
+        T w[WN];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) w[j] = P0[(size_t)g2_src(u0 + j, g.R, 0, g.R) * g.C];
+        if constexpr (KIND == 0) fir_colfilter<T, 8, MB>(w, tp.a, acc);
+        else fir_colifilt<T, 2, MB>(w, tp.a, tp.b, g.f0, acc);
+    }
+    {
+        T w[WN];
+        if (g.packed) {
+            const T *P1 = X1 + ((size_t)b * (g.R >> 1) * g.C + c) * 2;
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int r = g2_src(u0 + j, g.R, 0, g.R);
+                w[j] = P1[(size_t)(r >> 1) * g.C * 2 + (r & 1)];
+            }
+        } else {
+            const T *P1 = X1 + (size_t)b * g.R * g.C + c;
+#pragma unroll
+            for (int j = 0; j < WN; ++j) w[j] = P1[(size_t)g2_src(u0 + j, g.R, 0, g.R) * g.C];
+        }
+        if constexpr (KIND == 0) fir_colfilter<T, 8, MB>(w, tp.b, acc);
+        else fir_colifilt<T, 2, MB>(w, tp.c, tp.d, g.f1, acc);
+    }
+    T *Ob = Y + (size_t)b * g.Rout * g.C + c;
+    const int lo0 = (int)grp * 8 - g.crop;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (lo0 + k >= 0 && lo0 + k < g.Rout) Ob[(size_t)(lo0 + k) * g.C] = acc[k];
+}
+
 // ---- host side -----------------------------------------------------------------------------
 struct TapPrep {
     double a[G2_MAXB], b[G2_MAXB], c[G2_MAXB], d[G2_MAXB];
@@ -766,6 +859,117 @@ constexpr int G2_NA = -3;       // "use the filter-by-filter path"
         }                                                                                  \
     } while (0)
 
+// ---- dense single-axis pair / sum (declared in common.hpp) -----------------------------------
+// Return 1 when a kernel was launched, 0 when this geometry / these filters have none (caller
+// uses the one-output-per-thread kernels of filters.hip), < 0 on error.
+int dtcwt_g2_pair(dtcwt_hip_ctx *ctx, int dtype, int kind, const void *X, void *Y0, void *Y1,
+                  int64_t outer, int64_t n, int64_t inner, int pad_lo, int pad_hi,
+                  const double *lo_a, const double *lo_b, const double *hi_a, const double *hi_b,
+                  int m_lo, int m_hi, int pack_hi) {
+    TapPrep p;
+    if (kind == 0) {
+        if (!prep_level1(lo_a, m_lo, hi_a, m_hi, false, p)) return 0;
+    } else {
+        if (m_lo != m_hi || !prep_dfilt(lo_a, lo_b, hi_a, hi_b, m_lo, p)) return 0;
+    }
+    const int64_t L = n + pad_lo + pad_hi, nout = kind == 0 ? L : L / 2;
+    if (kind == 1 && (L & 3)) return 0;
+    if (L < p.mb + 4 || outer < 1) return 0;
+    if (pack_hi && (nout & 1)) return 0;
+    if (outer * L * inner >= ((int64_t)1 << 31)) return 0;
+    if (inner >= 32) {
+        P1Geo g;
+        g.B = (int)outer; g.R = (int)n; g.C = (int)inner; g.pad_lo = pad_lo; g.L = (int)L; g.nout = (int)nout;
+        g.ngroups = kind == 0 ? (int)((nout + 7) / 8) : (int)((nout / 2 + 3) / 4);
+        g.u_shift = p.u_shift; g.af0 = p.f0; g.af1 = p.f1; g.pack = pack_hi;
+        const unsigned blocks = (unsigned)(((int64_t)g.B * g.ngroups * g.C + 255) / 256);
+        if (dtype == DTCWT_HIP_F32) {
+            QTaps<float> t = to_device_taps<float>(p);
+            G2_SWITCH_FWD(k_g2_fwd_p1, float, <<<blocks, 256, 0, ctx->stream>>>((const float *)X, (float *)Y0, (float *)Y1, g, t));
+        } else {
+            QTaps<double> t = to_device_taps<double>(p);
+            G2_SWITCH_FWD(k_g2_fwd_p1, double, <<<blocks, 256, 0, ctx->stream>>>((const double *)X, (double *)Y0, (double *)Y1, g, t));
+        }
+        G2_LAUNCH_CHECK();
+        return 1;
+    }
+    if (inner == 1) {       // the filter axis is the contiguous one: LDS rows (interleaved hi = hi itself)
+        P2Geo g;
+        g.nlines = (int)outer; g.R1 = 0; g.Cin = (int)n; g.pad_lo = pad_lo; g.L = (int)L; g.Cout = (int)nout;
+        g.crop = 0; g.u_shift = p.u_shift; g.f0 = p.f0; g.f1 = p.f1;
+        const int in_step = kind == 0 ? 4 : 8;
+        const int win = kind == 0 ? (4 + p.mb - 1 + 3) / 4 * 4 : 4 + 2 * p.mb;
+        const size_t lds = dtype == DTCWT_HIP_F32 ? finish_rows<float>(g, in_step, win, (int)((nout + 3) / 4), 0, 1)
+                                                  : finish_rows<double>(g, in_step, win, (int)((nout + 3) / 4), 0, 1);
+        const int lpb = 256 / g.tpl;
+        const unsigned blocks = (unsigned)(((g.nlines + lpb - 1) / lpb) * g.nseg);
+        if (dtype == DTCWT_HIP_F32) {
+            QTaps<float> t = to_device_taps<float>(p);
+            G2_SWITCH_FWD(k_g2_rows_pair, float, <<<blocks, 256, lds, ctx->stream>>>((const float *)X, (float *)Y0, (float *)Y1, g, t));
+        } else {
+            QTaps<double> t = to_device_taps<double>(p);
+            G2_SWITCH_FWD(k_g2_rows_pair, double, <<<blocks, 256, lds, ctx->stream>>>((const double *)X, (double *)Y0, (double *)Y1, g, t));
+        }
+        G2_LAUNCH_CHECK();
+        return 1;
+    }
+    return 0;
+}
+
+int dtcwt_g2_sum(dtcwt_hip_ctx *ctx, int dtype, int kind, const void *X0, const void *X1, void *Y,
+                 int64_t outer, int64_t n, int64_t inner, int crop, const double *lo_a,
+                 const double *lo_b, const double *hi_a, const double *hi_b, int m_lo, int m_hi,
+                 int packed_x1, double gain1) {
+    TapPrep p;
+    if (kind == 0) {
+        if (crop || !prep_level1(lo_a, m_lo, hi_a, m_hi, false, p)) return 0;
+        for (int k = 0; k < G2_MAXB; ++k) p.b[k] *= gain1;
+    } else {
+        if (m_lo != m_hi || !prep_ifilt(lo_a, lo_b, hi_a, hi_b, m_lo, p)) return 0;
+        for (int k = 0; k < G2_MAXB; ++k) { p.c[k] *= gain1; p.d[k] *= gain1; }
+    }
+    if ((n & 1) || n < p.mb + 4 || outer < 1) return 0;
+    const int64_t nout = (kind == 0 ? n : 2 * n) - 2 * crop;
+    if (nout < 1 || outer * nout * inner >= ((int64_t)1 << 31)) return 0;
+    if (inner >= 32) {
+        S1Geo g;
+        g.B = (int)outer; g.R = (int)n; g.C = (int)inner; g.Rout = (int)nout; g.crop = crop;
+        g.ngroups = kind == 0 ? (int)((n + 7) / 8) : (int)((n / 2 + 1) / 2);
+        g.u_shift = p.u_shift; g.f0 = p.f0; g.f1 = p.f1; g.packed = packed_x1;
+        const unsigned blocks = (unsigned)(((int64_t)g.B * g.ngroups * g.C + 255) / 256);
+        if (dtype == DTCWT_HIP_F32) {
+            QTaps<float> t = to_device_taps<float>(p);
+            G2_SWITCH_INV(k_g2_sum_march, float, <<<blocks, 256, 0, ctx->stream>>>((const float *)X0, (const float *)X1, (float *)Y, g, t));
+        } else {
+            QTaps<double> t = to_device_taps<double>(p);
+            G2_SWITCH_INV(k_g2_sum_march, double, <<<blocks, 256, 0, ctx->stream>>>((const double *)X0, (const double *)X1, (double *)Y, g, t));
+        }
+        G2_LAUNCH_CHECK();
+        return 1;
+    }
+    if (inner == 1) {
+        P2Geo g;
+        g.nlines = (int)outer; g.R1 = 0; g.Cin = (int)n; g.pad_lo = 0; g.L = (int)n; g.Cout = (int)nout;
+        g.crop = crop; g.u_shift = p.u_shift; g.f0 = p.f0; g.f1 = p.f1;
+        const int win = kind == 0 ? (4 + p.mb - 1 + 3) / 4 * 4 : ((((p.mb / 2) & 1) ? p.mb : p.mb + 2) + 2);
+        const int need = kind == 0 ? (int)((n + 3) / 4) : (int)((n / 2 + 1) / 2);
+        const size_t lds = dtype == DTCWT_HIP_F32 ? finish_rows<float>(g, 4, win, need, 0)
+                                                  : finish_rows<double>(g, 4, win, need, 0);
+        const int lpb = 256 / g.tpl;
+        const unsigned blocks = (unsigned)(((g.nlines + lpb - 1) / lpb) * g.nseg);
+        if (dtype == DTCWT_HIP_F32) {
+            QTaps<float> t = to_device_taps<float>(p);
+            G2_SWITCH_INV(k_g2_inv_p2, float, <<<blocks, 256, lds, ctx->stream>>>((const float *)X0, (const float *)X1, (float *)Y, g, t));
+        } else {
+            QTaps<double> t = to_device_taps<double>(p);
+            G2_SWITCH_INV(k_g2_inv_p2, double, <<<blocks, 256, lds, ctx->stream>>>((const double *)X0, (const double *)X1, (double *)Y, g, t));
+        }
+        G2_LAUNCH_CHECK();
+        return 1;
+    }
+    return 0;
+}
+
 extern "C" {
 
 int dtcwt_hip_level2d_forward(dtcwt_hip_ctx *ctx, int dtype, int kind, const void *X, int64_t B,
@@ -797,7 +1001,7 @@ int dtcwt_hip_level2d_forward(dtcwt_hip_ctx *ctx, int dtype, int kind, const voi
     g1.B = (int)B; g1.R = (int)R; g1.C = (int)C;
     g1.pad_lo = pad_r_lo; g1.L = (int)LR; g1.nout = (int)R1;
     g1.ngroups = kind == 0 ? (int)((R1 + 7) / 8) : (int)((R1 / 2 + 3) / 4);
-    g1.u_shift = p.u_shift; g1.af0 = p.f0; g1.af1 = p.f1;
+    g1.u_shift = p.u_shift; g1.af0 = p.f0; g1.af1 = p.f1; g1.pack = 0;
     const unsigned blocks1 = (unsigned)(((int64_t)g1.B * g1.ngroups * g1.C + 255) / 256);
 
     P2Geo g2;
@@ -891,6 +1095,34 @@ int dtcwt_hip_level2d_inverse(dtcwt_hip_ctx *ctx, int dtype, int kind, const voi
     }
     G2_LAUNCH_CHECK();
     return 0;
+}
+
+int dtcwt_hip_level1d_forward(dtcwt_hip_ctx *ctx, int dtype, int kind, const void *X, int64_t n,
+                              int64_t k, int pad_lo, int pad_hi, const double *lo_a, const double *lo_b,
+                              const double *hi_a, const double *hi_b, int m_lo, int m_hi, void *Lo,
+                              void *Yh) {
+    DT_REQUIRE(ctx && X && Lo && Yh && lo_a && hi_a, "NULL argument");
+    DT_REQUIRE(dtype == DTCWT_HIP_F32 || dtype == DTCWT_HIP_F64, "bad dtype %d", dtype);
+    DT_REQUIRE(kind == 0 || (kind == 1 && lo_b && hi_b), "bad kind %d", kind);
+    DT_REQUIRE(n >= 1 && k >= 1 && pad_lo >= 0 && pad_hi >= 0, "bad extents");
+    DT_CHECK_HIP(hipSetDevice(ctx->device));
+    const int rc = dtcwt_g2_pair(ctx, dtype, kind, X, Lo, Yh, 1, n, k, pad_lo, pad_hi, lo_a, lo_b, hi_a, hi_b,
+                                 m_lo, m_hi, 1);
+    return rc < 0 ? rc : (rc == 1 ? 0 : G2_NA);
+}
+
+int dtcwt_hip_level1d_inverse(dtcwt_hip_ctx *ctx, int dtype, int kind, const void *Lo, const void *Yh,
+                              int64_t n, int64_t k, double gain, int crop, const double *lo_a,
+                              const double *lo_b, const double *hi_a, const double *hi_b, int m_lo,
+                              int m_hi, void *Z) {
+    DT_REQUIRE(ctx && Lo && Yh && Z && lo_a && hi_a, "NULL argument");
+    DT_REQUIRE(dtype == DTCWT_HIP_F32 || dtype == DTCWT_HIP_F64, "bad dtype %d", dtype);
+    DT_REQUIRE(kind == 0 || (kind == 1 && lo_b && hi_b), "bad kind %d", kind);
+    DT_REQUIRE(n >= 2 && k >= 1 && crop >= 0, "bad extents");
+    DT_CHECK_HIP(hipSetDevice(ctx->device));
+    const int rc = dtcwt_g2_sum(ctx, dtype, kind, Lo, Yh, Z, 1, n, k, crop, lo_a, lo_b, hi_a, hi_b, m_lo, m_hi,
+                                1, gain);
+    return rc < 0 ? rc : (rc == 1 ? 0 : G2_NA);
 }
 
 }  // extern "C"

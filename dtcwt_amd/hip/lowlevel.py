@@ -20,7 +20,7 @@ from dtcwt_amd.hip._lib import DeviceArray, View, check, dtype_code, taps_arg
 
 __all__ = ['colfilter', 'coldfilt', 'colifilt', 'axis_colfilter', 'axis_coldfilt',
            'axis_colifilt', 'axis_colfilter2', 'axis_colfilter_sum2', 'axis_coldfilt2',
-           'axis_colifilt_sum2', 'q2c', 'c2q', 'level2d_forward', 'level2d_inverse']
+           'axis_colifilt_sum2', 'q2c', 'c2q', 'level2d_forward', 'level2d_inverse', 'level1d_forward', 'level1d_inverse']
 
 
 def _prod(t):
@@ -273,6 +273,55 @@ def level2d_inverse(Zl, Yh, kind, gains, crop_r, crop_c, lo, hi):
     rc = _lib.lib().dtcwt_hip_level2d_inverse(
         Zl.ctx.handle, dtype_code(Zl.dtype), kind, Zl.ptr, Yh.ptr, B, Rl, Cl, g, int(crop_r), int(crop_c),
         pa0, pb0, pa1, pb1, m0, m1, Y1.ptr, Y2.ptr, Z.ptr)
+    return Z if _check_na(rc) else None
+
+
+def level1d_forward(X, kind, pad, lo, hi):
+    """One forward level of the 1-D transform on X [n, k] in one launch, highpass packing
+    included (dtcwt_hip_level1d_forward; dtcwt/numpy/transform1d.py:79-100): kind 0 with
+    lo = h0o, hi = h1o, kind 1 with lo = (h0b, h0a), hi = (h1b, h1a).  Returns (Lo, Yh) or None
+    when the library has no such kernel for these filters / sizes."""
+    n, k = X.shape
+    L = n + pad[0] + pad[1]
+    if kind == 0:
+        (k0, pa0, m0), (k1, pa1, m1) = taps_arg(lo), taps_arg(hi)
+        pb0 = pb1 = None
+        n1 = L
+    else:
+        k0, pa0, pb0, m0 = _pair_args(*lo)
+        k1, pa1, pb1, m1 = _pair_args(*hi)
+        n1 = L // 2
+    if n1 % 2 or (kind == 1 and L % 4) or not (k == 1 or k >= 32):
+        return None
+    cdt = np.complex64 if X.dtype == np.float32 else np.complex128
+    Lo = DeviceArray(X.ctx, (n1, k), X.dtype)
+    Yh = DeviceArray(X.ctx, (n1 // 2, k), cdt)
+    rc = _lib.lib().dtcwt_hip_level1d_forward(X.ctx.handle, dtype_code(X.dtype), kind, X.ptr, n, k, int(pad[0]),
+                                              int(pad[1]), pa0, pb0, pa1, pb1, m0, m1, Lo.ptr, Yh.ptr)
+    return (Lo, Yh) if _check_na(rc) else None
+
+
+def level1d_inverse(Lo, Yh, kind, gain, crop, lo, hi):
+    """One inverse level of the 1-D transform in one launch (dtcwt_hip_level1d_inverse;
+    dtcwt/numpy/transform1d.py:150-176): Lo [n, k], Yh [n/2, k] complex scaled by *gain*; kind 0
+    with lo = g0o, hi = g1o, kind 1 with lo = (g0b, g0a), hi = (g1b, g1a) and *crop* samples
+    dropped from both ends.  Returns Z or None."""
+    n, k = Lo.shape
+    if Yh.shape != (n // 2, k) or n % 2 or not (k == 1 or k >= 32):
+        return None
+    if kind == 0:
+        (k0, pa0, m0), (k1, pa1, m1) = taps_arg(lo), taps_arg(hi)
+        pb0 = pb1 = None
+        nz = n
+    else:
+        k0, pa0, pb0, m0 = _pair_args(*lo)
+        k1, pa1, pb1, m1 = _pair_args(*hi)
+        nz = 2 * n - 2 * crop
+    if nz < 1:
+        return None
+    Z = DeviceArray(Lo.ctx, (nz, k), Lo.dtype)
+    rc = _lib.lib().dtcwt_hip_level1d_inverse(Lo.ctx.handle, dtype_code(Lo.dtype), kind, Lo.ptr, Yh.ptr, n, k,
+                                              float(gain), int(crop), pa0, pb0, pa1, pb1, m0, m1, Z.ptr)
     return Z if _check_na(rc) else None
 
 

@@ -88,13 +88,25 @@ class Transform1d(object):
         if Xd is None:
             Xd = self.ctx.to_device(X)
         Yh, Ys = [], []
-        Lo, Hi = ll.axis_colfilter2(Xd, h0o, h1o, axis=0)
-        Yh.append(_pack(Hi))
+        # a level = one launch with the highpass packing fused (dtcwt_hip_level1d_forward);
+        # filters / shapes it declines go through the pair filter + pack kernels
+        whole = ll.level1d_forward(Xd, 0, (0, 0), h0o, h1o)
+        if whole is not None:
+            Lo, y = whole
+        else:
+            Lo, Hi = ll.axis_colfilter2(Xd, h0o, h1o, axis=0)
+            y = _pack(Hi)
+        Yh.append(y)
         Ys.append(Lo)
         for level in range(1, nlevels):
             pad = (1, 1) if Lo.shape[0] % 4 != 0 else (0, 0)      # transform1d.py:95-96
-            Lo, Hi = ll.axis_coldfilt2(Lo, (h0b, h0a), (h1b, h1a), axis=0, pad=pad)
-            Yh.append(_pack(Hi))
+            whole = ll.level1d_forward(Lo, 1, pad, (h0b, h0a), (h1b, h1a))
+            if whole is not None:
+                Lo, y = whole
+            else:
+                Lo, Hi = ll.axis_coldfilt2(Lo, (h0b, h0a), (h1b, h1a), axis=0, pad=pad)
+                y = _pack(Hi)
+            Yh.append(y)
             Ys.append(Lo)
         if include_scale:
             return Pyramid(Lo, tuple(Yh), tuple(Ys))
@@ -123,19 +135,24 @@ class Transform1d(object):
         Yh = [y if y.ndim == 2 else y.reshape(y.shape[0], 1) for y in Yh]
         level = a - 1
         while level >= 1:                                     # transform1d.py:150-160
-            Hi = _unpack(Yh[level], gain_mask[level])
             want = 2 * Yh[level - 1].shape[0]
             full = 2 * Lo.shape[0]
             crop = (1, 1) if full != want else (0, 0)
             if full - 2 * crop[0] != want or Lo.shape[1] != Yh[level - 1].shape[1] or \
-                    Hi.shape != Lo.shape:
+                    (2 * Yh[level].shape[0], Yh[level].shape[1]) != Lo.shape:
                 raise ValueError('Yh sizes are not valid for DTWAVEIFM')
-            Lo = ll.axis_colifilt_sum2(Lo, Hi, (g0b, g0a), (g1b, g1a), axis=0, crop=crop)
+            whole = ll.level1d_inverse(Lo, Yh[level], 1, gain_mask[level], crop[0], (g0b, g0a), (g1b, g1a))
+            if whole is not None:       # the level in one launch (dtcwt_hip_level1d_inverse)
+                Lo = whole
+            else:
+                Hi = _unpack(Yh[level], gain_mask[level])
+                Lo = ll.axis_colifilt_sum2(Lo, Hi, (g0b, g0a), (g1b, g1a), axis=0, crop=crop)
             level -= 1
-        Hi = _unpack(Yh[0], gain_mask[0])
-        if Hi.shape != Lo.shape:
+        if (2 * Yh[0].shape[0], Yh[0].shape[1]) != Lo.shape:
             raise ValueError('Yh sizes are not valid for DTWAVEIFM')
-        Z = ll.axis_colfilter_sum2(Lo, Hi, g0o, g1o, axis=0)
+        Z = ll.level1d_inverse(Lo, Yh[0], 0, gain_mask[0], 0, g0o, g1o)
+        if Z is None:
+            Z = ll.axis_colfilter_sum2(Lo, _unpack(Yh[0], gain_mask[0]), g0o, g1o, axis=0)
         if device_output:
             return Z
         Zh = Z.get()

@@ -175,6 +175,28 @@ int dtcwt_hip_level2d_inverse(dtcwt_hip_ctx *ctx, int dtype, int kind, const voi
                               int crop_r, int crop_c, const double *lo_a, const double *lo_b,
                               const double *hi_a, const double *hi_b, int m_lo, int m_hi,
                               void *Y1, void *Y2, void *Z);
+/* One level of the 1-D transform in ONE launch, float32 / float64, X: [n][k] (k signals side by
+ * side, k == 1 or k >= 32; other k return -3).
+ *
+ * level1d_forward replaces dtcwt/numpy/transform1d.py:79-88 (kind 0: Lo = colfilter(X, lo_a),
+ * Hi = colfilter(X, hi_a)) or :93-100 (kind 1: coldfilt with the pairs (lo_a, lo_b) / (hi_a,
+ * hi_b), rows replicated by (pad_lo, pad_hi) as :95-96 does) INCLUDING the packing
+ * Yh = Hi[::2] + 1j*Hi[1::2] (:88, :100).  Lo: [n1][k], Yh: [n1/2][k] complex, n1 = padded n
+ * (kind 0) or half of it (kind 1).
+ *
+ * level1d_inverse replaces :150-160 (kind 1) or :162-176 (kind 0): Z = filter(Lo, lo) +
+ * filter(gain * unpack(Yh), hi) with colifilt / colfilter; kind 1 drops `crop` samples from both
+ * ends (:156-157).  Lo: [n][k], Yh: [n/2][k] complex, Z: [n or 2n - 2 crop][k].
+ *
+ * Both return -3 where dtcwt_hip_level2d_* would. */
+int dtcwt_hip_level1d_forward(dtcwt_hip_ctx *ctx, int dtype, int kind, const void *X, int64_t n,
+                              int64_t k, int pad_lo, int pad_hi, const double *lo_a, const double *lo_b,
+                              const double *hi_a, const double *hi_b, int m_lo, int m_hi, void *Lo,
+                              void *Yh);
+int dtcwt_hip_level1d_inverse(dtcwt_hip_ctx *ctx, int dtype, int kind, const void *Lo, const void *Yh,
+                              int64_t n, int64_t k, double gain, int crop, const double *lo_a,
+                              const double *lo_b, const double *hi_a, const double *hi_b, int m_lo,
+                              int m_hi, void *Z);
 /* Fused float32 level 1 of the 3-D forward transform: replaces `_level1_xfm`
  * (dtcwt/numpy/transform3d.py:208-289) for odd-length biort filters -- the three axis
  * passes (h0o/h1o along axes 2, 1, 0) and the seven cube2c packings in ONE launch.

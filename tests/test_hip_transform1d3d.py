@@ -52,6 +52,30 @@ def test_1d_vs_oracle(shape):
             assert_close(z.reshape(X.shape), X, itol * 3, 'PR')
 
 
+@pytest.mark.parametrize('bn,qn', [('near_sym_a', 'qshift_a'), ('near_sym_b', 'qshift_d'), ('antonini', 'qshift_06'),
+                                   ('legall', 'qshift_c'), ('near_sym_b', 'qshift_b')])
+@pytest.mark.parametrize('shape', [(4096,), (1500, 1), (630, 40), (322, 64), (200, 130)])
+def test_1d_one_launch_levels_vs_oracle(bn, qn, shape):
+    """The one-launch levels (dtcwt_hip_level1d_*: k = 1 through LDS rows, k >= 32 marching down
+    the rows, highpass packing fused) against the oracle, lengths that need the (1, 1) padding
+    and the matching crop, gains on the way back."""
+    from dtcwt_amd.hip import lowlevel as ll, default_context
+    rs = np.random.RandomState(31)
+    to = o.Transform1d(biort(bn), qshift(qn))
+    for dt, tol, itol in ((np.float32, XFM_TOL, INV_TOL * 3), (np.float64, F64_TOL, 1e-11)):
+        X = rs.standard_normal(shape).astype(dt)
+        t = Transform1d(bn, qn)
+        Xd = default_context().to_device(X.reshape(shape[0], -1))
+        assert ll.level1d_forward(Xd, 0, (0, 0), *biort(bn)[0:3:2]) is not None      # this path is what runs
+        for nl in (1, 3, 5):
+            want = to.forward(X, nlevels=nl, include_scale=True)
+            p = t.forward(X, nlevels=nl, include_scale=True)
+            assert_pyramids_close(p, want, tol)
+            gm = rs.uniform(0.3, 1.4, size=nl)
+            for g in (None, gm):
+                assert_close(t.inverse(p, g), to.inverse(want, g), itol, 'inverse nl=%d' % nl)
+
+
 def test_1d_errors_and_zero_levels():
     t = Transform1d()
     with pytest.raises(ValueError):
