@@ -7,7 +7,9 @@ import never fails; the first *use* without a usable runtime raises
 import ctypes
 import importlib.util
 import os
+import sys
 import threading
+import weakref
 
 import numpy as np
 
@@ -293,6 +295,74 @@ class Event(object):
             pass
 
 
+class _HostPool(object):
+    """Recycles the host memory of downloaded arrays.
+
+    A device-to-host copy into a fresh ``np.empty`` spends 5x longer on first-touch page faults
+    than on the copy itself (4096^2 pyramid: 31 ms vs 6 ms, tools/bench_host_api.py).  Arrays
+    returned by :meth:`DeviceArray.get` are views of a byte buffer; when such an array is
+    garbage collected AND nothing else (a slice, a reshaped view ...) still refers to the buffer,
+    the buffer goes back to the pool for the next download of the same size.  Buffers under
+    1 MiB are not pooled; ``DTCWT_HIP_HOST_POOL_MB`` bounds the idle memory (default 2048, 0
+    disables)."""
+
+    MIN_BYTES = 1 << 20
+
+    def __init__(self):
+        self._free = {}
+        self._idle = 0
+        self._lock = threading.Lock()
+        self.limit = int(os.environ.get('DTCWT_HIP_HOST_POOL_MB', '2048')) << 20
+        self._quiet_refs = None
+        self._quiet_refs = self._calibrate()
+
+    def _calibrate(self):
+        # references to a buffer seen inside give() when no user view exists
+        seen = []
+        base = np.empty(8, dtype=np.uint8)
+        arr = base.view(np.float32).reshape(2)
+        weakref.finalize(arr, self.give, base, seen)
+        del base, arr
+        return seen[0] if seen else -1
+
+    def empty(self, shape, dtype):
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize if len(shape) else dtype.itemsize
+        if nbytes < self.MIN_BYTES or self.limit <= 0 or self._quiet_refs < 0:
+            return np.empty(shape, dtype=dtype)
+        base = None
+        with self._lock:
+            lst = self._free.get(nbytes)
+            if lst:
+                base = lst.pop()
+                self._idle -= nbytes
+        if base is None:
+            base = np.empty(nbytes, dtype=np.uint8)
+        arr = base.view(dtype).reshape(shape)
+        weakref.finalize(arr, self.give, base)
+        return arr
+
+    def give(self, base, probe=None):
+        refs = sys.getrefcount(base)
+        if probe is not None:
+            probe.append(refs)
+            return
+        if refs != self._quiet_refs:        # some view of the array outlived it: not ours to reuse
+            return
+        with self._lock:
+            if self._idle + base.nbytes <= self.limit:
+                self._free.setdefault(base.nbytes, []).append(base)
+                self._idle += base.nbytes
+
+    def trim(self):
+        with self._lock:
+            self._free.clear()
+            self._idle = 0
+
+
+host_pool = _HostPool()
+
+
 class DeviceArray(object):
     """A C-contiguous array in HBM: pointer + shape + dtype.  Owns its memory unless
     wrapping a foreign pointer (``DeviceArray.wrap``)."""
@@ -346,7 +416,7 @@ class DeviceArray(object):
 
     def get(self):
         """Copy to a NumPy array (synchronises the stream)."""
-        out = np.empty(self.shape, dtype=self.dtype)
+        out = host_pool.empty(self.shape, self.dtype)
         check(self.ctx._lib.dtcwt_hip_memcpy_d2h(self.ctx.handle, out.ctypes.data_as(_vp), self.ptr,
                                                  self.nbytes))
         return out
