@@ -734,6 +734,199 @@ __global__ void __launch_bounds__(256) k_g2_sum_march(const T *__restrict__ X0, 
         if (lo0 + k >= 0 && lo0 + k < g.Rout) Ob[(size_t)(lo0 + k) * g.C] = acc[k];
 }
 
+// ---- 3-D level 1, filter-by-filter form: the packings fused into the neighbouring axis pass ----
+// (float64 and every other case without a fused 3-D tile program.)  Forward: the LAST axis pass
+// (down axis 0) of one of the four (a1, a2) volumes computes its lo and hi octant for a 2 x 2
+// block of columns and 4 rows = two 2x2x2 cells, and stores them packed (cube2c,
+// dtcwt/numpy/transform3d.py:532-579) -- or plain, for the lowpass octant.  Inverse: the FIRST
+// merge pass (along axis 1) unpacks (c2cube, :581-619) its two inputs on load.  Seven volumes less
+// to write and read back per direction.
+struct G3Geo {
+    int n0, n1, n2;
+    int ngroups;
+    int u_shift;
+    int o_lo, o_hi;     // octant slot (0..6) of the lo / hi side, -1 = plain volume
+};
+
+template <typename T>
+__device__ inline void cube2c_store(T *rec, T A, T B, T C, T D, T E, T F, T G, T H) {
+    using V = typename Vec16<T>::type;
+    const T h = (T)0.5;
+    T r[8] = {(A - G - D - F) * h, (B - H + C + E) * h, (A - G + D + F) * h, (-B + H + C + E) * h,
+              (A + G + D - F) * h, (B + H - C + E) * h, (A + G - D + F) * h, (-B - H - C + E) * h};
+    constexpr int VN = Vec16<T>::N;
+#pragma unroll
+    for (int j = 0; j < 8 / VN; ++j) {
+        V v;
+        T *e = reinterpret_cast<T *>(&v);
+#pragma unroll
+        for (int t = 0; t < VN; ++t) e[t] = r[j * VN + t];
+        reinterpret_cast<V *>(rec)[j] = v;
+    }
+}
+
+template <typename T, int MB>
+__global__ void __launch_bounds__(256) k_g3_fwd_axis0_cube(const T *__restrict__ V, T *__restrict__ Plain,
+                                                           T *__restrict__ Yh, G3Geo g, QTaps<T> tp) {
+    using V2 = typename std::conditional<sizeof(T) == 4, float2, double2>::type;
+    constexpr int G = 4, WN = G + MB - 1;
+    const unsigned h1 = g.n1 >> 1, h2 = g.n2 >> 1;
+    const unsigned id = blockIdx.x * 256u + threadIdx.x;
+    if (id >= (unsigned)g.ngroups * h1 * h2) return;
+    const unsigned t = id / h2, j2 = id - t * h2;
+    const unsigned grp = t / h1, j1 = t - grp * h1;
+    const size_t s0 = (size_t)g.n1 * g.n2;
+    const int lo0 = grp * G, u0 = lo0 + g.u_shift;
+    T lo[G][2][2], hi[G][2][2];             // [row][i1][i2]
+#pragma unroll
+    for (int i1 = 0; i1 < 2; ++i1) {
+        const T *col = V + (size_t)(2 * j1 + i1) * g.n2 + 2 * j2;
+        T w0[WN], w1[WN];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const V2 v = *reinterpret_cast<const V2 *>(col + (size_t)g2_src(u0 + j, g.n0, 0, g.n0) * s0);
+            w0[j] = v.x; w1[j] = v.y;
+        }
+        T a[G], b[G], c[G], d[G];
+#pragma unroll
+        for (int q = 0; q < G; ++q) a[q] = b[q] = c[q] = d[q] = 0;
+        fir_colfilter<T, G, MB>(w0, tp.a, a);
+        fir_colfilter<T, G, MB>(w0, tp.b, b);
+        fir_colfilter<T, G, MB>(w1, tp.a, c);
+        fir_colfilter<T, G, MB>(w1, tp.b, d);
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+            lo[q][i1][0] = a[q]; hi[q][i1][0] = b[q];
+            lo[q][i1][1] = c[q]; hi[q][i1][1] = d[q];
+        }
+    }
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const int o = side ? g.o_hi : g.o_lo;
+        if (o < 0) {
+#pragma unroll
+            for (int q = 0; q < G; ++q)
+                if (lo0 + q < g.n0) {
+#pragma unroll
+                    for (int i1 = 0; i1 < 2; ++i1) {
+                        V2 v;
+                        v.x = side ? hi[q][i1][0] : lo[q][i1][0];
+                        v.y = side ? hi[q][i1][1] : lo[q][i1][1];
+                        *reinterpret_cast<V2 *>(Plain + (size_t)(lo0 + q) * s0 + (size_t)(2 * j1 + i1) * g.n2 + 2 * j2) = v;
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int c = 0; c < G / 2; ++c) {
+                const int u = (lo0 >> 1) + c;
+                if (2 * u < g.n0) {
+                    T *rec = Yh + (((size_t)u * h1 + j1) * h2 + j2) * 56 + o * 8;
+#define X_(r_, i1_, i2_) (side ? hi[2 * c + r_][i1_][i2_] : lo[2 * c + r_][i1_][i2_])
+                    cube2c_store<T>(rec, X_(0, 0, 0), X_(0, 1, 0), X_(1, 0, 0), X_(1, 1, 0), X_(0, 0, 1), X_(0, 1, 1),
+                                    X_(1, 0, 1), X_(1, 1, 1));
+#undef X_
+                }
+            }
+        }
+    }
+}
+
+// one side of the inverse merge along axis 1: the two image rows (2v, 2v+1) of the 2 x 2 column
+// block (i0, i2) of record (u, v, w), plain volume or octant o of Yh
+template <typename T>
+__device__ inline void g3_load_rows(const T *__restrict__ P, const T *__restrict__ Yh, int o, const G3Geo &g,
+                                    unsigned u, unsigned w, int r, T (&e)[4], T (&od)[4]) {
+    using V2 = typename std::conditional<sizeof(T) == 4, float2, double2>::type;
+    using V = typename Vec16<T>::type;
+    constexpr int VN = Vec16<T>::N;
+    const bool sw = r & 1;
+    const int v = r >> 1;
+    if (o < 0) {
+        const size_t s0 = (size_t)g.n1 * g.n2;
+        const T *b = P + (size_t)(2 * u) * s0 + (size_t)(2 * v) * g.n2 + 2 * w;
+        const V2 x00 = *reinterpret_cast<const V2 *>(b), x01 = *reinterpret_cast<const V2 *>(b + g.n2);
+        const V2 x10 = *reinterpret_cast<const V2 *>(b + s0), x11 = *reinterpret_cast<const V2 *>(b + s0 + g.n2);
+        // columns (i0, i2): 0 = (0,0), 1 = (0,1), 2 = (1,0), 3 = (1,1)
+        const T ev[4] = {x00.x, x00.y, x10.x, x10.y}, ov[4] = {x01.x, x01.y, x11.x, x11.y};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { e[k] = sw ? ov[k] : ev[k]; od[k] = sw ? ev[k] : ov[k]; }
+        return;
+    }
+    const T *rec = Yh + ((((size_t)u * (g.n1 >> 1)) + v) * (g.n2 >> 1) + w) * 56 + o * 8;
+    T z[8];
+#pragma unroll
+    for (int j = 0; j < 8 / VN; ++j) {
+        const V x = reinterpret_cast<const V *>(rec)[j];
+        const T *q = reinterpret_cast<const T *>(&x);
+#pragma unroll
+        for (int t = 0; t < VN; ++t) z[j * VN + t] = q[t];
+    }
+    const T h = (T)0.5;
+    const T pr = z[0], pi = z[1], qr = z[2], qi = z[3], rr = z[4], ri = z[5], sr = z[6], si = z[7];
+    const T A = (pr + qr + rr + sr) * h, G = (-pr - qr + rr + sr) * h, D = (-pr + qr + rr - sr) * h;
+    const T F = (-pr + qr - rr + sr) * h, B = (pi - qi + ri - si) * h, H = (-pi + qi + ri - si) * h;
+    const T C = (pi + qi - ri - si) * h, E = (pi + qi + ri + si) * h;
+    // row 2v: A (0,.,0) E (0,.,1) C (1,.,0) G (1,.,1);  row 2v+1: B F D H
+    const T ev[4] = {A, E, C, G}, ov[4] = {B, F, D, H};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { e[k] = sw ? ov[k] : ev[k]; od[k] = sw ? ev[k] : ov[k]; }
+}
+
+template <typename T, int MB>
+struct G3Inv {
+    static constexpr int NP = (8 + MB) / 2;
+    T acc[4][8];
+    template <int P>
+    __device__ inline void run(const T *__restrict__ P0, const T *__restrict__ Yh, const G3Geo &g, unsigned u,
+                               unsigned w, int u0, const QTaps<T> &tp) {
+        if constexpr (P < NP) {
+            int uu = u0 + 2 * P;
+            asm volatile("" : "+v"(uu));
+            const int r = g2_src(uu, g.n1, 0, g.n1);
+            T e[4], o[4];
+            g3_load_rows<T>(P0, Yh, g.o_lo, g, u, w, r, e, o);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) scatter_colfilter<T, MB, P, 8>(tp.a, e[k], o[k], acc[k]);
+            g3_load_rows<T>(nullptr, Yh, g.o_hi, g, u, w, r, e, o);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) scatter_colfilter<T, MB, P, 8>(tp.b, e[k], o[k], acc[k]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                asm volatile("" : "+v"(acc[0][k]), "+v"(acc[1][k]), "+v"(acc[2][k]), "+v"(acc[3][k]));
+            run<P + 1>(P0, Yh, g, u, w, u0, tp);
+        }
+    }
+};
+
+template <typename T, int MB>
+__global__ void __launch_bounds__(256) k_g3_inv_axis1_cube(const T *__restrict__ P0, const T *__restrict__ Yh,
+                                                           T *__restrict__ Out, G3Geo g, QTaps<T> tp) {
+    using V2 = typename std::conditional<sizeof(T) == 4, float2, double2>::type;
+    const unsigned h0 = g.n0 >> 1, h2 = g.n2 >> 1;
+    const unsigned id = blockIdx.x * 256u + threadIdx.x;
+    if (id >= h0 * (unsigned)g.ngroups * h2) return;
+    const unsigned t = id / h2, w = id - t * h2;
+    const unsigned u = t / g.ngroups, grp = t - u * g.ngroups;
+    G3Inv<T, MB> st;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) st.acc[k][q] = 0;
+    st.template run<0>(P0, Yh, g, u, w, (int)grp * 8 + g.u_shift, tp);
+    const size_t s0 = (size_t)g.n1 * g.n2;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int r = (int)grp * 8 + q;
+        if (r < g.n1) {
+#pragma unroll
+            for (int i0 = 0; i0 < 2; ++i0) {
+                V2 v; v.x = st.acc[2 * i0][q]; v.y = st.acc[2 * i0 + 1][q];
+                *reinterpret_cast<V2 *>(Out + (size_t)(2 * u + i0) * s0 + (size_t)r * g.n2 + 2 * w) = v;
+            }
+        }
+    }
+}
+
 // ---- host side -----------------------------------------------------------------------------
 struct TapPrep {
     double a[G2_MAXB], b[G2_MAXB], c[G2_MAXB], d[G2_MAXB];
@@ -1123,6 +1316,64 @@ int dtcwt_hip_level1d_inverse(dtcwt_hip_ctx *ctx, int dtype, int kind, const voi
     const int rc = dtcwt_g2_sum(ctx, dtype, kind, Lo, Yh, Z, 1, n, k, crop, lo_a, lo_b, hi_a, hi_b, m_lo, m_hi,
                                 1, gain);
     return rc < 0 ? rc : (rc == 1 ? 0 : G2_NA);
+}
+
+int dtcwt_hip_fwd3_axis0_cube2c(dtcwt_hip_ctx *ctx, int dtype, const void *V, int64_t n0, int64_t n1,
+                                int64_t n2, const double *h0, int m0, const double *h1, int m1,
+                                int octant_lo, int octant_hi, void *plain, void *Yh) {
+    DT_REQUIRE(ctx && V && Yh && h0 && h1, "NULL argument");
+    DT_REQUIRE(dtype == DTCWT_HIP_F32 || dtype == DTCWT_HIP_F64, "bad dtype %d", dtype);
+    DT_REQUIRE(octant_lo >= -1 && octant_lo < 7 && octant_hi >= -1 && octant_hi < 7, "bad octant");
+    DT_REQUIRE((octant_lo >= 0 && octant_hi >= 0) || plain, "a plain output needs a buffer");
+    TapPrep p;
+    if (!prep_level1(h0, m0, h1, m1, false, p)) return G2_NA;
+    if ((n0 & 1) || (n1 & 1) || (n2 & 1) || n0 < p.mb + 4 || n1 < 2 || n2 < 2) return G2_NA;
+    if (n0 * n1 * n2 >= ((int64_t)1 << 31)) return G2_NA;
+    DT_CHECK_HIP(hipSetDevice(ctx->device));
+    G3Geo g;
+    g.n0 = (int)n0; g.n1 = (int)n1; g.n2 = (int)n2; g.ngroups = (int)((n0 + 3) / 4); g.u_shift = p.u_shift;
+    g.o_lo = octant_lo; g.o_hi = octant_hi;
+    const unsigned blocks = (unsigned)(((int64_t)g.ngroups * (n1 / 2) * (n2 / 2) + 255) / 256);
+    if (dtype == DTCWT_HIP_F32) {
+        QTaps<float> t = to_device_taps<float>(p);
+        if (p.mb == 8) k_g3_fwd_axis0_cube<float, 8><<<blocks, 256, 0, ctx->stream>>>((const float *)V, (float *)plain, (float *)Yh, g, t);
+        else k_g3_fwd_axis0_cube<float, 20><<<blocks, 256, 0, ctx->stream>>>((const float *)V, (float *)plain, (float *)Yh, g, t);
+    } else {
+        QTaps<double> t = to_device_taps<double>(p);
+        if (p.mb == 8) k_g3_fwd_axis0_cube<double, 8><<<blocks, 256, 0, ctx->stream>>>((const double *)V, (double *)plain, (double *)Yh, g, t);
+        else k_g3_fwd_axis0_cube<double, 20><<<blocks, 256, 0, ctx->stream>>>((const double *)V, (double *)plain, (double *)Yh, g, t);
+    }
+    G2_LAUNCH_CHECK();
+    return 0;
+}
+
+int dtcwt_hip_inv3_axis1_c2cube(dtcwt_hip_ctx *ctx, int dtype, const void *plain, const void *Yh,
+                                int64_t n0, int64_t n1, int64_t n2, const double *g0, int m0,
+                                const double *g1, int m1, int octant_lo, int octant_hi, void *out) {
+    DT_REQUIRE(ctx && Yh && out && g0 && g1, "NULL argument");
+    DT_REQUIRE(dtype == DTCWT_HIP_F32 || dtype == DTCWT_HIP_F64, "bad dtype %d", dtype);
+    DT_REQUIRE(octant_lo >= -1 && octant_lo < 7 && octant_hi >= 0 && octant_hi < 7, "bad octant");
+    DT_REQUIRE(octant_lo >= 0 || plain, "a plain input needs a buffer");
+    TapPrep p;
+    if (!prep_level1(g0, m0, g1, m1, true, p)) return G2_NA;
+    if ((n0 & 1) || (n1 & 1) || (n2 & 1) || n1 < p.mb + 4 || n0 < 2 || n2 < 2) return G2_NA;
+    if (n0 * n1 * n2 >= ((int64_t)1 << 31)) return G2_NA;
+    DT_CHECK_HIP(hipSetDevice(ctx->device));
+    G3Geo g;
+    g.n0 = (int)n0; g.n1 = (int)n1; g.n2 = (int)n2; g.ngroups = (int)((n1 + 7) / 8); g.u_shift = p.u_shift;
+    g.o_lo = octant_lo; g.o_hi = octant_hi;
+    const unsigned blocks = (unsigned)(((int64_t)(n0 / 2) * g.ngroups * (n2 / 2) + 255) / 256);
+    if (dtype == DTCWT_HIP_F32) {
+        QTaps<float> t = to_device_taps<float>(p);
+        if (p.mb == 8) k_g3_inv_axis1_cube<float, 8><<<blocks, 256, 0, ctx->stream>>>((const float *)plain, (const float *)Yh, (float *)out, g, t);
+        else k_g3_inv_axis1_cube<float, 20><<<blocks, 256, 0, ctx->stream>>>((const float *)plain, (const float *)Yh, (float *)out, g, t);
+    } else {
+        QTaps<double> t = to_device_taps<double>(p);
+        if (p.mb == 8) k_g3_inv_axis1_cube<double, 8><<<blocks, 256, 0, ctx->stream>>>((const double *)plain, (const double *)Yh, (double *)out, g, t);
+        else k_g3_inv_axis1_cube<double, 20><<<blocks, 256, 0, ctx->stream>>>((const double *)plain, (const double *)Yh, (double *)out, g, t);
+    }
+    G2_LAUNCH_CHECK();
+    return 0;
 }
 
 }  // extern "C"

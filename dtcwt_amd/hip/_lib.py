@@ -82,6 +82,8 @@ SIGNATURES = {
     'dtcwt_hip_coldfilt2': (_i, [_vp, _i, _vp, _vp, _vp, ctypes.POINTER(View), _pd, _pd, _pd, _pd, _i]),
     'dtcwt_hip_colifilt_sum2': (_i, [_vp, _i, _vp, _vp, _vp, ctypes.POINTER(View), _pd, _pd, _pd, _pd, _i]),
     'dtcwt_hip_q2c': (_i, [_vp, _i, _vp, _i64, _i64, _i64, _i64, _i64, _vp, _i, _i]),
+    'dtcwt_hip_fwd3_axis0_cube2c': (_i, [_vp, _i, _vp, _i64, _i64, _i64, _pd, _i, _pd, _i, _i, _i, _vp, _vp]),
+    'dtcwt_hip_inv3_axis1_c2cube': (_i, [_vp, _i, _vp, _vp, _i64, _i64, _i64, _pd, _i, _pd, _i, _i, _i, _vp]),
     'dtcwt_hip_level1d_forward': (_i, [_vp, _i, _i, _vp, _i64, _i64, _i, _i, _pd, _pd, _pd, _pd, _i, _i, _vp, _vp]),
     'dtcwt_hip_level1d_inverse': (_i, [_vp, _i, _i, _vp, _vp, _i64, _i64, _dbl, _i, _pd, _pd, _pd, _pd, _i, _i, _vp]),
     'dtcwt_hip_level2d_forward': (_i, [_vp, _i, _i, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _pd, _pd, _pd, _pd,

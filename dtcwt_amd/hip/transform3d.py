@@ -161,16 +161,44 @@ class Transform3d(object):
 
     # ------------------------------------------------------------------ forward
     @staticmethod
-    def _split(V, fn2, lo, hi, pads):
+    def _split(V, fn2, lo, hi, pads, axes=(2, 1, 0), parts=None):
         """volume -> {(a0, a1, a2): octant}; axis order 2, 1, 0.  *fn2* filters one volume
         with the lo and the hi filter (pair) in a single pass."""
-        parts = {(): V}
-        for axis in (2, 1, 0):
+        parts = {(): V} if parts is None else parts
+        for axis in axes:
             nxt = {}
             for key, vol in parts.items():
                 nxt[(0,) + key], nxt[(1,) + key] = fn2(vol, lo, hi, axis=axis, pad=pads[axis])
             parts = nxt
         return parts
+
+    def _level1_axis_passes(self, V, h0o, h1o, cdt):
+        """Level 1 as axis passes (transform3d.py:256-289): axes 2 and 1 with the pair filters,
+        then the axis-0 pass of each of the four volumes with cube2c fused into it
+        (dtcwt_hip_fwd3_axis0_cube2c).  -> (LLL, Yh)"""
+        nopad = ((0, 0),) * 3
+        quarter = self._split(V, ll.axis_colfilter2, h0o, h1o, nopad, axes=(2, 1))
+        n0, n1, n2 = V.shape
+        h0, h1 = flat_taps(h0o), flat_taps(h1o)
+        pd = ctypes.POINTER(ctypes.c_double)
+        if h0.shape[0] % 2 and h1.shape[0] % 2 and not (n0 % 2 or n1 % 2 or n2 % 2):
+            LLL = DeviceArray(V.ctx, V.shape, V.dtype)
+            Yh = DeviceArray(V.ctx, (n0 // 2, n1 // 2, n2 // 2, 28), cdt)
+            done = True
+            for (a1, a2), vol in quarter.items():
+                o_lo = -1 if (a1, a2) == (0, 0) else _OCTANTS.index((0, a1, a2))
+                rc = _lib.lib().dtcwt_hip_fwd3_axis0_cube2c(
+                    V.ctx.handle, dtype_code(V.dtype), vol.ptr, n0, n1, n2, h0.ctypes.data_as(pd), h0.shape[0],
+                    h1.ctypes.data_as(pd), h1.shape[0], o_lo, _OCTANTS.index((1, a1, a2)), LLL.ptr, Yh.ptr)
+                if rc == -3:
+                    done = False
+                    break
+                check(rc)
+            if done:
+                return LLL, Yh
+        # even-length taps (octants are (N+1)^3, packed from [:N]) or a volume shorter than the filters
+        parts = self._split(V, ll.axis_colfilter2, h0o, h1o, nopad, axes=(0,), parts=quarter)
+        return parts[(0, 0, 0)], self._pack(parts, V.shape, cdt)
 
     def _pack(self, parts, sub, cdt):
         Yh = DeviceArray(parts[(0, 0, 0)].ctx, (sub[0] // 2, sub[1] // 2, sub[2] // 2, 28), cdt)
@@ -208,10 +236,7 @@ class Transform3d(object):
                     if fused is not None:
                         Yl, Yh[0] = fused
                     else:
-                        sub = Yl.shape  # even-length taps: octants are (N+1)^3, packed from [:N]
-                        parts = self._split(Yl, ll.axis_colfilter2, h0o, h1o, nopad)
-                        Yl = parts[(0, 0, 0)]
-                        Yh[0] = self._pack(parts, sub, cdt)
+                        Yl, Yh[0] = self._level1_axis_passes(Yl, h0o, h1o, cdt)
             else:                                              # :317-383
                 mult, npad = (4, 1) if self.ext_mode == 4 else (8, 2)
                 pads = tuple((npad, npad) if Yl.shape[a] % mult else (0, 0) for a in range(3))
@@ -229,16 +254,41 @@ class Transform3d(object):
 
     # ------------------------------------------------------------------ inverse
     @staticmethod
-    def _merge(Yl, Yh, fsum, lo, hi, crops):
-        """8 octants -> one volume; axis order 1, 0, 2 (transform3d.py:425-435, :485-495).
-        *fsum* computes filter(lo-branch) + filter(hi-branch) in a single pass."""
-        parts = {(0, 0, 0): Yl}
-        for n, o in enumerate(_OCTANTS):
-            parts[o] = _c2cube(Yh, n)
+    def _merge_axis1_fused(Yl, Yh, g0o, g1o):
+        """The axis-1 pass of the level-1 merge with c2cube on load (dtcwt_hip_inv3_axis1_c2cube):
+        {(a0, a2): volume}, or None where the library declines (even-length filters, ...)."""
+        g0, g1 = flat_taps(g0o), flat_taps(g1o)
+        if not (g0.shape[0] % 2 and g1.shape[0] % 2):
+            return None
+        n0, n1, n2 = Yl.shape
+        pd = ctypes.POINTER(ctypes.c_double)
         p1 = {}
         for a0 in (0, 1):
             for a2 in (0, 1):
-                p1[(a0, a2)] = fsum(parts[(a0, 0, a2)], parts[(a0, 1, a2)], lo, hi, axis=1, crop=crops[1])
+                out = DeviceArray(Yl.ctx, Yl.shape, Yl.dtype)
+                o_lo = -1 if (a0, a2) == (0, 0) else _OCTANTS.index((a0, 0, a2))
+                rc = _lib.lib().dtcwt_hip_inv3_axis1_c2cube(
+                    Yl.ctx.handle, dtype_code(Yl.dtype), Yl.ptr, Yh.ptr, n0, n1, n2, g0.ctypes.data_as(pd),
+                    g0.shape[0], g1.ctypes.data_as(pd), g1.shape[0], o_lo, _OCTANTS.index((a0, 1, a2)), out.ptr)
+                if rc == -3:
+                    return None
+                check(rc)
+                p1[(a0, a2)] = out
+        return p1
+
+    @staticmethod
+    def _merge(Yl, Yh, fsum, lo, hi, crops, p1=None):
+        """8 octants -> one volume; axis order 1, 0, 2 (transform3d.py:425-435, :485-495).
+        *fsum* computes filter(lo-branch) + filter(hi-branch) in a single pass; *p1* = the
+        axis-1 pass already done (:meth:`_merge_axis1_fused`)."""
+        if p1 is None:
+            parts = {(0, 0, 0): Yl}
+            for n, o in enumerate(_OCTANTS):
+                parts[o] = _c2cube(Yh, n)
+            p1 = {}
+            for a0 in (0, 1):
+                for a2 in (0, 1):
+                    p1[(a0, a2)] = fsum(parts[(a0, 0, a2)], parts[(a0, 1, a2)], lo, hi, axis=1, crop=crops[1])
         p0 = {}
         for a2 in (0, 1):
             p0[a2] = fsum(p1[(0, a2)], p1[(1, a2)], lo, hi, axis=0, crop=crops[0])
@@ -282,8 +332,11 @@ class Transform3d(object):
                     if tuple(Yl.shape) != tuple(2 * s for s in cur.shape[:3]):
                         raise ValueError('Sizes of highpasses are not valid for the 3D inverse')
                     fused = _fused_inverse_level1(Yl, cur, g0o, g1o) if self.fused else None
-                    Yl = fused if fused is not None else \
-                        self._merge(Yl, cur, ll.axis_colfilter_sum2, g0o, g1o, nocrop)
+                    if fused is not None:
+                        Yl = fused
+                    else:
+                        Yl = self._merge(Yl, cur, ll.axis_colfilter_sum2, g0o, g1o, nocrop,
+                                         p1=self._merge_axis1_fused(Yl, cur, g0o, g1o))
             else:                                              # :460-526
                 if tuple(Yl.shape) != tuple(2 * s for s in cur.shape[:3]):
                     raise ValueError('Sizes of highpasses are not valid for the 3D inverse')

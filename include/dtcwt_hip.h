@@ -197,6 +197,26 @@ int dtcwt_hip_level1d_inverse(dtcwt_hip_ctx *ctx, int dtype, int kind, const voi
                               int64_t n, int64_t k, double gain, int crop, const double *lo_a,
                               const double *lo_b, const double *hi_a, const double *hi_b, int m_lo,
                               int m_hi, void *Z);
+/* Level 1 of the 3-D transform in its filter-by-filter form (float64, and whatever else has no
+ * fused tile program), with the packings fused into the neighbouring axis pass.
+ *
+ * fwd3_axis0_cube2c: the last analysis pass of dtcwt/numpy/transform3d.py:256-273 on ONE of the
+ * four volumes V [n0][n1][n2] left by the axis-2 and axis-1 passes: lo = colfilter(V, h0) and
+ * hi = colfilter(V, h1) down axis 0, each stored either plain (octant_* = -1: the LLL lowpass,
+ * into `plain`) or as subbands 4 o .. 4 o + 3 of Yh [n0/2][n1/2][n2/2][28] complex (cube2c,
+ * :532-579; o = position in the concatenation order of :278-289).
+ *
+ * inv3_axis1_c2cube: the first synthesis pass of :425-435: out [n0][n1][n2] =
+ * colfilter(lo, g0) + colfilter(hi, g1) along axis 1, where hi is octant_hi of Yh unpacked on load
+ * (c2cube, :581-619) and lo is octant_lo of Yh or, for -1, the plain volume `plain`.
+ *
+ * Odd-length filters only; -3 otherwise (and for volumes shorter than the filter bucket). */
+int dtcwt_hip_fwd3_axis0_cube2c(dtcwt_hip_ctx *ctx, int dtype, const void *V, int64_t n0, int64_t n1,
+                                int64_t n2, const double *h0, int m0, const double *h1, int m1,
+                                int octant_lo, int octant_hi, void *plain, void *Yh);
+int dtcwt_hip_inv3_axis1_c2cube(dtcwt_hip_ctx *ctx, int dtype, const void *plain, const void *Yh,
+                                int64_t n0, int64_t n1, int64_t n2, const double *g0, int m0,
+                                const double *g1, int m1, int octant_lo, int octant_hi, void *out);
 /* Fused float32 level 1 of the 3-D forward transform: replaces `_level1_xfm`
  * (dtcwt/numpy/transform3d.py:208-289) for odd-length biort filters -- the three axis
  * passes (h0o/h1o along axes 2, 1, 0) and the seven cube2c packings in ONE launch.
