@@ -10,6 +10,14 @@
 #pragma once
 #include "fused2d_tiles.hpp"
 
+// 16-byte store of write-once data (subband records) with the non-temporal hint, so that the
+// lowpass plane the next level reads back is what stays in L2 / the Infinity Cache
+typedef float dt_v4f __attribute__((ext_vector_type(4)));
+#define DT_STREAM_STORE_F4(dst_, val_) \
+    __builtin_nontemporal_store(*reinterpret_cast<const dt_v4f *>(&(val_)), reinterpret_cast<dt_v4f *>(dst_))
+// ... and 16-byte load of read-once data (the records on the way back)
+#define DT_STREAM_LOAD_F4(src_) __builtin_nontemporal_load(reinterpret_cast<const dt_v4f *>(src_))
+
 namespace dt2d {
 
 // ======================================================================================
@@ -157,7 +165,7 @@ DT_HD void fwd1s_rows_flush(const Fwd1Params &p, const float *stage, int tid, in
         int R = r0 + 2 * u, Cc = c0 + 2 * v;
         if (task < NU * NV && R < p.LR && Cc < p.LC) {
             float *rec = p.Yh + (((int64_t)b * HR + R / 2) * HCc + Cc / 2) * 12;
-            reinterpret_cast<f4 *>(rec)[part] = slab[j];
+            DT_STREAM_STORE_F4(reinterpret_cast<f4 *>(rec) + part, slab[j]);
         }
     }
 }
@@ -288,7 +296,7 @@ DT_HD void fwd2s_rows_flush(const Fwd2Params &p, const float *stage, int tid, in
         int R = r0 + 2 * il, Cc = c0 + 2 * jl;
         if (task < C::TI * C::TJ && R < OR && Cc < OC) {
             float *rec = p.Yh + (((int64_t)b * HR + R / 2) * HCc + Cc / 2) * 12;
-            reinterpret_cast<f4 *>(rec)[part] = slab[j];
+            DT_STREAM_STORE_F4(reinterpret_cast<f4 *>(rec) + part, slab[j]);
         }
     }
 }
@@ -339,7 +347,8 @@ DT_HD void inv1d_rows(const Inv1Params &p, const float *y1, const float *y2, int
         }
         float *X = p.X + ((int64_t)b * p.R + R) * p.C + Cc;
         if (Cc + 3 < p.C && (p.C & 3) == 0) {
-            *reinterpret_cast<f4 *>(X) = f4{o[0], o[1], o[2], o[3]};
+            const f4 ov = f4{o[0], o[1], o[2], o[3]};      // the reconstruction: written once, not read again here
+            DT_STREAM_STORE_F4(X, ov);
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -398,7 +407,7 @@ DT_HD void inv_rec_stage(const float *Yhb, int zr, int zc, float *srec, int ro, 
         int uw = rec / QC, vw = rec - uw * QC;
         int ur = ro + 2 * uw, vc = co + 2 * vw;
         if (!interior) { ur = reflect_i(ur, zr); vc = reflect_i(vc, zc); }
-        f4 t = reinterpret_cast<const f4 *>(Yhb + ((int64_t)(ur >> 1) * hc + (vc >> 1)) * 12)[part];
+        const f4 t = reinterpret_cast<const f4 *>(Yhb + ((int64_t)(ur >> 1) * hc + (vc >> 1)) * 12)[part];
         px[k] = t.x; py[k] = t.y; pz[k] = t.z; pw[k] = t.w;
     }
     f4 *dst = reinterpret_cast<f4 *>(srec);

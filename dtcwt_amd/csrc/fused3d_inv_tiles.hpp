@@ -123,7 +123,7 @@ DT_HD void i3a_issue_rec(const Inv3AParams &p, Inv3AState<F> &st, int tid, int c
         bool ok = piece < I3_NPIECE && cj0 + row < e1 && within < ncell * 14;
         if (!ok) { row = 0; within = 0; }           // harmless in-range address, value unused
         const f4 *src = reinterpret_cast<const f4 *>(p.Yh + (((int64_t)rq * e1 + (cj0 + row)) * e2 + ck0) * 56);
-        f4 v = src[within];
+        const dt_v4f v = DT_STREAM_LOAD_F4(src + within);
         st.R[s][0] = v.x; st.R[s][1] = v.y; st.R[s][2] = v.z; st.R[s][3] = v.w;
     }
 }

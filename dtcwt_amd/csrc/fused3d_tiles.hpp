@@ -272,7 +272,7 @@ DT_HD void f3l1_pack_flush(const Fwd3L1Params &p, const float *stage, int tid, i
 #pragma unroll
     for (int it = 0; it < 7; ++it) {
         int piece = it * 64 + lane;                      // 16-byte piece of the row's 32 records
-        if (piece < ncell * 14) row[piece] = slab[slab_f4(piece)];
+        if (piece < ncell * 14) DT_STREAM_STORE_F4(row + piece, slab[slab_f4(piece)]);
     }
 }
 
@@ -397,7 +397,7 @@ DT_HD void f3l2_axis0_flush(const Fwd3L2Params &p, int first, int lane, const fl
 #pragma unroll
     for (int it = 0; it < 14; ++it) {
         int piece = it * 64 + lane;
-        if (piece < n * 14) dst[piece] = src[slab_f4(piece)];
+        if (piece < n * 14) DT_STREAM_STORE_F4(dst + piece, src[slab_f4(piece)]);
     }
 }
 

@@ -52,6 +52,29 @@ template <typename T> struct Vec16;
 template <> struct Vec16<float> { using type = float4; static constexpr int N = 4; };
 template <> struct Vec16<double> { using type = double2; static constexpr int N = 2; };
 
+// 16-byte accesses to write-once / read-once data (subband records): non-temporal, so that the
+// lowpass planes the next launch reads back are what stays in L2 / the Infinity Cache
+template <typename V> __device__ inline void stream_store(V *dst, const V &v);
+template <> __device__ inline void stream_store<float4>(float4 *dst, const float4 &v) {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(*reinterpret_cast<const v4 *>(&v), reinterpret_cast<v4 *>(dst));
+}
+template <> __device__ inline void stream_store<double2>(double2 *dst, const double2 &v) {
+    typedef double v2 __attribute__((ext_vector_type(2)));
+    __builtin_nontemporal_store(*reinterpret_cast<const v2 *>(&v), reinterpret_cast<v2 *>(dst));
+}
+template <typename V> __device__ inline V stream_load(const V *src);
+template <> __device__ inline float4 stream_load<float4>(const float4 *src) {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const v4 t = __builtin_nontemporal_load(reinterpret_cast<const v4 *>(src));
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+template <> __device__ inline double2 stream_load<double2>(const double2 *src) {
+    typedef double v2 __attribute__((ext_vector_type(2)));
+    const v2 t = __builtin_nontemporal_load(reinterpret_cast<const v2 *>(src));
+    return make_double2(t.x, t.y);
+}
+
 template <typename T, int N>
 __device__ inline void lds_window(const T *p, T (&w)[N]) {        // p 16-byte aligned
     using V = typename Vec16<T>::type;
@@ -391,7 +414,7 @@ __global__ void __launch_bounds__(256) k_g2_fwd_p2(const T *__restrict__ Lo, con
         const int nvec = npix > 0 ? npix * 12 / VN : 0;
         V *dst = reinterpret_cast<V *>(Yh + ((size_t)rpg * C2 + pix0) * 12);
         const V *src = reinterpret_cast<const V *>(sm);
-        for (int e = q; e < nvec; e += g.tpl) dst[e] = src[e];
+        for (int e = q; e < nvec; e += g.tpl) stream_store<V>(dst + e, src[e]);
     }
 }
 
@@ -535,7 +558,7 @@ struct InvP1 {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int idx = tid + 256 * i;
-            if (idx < nvec) rg[i] = src[idx];
+            if (idx < nvec) rg[i] = src[idx];      // temporal: the neighbouring row group wants these rows too
         }
         if (live) {
             z0 = *reinterpret_cast<const V2 *>(Zb + (size_t)r * C);
