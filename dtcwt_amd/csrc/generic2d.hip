@@ -63,6 +63,10 @@ template <> __device__ inline void stream_store<double2>(double2 *dst, const dou
     typedef double v2 __attribute__((ext_vector_type(2)));
     __builtin_nontemporal_store(*reinterpret_cast<const v2 *>(&v), reinterpret_cast<v2 *>(dst));
 }
+template <> __device__ inline void stream_store<float2>(float2 *dst, const float2 &v) {
+    typedef float v2 __attribute__((ext_vector_type(2)));
+    __builtin_nontemporal_store(*reinterpret_cast<const v2 *>(&v), reinterpret_cast<v2 *>(dst));
+}
 template <typename V> __device__ inline V stream_load(const V *src);
 template <> __device__ inline float4 stream_load<float4>(const float4 *src) {
     typedef float v4 __attribute__((ext_vector_type(4)));
@@ -180,7 +184,7 @@ __device__ inline void store_p1(T *Lb, T *Hb, T *Hi, const T (&l)[N], const T (&
         for (int q = 0; q < N; q += 2)
             if (row0 + q < g.nout) {
                 V2 v; v.x = h[q]; v.y = h[q + 1];
-                *reinterpret_cast<V2 *>(Pb + (size_t)((row0 + q) >> 1) * g.C * 2) = v;
+                stream_store<V2>(reinterpret_cast<V2 *>(Pb + (size_t)((row0 + q) >> 1) * g.C * 2), v);
             }
     } else {
 #pragma unroll
@@ -702,7 +706,20 @@ __global__ void __launch_bounds__(256) k_g2_rows_pair(const T *__restrict__ X, T
     fwd_row_fir<T, KIND, MB, RG::WIN>(sm + q * RG::IN_STEP, tp, g, lo, hi);
     const bool vec_ok = ((g.Cout * sizeof(T)) & 15) == 0;
     store4(Y0 + (size_t)line * g.Cout + col0, lo, valid, vec_ok);
-    store4(Y1 + (size_t)line * g.Cout + col0, hi, valid, vec_ok);
+    if (g.crop && valid >= 4 && vec_ok) {       // crop doubles as "Y1 is a highpass: write-once" here
+        using V = typename Vec16<T>::type;
+        constexpr int VN = Vec16<T>::N;
+#pragma unroll
+        for (int j = 0; j < 4 / VN; ++j) {
+            V x;
+            T *e = reinterpret_cast<T *>(&x);
+#pragma unroll
+            for (int t = 0; t < VN; ++t) e[t] = hi[j * VN + t];
+            stream_store<V>(reinterpret_cast<V *>(Y1 + (size_t)line * g.Cout + col0) + j, x);
+        }
+    } else {
+        store4(Y1 + (size_t)line * g.Cout + col0, hi, valid, vec_ok);
+    }
 }
 
 // Y = filter(X0, lo) + filter(X1, hi) down the rows of [B][R][C] arrays (lanes along C); X1 may be
@@ -1112,7 +1129,7 @@ int dtcwt_g2_pair(dtcwt_hip_ctx *ctx, int dtype, int kind, const void *X, void *
     if (inner == 1) {       // the filter axis is the contiguous one: LDS rows (interleaved hi = hi itself)
         P2Geo g;
         g.nlines = (int)outer; g.R1 = 0; g.Cin = (int)n; g.pad_lo = pad_lo; g.L = (int)L; g.Cout = (int)nout;
-        g.crop = 0; g.u_shift = p.u_shift; g.f0 = p.f0; g.f1 = p.f1;
+        g.crop = pack_hi; g.u_shift = p.u_shift; g.f0 = p.f0; g.f1 = p.f1;
         const int in_step = kind == 0 ? 4 : 8;
         const int win = kind == 0 ? (4 + p.mb - 1 + 3) / 4 * 4 : 4 + 2 * p.mb;
         const size_t lds = dtype == DTCWT_HIP_F32 ? finish_rows<float>(g, in_step, win, (int)((nout + 3) / 4), 0, 1)
