@@ -358,6 +358,9 @@ int dtcwt_hip_plan2d_forward(dtcwt_hip_plan2d *p, const float *X, float *Yl, voi
             q.X = in; q.LoLo = lo; q.Yh = (float *)Yh[l];
             q.B = p->batch; q.inR = L.inR; q.inC = L.inC; q.padR = L.padR; q.padC = L.padC;
             q.LR = L.LR; q.LC = L.LC; q.xcd_order = p->xcd_order < 0 ? 1 : p->xcd_order;
+            // record arrays of 32 MiB and more cannot wait in the caches for whoever reads them next:
+            // stream them past, so that they do not evict the lowpass plane the next level reads
+            q.stream_records = (int64_t)p->batch * (L.LR / 4) * (L.LC / 4) * 48 >= ((int64_t)32 << 20);
             // coldfilt(X, h0b, h0a) / coldfilt(X, h1b, h1a)   (transform2d.py:143-157)
             put_taps(q.l_a, p->qshift[1]); put_taps(q.l_b, p->qshift[0]);
             put_taps(q.h_a, p->qshift[5]); put_taps(q.h_b, p->qshift[4]);

@@ -100,6 +100,7 @@ struct Fwd2Params {
     int LR, LC;           // inR + 2 padR, multiples of 4
     int tilesR, tilesC;
     int xcd_order;        // 1: XCD-contiguous tile runs, 0: linear order
+    int stream_records;   // 1: records written with the non-temporal hint (arrays too big to stay cached)
     int lo_a_first, hi_a_first;   // sign of sum(ha*hb) of the lo / hi pair (lowlevel.py:143)
     // coldfilt(X, ha, hb) is called as (h0b, h0a) and (h1b, h1a): "a" arrays hold the
     // first argument, "b" the second.

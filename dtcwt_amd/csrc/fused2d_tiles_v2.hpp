@@ -296,7 +296,8 @@ DT_HD void fwd2s_rows_flush(const Fwd2Params &p, const float *stage, int tid, in
         int R = r0 + 2 * il, Cc = c0 + 2 * jl;
         if (task < C::TI * C::TJ && R < OR && Cc < OC) {
             float *rec = p.Yh + (((int64_t)b * HR + R / 2) * HCc + Cc / 2) * 12;
-            DT_STREAM_STORE_F4(reinterpret_cast<f4 *>(rec) + part, slab[j]);
+            if (p.stream_records) DT_STREAM_STORE_F4(reinterpret_cast<f4 *>(rec) + part, slab[j]);
+            else reinterpret_cast<f4 *>(rec)[part] = slab[j];
         }
     }
 }
