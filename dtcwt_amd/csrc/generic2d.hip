@@ -27,6 +27,7 @@
 #include "common.hpp"
 
 #include <type_traits>
+#include <cstdlib>
 
 namespace {
 
@@ -422,6 +423,130 @@ __global__ void __launch_bounds__(256) k_g2_fwd_p2(const T *__restrict__ Lo, con
     }
 }
 
+// ---- forward level in ONE launch: pass 1 -> LDS -> pass 2 -------------------------------------
+// A workgroup owns 8 rows (4 row pairs) x 256 logical columns of the level intermediate: thread c
+// filters its column down the rows (register window, as k_g2_fwd_p1) and leaves lo / hi in LDS;
+// after the barrier 4 x NQ threads run the row pass of k_g2_fwd_p2 from those LDS rows.  Lo and Hi
+// (twice the image, written and read back by the two-pass form) never reach HBM; the price is the
+// vertical halo (MB-1 of G+MB-1 window rows re-read, mostly from L2: vertically adjacent tiles are
+// launched next to each other) and idle threads in the row pass.
+struct FGeo {
+    int B, R, C;            // input [B][R][C]
+    int pad_r_lo, LR, R1;   // logical rows, rows of the intermediate (= of LoLo)
+    int pad_c_lo, LC, C1;   // logical columns, columns of LoLo
+    int nrt, nct;           // tiles along rows / columns
+    int u_shift;            // window start = group origin + u_shift (both passes)
+    int f0, f1;             // KIND 1: (A, B) order of the lo / hi pair
+};
+
+template <typename T, int KIND, int MB>
+struct FusedFwd {
+    using RG = RowGeo<KIND, MB, false>;
+    static constexpr int TW = 256, STR = TW + 4;
+    static constexpr int NQ = (TW - (RG::WIN - RG::IN_STEP)) / RG::IN_STEP;     // row-pass threads per row pair
+    static constexpr int PLANES = 2 * 8 * STR, RECS = 4 * NQ * 24;
+    static constexpr int LDS_ELEMS = PLANES > RECS ? PLANES : RECS;
+};
+
+template <typename T, int KIND, int MB>
+__global__ void __launch_bounds__(256) k_g2_fwd_fused(const T *__restrict__ X, T *__restrict__ LoLo,
+                                                      T *__restrict__ Yh, FGeo g, QTaps<T> tp) {
+    using F = FusedFwd<T, KIND, MB>;
+    using RG = typename F::RG;
+    __shared__ __align__(16) T sm[F::LDS_ELEMS];
+    T *sLo = sm, *sHi = sm + 8 * F::STR;
+    const int tid = threadIdx.x;
+    const int ct = blockIdx.x % g.nct, t1 = blockIdx.x / g.nct;
+    const int rt = t1 % g.nrt, b = t1 / g.nrt;
+    // ---- pass 1: column tid of the tile, 8 output rows
+    {
+        const int ucol = ct * F::NQ * RG::IN_STEP + g.u_shift + tid;      // logical column
+        const T *Xb = X + (size_t)b * g.R * g.C + g2_src(ucol, g.LC, g.pad_c_lo, g.C);
+        T l[8], h[8];
+        if constexpr (KIND == 0) {
+            constexpr int WN = 8 + MB - 1;
+            const int u0 = rt * 8 + g.u_shift;
+            T w[WN];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) w[j] = Xb[(size_t)g2_src(u0 + j, g.LR, g.pad_r_lo, g.R) * g.C];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) l[q] = h[q] = 0;
+            fir_colfilter<T, 8, MB>(w, tp.a, l);
+            fir_colfilter<T, 8, MB>(w, tp.b, h);
+        } else {
+            constexpr int GP = 4, WN = 4 * (GP - 1) + 2 * MB;
+            const int u0 = 4 * (rt * GP) + g.u_shift;
+            T w[WN];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) w[j] = Xb[(size_t)g2_src(u0 + j, g.LR, g.pad_r_lo, g.R) * g.C];
+            fir_coldfilt<T, GP, MB>(w, tp.a, tp.b, g.f0, l);
+            fir_coldfilt<T, GP, MB>(w, tp.c, tp.d, g.f1, h);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            sLo[q * F::STR + tid] = l[q];
+            sHi[q * F::STR + tid] = h[q];
+        }
+    }
+    __syncthreads();
+    // ---- pass 2: 4 row pairs x NQ threads, 4 output columns each
+    const int rp = tid / F::NQ, q = tid - rp * F::NQ;
+    const int i = rt * 4 + rp;                                  // row pair within the image
+    const int col0 = (ct * F::NQ + q) * 4;
+    const int valid = g.C1 - col0;
+    const bool work = tid < 4 * F::NQ && 2 * i < g.R1 && valid > 0;
+    const int C2 = g.C1 >> 1;
+    T rec[2][12];
+    if (work) {
+        P2Geo pg;
+        pg.f0 = g.f0; pg.f1 = g.f1;
+        const T *wl = sLo + (2 * rp) * F::STR + q * RG::IN_STEP, *wh = sHi + (2 * rp) * F::STR + q * RG::IN_STEP;
+        T ll0[4], lh0[4], ll1[4], lh1[4];
+        fwd_row_fir<T, KIND, MB, RG::WIN>(wl, tp, pg, ll0, lh0);
+        fwd_row_fir<T, KIND, MB, RG::WIN>(wl + F::STR, tp, pg, ll1, lh1);
+        T *o = LoLo + ((size_t)b * g.R1 + 2 * i) * g.C1 + col0;
+        const bool vec_ok = ((g.C1 * sizeof(T)) & 15) == 0;
+        store4(o, ll0, valid, vec_ok);
+        store4(o + g.C1, ll1, valid, vec_ok);
+        q2c_pair(lh0, lh1, rec, 2, 3);
+        T hl0[4], hh0[4], hl1[4], hh1[4];
+        fwd_row_fir<T, KIND, MB, RG::WIN>(wh, tp, pg, hl0, hh0);
+        fwd_row_fir<T, KIND, MB, RG::WIN>(wh + F::STR, tp, pg, hl1, hh1);
+        q2c_pair(hl0, hl1, rec, 0, 5);
+        q2c_pair(hh0, hh1, rec, 1, 4);
+    }
+    __syncthreads();
+    using V = typename Vec16<T>::type;
+    constexpr int VN = Vec16<T>::N;
+    if (work) {
+        V *dst = reinterpret_cast<V *>(sm + tid * 24);
+        const T *src = &rec[0][0];
+#pragma unroll
+        for (int j = 0; j < 24 / VN; ++j) {
+            V x;
+            T *e = reinterpret_cast<T *>(&x);
+#pragma unroll
+            for (int t = 0; t < VN; ++t) e[t] = src[j * VN + t];
+            dst[j] = x;
+        }
+    }
+    __syncthreads();
+    // records of row pair r: 2 NQ pixels x 12, contiguous in LDS and in Yh; one wavefront per row pair
+    {
+        const int r = tid >> 6, lane = tid & 63;
+        const int ir = rt * 4 + r;
+        const int pix0 = ct * F::NQ * 2;
+        int npix = C2 - pix0;
+        npix = npix > 2 * F::NQ ? 2 * F::NQ : npix;
+        if (2 * ir < g.R1 && npix > 0) {
+            const int nvec = npix * 12 / VN;
+            V *dst = reinterpret_cast<V *>(Yh + (((size_t)b * (g.R1 >> 1) + ir) * C2 + pix0) * 12);
+            const V *src = reinterpret_cast<const V *>(sm + r * F::NQ * 24);
+            for (int e = lane; e < nvec; e += 64) stream_store<V>(dst + e, src[e]);
+        }
+    }
+}
+
 // inverse pass 2: Z = filter(y1, lo) + filter(y2, hi) along the contiguous axis
 template <typename T, int KIND, int MB>
 __global__ void __launch_bounds__(256) k_g2_inv_p2(const T *__restrict__ Y1, const T *__restrict__ Y2,
@@ -678,6 +803,204 @@ __global__ void __launch_bounds__(256) k_g2_inv_p1(const T *__restrict__ Zl, con
             v2.x = st.y2a[k]; v2.y = st.y2b[k];
             *reinterpret_cast<typename S::V2 *>(Y1 + ob + (size_t)r * g.C) = v1;
             *reinterpret_cast<typename S::V2 *>(Y2 + ob + (size_t)r * g.C) = v2;
+        }
+    }
+}
+
+// ---- inverse level in ONE launch: pass 1 -> LDS -> pass 2 -------------------------------------
+// A workgroup owns 8 output rows x 256 logical columns of the level intermediate (y1, y2).  Pass 1 is
+// the streaming form of k_g2_inv_p1 with ONE column per thread (two threads share a record): the
+// record rows of the window pass through a double-buffered LDS copy, every thread undoes q2c for
+// its column and scatters into y1[8], y2[8]; these go to LDS (over the record buffers) and
+// 8 x NQ thread-tasks run the row pass of k_g2_inv_p2 from there.  y1 / y2 never reach HBM.
+struct IGeo {
+    int B, Rl, Cl;          // lowpass input [B][Rl][Cl]; subbands [B][Rl/2][Cl/2][6]
+    int Rout, Cout;         // written rows / columns of Z
+    int crop_r, crop_c;
+    int nrt, nct;
+    int u_shift;
+    int f0, f1;             // KIND 1: pos of the lo / hi pair
+};
+
+template <typename T, int KIND, int MB>
+struct FusedInv {
+    using RG = RowGeo<KIND, MB, true>;
+    using V = typename Vec16<T>::type;
+    static constexpr int TW = 256, STR = TW + 4, NREC = 130;
+    static constexpr int NQ = (TW - (RG::WIN - RG::IN_STEP)) / RG::IN_STEP;
+    static constexpr int VN = Vec16<T>::N, NV = 12 / VN;
+    static constexpr int NVEC = NREC * NV, NVT = (NVEC + 255) / 256;
+    static constexpr int NP = (KIND == 0 ? 8 + MB : IfiltGeo<MB>::WN + 2) / 2;
+    static constexpr int RECBUF = NREC * 12;
+    static constexpr int LDS_ELEMS = 2 * RECBUF > 2 * 8 * STR ? 2 * RECBUF : 2 * 8 * STR;
+
+    const T *Zc, *Yrow0;    // lowpass column of this thread; records of the tile, row 0
+    int tid, nvec, u0, Rl, Cl, ridx, par;
+    size_t rstride;
+    bool swn;
+    T y1[8], y2[8];
+    V rg[NVT];
+    T z0, z1;
+
+    __device__ inline void issue(int p) {
+        int u = u0 + 2 * p;
+        asm volatile("" : "+v"(u));
+        const int r = g2_src(u, Rl, 0, Rl);
+        swn = r & 1;
+        const V *src = reinterpret_cast<const V *>(Yrow0 + (size_t)(r >> 1) * rstride);
+#pragma unroll
+        for (int i = 0; i < NVT; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < nvec) rg[i] = src[idx];
+        }
+        z0 = Zc[(size_t)r * Cl];
+        z1 = Zc[(size_t)g2_src(u + 1, Rl, 0, Rl) * Cl];
+    }
+
+    template <int P, int HI>
+    __device__ inline void acc(const QTaps<T> &tp, int pos, T e, T o, T (&a)[8]) {
+        if constexpr (KIND == 0) scatter_colfilter<T, MB, P, 8>(HI ? tp.b : tp.a, e, o, a);
+        else scatter_colifilt<T, MB, P, 8>(HI ? tp.c : tp.a, HI ? tp.d : tp.b, pos, e, o, a);
+    }
+
+    template <int P, int HI>
+    __device__ inline void plane(const T (&rec)[12], int s0, int s1, const Gains<T> &gn, bool sw,
+                                 const QTaps<T> &tp, int pos, T (&y)[8]) {
+        const T w0r = rec[2 * s0] * gn.g[s0], w0i = rec[2 * s0 + 1] * gn.g[s0];
+        const T w1r = rec[2 * s1] * gn.g[s1], w1i = rec[2 * s1 + 1] * gn.g[s1];
+        const T a = w0r + w1r, b = w0i + w1i, c = w0i - w1i, d = -(w0r - w1r);
+        const T top = par ? b : a, bot = par ? d : c;       // image rows (a b) / (c d), this thread's column
+        acc<P, HI>(tp, pos, sw ? bot : top, sw ? top : bot, y);
+    }
+
+    template <int S, bool REV>
+    __device__ inline void step(T *sm, const QTaps<T> &tp, const Gains<T> &gn, int f0, int f1) {
+        constexpr int P = REV ? NP - 1 - S : S;
+        constexpr int PN = REV ? P - 1 : P + 1;
+        V *bw = reinterpret_cast<V *>(sm + (S & 1) * RECBUF);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < NVT; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < NVEC) bw[idx] = rg[i];
+        }
+        const T c0 = z0, c1 = z1;
+        const bool sw = swn;
+        if (S + 1 < NP) issue(PN);
+        __syncthreads();
+        T rec[12];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            V v = bw[ridx * NV + i];
+            const T *e = reinterpret_cast<const T *>(&v);
+#pragma unroll
+            for (int t = 0; t < VN; ++t) rec[i * VN + t] = e[t];
+        }
+        acc<P, 0>(tp, f0, c0, c1, y1);
+        plane<P, 1>(rec, 0, 5, gn, sw, tp, f1, y1);
+        plane<P, 0>(rec, 2, 3, gn, sw, tp, f0, y2);
+        plane<P, 1>(rec, 1, 4, gn, sw, tp, f1, y2);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(y1[k]), "+v"(y2[k]));
+    }
+
+    template <int S, bool REV>
+    __device__ inline void run(T *sm, const QTaps<T> &tp, const Gains<T> &gn, int f0, int f1) {
+        if constexpr (S < NP) {
+            step<S, REV>(sm, tp, gn, f0, f1);
+            run<S + 1, REV>(sm, tp, gn, f0, f1);
+        }
+    }
+};
+
+template <typename T, int KIND, int MB>
+__global__ void __launch_bounds__(256) k_g2_inv_fused(const T *__restrict__ Zl, const T *__restrict__ Yh,
+                                                      T *__restrict__ Z, IGeo g, QTaps<T> tp, Gains<T> gn) {
+    using F = FusedInv<T, KIND, MB>;
+    using RG = typename F::RG;
+    __shared__ __align__(16) T sm[F::LDS_ELEMS];
+    const int tid = threadIdx.x;
+    const int ct = blockIdx.x % g.nct, t1 = blockIdx.x / g.nct;
+    const int rt = t1 % g.nrt, b = t1 / g.nrt;
+    const int C2 = g.Cl >> 1;
+    // ---- pass 1
+    F st;
+    {
+        const int ucol0 = ct * F::NQ * 4 + g.u_shift;           // logical column of LDS column 0
+        const int sc = g2_src(ucol0 + tid, g.Cl, 0, g.Cl);
+        // smallest source column of the tile (the reflection folds the edge tiles back)
+        int smin = ucol0 < 0 ? 0 : ucol0;
+        if (ucol0 + F::TW - 1 >= g.Cl) {
+            const int m = 2 * g.Cl - 1 - (ucol0 + F::TW - 1);
+            smin = m < smin ? (m < 0 ? 0 : m) : smin;
+        }
+        if (smin > g.Cl - 1) smin = g.Cl - 1;
+        const int rec0 = smin >> 1;
+        st.tid = tid;
+        st.ridx = (sc >> 1) - rec0;
+        st.par = sc & 1;
+        const int nrec = C2 - rec0 < F::NREC ? C2 - rec0 : F::NREC;
+        st.nvec = nrec * F::NV;
+        st.u0 = (KIND == 0 ? rt * 8 : rt * 4) + g.u_shift;
+        st.Rl = g.Rl; st.Cl = g.Cl;
+        st.rstride = (size_t)C2 * 12;
+        st.Zc = Zl + (size_t)b * g.Rl * g.Cl + sc;
+        st.Yrow0 = Yh + ((size_t)b * (g.Rl >> 1) * C2 + rec0) * 12;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) st.y1[k] = st.y2[k] = 0;
+#pragma unroll
+        for (int i = 0; i < F::NVT; ++i) st.rg[i] = typename F::V{};
+        if (rt & 1) {
+            st.issue(F::NP - 1);
+            st.template run<0, true>(sm, tp, gn, g.f0, g.f1);
+        } else {
+            st.issue(0);
+            st.template run<0, false>(sm, tp, gn, g.f0, g.f1);
+        }
+    }
+    __syncthreads();            // every record read is done: y1 / y2 take the buffers over
+    T *sY1 = sm, *sY2 = sm + 8 * F::STR;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sY1[k * F::STR + tid] = st.y1[k];
+        sY2[k * F::STR + tid] = st.y2[k];
+    }
+    __syncthreads();
+    // ---- pass 2: 8 rows x NQ threads
+    const bool vec_ok = g.crop_c == 0 && ((g.Cout * sizeof(T)) & 15) == 0;
+#pragma unroll
+    for (int it = 0; it < (8 * F::NQ + 255) / 256; ++it) {
+        const int task = it * 256 + tid;
+        const int row = task / F::NQ, q = task - row * F::NQ;
+        const int orow = rt * 8 + row - g.crop_r;
+        if (row >= 8 || orow < 0 || orow >= g.Rout) continue;
+        T acc[RG::OUTS];
+#pragma unroll
+        for (int k = 0; k < RG::OUTS; ++k) acc[k] = 0;
+        {
+            T w[RG::WIN];
+            lds_window<T, RG::WIN>(sY1 + row * F::STR + q * 4, w);
+            if constexpr (KIND == 0) fir_colfilter<T, 4, MB>(w, tp.a, acc);
+            else fir_colifilt<T, 2, MB>(w, tp.a, tp.b, g.f0, acc);
+        }
+        {
+            T w[RG::WIN];
+            lds_window<T, RG::WIN>(sY2 + row * F::STR + q * 4, w);
+            if constexpr (KIND == 0) fir_colfilter<T, 4, MB>(w, tp.b, acc);
+            else fir_colifilt<T, 2, MB>(w, tp.c, tp.d, g.f1, acc);
+        }
+        const int lo0 = (ct * F::NQ + q) * RG::OUTS - g.crop_c;
+        T *o = Z + ((size_t)b * g.Rout + orow) * g.Cout;
+#pragma unroll
+        for (int h = 0; h < RG::OUTS / 4; ++h) {
+            const int w0 = lo0 + 4 * h;
+            T v[4] = {acc[4 * h], acc[4 * h + 1], acc[4 * h + 2], acc[4 * h + 3]};
+            if (w0 >= 0 && w0 + 4 <= g.Cout && vec_ok) store4(o + w0, v, 4, true);
+            else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (w0 + t >= 0 && w0 + t < g.Cout) o[w0 + t] = v[t];
+            }
         }
     }
 }
@@ -1230,6 +1553,29 @@ int dtcwt_hip_level2d_forward(dtcwt_hip_ctx *ctx, int dtype, int kind, const voi
     if (B * LR * LC >= ((int64_t)1 << 31) || B * R1 * C1 * 6 >= ((int64_t)1 << 31)) return G2_NA;
     DT_CHECK_HIP(hipSetDevice(ctx->device));
 
+    if (!getenv("DTCWT_HIP_TWO_PASS")) {        // pass 1 -> LDS -> pass 2 in one launch; Lo / Hi stay unused
+        FGeo f;
+        f.B = (int)B; f.R = (int)R; f.C = (int)C; f.pad_r_lo = pad_r_lo; f.LR = (int)LR; f.R1 = (int)R1;
+        f.pad_c_lo = pad_c_lo; f.LC = (int)LC; f.C1 = (int)C1; f.u_shift = p.u_shift; f.f0 = p.f0; f.f1 = p.f1;
+        f.nrt = (int)((R1 + 7) / 8);
+#define G2_FUSED_LAUNCH(T_, KIND_, MB_)                                                                   \
+        do {                                                                                              \
+            f.nct = (int)((C1 + 4 * FusedFwd<T_, KIND_, MB_>::NQ - 1) / (4 * FusedFwd<T_, KIND_, MB_>::NQ));    \
+            k_g2_fwd_fused<T_, KIND_, MB_><<<(unsigned)((int64_t)f.B * f.nrt * f.nct), 256, 0, ctx->stream>>>( \
+                (const T_ *)X, (T_ *)LoLo, (T_ *)Yh, f, to_device_taps<T_>(p));                           \
+        } while (0)
+        if (dtype == DTCWT_HIP_F32) {
+            if (kind == 0) { if (p.mb == 8) G2_FUSED_LAUNCH(float, 0, 8); else G2_FUSED_LAUNCH(float, 0, 20); }
+            else { if (p.mb == 10) G2_FUSED_LAUNCH(float, 1, 10); else G2_FUSED_LAUNCH(float, 1, 20); }
+        } else {
+            if (kind == 0) { if (p.mb == 8) G2_FUSED_LAUNCH(double, 0, 8); else G2_FUSED_LAUNCH(double, 0, 20); }
+            else { if (p.mb == 10) G2_FUSED_LAUNCH(double, 1, 10); else G2_FUSED_LAUNCH(double, 1, 20); }
+        }
+#undef G2_FUSED_LAUNCH
+        G2_LAUNCH_CHECK();
+        return 0;
+    }
+
     P1Geo g1;
     g1.B = (int)B; g1.R = (int)R; g1.C = (int)C;
     g1.pad_lo = pad_r_lo; g1.L = (int)LR; g1.nout = (int)R1;
@@ -1288,6 +1634,36 @@ int dtcwt_hip_level2d_inverse(dtcwt_hip_ctx *ctx, int dtype, int kind, const voi
     const int64_t Rout = (kind == 0 ? Rl : 2 * Rl) - 2 * crop_r, Cout = (kind == 0 ? Cl : 2 * Cl) - 2 * crop_c;
     if (B * Rout * Cout >= ((int64_t)1 << 31) || B * Rl * Cl * 3 >= ((int64_t)1 << 31)) return G2_NA;
     DT_CHECK_HIP(hipSetDevice(ctx->device));
+
+    if (!getenv("DTCWT_HIP_TWO_PASS")) {        // pass 1 -> LDS -> pass 2 in one launch; Y1 / Y2 stay unused
+        IGeo f;
+        f.B = (int)B; f.Rl = (int)Rl; f.Cl = (int)Cl; f.Rout = (int)Rout; f.Cout = (int)Cout;
+        f.crop_r = crop_r; f.crop_c = crop_c; f.u_shift = p.u_shift; f.f0 = p.f0; f.f1 = p.f1;
+        f.nrt = kind == 0 ? (int)((Rl + 7) / 8) : (int)((Rl + 3) / 4);
+        const int need = kind == 0 ? (int)((Cl + 3) / 4) : (int)((Cl / 2 + 1) / 2);      // row-pass threads per row
+        const double s2 = 0.70710678118654752440;
+#define G2_FUSED_LAUNCH(T_, KIND_, MB_)                                                                   \
+        do {                                                                                              \
+            Gains<T_> gn;                                                                                 \
+            for (int k = 0; k < 6; ++k) gn.g[k] = (T_)(s2 * gains6[k]);                                   \
+            f.nct = (need + FusedInv<T_, KIND_, MB_>::NQ - 1) / FusedInv<T_, KIND_, MB_>::NQ;              \
+            k_g2_inv_fused<T_, KIND_, MB_><<<(unsigned)((int64_t)f.B * f.nrt * f.nct), 256, 0, ctx->stream>>>( \
+                (const T_ *)Zl, (const T_ *)Yh, (T_ *)Z, f, to_device_taps<T_>(p), gn);                   \
+        } while (0)
+#define G2_FUSED_KINDS(T_)                                                                                \
+        do {                                                                                              \
+            if (kind == 0) { if (p.mb == 8) G2_FUSED_LAUNCH(T_, 0, 8); else G2_FUSED_LAUNCH(T_, 0, 20); }  \
+            else if (p.mb == 8) G2_FUSED_LAUNCH(T_, 1, 8);                                                \
+            else if (p.mb == 10) G2_FUSED_LAUNCH(T_, 1, 10);                                              \
+            else if (p.mb == 16) G2_FUSED_LAUNCH(T_, 1, 16);                                              \
+            else G2_FUSED_LAUNCH(T_, 1, 18);                                                              \
+        } while (0)
+        if (dtype == DTCWT_HIP_F32) G2_FUSED_KINDS(float); else G2_FUSED_KINDS(double);
+#undef G2_FUSED_KINDS
+#undef G2_FUSED_LAUNCH
+        G2_LAUNCH_CHECK();
+        return 0;
+    }
 
     I1Geo g1;
     g1.B = (int)B; g1.Rl = (int)Rl; g1.C = (int)Cl;
