@@ -368,7 +368,7 @@ GENERIC_WAVES = [w for w in WAVES if 'bp' not in w[0]]
 
 
 @pytest.mark.parametrize('bn,qn', GENERIC_WAVES)
-@pytest.mark.parametrize('shape', [(96, 128), (97, 123), (130, 70), (200, 88)])
+@pytest.mark.parametrize('shape', [(96, 128), (97, 123), (130, 70), (200, 88), (64, 1030), (520, 300)])
 def test_float64_levels_vs_oracle(bn, qn, shape):
     rs = np.random.RandomState(23)
     X = rs.standard_normal(shape)
@@ -383,13 +383,17 @@ def test_float64_levels_vs_oracle(bn, qn, shape):
             assert_close(t.inverse(want, g), to.inverse(want, g), 1e-11, 'inverse f64 nl=%d' % nl)
 
 
+@pytest.mark.parametrize('two_pass', [False, True])
 @pytest.mark.parametrize('dtype', [np.float32, np.float64])
 @pytest.mark.parametrize('bn,qn', [('near_sym_a', 'qshift_a'), ('near_sym_b', 'qshift_d'), ('antonini', 'qshift_06'),
                                    ('legall', 'qshift_c'), ('near_sym_b', 'qshift_b')])
-def test_two_launch_level_matches_filter_by_filter(dtype, bn, qn):
-    """dtcwt_hip_level2d_forward / _inverse against the same level built from the public
-    colfilter / coldfilt / colifilt + q2c / c2q launches, batch of 3, padded and cropped."""
+def test_two_launch_level_matches_filter_by_filter(dtype, bn, qn, two_pass, monkeypatch):
+    """dtcwt_hip_level2d_forward / _inverse (the one-launch form, and the two-launch form it
+    replaced, DTCWT_HIP_TWO_PASS=1) against the same level built from the public colfilter /
+    coldfilt / colifilt + q2c / c2q launches, batch of 3, padded and cropped."""
     from dtcwt_amd.hip import lowlevel as ll
+    if two_pass:
+        monkeypatch.setenv('DTCWT_HIP_TWO_PASS', '1')
     ctx = default_context()
     rs = np.random.RandomState(5)
     h0o, g0o, h1o, g1o = biort(bn)[:4]
