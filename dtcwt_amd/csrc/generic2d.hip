@@ -1307,11 +1307,14 @@ double dotp(const double *x, const double *y, int m) {
 bool prep_level1(const double *h0, int m0, const double *h1, int m1, bool even_start, TapPrep &p) {
     if (!(m0 & 1) || !(m1 & 1)) return false;
     const int mm = m0 > m1 ? m0 : m1, cc = (mm - 1) / 2;
-    int mb = mm <= 7 ? 8 : 20;
-    int front = 0;
-    if (even_start && ((cc - (mb - 1)) & 1)) front = 1;
-    if (mm + front > mb) { if (mb == 8) { mb = 20; front = even_start && ((cc - 19) & 1) ? 1 : 0; } }
-    if (mm + front > mb) return false;
+    // smallest bucket (8 / 12 / 20) that holds the filters plus, where the window must start on an
+    // even row, one zero in front
+    int mb = 0, front = 0;
+    for (int cand : {8, 12, 20}) {
+        front = (even_start && ((cc - (cand - 1)) & 1)) ? 1 : 0;
+        if (mm + front <= cand) { mb = cand; break; }
+    }
+    if (!mb) return false;
     for (int k = 0; k < G2_MAXB; ++k) p.a[k] = p.b[k] = p.c[k] = p.d[k] = 0;
     for (int k = 0; k < m0; ++k) p.a[front + (mm - m0) / 2 + k] = h0[k];
     for (int k = 0; k < m1; ++k) p.b[front + (mm - m1) / 2 + k] = h1[k];
@@ -1390,11 +1393,12 @@ constexpr int G2_NA = -3;       // "use the filter-by-filter path"
 
 #define G2_LAUNCH_CHECK() DT_CHECK_HIP(hipGetLastError())
 
-// KIND 0 buckets 8 / 20; coldfilt buckets 10 / 20; colifilt buckets 8 / 10 / 16 / 18
+// KIND 0 buckets 8 / 12 / 20; coldfilt buckets 10 / 20; colifilt buckets 8 / 10 / 16 / 18
 #define G2_SWITCH_FWD(KERNEL, T_, ...)                                                     \
     do {                                                                                   \
         if (kind == 0) {                                                                   \
             if (p.mb == 8) KERNEL<T_, 0, 8> __VA_ARGS__;                                    \
+            else if (p.mb == 12) KERNEL<T_, 0, 12> __VA_ARGS__;                             \
             else KERNEL<T_, 0, 20> __VA_ARGS__;                                             \
         } else {                                                                           \
             if (p.mb == 10) KERNEL<T_, 1, 10> __VA_ARGS__;                                  \
@@ -1406,6 +1410,7 @@ constexpr int G2_NA = -3;       // "use the filter-by-filter path"
     do {                                                                                   \
         if (kind == 0) {                                                                   \
             if (p.mb == 8) KERNEL<T_, 0, 8> __VA_ARGS__;                                    \
+            else if (p.mb == 12) KERNEL<T_, 0, 12> __VA_ARGS__;                             \
             else KERNEL<T_, 0, 20> __VA_ARGS__;                                             \
         } else {                                                                           \
             if (p.mb == 8) KERNEL<T_, 1, 8> __VA_ARGS__;                                    \
@@ -1565,10 +1570,10 @@ int dtcwt_hip_level2d_forward(dtcwt_hip_ctx *ctx, int dtype, int kind, const voi
                 (const T_ *)X, (T_ *)LoLo, (T_ *)Yh, f, to_device_taps<T_>(p));                           \
         } while (0)
         if (dtype == DTCWT_HIP_F32) {
-            if (kind == 0) { if (p.mb == 8) G2_FUSED_LAUNCH(float, 0, 8); else G2_FUSED_LAUNCH(float, 0, 20); }
+            if (kind == 0) { if (p.mb == 8) G2_FUSED_LAUNCH(float, 0, 8); else if (p.mb == 12) G2_FUSED_LAUNCH(float, 0, 12); else G2_FUSED_LAUNCH(float, 0, 20); }
             else { if (p.mb == 10) G2_FUSED_LAUNCH(float, 1, 10); else G2_FUSED_LAUNCH(float, 1, 20); }
         } else {
-            if (kind == 0) { if (p.mb == 8) G2_FUSED_LAUNCH(double, 0, 8); else G2_FUSED_LAUNCH(double, 0, 20); }
+            if (kind == 0) { if (p.mb == 8) G2_FUSED_LAUNCH(double, 0, 8); else if (p.mb == 12) G2_FUSED_LAUNCH(double, 0, 12); else G2_FUSED_LAUNCH(double, 0, 20); }
             else { if (p.mb == 10) G2_FUSED_LAUNCH(double, 1, 10); else G2_FUSED_LAUNCH(double, 1, 20); }
         }
 #undef G2_FUSED_LAUNCH
@@ -1652,7 +1657,7 @@ int dtcwt_hip_level2d_inverse(dtcwt_hip_ctx *ctx, int dtype, int kind, const voi
         } while (0)
 #define G2_FUSED_KINDS(T_)                                                                                \
         do {                                                                                              \
-            if (kind == 0) { if (p.mb == 8) G2_FUSED_LAUNCH(T_, 0, 8); else G2_FUSED_LAUNCH(T_, 0, 20); }  \
+            if (kind == 0) { if (p.mb == 8) G2_FUSED_LAUNCH(T_, 0, 8); else if (p.mb == 12) G2_FUSED_LAUNCH(T_, 0, 12); else G2_FUSED_LAUNCH(T_, 0, 20); }  \
             else if (p.mb == 8) G2_FUSED_LAUNCH(T_, 1, 8);                                                \
             else if (p.mb == 10) G2_FUSED_LAUNCH(T_, 1, 10);                                              \
             else if (p.mb == 16) G2_FUSED_LAUNCH(T_, 1, 16);                                              \
@@ -1753,10 +1758,12 @@ int dtcwt_hip_fwd3_axis0_cube2c(dtcwt_hip_ctx *ctx, int dtype, const void *V, in
     if (dtype == DTCWT_HIP_F32) {
         QTaps<float> t = to_device_taps<float>(p);
         if (p.mb == 8) k_g3_fwd_axis0_cube<float, 8><<<blocks, 256, 0, ctx->stream>>>((const float *)V, (float *)plain, (float *)Yh, g, t);
+        else if (p.mb == 12) k_g3_fwd_axis0_cube<float, 12><<<blocks, 256, 0, ctx->stream>>>((const float *)V, (float *)plain, (float *)Yh, g, t);
         else k_g3_fwd_axis0_cube<float, 20><<<blocks, 256, 0, ctx->stream>>>((const float *)V, (float *)plain, (float *)Yh, g, t);
     } else {
         QTaps<double> t = to_device_taps<double>(p);
         if (p.mb == 8) k_g3_fwd_axis0_cube<double, 8><<<blocks, 256, 0, ctx->stream>>>((const double *)V, (double *)plain, (double *)Yh, g, t);
+        else if (p.mb == 12) k_g3_fwd_axis0_cube<double, 12><<<blocks, 256, 0, ctx->stream>>>((const double *)V, (double *)plain, (double *)Yh, g, t);
         else k_g3_fwd_axis0_cube<double, 20><<<blocks, 256, 0, ctx->stream>>>((const double *)V, (double *)plain, (double *)Yh, g, t);
     }
     G2_LAUNCH_CHECK();
@@ -1782,10 +1789,12 @@ int dtcwt_hip_inv3_axis1_c2cube(dtcwt_hip_ctx *ctx, int dtype, const void *plain
     if (dtype == DTCWT_HIP_F32) {
         QTaps<float> t = to_device_taps<float>(p);
         if (p.mb == 8) k_g3_inv_axis1_cube<float, 8><<<blocks, 256, 0, ctx->stream>>>((const float *)plain, (const float *)Yh, (float *)out, g, t);
+        else if (p.mb == 12) k_g3_inv_axis1_cube<float, 12><<<blocks, 256, 0, ctx->stream>>>((const float *)plain, (const float *)Yh, (float *)out, g, t);
         else k_g3_inv_axis1_cube<float, 20><<<blocks, 256, 0, ctx->stream>>>((const float *)plain, (const float *)Yh, (float *)out, g, t);
     } else {
         QTaps<double> t = to_device_taps<double>(p);
         if (p.mb == 8) k_g3_inv_axis1_cube<double, 8><<<blocks, 256, 0, ctx->stream>>>((const double *)plain, (const double *)Yh, (double *)out, g, t);
+        else if (p.mb == 12) k_g3_inv_axis1_cube<double, 12><<<blocks, 256, 0, ctx->stream>>>((const double *)plain, (const double *)Yh, (double *)out, g, t);
         else k_g3_inv_axis1_cube<double, 20><<<blocks, 256, 0, ctx->stream>>>((const double *)plain, (const double *)Yh, (double *)out, g, t);
     }
     G2_LAUNCH_CHECK();
