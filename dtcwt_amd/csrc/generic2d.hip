@@ -1,8 +1,9 @@
-// One 2-D DT-CWT level in two launches for ANY wavelet length and float32 / float64: the path
-// of every (dtype, wavelet) combination that has no fused tile program in fused2d.hip --
-// above all float64, which is what the reference computes in for non-float32 input
-// (dtcwt/utils.py:104-134 asfarray).  It replaces the seven-to-nine launches of the
-// filter-by-filter level (colfilter2 / coldfilt2 x3 + q2c x3, c2q x3 + *_sum2 x3) with
+// One 2-D DT-CWT level for ANY wavelet length and float32 / float64: the path of every (dtype,
+// wavelet) combination that has no fused tile program in fused2d.hip -- above all float64, which
+// is what the reference computes in for non-float32 input (dtcwt/utils.py:104-134 asfarray).  It
+// replaces the seven-to-nine launches of the filter-by-filter level (colfilter2 / coldfilt2 x3 +
+// q2c x3, c2q x3 + *_sum2 x3) with ONE (k_g2_fwd_fused / k_g2_inv_fused: both passes, the level
+// intermediate in LDS) or, as building blocks and with DTCWT_HIP_TWO_PASS=1, two:
 //
 //   forward   pass 1  (Lo, Hi)  = filter pair down the image columns        (marching)
 //             pass 2  LoLo + the six q2c-packed subbands from (Lo, Hi)      (LDS rows)
@@ -12,7 +13,8 @@
 // so the quad <-> complex packings (dtcwt/numpy/transform2d.py:301-350) never make a trip
 // through HBM of their own.  KIND 0 is level 1 (odd-length biorthogonal pair, colfilter
 // algebra, transform2d.py:112-130 / :275-293), KIND 1 levels >= 2 (q-shift pairs, coldfilt /
-// colifilt algebra, :132-160 / :242-273).
+// colifilt algebra, :132-160 / :242-273).  The same passes serve the 1-D levels and, on dense
+// arrays, the axis passes of the filter-by-filter 3-D levels.
 //
 // "Marching" kernels: lanes along the contiguous image axis, every thread slides a register
 // window down the rows.  "LDS rows" kernels filter ALONG the contiguous axis: a block stages

@@ -219,7 +219,7 @@ def _check_na(rc):
 
 
 def level2d_forward(X, kind, pad_r, pad_c, lo, hi):
-    """One whole forward level of the 2-D transform on X [B, R, C] in two launches
+    """One whole forward level of the 2-D transform on X [B, R, C] in one launch
     (dtcwt_hip_level2d_forward): kind 0 = level 1 with the odd-length pair lo = h0o, hi = h1o
     (dtcwt/numpy/transform2d.py:112-130); kind 1 = a level >= 2 with the q-shift pairs
     lo = (h0b, h0a), hi = (h1b, h1a) in coldfilt's argument order (:132-160).  Returns
@@ -248,7 +248,7 @@ def level2d_forward(X, kind, pad_r, pad_c, lo, hi):
 
 
 def level2d_inverse(Zl, Yh, kind, gains, crop_r, crop_c, lo, hi):
-    """One whole inverse level in two launches (dtcwt_hip_level2d_inverse): Zl [B, Rl, Cl]
+    """One whole inverse level in one launch (dtcwt_hip_level2d_inverse): Zl [B, Rl, Cl]
     lowpass, Yh [B, Rl/2, Cl/2, 6] subbands with per-subband *gains*; kind 0 = level 1 with
     lo = g0o, hi = g1o (dtcwt/numpy/transform2d.py:275-293), kind 1 = a level >= 2 with
     lo = (g0b, g0a), hi = (g1b, g1a) in colifilt's argument order and crop_r / crop_c output

@@ -256,7 +256,7 @@ class Transform2d(object):
             lo, hi = (h0b, h0a), (h1b, h1a)
             prev = LoLo
             whole = None if bp2 else ll.level2d_forward(prev, 1, pr, pc, lo, hi)
-            if whole is not None:       # the level in two launches (dtcwt_hip_level2d_forward)
+            if whole is not None:       # the whole level in one launch (dtcwt_hip_level2d_forward)
                 LoLo, y = whole
                 Yh.append(y)
                 Ys.append(LoLo)
@@ -285,7 +285,7 @@ class Transform2d(object):
         # level 1 (transform2d.py:112-130); odd sizes extended by index math (:86-94)
         pr, pc = (0, lv[0]['padR']), (0, lv[0]['padC'])
         whole = None if bp1 else ll.level2d_forward(Xd, 0, pr, pc, h0o, h1o)
-        if whole is not None:           # the level in two launches (dtcwt_hip_level2d_forward)
+        if whole is not None:           # the whole level in one launch (dtcwt_hip_level2d_forward)
             Yh.append(whole[1])
             Ys.append(whole[0])
             return whole[0]
@@ -421,7 +421,7 @@ class Transform2d(object):
             cr, cc = crops[level - 1]
             lo, hi = (g0b, g0a), (g1b, g1a)
             whole = None if bp2 else ll.level2d_inverse(Z, w, 1, g, cr, cc, lo, hi)
-            if whole is not None:       # the level in two launches (dtcwt_hip_level2d_inverse)
+            if whole is not None:       # the whole level in one launch (dtcwt_hip_level2d_inverse)
                 Z = whole
                 level -= 1
                 continue

@@ -143,7 +143,7 @@ int dtcwt_hip_q2c(dtcwt_hip_ctx *ctx, int dtype, const void *y, int64_t batch, i
 int dtcwt_hip_c2q(dtcwt_hip_ctx *ctx, int dtype, const void *Yh, int64_t batch, int64_t rows,
                   int64_t cols, int slot0, int slot1, double gain0, double gain1, void *x,
                   int64_t x_sb, int64_t x_sr);
-/* One whole 2-D level, any wavelet length, float32 or float64, in two launches (the path of
+/* One whole 2-D level, any wavelet length, float32 or float64, in one launch (the path of
  * every dtype / wavelet without a fused float32 tile program; float64 is what the reference
  * computes in for non-float32 input, dtcwt/utils.py:104-134).
  *
@@ -153,14 +153,15 @@ int dtcwt_hip_c2q(dtcwt_hip_ctx *ctx, int dtype, const void *Yh, int64_t batch, 
  * (lo_a, lo_b) / (hi_a, hi_b) in the argument order of coldfilt).  X: [B][R][C]; rows / columns
  * are logically replicated by (pad_r_lo, pad_r_hi) / (pad_c_lo, pad_c_hi) (the odd-size and
  * multiple-of-4 extensions of :86-94, :134-143).  R1 x C1 = padded size (kind 0) or half of it
- * (kind 1).  Lo, Hi: scratch [B][R1][C]; LoLo: [B][R1][C1]; Yh: [B][R1/2][C1/2][6] complex.
+ * (kind 1).  Lo, Hi: scratch [B][R1][C] (touched only by the two-launch form, DTCWT_HIP_TWO_PASS=1);
+ * LoLo: [B][R1][C1]; Yh: [B][R1/2][C1/2][6] complex.
  *
  * level2d_inverse replaces one iteration of :275-293 (kind 0) or :242-273 (kind 1): the three
  * c2q (:324-350, gains6[k] = gain of subband k) and the column / row synthesis filters with
  * their sums.  Zl: [B][Rl][Cl] lowpass; Yh: [B][Rl/2][Cl/2][6]; kind 1 drops crop_r / crop_c
  * output samples from both ends of the rows / columns (the size fix-up of :246-252).  With
  * (Rz, Cz) = (Rl, Cl) for kind 0, (2 Rl - 2 crop_r, 2 Cl - 2 crop_c) for kind 1:
- * Y1, Y2: scratch [B][Rz][Cl]; Z: [B][Rz][Cz].
+ * Y1, Y2: scratch [B][Rz][Cl] (two-launch form only); Z: [B][Rz][Cz].
  *
  * Both return -3 (caller uses the filter-by-filter entry points above) for even-length
  * level-1 filters, pairs of unequal length, wavelets longer than the largest compile-time
