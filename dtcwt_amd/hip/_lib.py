@@ -6,6 +6,7 @@ import never fails; the first *use* without a usable runtime raises
 """
 import ctypes
 import importlib.util
+import math
 import os
 import sys
 import threading
@@ -329,7 +330,7 @@ class _HostPool(object):
 
     def empty(self, shape, dtype):
         dtype = np.dtype(dtype)
-        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize if len(shape) else dtype.itemsize
+        nbytes = math.prod(int(v) for v in shape) * dtype.itemsize
         if nbytes < self.MIN_BYTES or self.limit <= 0 or self._quiet_refs < 0:
             return np.empty(shape, dtype=dtype)
         base = None
@@ -373,7 +374,7 @@ class DeviceArray(object):
         self.ctx = ctx
         self.shape = tuple(int(s) for s in shape)
         self.dtype = np.dtype(dtype)
-        self.size = int(np.prod(self.shape, dtype=np.int64)) if self.shape else 1
+        self.size = math.prod(self.shape)         # (np.prod costs 2 us a call: the top host cost of a transform)
         self.nbytes = self.size * self.dtype.itemsize
         self._owner = owner
         if ptr is None:
@@ -407,7 +408,7 @@ class DeviceArray(object):
     def reshape(self, *shape):
         if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
             shape = tuple(shape[0])
-        assert int(np.prod(shape, dtype=np.int64)) == self.size
+        assert math.prod(int(v) for v in shape) == self.size
         return DeviceArray(self.ctx, shape, self.dtype, ptr=self.ptr, owner=self)
 
     def view(self, dtype):
