@@ -394,7 +394,7 @@ struct Inv1RCfg {
 // stage the window's records verbatim: srec[uw][vw][12], source record reflected.  All of a
 // thread's 16-byte pieces are requested before the first one is written to LDS (one memory
 // latency per tile, not one per piece).
-template <int QR, int QC>
+template <int QR, int QC, bool STREAM = false>
 DT_HD void inv_rec_stage(const float *Yhb, int zr, int zc, float *srec, int ro, int co, int tid) {
     constexpr int NPIECE = 3 * QR * QC, NP = (NPIECE + DT_NT - 1) / DT_NT;
     const int hc = zc / 2;
@@ -408,8 +408,14 @@ DT_HD void inv_rec_stage(const float *Yhb, int zr, int zc, float *srec, int ro, 
         int uw = rec / QC, vw = rec - uw * QC;
         int ur = ro + 2 * uw, vc = co + 2 * vw;
         if (!interior) { ur = reflect_i(ur, zr); vc = reflect_i(vc, zc); }
-        const f4 t = reinterpret_cast<const f4 *>(Yhb + ((int64_t)(ur >> 1) * hc + (vc >> 1)) * 12)[part];
-        px[k] = t.x; py[k] = t.y; pz[k] = t.z; pw[k] = t.w;
+        const f4 *src = reinterpret_cast<const f4 *>(Yhb + ((int64_t)(ur >> 1) * hc + (vc >> 1)) * 12) + part;
+        if (STREAM) {
+            const dt_v4f t = __builtin_nontemporal_load(reinterpret_cast<const dt_v4f *>(src));
+            px[k] = t.x; py[k] = t.y; pz[k] = t.z; pw[k] = t.w;
+        } else {
+            const f4 t = *src;
+            px[k] = t.x; py[k] = t.y; pz[k] = t.z; pw[k] = t.w;
+        }
     }
     f4 *dst = reinterpret_cast<f4 *>(srec);
 #pragma unroll
