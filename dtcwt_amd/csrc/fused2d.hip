@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(DT_NT) k_inv1(Inv1Params p) {
     const float *Yhb = p.Yh + (int64_t)b * (p.R / 2) * (p.C / 2) * 12;
     float wz[C::WN], w1[C::WN], w2[C::WN], w3[C::WN];
     inv1r_fetch<C>(p, wz, threadIdx.x, b, r0, c0);
-    inv_rec_stage<C::QR, C::QC, true>(Yhb, p.R, p.C, srec, r0 - C::HE, c0 - C::HE, threadIdx.x);
+    inv_rec_stage<C::QR, C::QC>(Yhb, p.R, p.C, srec, r0 - C::HE, c0 - C::HE, threadIdx.x);
     __syncthreads();
     inv1r_gather<C>(p, srec, w1, w2, w3, threadIdx.x, r0, c0);
     __syncthreads();
