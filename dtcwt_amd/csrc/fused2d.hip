@@ -440,4 +440,53 @@ int dtcwt_hip_plan2d_inverse(dtcwt_hip_plan2d *p, const float *Yl, const void *c
     return 0;
 }
 
+// ---- hipGraph of a forward (+ inverse) into fixed buffers ---------------------------------------
+struct dtcwt_hip_graph {
+    dtcwt_hip_ctx *ctx;
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
+
+int dtcwt_hip_plan2d_capture(dtcwt_hip_plan2d *p, const float *X, float *Yl, void *const *Yh,
+                             float *const *Ys, const double *gain_mask_host, float *Z,
+                             dtcwt_hip_graph **out) {
+    DT_REQUIRE(p && X && Yl && Yh && out, "NULL argument");
+    DT_REQUIRE(!p->profiling, "switch per-kernel profiling off before capturing a graph");
+    DT_CHECK_HIP(hipSetDevice(p->ctx->device));
+    hipStream_t s = p->ctx->stream;
+    DT_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    int rc = dtcwt_hip_plan2d_forward(p, X, Yl, Yh, Ys);
+    if (!rc && Z) rc = dtcwt_hip_plan2d_inverse(p, Yl, (const void *const *)Yh, gain_mask_host, Z);
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(s, &g);
+    if (rc) {
+        if (g) (void)hipGraphDestroy(g);
+        return rc;
+    }
+    DT_CHECK_HIP(e);
+    hipGraphExec_t ex = nullptr;
+    e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        return dtcwt_set_error(-2, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    }
+    *out = new dtcwt_hip_graph{p->ctx, g, ex};
+    return 0;
+}
+
+int dtcwt_hip_graph_launch(dtcwt_hip_graph *g) {
+    DT_REQUIRE(g, "graph is NULL");
+    DT_CHECK_HIP(hipSetDevice(g->ctx->device));
+    DT_CHECK_HIP(hipGraphLaunch(g->exec, g->ctx->stream));
+    return 0;
+}
+
+int dtcwt_hip_graph_destroy(dtcwt_hip_graph *g) {
+    if (!g) return 0;
+    (void)hipGraphExecDestroy(g->exec);
+    (void)hipGraphDestroy(g->graph);
+    delete g;
+    return 0;
+}
+
 }  // extern "C"

@@ -124,6 +124,10 @@ SIGNATURES = {
     'dtcwt_hip_plan2d_forward': (_i, [_vp, _vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     'dtcwt_hip_plan2d_inverse': (_i, [_vp, _vp, ctypes.POINTER(_vp), _pd, _vp]),
     'dtcwt_hip_plan2d_set_profiling': (_i, [_vp, _i]),
+    'dtcwt_hip_plan2d_capture': (_i, [_vp, _vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _pd, _vp,
+                                      ctypes.POINTER(_vp)]),
+    'dtcwt_hip_graph_launch': (_i, [_vp]),
+    'dtcwt_hip_graph_destroy': (_i, [_vp]),
     'dtcwt_hip_plan2d_kernel_ms': (_i, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
 }
 

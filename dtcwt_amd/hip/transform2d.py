@@ -110,6 +110,21 @@ class _Plan2d(object):
         self.inverse_into(Yl, Yh, gain_mask, Z)
         return Z
 
+    def capture(self, Xd, Yl, Yh, Z=None, gain_mask=None, Ys=None):
+        """hipGraph of forward_into (and inverse_into when *Z* is given) on these buffers:
+        ``g = plan.capture(X, Yl, Yh, Z); g.launch()`` replays the level loop with one call."""
+        nl = self.nlevels
+        yh_p = (_vp * nl)(*[a.ptr for a in Yh])
+        ys_p = (_vp * nl)(*[a.ptr for a in Ys]) if Ys else None
+        gp = None
+        if gain_mask is not None:
+            gm = np.ascontiguousarray(np.asarray(gain_mask, dtype=np.float64).reshape(6, nl))
+            gp = gm.ctypes.data_as(_pd)
+        h = _vp()
+        check(self._lib.dtcwt_hip_plan2d_capture(self._h, Xd.ptr, Yl.ptr, yh_p, ys_p, gp,
+                                                 Z.ptr if Z is not None else None, ctypes.byref(h)))
+        return _Graph(self, h, (Xd, Yl, list(Yh), Z, Ys))
+
     def set_profiling(self, enable=True):
         check(self._lib.dtcwt_hip_plan2d_set_profiling(self._h, 1 if enable else 0))
 
@@ -127,6 +142,25 @@ class _Plan2d(object):
         try:
             if getattr(self, '_h', None) and getattr(self.ctx, '_h', None):
                 self._lib.dtcwt_hip_plan2d_destroy(self._h)
+            self._h = None
+        except Exception:
+            pass
+
+
+class _Graph(object):
+    """A captured level loop (dtcwt_hip_graph); keeps its plan and buffers alive."""
+
+    def __init__(self, plan, handle, keep):
+        self._plan, self._h, self._keep = plan, handle, keep
+        self._lib = plan._lib
+
+    def launch(self):
+        check(self._lib.dtcwt_hip_graph_launch(self._h))
+
+    def __del__(self):
+        try:
+            if getattr(self, '_h', None) and getattr(self._plan.ctx, '_h', None):
+                self._lib.dtcwt_hip_graph_destroy(self._h)
             self._h = None
         except Exception:
             pass

@@ -321,6 +321,18 @@ int dtcwt_hip_plan2d_set_bandpass(dtcwt_hip_plan2d *plan, const double *h2o, con
 int dtcwt_hip_plan2d_set_profiling(dtcwt_hip_plan2d *plan, int enable);
 int dtcwt_hip_plan2d_kernel_ms(dtcwt_hip_plan2d *plan, float *fwd_ms, float *inv_ms);
 
+/* A plan's level loop as a hipGraph on fixed buffers: the forward transform of X into (Yl, Yh[, Ys])
+ * and, when Z is not NULL, the inverse of that pyramid into Z (gain_mask_host as for
+ * dtcwt_hip_plan2d_inverse, read at capture time), captured from the plan's stream once and
+ * replayed by graph_launch on the same stream.  For loops over same-shaped inputs that are copied
+ * into X (dtcwt/numpy/transform2d.py:40-295 called repeatedly); profiling must be off. */
+typedef struct dtcwt_hip_graph dtcwt_hip_graph;
+int dtcwt_hip_plan2d_capture(dtcwt_hip_plan2d *plan, const float *X, float *Yl, void *const *Yh,
+                             float *const *Ys, const double *gain_mask_host, float *Z,
+                             dtcwt_hip_graph **graph);
+int dtcwt_hip_graph_launch(dtcwt_hip_graph *graph);
+int dtcwt_hip_graph_destroy(dtcwt_hip_graph *graph);
+
 /* ---------------------------------------------------------------- re-sampling ------ */
 /* Replaces dtcwt/sampling.py.  An image is [H][W][ncomp] of the real
  * dtype (channels; complex data counts two components per channel).  Coordinates are DEVICE
