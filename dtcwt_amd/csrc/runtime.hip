@@ -14,6 +14,36 @@ int dtcwt_set_error(int code, const char *fmt, ...) {
     return code;
 }
 
+// integer / bool samples -> floating point on the device: the reference converts every non-float
+// input to float64 on the host first (dtcwt/utils.py:98-105 asfarray); an 8-bit image is an eighth of
+// the bytes over the host link when it is widened here instead.
+template <typename S, typename D>
+__global__ void __launch_bounds__(256) k_to_float(const S *__restrict__ src, D *__restrict__ dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = (D)src[i];
+}
+
+template <typename D>
+static int to_float_dispatch(dtcwt_hip_ctx *c, int src_kind, const void *src, D *dst, int64_t n) {
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+#define DT_TF(S_) k_to_float<S_, D><<<blocks, 256, 0, c->stream>>>((const S_ *)src, dst, n)
+    switch (src_kind) {
+        case 0: DT_TF(uint8_t); break;
+        case 1: DT_TF(int8_t); break;
+        case 2: DT_TF(uint16_t); break;
+        case 3: DT_TF(int16_t); break;
+        case 4: DT_TF(uint32_t); break;
+        case 5: DT_TF(int32_t); break;
+        case 6: DT_TF(uint64_t); break;
+        case 7: DT_TF(int64_t); break;
+        case 8: DT_TF(bool); break;
+        default: return dtcwt_set_error(-1, "bad integer kind %d", src_kind);
+    }
+#undef DT_TF
+    DT_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 extern "C" {
 
 int dtcwt_hip_abi_version(void) { return DTCWT_HIP_ABI_VERSION; }
@@ -223,6 +253,16 @@ int dtcwt_hip_event_destroy(dtcwt_hip_event *ev) {
     (void)hipEventDestroy(ev->ev);
     delete ev;
     return 0;
+}
+
+int dtcwt_hip_to_float(dtcwt_hip_ctx *c, int src_kind, const void *src, int dst_dtype, void *dst, int64_t count) {
+    DT_REQUIRE(c && src && dst, "NULL argument");
+    DT_REQUIRE(count >= 0 && count < ((int64_t)1 << 39), "bad count");
+    if (!count) return 0;
+    DT_CHECK_HIP(hipSetDevice(c->device));
+    if (dst_dtype == DTCWT_HIP_F32) return to_float_dispatch<float>(c, src_kind, src, (float *)dst, count);
+    if (dst_dtype == DTCWT_HIP_F64) return to_float_dispatch<double>(c, src_kind, src, (double *)dst, count);
+    return dtcwt_set_error(-1, "bad dtype %d", dst_dtype);
 }
 
 }  // extern "C"

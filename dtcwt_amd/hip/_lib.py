@@ -70,6 +70,7 @@ SIGNATURES = {
     'dtcwt_hip_memcpy_h2d': (_i, [_vp, _vp, _vp, _sz]),
     'dtcwt_hip_memcpy_d2h': (_i, [_vp, _vp, _vp, _sz]),
     'dtcwt_hip_memcpy_d2d': (_i, [_vp, _vp, _vp, _sz]),
+    'dtcwt_hip_to_float': (_i, [_vp, _i, _vp, _i, _vp, _i64]),
     'dtcwt_hip_memset': (_i, [_vp, _vp, _i, _sz]),
     'dtcwt_hip_event_create': (_i, [_vp, ctypes.POINTER(_vp)]),
     'dtcwt_hip_event_record': (_i, [_vp, _vp]),
@@ -264,6 +265,24 @@ class Context(object):
         a = DeviceArray(self, X.shape, X.dtype)
         check(self._lib.dtcwt_hip_memcpy_h2d(self._h, a.ptr, X.ctypes.data_as(_vp), X.nbytes))
         return a
+
+    _INT_KINDS = {'u1': 0, 'i1': 1, 'u2': 2, 'i2': 3, 'u4': 4, 'i4': 5, 'u8': 6, 'i8': 7, 'b1': 8}
+
+    def to_device_float(self, X):
+        """Upload a real array as floating point the way the reference's ``asfarray`` decides it
+        (dtcwt/utils.py:98-105): float32 / float64 as they are, everything else float64 -- integer
+        and bool arrays travel in their own width and are widened on the device
+        (dtcwt_hip_to_float; a uint8 image is 1/8 of the float64 bytes over the host link)."""
+        X = np.asanyarray(X)
+        if X.dtype == np.float32 or X.dtype == np.float64:
+            return self.to_device(X)
+        kind = self._INT_KINDS.get(X.dtype.str[1:]) if X.dtype.isnative or X.dtype.itemsize == 1 else None
+        if kind is None or X.size == 0:
+            return self.to_device(X.astype(np.float64))
+        raw = self.to_device(X)
+        out = DeviceArray(self, X.shape, np.float64)
+        check(self._lib.dtcwt_hip_to_float(self._h, kind, raw.ptr, F64, out.ptr, X.size))
+        return out
 
     def event(self):
         return Event(self)

@@ -75,7 +75,9 @@ class Transform1d(object):
         if isinstance(X, DeviceArray):
             Xd = X if X.ndim == 2 else X.reshape(X.shape[0], 1)
         else:
-            X = asfarray(X)
+            X = np.asanyarray(X)
+            if np.issubdtype(X.dtype, np.complexfloating):
+                X = asfarray(X)
             if X.ndim == 1:
                 X = np.atleast_2d(X).T
             Xd = None
@@ -83,10 +85,10 @@ class Transform1d(object):
         if shape0 % 2 != 0:
             raise ValueError('Size of input X must be a multiple of 2')
         if nlevels == 0:
-            Xh = Xd.get() if Xd is not None else X
+            Xh = Xd.get() if Xd is not None else asfarray(X)
             return Pyramid(Xh, (), ()) if include_scale else Pyramid(Xh, ())
         if Xd is None:
-            Xd = self.ctx.to_device(X)
+            Xd = self.ctx.to_device_float(X)     # asfarray semantics; integers are widened on the device
         Yh, Ys = [], []
         # a level = one launch with the highpass packing fused (dtcwt_hip_level1d_forward);
         # filters / shapes it declines go through the pair filter + pack kernels

@@ -370,12 +370,14 @@ class Transform2d(object):
                 raise ValueError('Input array must be two-dimensional')
             Xd = X
         else:
-            X = np.atleast_2d(asfarray(X))
+            X = np.atleast_2d(np.asanyarray(X))
+            if np.issubdtype(X.dtype, np.complexfloating):
+                X = asfarray(X)
             if X.ndim >= 3:
                 raise ValueError('The entered image is {0}, which is invalid '.format(
                     'x'.join(str(s) for s in X.shape)) + 'for the 2D transform in a hip backend. ' +
                     'Please enter each image slice separately.')
-            Xd = self.ctx.to_device(X)
+            Xd = self.ctx.to_device_float(X)         # asfarray semantics; integers are widened on the device
         r, c = Xd.shape
         R, C = r + (r & 1), c + (c & 1)
         if nlevels == 0:
@@ -580,8 +582,9 @@ class Transform2d(object):
                 raise ValueError('device inputs must be in nhw/chw layout')
             Xd, info = X, None
         else:
-            Xh, info = self._to_nhw(asfarray(X), data_format)
-            Xd = self.ctx.to_device(Xh)
+            X = np.asanyarray(X)
+            Xh, info = self._to_nhw(asfarray(X) if np.issubdtype(X.dtype, np.complexfloating) else X, data_format)
+            Xd = self.ctx.to_device_float(Xh)
         B, r, c = Xd.shape
         if nlevels == 0:
             Xe = Xd.get()

@@ -216,7 +216,8 @@ class Transform3d(object):
             if Xd.ndim != 3:
                 raise ValueError('device input must be three-dimensional')
         else:
-            Xd = self.ctx.to_device(np.atleast_3d(asfarray(X)))
+            X = np.asanyarray(X)
+            Xd = self.ctx.to_device_float(np.atleast_3d(asfarray(X) if np.issubdtype(X.dtype, np.complexfloating) else X))
         cdt = np.complex64 if Xd.dtype == np.float32 else np.complex128
         Yl = Xd
         Yh = [None] * nlevels

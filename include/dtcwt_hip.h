@@ -70,6 +70,11 @@ int dtcwt_hip_memcpy_h2d(dtcwt_hip_ctx *ctx, void *dst, const void *src_host, si
 int dtcwt_hip_memcpy_d2h(dtcwt_hip_ctx *ctx, void *dst_host, const void *src, size_t bytes);
 int dtcwt_hip_memcpy_d2d(dtcwt_hip_ctx *ctx, void *dst, const void *src, size_t bytes);
 int dtcwt_hip_memset(dtcwt_hip_ctx *ctx, void *dst, int value, size_t bytes);
+/* Integer / bool samples -> float32 / float64 on the device: `asfarray` of dtcwt/utils.py:98-105 (every
+ * non-float input becomes float64) done after the upload, so that an 8-bit image crosses the host link
+ * as 1 byte per sample.  src_kind: 0 u8, 1 i8, 2 u16, 3 i16, 4 u32, 5 i32, 6 u64, 7 i64, 8 bool. */
+int dtcwt_hip_to_float(dtcwt_hip_ctx *ctx, int src_kind, const void *src, int dst_dtype, void *dst,
+                       int64_t count);
 
 /* HIP events on the context's stream (timing of the benchmark harness). */
 int dtcwt_hip_event_create(dtcwt_hip_ctx *ctx, dtcwt_hip_event **ev);

@@ -474,3 +474,24 @@ def test_plan_graph_replays_forward_and_inverse():
     X.set(rs.standard_normal((1, 256, 320)).astype(np.float32))       # same buffer, new image
     g.launch()
     assert_close(Z2.get(), X.get(), INV_TOL, 'graph replay on new data')
+
+
+@pytest.mark.parametrize('dt', [np.uint8, np.int8, np.uint16, np.int16, np.int32, np.uint32, np.int64, np.uint64, np.bool_])
+def test_integer_images_are_widened_on_the_device(dt):
+    """Integer / bool input is float64 for the transform (dtcwt/utils.py:98-105); it is uploaded in its
+    own width and widened by dtcwt_hip_to_float: same pyramid as for the float64 copy of the image."""
+    rs = np.random.RandomState(9)
+    if dt == np.bool_:
+        X = rs.uniform(size=(70, 90)) > 0.5
+    else:
+        info = np.iinfo(dt)
+        X = rs.randint(max(info.min, -2 ** 62), min(info.max, 2 ** 62), size=(70, 90), dtype=np.int64).astype(dt) \
+            if dt != np.uint64 else rs.randint(0, 2 ** 62, size=(70, 90), dtype=np.int64).astype(dt) * 3
+    t = Transform2d()
+    p, q = t.forward(X, nlevels=2), t.forward(X.astype(np.float64), nlevels=2)
+    assert p.lowpass.dtype == np.float64
+    assert np.array_equal(p.lowpass, q.lowpass)
+    assert all(np.array_equal(a, b) for a, b in zip(p.highpasses, q.highpasses))
+    # strided / byte-swapped views still arrive right (host fallback or contiguous copy)
+    Xs = np.asfortranarray(X)
+    assert np.array_equal(t.forward(Xs, nlevels=1).lowpass, t.forward(X.astype(np.float64), nlevels=1).lowpass)

@@ -28,3 +28,10 @@ t = best(fwd, 3); print('Transform2d.forward host->host 4096^2 nl=4: %.1f ms (%.
 p = tr.forward(X, nlevels=4); lo, hi = p.lowpass, p.highpasses
 from dtcwt_amd.hip import Pyramid
 t = best(lambda: tr.inverse(Pyramid(lo, hi)), 3); print('Transform2d.inverse host->host 4096^2 nl=4: %.1f ms (%.0f Mpix/s)' % (t * 1e3, 16.78 / t))
+X8 = (np.random.RandomState(2).uniform(size=(4096, 4096)) * 255).astype(np.uint8)
+def fwd8(widen_on_host):
+    p = tr.forward(X8.astype(np.float64) if widen_on_host else X8, nlevels=4)
+    ctx.device_sync()
+    return p
+t = best(lambda: fwd8(True), 3); print('uint8 4096^2 -> device pyramid, widened to float64 on the host:   %.1f ms' % (t * 1e3))
+t = best(lambda: fwd8(False), 3); print('uint8 4096^2 -> device pyramid, widened on the device:            %.1f ms' % (t * 1e3))
