@@ -125,6 +125,58 @@ __device__ inline void fir_coldfilt(const T (&w)[WN], const T *ha, const T *hb, 
     }
 }
 
+// coldfilt in streaming form for long filters: window sample j (logical row u0 + j) is consumed as it
+// arrives instead of being kept -- it feeds pair q with exactly one tap of ha (j - 4q even) or hb (odd),
+// tap index static after unrolling.  Two filter pairs (lo: a, b; hi: c, d) at once; no WN-register window
+// (float64 x 20 taps: 52 doubles), only the 4 GP accumulators per pair.
+template <typename T, int GP, int MB, int J>
+__device__ inline void scatter_coldfilt(T x, const T *a, const T *b, const T *c, const T *d, T (&A0)[GP], T (&B0)[GP],
+                                        T (&A1)[GP], T (&B1)[GP]) {
+#pragma unroll
+    for (int q = 0; q < GP; ++q) {
+        constexpr int dummy = 0; (void)dummy;
+        const int dd = J - 4 * q;
+        if (dd < 0 || dd >= 2 * MB) continue;
+        if ((dd & 1) == 0) {
+            // A: w[4q + 2MB-2-4k] with ha[2k], w[4q + 2MB-4-4k] with ha[2k+1]
+            const int r = 2 * MB - 2 - dd;
+            const int t = (r % 4 == 0) ? 2 * (r / 4) : 2 * ((r - 2) / 4) + 1;
+            A0[q] += a[t] * x; A1[q] += c[t] * x;
+        } else {
+            // B: w[4q + 2MB-1-4k] with hb[2k], w[4q + 2MB-3-4k] with hb[2k+1]
+            const int r = 2 * MB - 1 - dd;
+            const int t = (r % 4 == 0) ? 2 * (r / 4) : 2 * ((r - 2) / 4) + 1;
+            B0[q] += b[t] * x; B1[q] += d[t] * x;
+        }
+    }
+}
+
+template <typename T, int GP, int MB, int J0, int I, int CH>
+__device__ inline void stream_coldfilt_apply(const T (&x)[CH], const T *a, const T *b, const T *c, const T *d,
+                                             T (&A0)[GP], T (&B0)[GP], T (&A1)[GP], T (&B1)[GP]) {
+    if constexpr (I < CH) {
+        scatter_coldfilt<T, GP, MB, J0 + I>(x[I], a, b, c, d, A0, B0, A1, B1);
+        stream_coldfilt_apply<T, GP, MB, J0, I + 1, CH>(x, a, b, c, d, A0, B0, A1, B1);
+    }
+}
+
+template <typename T, int GP, int MB, int J0, int N, typename LOAD>
+__device__ inline void stream_coldfilt_chunk(LOAD &&load, const T *a, const T *b, const T *c, const T *d,
+                                             T (&A0)[GP], T (&B0)[GP], T (&A1)[GP], T (&B1)[GP]) {
+    constexpr int WN = 4 * (GP - 1) + 2 * MB;
+    if constexpr (J0 < WN) {
+        constexpr int CH = J0 + N <= WN ? N : WN - J0;
+        T x[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) x[i] = load(J0 + i);
+        stream_coldfilt_apply<T, GP, MB, J0, 0, CH>(x, a, b, c, d, A0, B0, A1, B1);
+        // this chunk is consumed before the next one is requested beyond what the chunk size allows
+#pragma unroll
+        for (int q = 0; q < GP; ++q) asm volatile("" : "+v"(A0[q]), "+v"(B0[q]), "+v"(A1[q]), "+v"(B1[q]));
+        stream_coldfilt_chunk<T, GP, MB, J0 + N, N>(load, a, b, c, d, A0, B0, A1, B1);
+    }
+}
+
 // colifilt, taps centre padded to MB (cf. k_colifilt_march): input pair q -> outputs 4q..4q+3,
 // ACCUMULATED into acc
 template <int MB> struct IfiltGeo {
@@ -306,6 +358,19 @@ __device__ inline void fwd_row_fir(const T *wp, const QTaps<T> &tp, const P2Geo 
     }
 }
 
+// the same for long q-shift filters, streaming from LDS (no WIN-register window, cf. scatter_coldfilt)
+template <typename T, int MB>
+__device__ inline void fwd_row_fir_stream(const T *wp, const QTaps<T> &tp, int f0, int f1, T (&lo)[4], T (&hi)[4]) {
+    T A0[2] = {0, 0}, B0[2] = {0, 0}, A1[2] = {0, 0}, B1[2] = {0, 0};
+    auto load = [&](int j) { return wp[j]; };
+    stream_coldfilt_chunk<T, 2, MB, 0, 8>(load, tp.a, tp.b, tp.c, tp.d, A0, B0, A1, B1);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        lo[2 * q] = f0 ? A0[q] : B0[q]; lo[2 * q + 1] = f0 ? B0[q] : A0[q];
+        hi[2 * q] = f1 ? A1[q] : B1[q]; hi[2 * q + 1] = f1 ? B1[q] : A1[q];
+    }
+}
+
 // q2c of the two quads held as rows r0 / r1 of four columns into slots (s0, s1) of the two
 // pixel records rec[0], rec[1]  (dtcwt/numpy/transform2d.py:301-322)
 template <typename T>
@@ -478,11 +543,24 @@ __global__ void __launch_bounds__(256) k_g2_fwd_fused(const T *__restrict__ X, T
         } else {
             constexpr int GP = 4, WN = 4 * (GP - 1) + 2 * MB;
             const int u0 = 4 * (rt * GP) + g.u_shift;
-            T w[WN];
+            if constexpr (MB > 10) {        // long q-shift filters: streaming form, 8 rows in flight
+                T A0[GP], B0[GP], A1[GP], B1[GP];
 #pragma unroll
-            for (int j = 0; j < WN; ++j) w[j] = Xb[(size_t)g2_src(u0 + j, g.LR, g.pad_r_lo, g.R) * g.C];
-            fir_coldfilt<T, GP, MB>(w, tp.a, tp.b, g.f0, l);
-            fir_coldfilt<T, GP, MB>(w, tp.c, tp.d, g.f1, h);
+                for (int q = 0; q < GP; ++q) A0[q] = B0[q] = A1[q] = B1[q] = 0;
+                auto load = [&](int j) { return Xb[(size_t)g2_src(u0 + j, g.LR, g.pad_r_lo, g.R) * g.C]; };
+                stream_coldfilt_chunk<T, GP, MB, 0, 8>(load, tp.a, tp.b, tp.c, tp.d, A0, B0, A1, B1);
+#pragma unroll
+                for (int q = 0; q < GP; ++q) {
+                    l[2 * q] = g.f0 ? A0[q] : B0[q]; l[2 * q + 1] = g.f0 ? B0[q] : A0[q];
+                    h[2 * q] = g.f1 ? A1[q] : B1[q]; h[2 * q + 1] = g.f1 ? B1[q] : A1[q];
+                }
+            } else {
+                T w[WN];
+#pragma unroll
+                for (int j = 0; j < WN; ++j) w[j] = Xb[(size_t)g2_src(u0 + j, g.LR, g.pad_r_lo, g.R) * g.C];
+                fir_coldfilt<T, GP, MB>(w, tp.a, tp.b, g.f0, l);
+                fir_coldfilt<T, GP, MB>(w, tp.c, tp.d, g.f1, h);
+            }
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -504,16 +582,27 @@ __global__ void __launch_bounds__(256) k_g2_fwd_fused(const T *__restrict__ X, T
         pg.f0 = g.f0; pg.f1 = g.f1;
         const T *wl = sLo + (2 * rp) * F::STR + q * RG::IN_STEP, *wh = sHi + (2 * rp) * F::STR + q * RG::IN_STEP;
         T ll0[4], lh0[4], ll1[4], lh1[4];
-        fwd_row_fir<T, KIND, MB, RG::WIN>(wl, tp, pg, ll0, lh0);
-        fwd_row_fir<T, KIND, MB, RG::WIN>(wl + F::STR, tp, pg, ll1, lh1);
+        constexpr bool STREAM = KIND == 1 && MB > 10;
+        if constexpr (STREAM) {
+            fwd_row_fir_stream<T, MB>(wl, tp, g.f0, g.f1, ll0, lh0);
+            fwd_row_fir_stream<T, MB>(wl + F::STR, tp, g.f0, g.f1, ll1, lh1);
+        } else {
+            fwd_row_fir<T, KIND, MB, RG::WIN>(wl, tp, pg, ll0, lh0);
+            fwd_row_fir<T, KIND, MB, RG::WIN>(wl + F::STR, tp, pg, ll1, lh1);
+        }
         T *o = LoLo + ((size_t)b * g.R1 + 2 * i) * g.C1 + col0;
         const bool vec_ok = ((g.C1 * sizeof(T)) & 15) == 0;
         store4(o, ll0, valid, vec_ok);
         store4(o + g.C1, ll1, valid, vec_ok);
         q2c_pair(lh0, lh1, rec, 2, 3);
         T hl0[4], hh0[4], hl1[4], hh1[4];
-        fwd_row_fir<T, KIND, MB, RG::WIN>(wh, tp, pg, hl0, hh0);
-        fwd_row_fir<T, KIND, MB, RG::WIN>(wh + F::STR, tp, pg, hl1, hh1);
+        if constexpr (STREAM) {
+            fwd_row_fir_stream<T, MB>(wh, tp, g.f0, g.f1, hl0, hh0);
+            fwd_row_fir_stream<T, MB>(wh + F::STR, tp, g.f0, g.f1, hl1, hh1);
+        } else {
+            fwd_row_fir<T, KIND, MB, RG::WIN>(wh, tp, pg, hl0, hh0);
+            fwd_row_fir<T, KIND, MB, RG::WIN>(wh + F::STR, tp, pg, hl1, hh1);
+        }
         q2c_pair(hl0, hl1, rec, 0, 5);
         q2c_pair(hh0, hh1, rec, 1, 4);
     }
@@ -1325,10 +1414,10 @@ bool prep_level1(const double *h0, int m0, const double *h1, int m1, bool even_s
     return true;
 }
 
-// q-shift pairs for coldfilt: front padded to 10 / 20
+// q-shift pairs for coldfilt: front padded to 10 / 14 / 18 / 20
 bool prep_dfilt(const double *ha0, const double *hb0, const double *ha1, const double *hb1, int m, TapPrep &p) {
     if (m < 2 || (m & 1) || m > 20) return false;
-    const int mb = m <= 10 ? 10 : 20;
+    const int mb = m <= 10 ? 10 : (m <= 14 ? 14 : (m <= 18 ? 18 : 20));
     for (int k = 0; k < G2_MAXB; ++k) p.a[k] = p.b[k] = p.c[k] = p.d[k] = 0;
     for (int k = 0; k < m; ++k) {
         p.a[mb - m + k] = ha0[k]; p.b[mb - m + k] = hb0[k];
@@ -1395,7 +1484,7 @@ constexpr int G2_NA = -3;       // "use the filter-by-filter path"
 
 #define G2_LAUNCH_CHECK() DT_CHECK_HIP(hipGetLastError())
 
-// KIND 0 buckets 8 / 12 / 20; coldfilt buckets 10 / 20; colifilt buckets 8 / 10 / 16 / 18
+// KIND 0 buckets 8 / 12 / 20; coldfilt buckets 10 / 14 / 18 / 20; colifilt buckets 8 / 10 / 16 / 18
 #define G2_SWITCH_FWD(KERNEL, T_, ...)                                                     \
     do {                                                                                   \
         if (kind == 0) {                                                                   \
@@ -1404,6 +1493,8 @@ constexpr int G2_NA = -3;       // "use the filter-by-filter path"
             else KERNEL<T_, 0, 20> __VA_ARGS__;                                             \
         } else {                                                                           \
             if (p.mb == 10) KERNEL<T_, 1, 10> __VA_ARGS__;                                  \
+            else if (p.mb == 14) KERNEL<T_, 1, 14> __VA_ARGS__;                             \
+            else if (p.mb == 18) KERNEL<T_, 1, 18> __VA_ARGS__;                             \
             else KERNEL<T_, 1, 20> __VA_ARGS__;                                             \
         }                                                                                  \
     } while (0)
@@ -1573,10 +1664,10 @@ int dtcwt_hip_level2d_forward(dtcwt_hip_ctx *ctx, int dtype, int kind, const voi
         } while (0)
         if (dtype == DTCWT_HIP_F32) {
             if (kind == 0) { if (p.mb == 8) G2_FUSED_LAUNCH(float, 0, 8); else if (p.mb == 12) G2_FUSED_LAUNCH(float, 0, 12); else G2_FUSED_LAUNCH(float, 0, 20); }
-            else { if (p.mb == 10) G2_FUSED_LAUNCH(float, 1, 10); else G2_FUSED_LAUNCH(float, 1, 20); }
+            else { if (p.mb == 10) G2_FUSED_LAUNCH(float, 1, 10); else if (p.mb == 14) G2_FUSED_LAUNCH(float, 1, 14); else if (p.mb == 18) G2_FUSED_LAUNCH(float, 1, 18); else G2_FUSED_LAUNCH(float, 1, 20); }
         } else {
             if (kind == 0) { if (p.mb == 8) G2_FUSED_LAUNCH(double, 0, 8); else if (p.mb == 12) G2_FUSED_LAUNCH(double, 0, 12); else G2_FUSED_LAUNCH(double, 0, 20); }
-            else { if (p.mb == 10) G2_FUSED_LAUNCH(double, 1, 10); else G2_FUSED_LAUNCH(double, 1, 20); }
+            else { if (p.mb == 10) G2_FUSED_LAUNCH(double, 1, 10); else if (p.mb == 14) G2_FUSED_LAUNCH(double, 1, 14); else if (p.mb == 18) G2_FUSED_LAUNCH(double, 1, 18); else G2_FUSED_LAUNCH(double, 1, 20); }
         }
 #undef G2_FUSED_LAUNCH
         G2_LAUNCH_CHECK();
