@@ -2,20 +2,32 @@
 """Benchmark of the hot path: 2-D DT-CWT forward + inverse, 4096x4096 float32, nlevels=4,
 near_sym_a / qshift_a (BASELINE.json metric, configs[1]) on N MI355X GPUs of one node.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one forward + one inverse of one image per GPU, input and pyramid resident in
-HBM.  N > 1 is weak scaling over independent images (the path shards by image, no
-data-path collective; the only collective is one RCCL broadcast of the filter taps at
-set-up).  Rank 0 prints ONE JSON line.  The roofline object is for the dominant kernel
-(the slower of the two level-1 kernels), its duration measured with hipEvent pairs on the
-library's stream; cpu_baseline times the NumPy oracle (a port of the reference's
-algorithm) on one image on the host.
+One "step" = one forward + one inverse of one batch per GPU, input and pyramid resident in
+HBM.  N > 1 is weak scaling over independent images (the path shards by image, no data-path
+collective; the only collective is one RCCL broadcast of the filter taps at set-up), one
+process per GPU: started without a launcher (`python bench.py --gpus N`, no WORLD_SIZE in the
+environment) the script re-executes itself under `torch.distributed.run` with N ranks;
+`--mgpu` instead drives the N devices from ONE process through dtcwt_hip_mgpu_* (one host
+thread per device).  Rank 0 prints ONE JSON line.
+
+Steps rotate over `--sets` (default 4) distinct sets of input / pyramid / output buffers, about
+0.4 GB each for the headline config, so that no step finds its input or the previous step's
+pyramid in the 256 MiB Infinity Cache; `resident_ms_per_step` in the JSON line is the same
+step on ONE buffer set (what round 1 reported), for comparison.
+
+The roofline object is for the dominant kernel (the slowest level kernel of a step), its
+duration measured with hipEvent pairs on the library's stream minus the duration of an empty
+event pair; cpu_baseline times the NumPy oracle (a port of the reference's algorithm) on the
+host, rank 0 only.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,34 +37,95 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-ROWS = COLS = 4096
-NLEVELS = 4
 BIORT, QSHIFT = 'near_sym_a', 'qshift_a'
 HBM_PEAK = 8.0e12             # B/s, MI355X spec (MI355X_MICROARCH.md)
 FWD_BYTES_PER_PX = 20.0       # read X, write Yl + all Yh
 STEP_BYTES_PER_PX = 40.0      # forward + inverse
-L1_BYTES_PER_PX = 20.0        # level-1 kernel: X 4 + LoLo 4 + Yh[0] 12 (inverse: mirrored)
+
+# BASELINE.json configs that run on one GPU (c5: one GPU's share of the 512-image batch)
+CONFIGS = {
+    'c2': dict(rows=4096, cols=4096, batch=1, nlevels=4, seed=lambda rank: 1000 * rank,
+               name='2D forward+inverse 4096x4096 f32, nlevels=4'),
+    'c3': dict(rows=1024, cols=1024, batch=64, nlevels=5, seed=lambda rank: 2 + 1000 * rank,
+               name='batched 2D 64x1024x1024 f32, nlevels=5'),
+    'c5': dict(rows=2048, cols=2048, batch=64, nlevels=4, seed=lambda rank: 3 + 1000 * rank,
+               name='batched 2D 512x2048x2048 f32 nlevels=4 sharded over 8 GPUs: 64 images per GPU'),
+}
 
 
-def main():
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=500)
     ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--config', choices=sorted(CONFIGS), default='c2')
+    ap.add_argument('--sets', type=int, default=4, help='distinct buffer sets the steps rotate over')
+    ap.add_argument('--mgpu', action='store_true', help='N > 1 from ONE process: dtcwt_hip_mgpu_* with a host '
+                    'thread per device instead of one process per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--graph', action='store_true', help='replay the eight level kernels of a step as one hipGraph '
-                    '(measured: 0.234 vs 0.229 ms/step for plain stream launches, so not the default)')
+    ap.add_argument('--graph', action='store_true', help='replay the level kernels of a step as one hipGraph '
+                    '(measured: not faster than plain stream launches, so not the default)')
     ap.add_argument('--settle-ms', type=float, default=300.0,
                     help='untimed steps for this long before the W warmup steps: after an idle period the '
                          'device needs ~20 ms of load to reach its sustained clock (0 disables)')
-    ap.add_argument('--rows', type=int, default=ROWS)
-    ap.add_argument('--cols', type=int, default=COLS)
-    ap.add_argument('--batch', type=int, default=1, help='images per GPU per step')
-    args = ap.parse_args()
+    ap.add_argument('--rows', type=int, default=None)
+    ap.add_argument('--cols', type=int, default=None)
+    ap.add_argument('--batch', type=int, default=None, help='images per GPU per step')
+    return ap.parse_args(argv)
+
+
+def respawn_under_launcher(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher: one process per GPU via torch.distributed.run."""
+    from dtcwt_amd.hip import _lib
+    ndev = _lib.device_count()
+    if ndev < args.gpus:
+        raise SystemExit('bench.py --gpus %d: only %d HIP device(s) visible' % (args.gpus, ndev))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def cpu_baseline(cfg, Xh):
+    """The NumPy oracle (port of the reference's algorithm, one core) on a bounded sample: one image."""
+    from dtcwt_amd.coeffs import biort, qshift
+    from oracle import dtcwt_oracle as o
+    R, C = Xh.shape
+    to = o.Transform2d(biort(BIORT), qshift(QSHIFT))
+    c0 = time.perf_counter()
+    p = to.forward(Xh, nlevels=cfg['nlevels'])
+    zc = to.inverse(p)
+    cdt = time.perf_counter() - c0
+    return {'value': round(R * C / cdt / 1e6, 3), 'unit': 'Mpixels/s', 'cores': 1, 'kind': 'port',
+            'host_cpus': os.cpu_count(), 'numpy': np.__version__,
+            'sample': '1 image %dx%d f32 fwd+inv nlevels=%d (%.1f s)' % (R, C, cfg['nlevels'], cdt)}, zc
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and not args.mgpu:
+        respawn_under_launcher(args)
+    if args.mgpu:
+        return main_mgpu(args)
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus and rank == 0:
+        print('bench.py: --gpus %d but the launcher started %d rank(s); reporting n_gpus=%d'
+              % (args.gpus, world, world), file=sys.stderr)
+    cfg = dict(CONFIGS[args.config])
+    for k in ('rows', 'cols', 'batch'):
+        if getattr(args, k) is not None:
+            cfg[k] = getattr(args, k)
     dist = None
     torch = None
     # torch is plumbing only (RCCL barrier / broadcast, device sync): imported for N > 1 or
@@ -86,28 +159,37 @@ def main():
         from dtcwt_amd.hip.sharding import broadcast_taps
         bt, qt = broadcast_taps(bt, qt, dist, device=torch.device('cuda', local_rank), src=0)
 
-    B, R, C = args.batch, args.rows, args.cols
+    B, R, C, NL = cfg['batch'], cfg['rows'], cfg['cols'], cfg['nlevels']
     t2 = dtcwt_amd.hip.Transform2d(tuple(bt), tuple(qt), ctx=ctx)
-    plan = t2.plan(B, R, C, NLEVELS)
-    rs = np.random.RandomState(1000 * rank)             # random, not zero: DVFS
-    X = ctx.to_device(rs.standard_normal((B, R, C)).astype(np.float32))
-    Yl = DeviceArray(ctx, (B,) + plan.low, np.float32)
-    Yh = [DeviceArray(ctx, (B,) + plan.high[l] + (6,), np.complex64) for l in range(NLEVELS)]
-    Z = DeviceArray(ctx, (B,) + plan.ext, np.float32)
+    plan = t2.plan(B, R, C, NL)
+    rs = np.random.RandomState(cfg['seed'](rank))       # random, not zero: DVFS; per-shard seed
+    nsets = max(1, args.sets)
+    sets = []
+    for _ in range(nsets):
+        X = ctx.to_device(rs.standard_normal((B, R, C)).astype(np.float32))
+        Yl = DeviceArray(ctx, (B,) + plan.low, np.float32)
+        Yh = [DeviceArray(ctx, (B,) + plan.high[l] + (6,), np.complex64) for l in range(NL)]
+        Z = DeviceArray(ctx, (B,) + plan.ext, np.float32)
+        sets.append((X, Yl, Yh, Z))
+    set_bytes = sum(a.nbytes for a in (sets[0][0], sets[0][1], sets[0][3])) + sum(a.nbytes for a in sets[0][2])
 
-    # one step = the forward and the inverse level loops on fixed buffers, 8 launches on one stream; --graph
-    # replays them as one captured hipGraph instead (same kernels, same order)
-    graph = plan.capture(X, Yl, Yh, Z) if args.graph else None
+    # one step = the forward and the inverse level loops of one buffer set on one stream; --graph replays
+    # them as one captured hipGraph per set instead (same kernels, same order)
+    graphs = [plan.capture(*s[:3], s[3]) for s in sets] if args.graph else None
+    counter = [0]
 
-    def step_direct():
+    def step_on(k):
+        X, Yl, Yh, Z = sets[k]
         plan.forward_into(X, Yl, Yh)
         plan.inverse_into(Yl, Yh, None, Z)
 
     def step():
-        if graph is not None:
-            graph.launch()
+        k = counter[0] % nsets
+        counter[0] += 1
+        if graphs is not None:
+            graphs[k].launch()
         else:
-            step_direct()
+            step_on(k)
 
     def fence():
         ctx.sync()
@@ -141,63 +223,83 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # sanity of the timed work: reconstruction equals the input
-    err = float(np.abs(Z.get()[0, :64, :64] - X.get()[0, :64, :64]).max())
+    # sanity of the timed work: reconstruction equals the input, on every buffer set
+    err = max(float(np.abs(s[3].get()[0, :64, :64] - s[0].get()[0, :64, :64]).max()) for s in sets)
+
+    # the same step on one buffer set only (input and pyramid may stay in the Infinity Cache)
+    nres = max(5, min(args.steps, 100))
+    for _ in range(5):
+        step_on(0)
+    ctx.sync()
+    r0 = time.perf_counter()
+    for _ in range(nres):
+        step_on(0)
+    ctx.sync()
+    resident_ms = (time.perf_counter() - r0) / nres * 1e3
 
     # ---- roofline of the dominant kernel: hipEvent pair around every level kernel -------
+    ev0, ev1 = ctx.event(), ctx.event()
+    null_ms = []
+    for _ in range(20):
+        ev0.record(); ev1.record()
+        null_ms.append(ev0.elapsed_ms(ev1))
+    null_ms = float(np.median(null_ms))                 # an event pair with nothing in between
     plan.set_profiling(True)
-    kf = np.zeros(NLEVELS); ki = np.zeros(NLEVELS)
+    kf = np.zeros(NL); ki = np.zeros(NL)
     nprof = max(5, min(args.steps, 50))
-    for _ in range(nprof):
-        step_direct()          # per-kernel hipEvent pairs need the plain launches
-        f, i = plan.kernel_ms()
-        kf += f; ki += i
+    for i in range(nprof):
+        step_on(i % nsets)     # per-kernel hipEvent pairs need the plain launches
+        f, g = plan.kernel_ms()
+        kf += f; ki += g
     plan.set_profiling(False)
-    kf /= nprof; ki /= nprof
+    kf = np.maximum(kf / nprof - null_ms, 0.0); ki = np.maximum(ki / nprof - null_ms, 0.0)
     px = float(B) * R * C
-    cand = [('k_fwd1 (level-1 forward)', kf[0]), ('k_inv1 (level-1 inverse)', ki[0])]
-    name, ms = max(cand, key=lambda c: c[1])
-    achieved = L1_BYTES_PER_PX * px / (ms * 1e-3) / 1e9       # GB/s
+    fused12 = bool(getattr(plan, 'fused12', False))
+    # algorithmic bytes per launch of the level-1 kernels (SURVEY 8(d) per-unit figures x pixels):
+    #   one launch per level:   X 4 + LoLo1 4 + Yh[0] 12          = 20 B/px (inverse mirrored)
+    #   levels 1+2 in one launch: X 4 + Yh[0] 12 + LoLo2 1 + Yh[1] 3 = 20 B/px (LoLo1 stays on chip)
+    cand = [('k_fwd12 (levels 1+2 forward)' if fused12 else 'k_fwd1 (level-1 forward)', kf[0], 20.0),
+            ('k_inv1 (level-1 inverse)', ki[0], 20.0)]
+    name, ms, bpp = max(cand, key=lambda c: c[1])
+    achieved = bpp * px / (ms * 1e-3) / 1e9       # GB/s
     roofline = {'bound': 'hbm', 'kernel': name, 'achieved': round(achieved, 1), 'peak': HBM_PEAK / 1e9,
                 'unit': 'GB/s', 'frac': round(achieved * 1e9 / HBM_PEAK, 4), 'traffic': None,
-                'kernel_ms': round(float(ms), 5), 'algorithmic_bytes_per_launch': L1_BYTES_PER_PX * px,
+                'kernel_ms': round(float(ms), 5), 'algorithmic_bytes_per_launch': bpp * px,
                 'fwd_kernel_ms': [round(float(x), 5) for x in kf],
                 'inv_kernel_ms': [round(float(x), 5) for x in ki],
+                'sum_kernel_ms': round(float(kf.sum() + ki.sum()), 5), 'event_pair_overhead_ms': round(null_ms, 5),
                 'step_frac': round(STEP_BYTES_PER_PX * px / (dt / args.steps) / HBM_PEAK, 4)}
     tr = os.path.join(ROOT, 'profiles', 'traffic.json')
-    if os.path.exists(tr):
+    if os.path.exists(tr) and args.config == 'c2':
         try:
-            roofline['traffic'] = json.load(open(tr)).get(name.split(' ')[0])
+            tj = json.load(open(tr))
+            roofline['traffic'] = tj.get(name.split(' ')[0])
+            roofline['traffic_source'] = tj.get('source')
         except Exception:
             pass
 
     value = world * px * args.steps / dt / 1e6
     out = {
-        'metric': 'Mpixels/s 2D DT-CWT fwd+inv, 4096^2 f32 nlevels=4',
+        'metric': 'Mpixels/s 2D DT-CWT fwd+inv, 4096^2 f32 nlevels=4' if args.config == 'c2' else
+                  'Mpixels/s 2D DT-CWT fwd+inv, %s' % cfg['name'],
         'value': round(value, 1), 'unit': 'Mpixels/s', 'n_gpus': world, 'steps': args.steps,
-        'warmup': args.warmup, 'settle_ms': args.settle_ms, 'launch': 'hipGraph' if graph is not None else 'stream', 'ms_per_step': round(dt / args.steps * 1e3, 5),
+        'warmup': args.warmup, 'settle_ms': args.settle_ms, 'launch': 'hipGraph' if graphs is not None else 'stream',
+        'ms_per_step': round(dt / args.steps * 1e3, 5),
         'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': '2D forward+inverse %dx%d f32, nlevels=%d, %s/%s, %d image(s) per GPU per step'
-                               % (R, C, NLEVELS, BIORT, QSHIFT, B),
-                   'sharding': 'independent images per GPU, no data-path collective'},
+        'config': {'workload': '%s, %s/%s, %d image(s) per GPU per step' % (cfg['name'], BIORT, QSHIFT, B),
+                   'sharding': 'independent images per GPU, no data-path collective',
+                   'buffer_sets': nsets, 'bytes_per_set': set_bytes,
+                   'levels_1_2_fused_forward': fused12},
+        'resident_ms_per_step': round(resident_ms, 5),
         'roofline': roofline, 'recon_max_abs_err': err,
     }
 
     # ---- CPU baseline: the oracle (a NumPy port of the reference's algorithm), rank 0 ----
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import dtcwt_oracle as o
-        Xh = X.get()[0]
-        to = o.Transform2d(biort(BIORT), qshift(QSHIFT))
-        c0 = time.perf_counter()
-        p = to.forward(Xh, nlevels=NLEVELS)
-        zc = to.inverse(p)
-        cdt = time.perf_counter() - c0
-        out['cpu_baseline'] = {'value': round(R * C / cdt / 1e6, 3), 'unit': 'Mpixels/s', 'cores': 1,
-                               'kind': 'port', 'host_cpus': os.cpu_count(), 'numpy': np.__version__,
-                               'sample': '1 image %dx%d f32 fwd+inv nlevels=%d (%.1f s)' % (R, C, NLEVELS, cdt)}
+    if rank == 0 and not args.no_cpu_baseline:
+        out['cpu_baseline'], zc = cpu_baseline(cfg, sets[0][0].get()[0])
         # the timed GPU output against the CPU port on the same input
-        out['gpu_vs_cpu_recon_max_abs_diff'] = float(np.abs(Z.get()[0] - zc).max())
+        out['gpu_vs_cpu_recon_max_abs_diff'] = float(np.abs(sets[0][3].get()[0] - zc).max())
     elif rank == 0:
         out['cpu_baseline'] = None
     if rank == 0:
@@ -210,6 +312,78 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main_mgpu(args):
+    """N devices from one process: dtcwt_hip_mgpu_* (a host thread per device, taps broadcast with RCCL)."""
+    from dtcwt_amd.coeffs import biort, qshift
+    from dtcwt_amd.hip import _lib
+    from dtcwt_amd.hip.multigpu import MultiGPUTransform2d
+    cfg = dict(CONFIGS[args.config])
+    for k in ('rows', 'cols', 'batch'):
+        if getattr(args, k) is not None:
+            cfg[k] = getattr(args, k)
+    ndev = _lib.device_count()
+    if ndev < args.gpus:
+        raise SystemExit('bench.py --mgpu --gpus %d: only %d HIP device(s) visible' % (args.gpus, ndev))
+    N = args.gpus
+    B, R, C, NL = cfg['batch'], cfg['rows'], cfg['cols'], cfg['nlevels']
+    m = MultiGPUTransform2d(biort(BIORT), qshift(QSHIFT), devices=list(range(N)), batch=N * B, rows=R, cols=C,
+                            nlevels=NL, broadcast_taps=True)
+    nsets = max(1, args.sets)
+    sets = []
+    for k in range(nsets):
+        rs = np.random.RandomState(cfg['seed'](0) + 17 * k)
+        bufs = m.alloc()
+        m.scatter(rs.standard_normal((N * B, R, C)).astype(np.float32), bufs.X)
+        sets.append(bufs)
+    counter = [0]
+
+    def step():
+        s = sets[counter[0] % nsets]
+        counter[0] += 1
+        m.forward_into(s)
+        m.inverse_into(s)
+
+    if args.settle_ms > 0:
+        t_settle = time.perf_counter()
+        for _ in range(20):
+            step()
+        m.sync()
+        per_step = max((time.perf_counter() - t_settle) / 20, 1e-5)
+        for _ in range(int(args.settle_ms * 1e-3 / per_step) + 1):
+            step()
+    for _ in range(args.warmup):
+        step()
+    m.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    m.sync()
+    dt = time.perf_counter() - t0
+    px = float(N * B) * R * C
+    Zh, Xh = m.gather(sets[0].Z, (R + (R & 1), C + (C & 1)), np.float32), m.gather(sets[0].X, (R, C), np.float32)
+    err = float(np.abs(Zh[:, :64, :64] - Xh[:, :64, :64]).max())
+    out = {
+        'metric': 'Mpixels/s 2D DT-CWT fwd+inv, 4096^2 f32 nlevels=4' if args.config == 'c2' else
+                  'Mpixels/s 2D DT-CWT fwd+inv, %s' % cfg['name'],
+        'value': round(px * args.steps / dt / 1e6, 1), 'unit': 'Mpixels/s', 'n_gpus': N, 'steps': args.steps,
+        'warmup': args.warmup, 'settle_ms': args.settle_ms, 'launch': 'mgpu (one process, a host thread per device)',
+        'ms_per_step': round(dt / args.steps * 1e3, 5), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': '%s, %s/%s, %d image(s) per GPU per step' % (cfg['name'], BIORT, QSHIFT, B),
+                   'sharding': 'contiguous batch split over %d device(s), no data-path collective' % N,
+                   'buffer_sets': nsets, 'taps_broadcast_with_rccl': bool(m.taps_broadcast)},
+        'roofline': {'bound': 'hbm', 'kernel': 'whole step', 'achieved': round(STEP_BYTES_PER_PX * px / dt * args.steps / N / 1e9, 1),
+                     'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                     'frac': round(STEP_BYTES_PER_PX * px / N / (dt / args.steps) / HBM_PEAK, 4), 'traffic': None},
+        'recon_max_abs_err': err,
+    }
+    if not args.no_cpu_baseline:
+        out['cpu_baseline'], _ = cpu_baseline(cfg, Xh[0])
+    else:
+        out['cpu_baseline'] = None
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':

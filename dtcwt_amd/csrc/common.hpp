@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include <unordered_map>
 #include <vector>
 
@@ -22,7 +23,10 @@ struct dtcwt_hip_ctx {
     std::unordered_map<size_t, std::vector<void *>> pool;   // size -> free buffers
     std::unordered_map<void *, size_t> live;                // buffer -> size
     size_t pooled_bytes = 0;
-    size_t pool_limit = (size_t)16 << 30;                   // raised to HBM/2 at creation; DTCWT_HIP_POOL_MB overrides
+    size_t pool_limit = (size_t)16 << 30;                   // raised to HBM/4 at creation; DTCWT_HIP_POOL_MB overrides
+    // malloc / free / trim may come from different host threads: the Python layer shares one default context
+    // per device, ctypes releases the GIL during calls and garbage collection frees arrays from any thread
+    std::mutex pool_mu;
 };
 
 struct dtcwt_hip_event {

@@ -11,6 +11,7 @@
 #include "common.hpp"
 #include "fused2d_tiles.hpp"
 #include "fused2d_tiles_v2.hpp"
+#include "fused2d_l12.hpp"
 #include "fused2d_table.hpp"
 
 using namespace dt2d;
@@ -103,6 +104,149 @@ __global__ void __launch_bounds__(DT_NT) k_inv2(Inv2Params p) {
     inv2_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0, y3);
 }
 
+#define DT_WAIT_VMEM() __builtin_amdgcn_s_waitcnt(0x0F70)      /* s_waitcnt vmcnt(0), gfx9 encoding (expcnt 7, lgkmcnt 15 = no wait) */
+#define DT_OPAQUE(v_) asm volatile("" : "+v"(v_))             /* the value may have changed: nothing derived from it is loop-invariant */
+
+// Levels 1 and 2 forward in one launch (fused2d_l12.hpp): LoLo1 stays in LDS.
+// SKIP: phase knock-out bits for tools/kbench/fwd12_bench (timing experiments only; always 0 in the library)
+template <class C, int SKIP = 0>
+__global__ void __launch_bounds__(C::NT, C::MIN_WAVES) k_fwd12(Fwd1Params p1, Fwd2Params p2) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];       // C::LDS_FLOATS (may exceed 64 KiB)
+    const int ntile = p2.tilesR * p2.tilesC * p2.B;
+    int t = tile_of(blockIdx.x, ntile, p2.xcd_order);
+    if (t >= ntile) return;
+    int tc = t % p2.tilesC, tr = (t / p2.tilesC) % p2.tilesR, b = t / (p2.tilesC * p2.tilesR);
+    float *sLo = smem, *sHi = sLo + C::SLO, *stage = sHi + C::SB;
+    float *sLo2 = sHi, *sHi2 = sHi + C::S2;            // level-2 planes over the (dead) Hi plane
+    const int tid = threadIdx.x;
+    const int tidp = lds128_perm(tid);              // task index of this lane in the phases that read LDS 16 bytes at a time
+    if (SKIP & 64) { tr = 2 + (tr & 3); tc = 2 + (tc & 3); }     // timing experiment: every workgroup on the same few (cache-resident) tiles
+    const int r2 = tr * C::T2R, c2 = tc * C::T2C, r1 = 2 * r2, c1 = 2 * c2;
+    if (!(SKIP & 1)) fwd12_cols<C>(p1, sLo, sHi, tid, b, r1, c1);
+    // Every load of this workgroup has been consumed by now.  Saying so keeps the compiler from guarding later
+    // re-uses of the window registers with s_waitcnt vmcnt(0) -- which, further down, would also wait for the
+    // record STORES issued in between (vmcnt counts loads and stores in order) and put the HBM write latency
+    // on the critical path of the tile.
+    DT_WAIT_VMEM();
+    __syncthreads();
+    Fwd12State<C> st;
+    if (!(SKIP & 2))
+#pragma unroll
+    for (int round = 0; round < C::NCR; ++round) {
+        alignas(16) float rec[2][12];
+        fwd12_core_compute<C>(p1, sLo, sHi, tidp, round, st, rec);
+        if (!(SKIP & 32))
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            fwd12_core_deposit<C>(stage, tidp, round, half, rec);
+            fwd12_core_flush<C>(p1, stage, tid, round, half, b, r1, c1);
+        }
+    }
+    if (!(SKIP & 4)) fwd12_halo_compute<C>(p1, sLo, tidp, st);
+    __syncthreads();                                // every read of the Lo plane is done: LoLo1 goes over it
+    if (!(SKIP & 6)) fwd12_writeback<C>(p1, sLo, tidp, b, r1, c1, st);
+    __syncthreads();
+    if (fwd12_needs_fix<C>(p1, r1, c1)) {           // uniform per workgroup
+        fwd12_fix<C>(p1, sLo, tid, r1, c1);
+        __syncthreads();
+    }
+    if (!(SKIP & 8)) fwd12_cols2<C>(p2, sLo, sLo2, sHi2, tid);
+    __syncthreads();
+    if (!(SKIP & 16))
+    for (int base = 0; base < C::TI * C::TJ; base += C::NT) {
+        fwd2s_rows_compute<typename C::L2View>(p2, sLo2, sHi2, stage, tidp, base, b, r2, c2);
+        fwd2s_rows_flush<typename C::L2View>(p2, stage, tid, base, b, r2, c2);
+    }
+}
+
+// The same tile program as a PERSISTENT kernel over the tiles whose core lies wholly inside the image: a
+// workgroup walks a list of tiles and requests the next tile's input window right after the column pass has
+// consumed the current one, so that those loads are in flight while phases 2-4 compute and store, and a
+// workgroup never sits on a CU slot waiting for its last stores to be acknowledged.  (k_fwd12 alone leaves
+// arithmetic and HBM time un-overlapped: 113 us against a 55 us arithmetic floor and ~55 us of HBM traffic.)
+// vmcnt counts loads and stores in order: the wait for the prefetched window at the top of the loop must not
+// reach past the loads into the stores issued after them.  The compiler derives that count from the code
+// between the loads and the wait on EVERY path into the loop header, hence (a) the first tile is peeled (its
+// window comes from the prologue, with nothing after it), (b) the stores in the loop body are unconditional
+// (FULL tiles), so no path skips them.
+// Tile order: workgroup w runs on XCD w % 8 (observed dispatch rule); each XCD owns a contiguous run of
+// tiles, dealt round-robin to its workgroups, so neighbouring tiles share halo rows through one L2.
+template <class C>
+__device__ __forceinline__ void fwd12p_tile(const Fwd1Params &p1, const Fwd2Params &p2, float *sLo, float *sHi,
+                                            float *stage, int tid0, int b, int tr, int tc, int bn, int trn, int tcn,
+                                            Fwd12Win<C> &win) {
+    float *sLo2 = sHi, *sHi2 = sHi + C::S2;
+    // without this the compiler hoists every per-thread LDS address of every phase out of the tile loop
+    // (they do not depend on the tile) and spills them: 66 scratch accesses per tile
+    int tid = tid0;
+    DT_OPAQUE(tid);
+    const int tidp = lds128_perm(tid);
+    const int r2 = tr * C::T2R, c2 = tc * C::T2C, r1 = 2 * r2, c1 = 2 * c2;
+    fwd12_cols_compute<C>(p1, sLo, sHi, tid, win);
+    // the next tile's window (after the last tile: the same tile again, unused -- an unconditional load keeps
+    // the window in ONE set of registers; a conditional one makes the compiler copy it, and every copy is a wait)
+    fwd12_cols_load<C>(p1, tid, bn, 2 * trn * C::T2R, 2 * tcn * C::T2C, win);
+    __syncthreads();
+    Fwd12State<C> st;
+#pragma unroll
+    for (int round = 0; round < C::NCR; ++round) {
+        alignas(16) float rec[2][12];
+        fwd12_core_compute<C>(p1, sLo, sHi, tidp, round, st, rec);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            fwd12_core_deposit<C, C::CORE_EXACT>(stage, tidp, round, half, rec);
+            fwd12_core_flush<C, C::CORE_EXACT>(p1, stage, tid, round, half, b, r1, c1);
+        }
+    }
+    fwd12_halo_compute<C>(p1, sLo, tidp, st);
+    __syncthreads();
+    fwd12_writeback<C>(p1, sLo, tidp, b, r1, c1, st);
+    __syncthreads();
+    if (fwd12_needs_fix<C>(p1, r1, c1)) {
+        fwd12_fix<C>(p1, sLo, tid, r1, c1);
+        __syncthreads();
+    }
+    fwd12_cols2<C>(p2, sLo, sLo2, sHi2, tid);
+    __syncthreads();
+    for (int base = 0; base < C::TI * C::TJ; base += C::NT) {
+        fwd2s_rows_compute<typename C::L2View>(p2, sLo2, sHi2, stage, tidp, base, b, r2, c2);
+        fwd2s_rows_flush<typename C::L2View>(p2, stage, tid, base, b, r2, c2);
+    }
+}
+
+template <class C, int SKIP = 0, int MW = (C::NT == 256 ? 3 : 2)>
+__global__ void __launch_bounds__(C::NT, MW) k_fwd12p(Fwd1Params p1, Fwd2Params p2) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // full tiles only: tilesR / tilesC here count the tiles whose core is inside the image
+    const int ntile = p2.tilesR * p2.tilesC * p2.B;
+    const int per = (ntile + 7) / 8, nwx = gridDim.x / 8;          // tiles per XCD, workgroups per XCD
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tend = min(ntile, (xcd + 1) * per);
+    int t = xcd * per + slot;
+    if (t >= tend) return;
+    float *sLo = smem, *sHi = sLo + C::SLO, *stage = sHi + C::SB;
+    Fwd12Win<C> win;
+    int tc = t % p2.tilesC, tr = (t / p2.tilesC) % p2.tilesR, b = t / (p2.tilesC * p2.tilesR);
+    fwd12_cols_load<C>(p1, threadIdx.x, b, 2 * tr * C::T2R, 2 * tc * C::T2C, win);
+    const int tid0 = threadIdx.x;
+    // first tile, peeled
+    {
+        const int tn = t + nwx, tl = tn < tend ? tn : t;
+        const int tcn = tl % p2.tilesC, trn = (tl / p2.tilesC) % p2.tilesR, bn = tl / (p2.tilesC * p2.tilesR);
+        fwd12p_tile<C>(p1, p2, sLo, sHi, stage, tid0, b, tr, tc, bn, trn, tcn, win);
+        if (tn >= tend) return;
+        t = tn; tc = tcn; tr = trn; b = bn;
+    }
+    for (;;) {
+        __syncthreads();                                // the planes are free for this tile's column pass
+        const int tn = t + nwx, tl = tn < tend ? tn : t;
+        const int tcn = tl % p2.tilesC, trn = (tl / p2.tilesC) % p2.tilesR, bn = tl / (p2.tilesC * p2.tilesR);
+        fwd12p_tile<C>(p1, p2, sLo, sHi, stage, tid0, b, tr, tc, bn, trn, tcn, win);
+        if (tn >= tend) break;
+        t = tn; tc = tcn; tr = trn; b = bn;
+    }
+}
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline unsigned grid_for(int ntile) { return (unsigned)(cdiv(ntile, 8) * 8); }
 
@@ -129,6 +273,39 @@ template <class C>
 int launch_inv2(Inv2Params &p, hipStream_t s) {
     p.tilesR = cdiv(p.zr, C::TR); p.tilesC = cdiv(p.zc, C::TC);
     k_inv2<C><<<grid_for(p.tilesR * p.tilesC * p.B), DT_NT, 0, s>>>(p);
+    return 0;
+}
+
+template <class C, int SKIP = 0>
+int launch_fwd12(Fwd1Params &p1, Fwd2Params &p2, hipStream_t s) {
+    p2.tilesR = cdiv(p2.LR / 2, C::T2R); p2.tilesC = cdiv(p2.LC / 2, C::T2C);
+    constexpr size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
+    static bool raised = false;         // per instantiation: allow more than the default 64 KiB of dynamic LDS
+    if (lds > (48u << 10) && !raised) {
+        if (hipFuncSetAttribute((const void *)k_fwd12<C, SKIP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return -2;
+        raised = true;
+    }
+    k_fwd12<C, SKIP><<<grid_for(p2.tilesR * p2.tilesC * p2.B), C::NT, lds, s>>>(p1, p2);
+    return 0;
+}
+
+template <class C, int SKIP = 0, int MW = (C::NT == 256 ? 3 : 2)>
+int launch_fwd12p(Fwd1Params &p1, Fwd2Params &p2, hipStream_t s, int wg_per_cu = 4, int cus = 256) {
+    // the persistent kernel takes the tiles that lie wholly inside the image (all of them when the level-2
+    // lowpass is a multiple of the tile: the caller checks that; otherwise it uses k_fwd12)
+    p2.tilesR = (p2.LR / 2) / C::T2R; p2.tilesC = (p2.LC / 2) / C::T2C;
+    constexpr size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
+    static bool raised = false;
+    if (lds > (48u << 10) && !raised) {
+        if (hipFuncSetAttribute((const void *)k_fwd12p<C, SKIP, MW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return -2;
+        raised = true;
+    }
+    const int ntile = p2.tilesR * p2.tilesC * p2.B;
+    int grid = cus * wg_per_cu;                       // a multiple of 8
+    if (grid > ((ntile + 7) / 8) * 8) grid = ((ntile + 7) / 8) * 8;
+    k_fwd12p<C, SKIP, MW><<<grid, C::NT, lds, s>>>(p1, p2);
     return 0;
 }
 
@@ -161,6 +338,12 @@ int dispatch_inv2(int m, bool bp, Inv2Params &p, hipStream_t s, bool small) {
     if (small) { DT_INV2_SMALL_TABLE(DT_CASE_INV2) }
     DT_INV2_TABLE(DT_CASE_INV2) return -3;
 }
+#define DT_CASE_FWD12(T2R, T2C, RS, PS, A, B, M) if (m0 == A && m1 == B && m == M) return launch_fwd12<Fwd12Cfg<T2R, T2C, RS, PS, A, B, M>>(p1, p2, s);
+int dispatch_fwd12(int m0, int m1, int m, Fwd1Params &p1, Fwd2Params &p2, hipStream_t s) {
+    DT_FWD12_TABLE(DT_CASE_FWD12) return -3;
+}
+#define DT_HAS12(T2R, T2C, RS, PS, A, B, M) if (m0 == A && m1 == B && m == M) return true;
+bool fwd12_supported(int m0, int m1, int m) { DT_FWD12_TABLE(DT_HAS12) return false; }
 #define DT_HAS3(TR, TC, RS, A, B, C2) if (m0 == A && m1 == B && m2 == C2) return true;
 bool fwd1_bp_supported(int m0, int m1, int m2) { DT_FWD1_BP_TABLE(DT_HAS3) return false; }
 bool inv1_bp_supported(int m0, int m1, int m2) { DT_INV1_BP_TABLE(DT_HAS3) return false; }
@@ -207,7 +390,18 @@ struct dtcwt_hip_plan2d {
     std::vector<hipEvent_t> ev;       // [fwd: 2 per level][inv: 2 per level]
     int xcd_order = -1;               // -1: per-kernel default, 0/1: forced (DTCWT_HIP_XCD_ORDER)
     int small_tiles = -1;             // -1: by size, 0/1: forced (DTCWT_HIP_SMALL_TILES)
+    int fuse12 = 1;                   // levels 1+2 in one launch where possible (DTCWT_HIP_FUSE12=0 disables)
 };
+
+namespace {
+// levels 1 and 2 of the forward transform can run as one launch (fused2d_l12.hpp)
+bool can_fuse12_fwd(const dtcwt_hip_plan2d *p) {
+    if (!p->fuse12 || p->nlevels < 2 || !p->bp1[0].empty() || !p->bp2[0].empty()) return false;
+    const Level &L = p->lv[1];
+    if (L.padR || L.padC || L.LR < DT_MIN_FUSE12_DIM || L.LC < DT_MIN_FUSE12_DIM) return false;
+    return fwd12_supported((int)p->biort[0].size(), (int)p->biort[2].size(), (int)p->qshift[0].size());
+}
+}  // namespace
 
 extern "C" {
 
@@ -231,6 +425,7 @@ int dtcwt_hip_plan2d_create(dtcwt_hip_ctx *ctx, int batch, int rows, int cols, i
     for (int i = 0; i < 8; ++i) p->qshift[i].assign(qshift_host[i], qshift_host[i] + qshift_len[i]);
     { const char *e = getenv("DTCWT_HIP_XCD_ORDER"); p->xcd_order = e ? (e[0] == '1' ? 1 : 0) : -1; }
     { const char *e = getenv("DTCWT_HIP_SMALL_TILES"); p->small_tiles = e ? (e[0] == '1' ? 1 : 0) : -1; }
+    { const char *e = getenv("DTCWT_HIP_FUSE12"); p->fuse12 = e ? (e[0] != '0') : 1; }
     p->extR = rows + (rows & 1);
     p->extC = cols + (cols & 1);
     Level l0{rows, cols, 0, 0, p->extR, p->extC, p->extR, p->extC, p->extR / 2, p->extC / 2};
@@ -300,6 +495,11 @@ int dtcwt_hip_plan2d_set_bandpass(dtcwt_hip_plan2d *p, const double *h2o, const 
     return 0;
 }
 
+int dtcwt_hip_plan2d_fused_levels(const dtcwt_hip_plan2d *p) {
+    if (!p) return 0;
+    return (can_fuse12_fwd(p) ? 1 : 0);
+}
+
 int dtcwt_hip_plan2d_set_profiling(dtcwt_hip_plan2d *p, int enable) {
     DT_REQUIRE(p, "NULL plan");
     if (enable && p->ev.empty()) {
@@ -340,10 +540,19 @@ int dtcwt_hip_plan2d_forward(dtcwt_hip_plan2d *p, const float *X, float *Yl, voi
     hipStream_t s = p->ctx->stream;
     const int nl = p->nlevels;
     const float *in = X;
+    const bool f12 = can_fuse12_fwd(p);
     for (int l = 0; l < nl; ++l) {
         const Level &L = p->lv[l];
         float *lo = (l == nl - 1 && !Ys) ? Yl : (Ys ? Ys[l] : p->work[l]);
         DT_REQUIRE(lo && Yh[l], "NULL output buffer at level %d", l);
+        if (f12 && l == 1) {            // done by the level-1 launch
+            if (p->profiling) {
+                DT_CHECK_HIP(hipEventRecord(p->ev[2], s));
+                DT_CHECK_HIP(hipEventRecord(p->ev[3], s));
+            }
+            in = lo;
+            continue;
+        }
         int rc;
         if (p->profiling) DT_CHECK_HIP(hipEventRecord(p->ev[2 * l], s));
         if (l == 0) {
@@ -352,6 +561,23 @@ int dtcwt_hip_plan2d_forward(dtcwt_hip_plan2d *p, const float *X, float *Yl, voi
             q.B = p->batch; q.inR = L.inR; q.inC = L.inC; q.LR = L.LR; q.LC = L.LC;
             q.xcd_order = p->xcd_order < 0 ? 0 : p->xcd_order;      // write-heavy: linear order
             put_taps(q.h0, p->biort[0]); put_taps(q.h1, p->biort[2]); put_taps(q.h2, p->bp1[0]);
+            if (f12) {
+                // one launch for levels 1 and 2: LoLo1 only leaves the chip when it is an output (Ys)
+                const Level &L2 = p->lv[1];
+                Fwd2Params q2{};
+                q.LoLo = Ys ? Ys[0] : nullptr;
+                q2.X = nullptr; q2.Yh = (float *)Yh[1];
+                q2.LoLo = (nl == 2 && !Ys) ? Yl : (Ys ? Ys[1] : p->work[1]);
+                DT_REQUIRE(q2.LoLo && q2.Yh, "NULL output buffer at level 1");
+                q2.B = p->batch; q2.inR = L2.inR; q2.inC = L2.inC; q2.LR = L2.LR; q2.LC = L2.LC;
+                q2.xcd_order = p->xcd_order < 0 ? 0 : p->xcd_order;
+                q2.stream_records = (int64_t)p->batch * (L2.LR / 4) * (L2.LC / 4) * 48 >= ((int64_t)32 << 20);
+                put_taps(q2.l_a, p->qshift[1]); put_taps(q2.l_b, p->qshift[0]);
+                put_taps(q2.h_a, p->qshift[5]); put_taps(q2.h_b, p->qshift[4]);
+                q2.lo_a_first = dotd(p->qshift[1], p->qshift[0]) > 0;
+                q2.hi_a_first = dotd(p->qshift[5], p->qshift[4]) > 0;
+                rc = dispatch_fwd12((int)p->biort[0].size(), (int)p->biort[2].size(), (int)p->qshift[0].size(), q, q2, s);
+            } else
             rc = dispatch_fwd1((int)p->biort[0].size(), (int)p->biort[2].size(), (int)p->bp1[0].size(), q, s);
         } else {
             Fwd2Params q{};

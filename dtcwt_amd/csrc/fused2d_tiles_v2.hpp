@@ -13,6 +13,7 @@
 // 16-byte store of write-once data (subband records) with the non-temporal hint, so that the
 // lowpass plane the next level reads back is what stays in L2 / the Infinity Cache
 typedef float dt_v4f __attribute__((ext_vector_type(4)));
+typedef float dt_v2f __attribute__((ext_vector_type(2)));
 #define DT_STREAM_STORE_F4(dst_, val_) \
     __builtin_nontemporal_store(*reinterpret_cast<const dt_v4f *>(&(val_)), reinterpret_cast<dt_v4f *>(dst_))
 // ... and 16-byte load of read-once data (the records on the way back)

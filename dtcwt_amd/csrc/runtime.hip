@@ -44,6 +44,17 @@ static int to_float_dispatch(dtcwt_hip_ctx *c, int src_kind, const void *src, D 
     return 0;
 }
 
+// pool_mu held by the caller
+static int trim_locked(dtcwt_hip_ctx *c) {
+    DT_CHECK_HIP(hipSetDevice(c->device));
+    DT_CHECK_HIP(hipStreamSynchronize(c->stream));
+    for (auto &kv : c->pool)
+        for (void *b : kv.second) (void)hipFree(b);
+    c->pool.clear();
+    c->pooled_bytes = 0;
+    return 0;
+}
+
 extern "C" {
 
 int dtcwt_hip_abi_version(void) { return DTCWT_HIP_ABI_VERSION; }
@@ -94,9 +105,9 @@ int dtcwt_hip_ctx_create(int device, void *stream, dtcwt_hip_ctx **out) {
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, device) == hipSuccess) {
         c->cus = p.multiProcessorCount;
-        // cache of freed buffers: up to half of the HBM (288 GB on MI355X) -- pyramids of large
+        // cache of freed buffers: up to a quarter of the HBM (288 GB on MI355X) -- pyramids of large
         // volumes are several GB per buffer, and every hipFree / hipMalloc is a device-wide sync
-        if (p.totalGlobalMem / 2 > c->pool_limit) c->pool_limit = p.totalGlobalMem / 2;
+        if (p.totalGlobalMem / 4 > c->pool_limit) c->pool_limit = p.totalGlobalMem / 4;
     } else {
         c->cus = 256;
     }
@@ -137,6 +148,7 @@ int dtcwt_hip_malloc(dtcwt_hip_ctx *c, size_t bytes, void **dptr) {
     *dptr = nullptr;
     if (bytes == 0) bytes = 16;
     bytes = (bytes + 255) & ~(size_t)255;
+    std::lock_guard<std::mutex> lk(c->pool_mu);
     auto it = c->pool.find(bytes);
     if (it != c->pool.end() && !it->second.empty()) {
         *dptr = it->second.back();
@@ -149,7 +161,7 @@ int dtcwt_hip_malloc(dtcwt_hip_ctx *c, size_t bytes, void **dptr) {
     hipError_t e = hipMalloc(dptr, bytes);
     if (e != hipSuccess && c->pooled_bytes) {        // out of memory: drop the cache and retry
         (void)hipGetLastError();
-        dtcwt_hip_trim(c);
+        trim_locked(c);
         e = hipMalloc(dptr, bytes);
     }
     if (e != hipSuccess)
@@ -161,6 +173,7 @@ int dtcwt_hip_malloc(dtcwt_hip_ctx *c, size_t bytes, void **dptr) {
 int dtcwt_hip_free(dtcwt_hip_ctx *c, void *dptr) {
     DT_REQUIRE(c, "ctx is NULL");
     if (!dptr) return 0;
+    std::lock_guard<std::mutex> lk(c->pool_mu);
     auto it = c->live.find(dptr);
     if (it == c->live.end()) return dtcwt_set_error(-1, "free of a pointer this context did not allocate");
     size_t bytes = it->second;
@@ -178,13 +191,8 @@ int dtcwt_hip_free(dtcwt_hip_ctx *c, void *dptr) {
 
 int dtcwt_hip_trim(dtcwt_hip_ctx *c) {
     DT_REQUIRE(c, "ctx is NULL");
-    DT_CHECK_HIP(hipSetDevice(c->device));
-    DT_CHECK_HIP(hipStreamSynchronize(c->stream));
-    for (auto &kv : c->pool)
-        for (void *b : kv.second) (void)hipFree(b);
-    c->pool.clear();
-    c->pooled_bytes = 0;
-    return 0;
+    std::lock_guard<std::mutex> lk(c->pool_mu);
+    return trim_locked(c);
 }
 
 int dtcwt_hip_memcpy_h2d(dtcwt_hip_ctx *c, void *dst, const void *src, size_t bytes) {

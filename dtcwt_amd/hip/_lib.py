@@ -130,6 +130,20 @@ SIGNATURES = {
     'dtcwt_hip_graph_launch': (_i, [_vp]),
     'dtcwt_hip_graph_destroy': (_i, [_vp]),
     'dtcwt_hip_plan2d_kernel_ms': (_i, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
+    'dtcwt_hip_plan2d_fused_levels': (_i, [_vp]),
+    'dtcwt_hip_mgpu_create': (_i, [_i, ctypes.POINTER(_i), _i, _i, _i, _i, ctypes.POINTER(_pd), ctypes.POINTER(_i),
+                                   ctypes.POINTER(_pd), ctypes.POINTER(_i), _i, ctypes.POINTER(_vp)]),
+    'dtcwt_hip_mgpu_destroy': (_i, [_vp]),
+    'dtcwt_hip_mgpu_ndev': (_i, [_vp]),
+    'dtcwt_hip_mgpu_taps_broadcast': (_i, [_vp]),
+    'dtcwt_hip_mgpu_shard': (_i, [_vp, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    'dtcwt_hip_mgpu_ctx': (_vp, [_vp, _i]),
+    'dtcwt_hip_mgpu_shapes': (_i, [_vp, ctypes.POINTER(_i)]),
+    'dtcwt_hip_mgpu_forward2d': (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
+    'dtcwt_hip_mgpu_inverse2d': (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _pd, ctypes.POINTER(_vp)]),
+    'dtcwt_hip_mgpu_sync': (_i, [_vp]),
+    'dtcwt_hip_mgpu_scatter': (_i, [_vp, _vp, _sz, ctypes.POINTER(_vp)]),
+    'dtcwt_hip_mgpu_gather': (_i, [_vp, ctypes.POINTER(_vp), _sz, _vp]),
 }
 
 
@@ -241,6 +255,11 @@ class Context(object):
     def handle(self):
         return self._h
 
+    @property
+    def stream(self):
+        """The raw ``hipStream_t`` of this context as an integer (``__cuda_array_interface__`` v3 ``stream``)."""
+        return int(self._lib.dtcwt_hip_ctx_stream(self._h) or 0)
+
     def sync(self):
         check(self._lib.dtcwt_hip_sync(self._h))
 
@@ -276,6 +295,11 @@ class Context(object):
         X = np.asanyarray(X)
         if X.dtype == np.float32 or X.dtype == np.float64:
             return self.to_device(X)
+        if np.issubdtype(X.dtype, np.complexfloating):
+            # the reference keeps complex input complex (np.asfarray(X, dtype=X.dtype), dtcwt/utils.py:98-105) and
+            # filters it as such; the device kernels are real: refuse instead of silently dropping the imaginary part
+            raise TypeError('complex input is not supported by the hip backend: transform the real and the '
+                            'imaginary part separately (the transform is linear)')
         kind = self._INT_KINDS.get(X.dtype.str[1:]) if X.dtype.isnative or X.dtype.itemsize == 1 else None
         if kind is None or X.size == 0:
             return self.to_device(X.astype(np.float64))
@@ -416,8 +440,13 @@ class DeviceArray(object):
         OpenCL backend accepting pyopencl arrays (dtcwt/opencl/transform2d.py:133-135)."""
         if hasattr(obj, 'is_contiguous') and not obj.is_contiguous():
             raise ValueError('device tensors must be contiguous')
-        dt = str(obj.dtype).replace('torch.', '')
-        return cls(ctx, tuple(obj.shape), np.dtype(dt), ptr=obj.data_ptr(), owner=obj)
+        dt = np.dtype(str(obj.dtype).replace('torch.', ''))
+        if dt not in (np.dtype(np.float32), np.dtype(np.float64), np.dtype(np.complex64), np.dtype(np.complex128)):
+            raise TypeError('device tensors must be float32 / float64 (complex64 / complex128 for subbands), not %s' % dt)
+        # The producer's stream (torch's current stream) and this context's stream are unrelated: nothing
+        # orders our kernels after the work that filled the tensor.  Wait for the device once, here.
+        check(ctx._lib.dtcwt_hip_device_sync(ctx.handle))
+        return cls(ctx, tuple(obj.shape), dt, ptr=obj.data_ptr(), owner=obj)
 
     @property
     def ndim(self):
@@ -425,8 +454,10 @@ class DeviceArray(object):
 
     @property
     def __cuda_array_interface__(self):
+        # version 3: consumers (torch, cupy) synchronise with the stream our kernels run on before reading
+        st = getattr(self.ctx, 'stream', 0)
         return {'shape': self.shape, 'typestr': self.dtype.str, 'data': (self.ptr, False),
-                'version': 2, 'strides': None}
+                'version': 3, 'strides': None, 'stream': st if st else 1}
 
     def reshape(self, *shape):
         if len(shape) == 1 and isinstance(shape[0], (tuple, list)):

@@ -7,6 +7,12 @@ device-resident behaviour of the reference's OpenCL pyramid
 the NumPy attributes are filled by ONE device-to-host copy on first access and memoised.
 Constructed from NumPy arrays it behaves like the NumPy pyramid and uploads lazily when
 an inverse transform needs device buffers.
+
+Once an entry has been read through ``lowpass`` / ``highpasses`` / ``scales`` the host array is
+the authoritative copy of that entry -- the reference's idiom
+``p = t.forward(x); p.highpasses[2][mask] = 0; t.inverse(p)`` edits it in place -- so the inverse
+transforms upload it again instead of using the device buffer it came from.  Code that wants
+to stay on the device uses the ``hip_*`` handles and never touches the NumPy attributes.
 """
 import numpy as np
 
@@ -79,12 +85,15 @@ class Pyramid(object):
     # ---- used by the inverse transforms ---------------------------------------
     def device_parts(self, ctx, real_dtype=None):
         """(lowpass, highpasses) as DeviceArrays on *ctx* (uploading host arrays);
-        highpass entries may be None."""
-        def up(x, cplx):
+        highpass entries may be None.  An entry whose host view has been handed out is uploaded from
+        that view: the caller may have edited it."""
+        def up(x, cplx, key):
+            if x is not None and key in self._host:
+                x = self._host[key]
             if x is None or _is_dev(x):
                 return x
             if real_dtype is not None:
                 dt = (np.complex64 if real_dtype == np.float32 else np.complex128) if cplx else real_dtype
                 return ctx.to_device(x, dtype=dt)
             return ctx.to_device(x)
-        return up(self._low, False), tuple(up(x, True) for x in self._high)
+        return up(self._low, False, 'l'), tuple(up(x, True, ('h', i)) for i, x in enumerate(self._high))

@@ -1,0 +1,185 @@
+"""Batches of images over the GPUs of one node, from one process.
+
+``MultiGPUTransform2d`` is the host side of ``dtcwt_hip_mgpu_*`` (include/dtcwt_hip.h): a batch
+of B equally sized images is split contiguously over the devices (:func:`shard_range`), every
+shard has its own context, stream, fused plan and host worker thread inside the library, and
+the pyramids stay in the HBM of the device that computed them.  Nothing is exchanged between
+shards -- the shape of the reference's only parallel code, the MPI scatter / transform / gather of
+frame groups in examples/register_video.py:125-156.  With ``broadcast_taps=True`` the filter-tap
+table travels to the other devices by one RCCL broadcast over xGMI at set-up and each shard's plan
+is built from the copy that arrived on its device.
+
+    m = MultiGPUTransform2d('near_sym_a', 'qshift_a', devices=range(8), batch=512, rows=2048,
+                            cols=2048, nlevels=4)
+    pyr = m.forward(X)            # X: host array [512, 2048, 2048]; pyramids stay on the devices
+    Z = m.inverse(pyr)            # host array [512, 2048, 2048]
+
+The one-process-per-GPU form (``torch.distributed``, what ``bench.py`` runs under a launcher) is in
+:mod:`dtcwt_amd.hip.sharding`.
+"""
+import ctypes
+
+import numpy as np
+
+from dtcwt_amd.coeffs import biort as _biort, qshift as _qshift
+from dtcwt_amd.utils import flat_taps
+from dtcwt_amd.hip import _lib
+from dtcwt_amd.hip._lib import check
+from dtcwt_amd.hip.sharding import shard_range
+
+__all__ = ['MultiGPUTransform2d', 'ShardedBuffers']
+
+_vp = ctypes.c_void_p
+_pd = ctypes.POINTER(ctypes.c_double)
+BCAST_TAPS = 1          # DTCWT_HIP_MGPU_BCAST_TAPS
+
+
+class _ShardCtx(object):
+    """Borrowed view of the context the library created for a shard (never destroyed from here)."""
+
+    def __init__(self, handle, device, lib):
+        self._h = _vp(handle)
+        self.device = device
+        self._lib = lib
+
+    @property
+    def handle(self):
+        return self._h
+
+
+class ShardedBuffers(object):
+    """Device buffers of one batch: per shard X, Yl, Yh[level], Z (``DeviceArray``; None for empty shards)."""
+
+    def __init__(self, X, Yl, Yh, Z):
+        self.X, self.Yl, self.Yh, self.Z = X, Yl, Yh, Z
+
+
+class MultiGPUTransform2d(object):
+    def __init__(self, biort, qshift, devices, batch, rows, cols, nlevels, broadcast_taps=False):
+        try:
+            biort = _biort(biort)
+        except TypeError:
+            pass
+        try:
+            qshift = _qshift(qshift)
+        except TypeError:
+            pass
+        if len(biort) != 4 or len(qshift) != 8:
+            raise ValueError('the multi-GPU plan takes 4-vector biort and 8-vector q-shift sets')
+        L = _lib.lib()
+        if _lib.device_count() < 1:
+            raise _lib.NoHIPPresentError('no HIP device visible to libdtcwt_hip.so')
+        devices = [int(d) for d in devices]
+        self._keep = [flat_taps(h) for h in biort] + [flat_taps(h) for h in qshift]
+        bp = (_pd * 4)(*[a.ctypes.data_as(_pd) for a in self._keep[:4]])
+        bl = (ctypes.c_int * 4)(*[a.shape[0] for a in self._keep[:4]])
+        qp = (_pd * 8)(*[a.ctypes.data_as(_pd) for a in self._keep[4:]])
+        ql = (ctypes.c_int * 8)(*[a.shape[0] for a in self._keep[4:]])
+        dv = (ctypes.c_int * len(devices))(*devices)
+        h = _vp()
+        rc = L.dtcwt_hip_mgpu_create(len(devices), dv, batch, rows, cols, nlevels, bp, bl, qp, ql,
+                                     BCAST_TAPS if broadcast_taps else 0, ctypes.byref(h))
+        if rc == -3:
+            raise NotImplementedError(L.dtcwt_hip_last_error().decode())
+        check(rc)
+        self._h, self._lib = h, L
+        self.devices, self.batch, self.rows, self.cols, self.nlevels = devices, batch, rows, cols, nlevels
+        self.ndev = len(devices)
+        s = (ctypes.c_int * (4 + 4 * nlevels))()
+        check(L.dtcwt_hip_mgpu_shapes(h, s))
+        self.ext, self.low = (s[0], s[1]), (s[2], s[3])
+        self.high = [(s[4 + 4 * l], s[5 + 4 * l]) for l in range(nlevels)]
+        self.shards = []
+        self.ctxs = []
+        for d in range(self.ndev):
+            dev, st, cnt = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            check(L.dtcwt_hip_mgpu_shard(h, d, ctypes.byref(dev), ctypes.byref(st), ctypes.byref(cnt)))
+            assert (st.value, st.value + cnt.value) == shard_range(batch, d, self.ndev)
+            self.shards.append((dev.value, st.value, cnt.value))
+            self.ctxs.append(_ShardCtx(L.dtcwt_hip_mgpu_ctx(h, d), dev.value, L))
+
+    @property
+    def taps_broadcast(self):
+        return bool(self._lib.dtcwt_hip_mgpu_taps_broadcast(self._h))
+
+    # ---- buffers ---------------------------------------------------------------------
+    def _per_shard(self, shape_tail, dtype):
+        out = []
+        for d, (_, _, cnt) in enumerate(self.shards):
+            out.append(_lib.DeviceArray(self.ctxs[d], (cnt,) + tuple(shape_tail), dtype) if cnt else None)
+        return out
+
+    def alloc(self, with_input=True):
+        X = self._per_shard((self.rows, self.cols), np.float32) if with_input else None
+        Yl = self._per_shard(self.low, np.float32)
+        Yh = [[None] * self.nlevels for _ in range(self.ndev)]
+        for l in range(self.nlevels):
+            col = self._per_shard(self.high[l] + (6,), np.complex64)
+            for d in range(self.ndev):
+                Yh[d][l] = col[d]
+        Z = self._per_shard(self.ext, np.float32)
+        return ShardedBuffers(X, Yl, Yh, Z)
+
+    @staticmethod
+    def _ptrs(arrs):
+        return (_vp * len(arrs))(*[(a.ptr if a is not None else None) for a in arrs])
+
+    def scatter(self, host, dev):
+        """Host batch [batch, ...] -> the shards' buffers *dev* (list of DeviceArray per shard)."""
+        host = np.ascontiguousarray(host)
+        assert host.shape[0] == self.batch
+        per = host.nbytes // self.batch
+        check(self._lib.dtcwt_hip_mgpu_scatter(self._h, host.ctypes.data_as(_vp), per, self._ptrs(dev)))
+
+    def gather(self, dev, shape_tail, dtype):
+        out = np.empty((self.batch,) + tuple(shape_tail), dtype=dtype)
+        per = out.nbytes // self.batch
+        check(self._lib.dtcwt_hip_mgpu_gather(self._h, self._ptrs(dev), per, out.ctypes.data_as(_vp)))
+        return out
+
+    # ---- transforms ------------------------------------------------------------------
+    def forward_into(self, bufs):
+        flat = [bufs.Yh[d][l] for d in range(self.ndev) for l in range(self.nlevels)]
+        check(self._lib.dtcwt_hip_mgpu_forward2d(self._h, self._ptrs(bufs.X), self._ptrs(bufs.Yl), self._ptrs(flat)))
+
+    def inverse_into(self, bufs, gain_mask=None):
+        flat = [bufs.Yh[d][l] for d in range(self.ndev) for l in range(self.nlevels)]
+        gp = None
+        if gain_mask is not None:
+            g = np.ascontiguousarray(np.asarray(gain_mask, dtype=np.float64).reshape(6, self.nlevels))
+            gp = g.ctypes.data_as(_pd)
+        check(self._lib.dtcwt_hip_mgpu_inverse2d(self._h, self._ptrs(bufs.Yl), self._ptrs(flat), gp, self._ptrs(bufs.Z)))
+
+    def sync(self):
+        check(self._lib.dtcwt_hip_mgpu_sync(self._h))
+
+    def forward(self, X):
+        """Host batch [batch, rows, cols] float32 -> :class:`ShardedBuffers` (pyramids resident per device)."""
+        X = np.asarray(X)
+        if X.shape != (self.batch, self.rows, self.cols):
+            raise ValueError('expected a batch of shape %r' % ((self.batch, self.rows, self.cols),))
+        bufs = self.alloc()
+        self.scatter(X.astype(np.float32, copy=False), bufs.X)
+        self.forward_into(bufs)
+        return bufs
+
+    def inverse(self, bufs, gain_mask=None):
+        self.inverse_into(bufs, gain_mask)
+        return self.gather(bufs.Z, self.ext, np.float32)
+
+    def gather_pyramid(self, bufs):
+        """(lowpass [B, ...], [highpasses[l] [B, hr, hc, 6]]) on the host."""
+        low = self.gather(bufs.Yl, self.low, np.float32)
+        high = [self.gather([bufs.Yh[d][l] for d in range(self.ndev)], self.high[l] + (6,), np.complex64)
+                for l in range(self.nlevels)]
+        return low, high
+
+    def __del__(self):
+        try:
+            if getattr(self, '_h', None):
+                for c in self.ctxs:         # buffers that outlive the plan must not touch its contexts
+                    c._h = None
+                self._lib.dtcwt_hip_mgpu_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass

@@ -14,6 +14,7 @@ There is no host fallback: without the library or a GPU the first use raises
 ``forward_channels`` / ``inverse_channels`` (interface of the reference's TensorFlow
 backend, dtcwt/tf/transform2d.py:179-336, :422-588).
 """
+import collections
 import ctypes
 import logging
 
@@ -77,6 +78,11 @@ class _Plan2d(object):
         self.low = (s[2], s[3])
         self.high = [(s[4 + 4 * l], s[5 + 4 * l]) for l in range(nlevels)]
         self.scale = [(s[6 + 4 * l], s[7 + 4 * l]) for l in range(nlevels)]
+
+    @property
+    def fused12(self):
+        """True when levels 1 and 2 of the forward transform run as one launch (LoLo1 stays on chip)."""
+        return bool(self._lib.dtcwt_hip_plan2d_fused_levels(self._h) & 1)
 
     def forward(self, Xd, include_scale):
         ctx, B, nl = self.ctx, self.batch, self.nlevels
@@ -213,7 +219,13 @@ class Transform2d(object):
         except TypeError:
             self.qshift = qshift
         self._ctx = ctx
-        self._plans = {}
+        self._plans = collections.OrderedDict()
+
+    MAX_PLANS = 8       # fused plans kept per transform object (each owns per-level workspaces in HBM)
+
+    def clear_plans(self):
+        """Drop every cached fused plan (and its device workspaces)."""
+        self._plans.clear()
 
     # ------------------------------------------------------------------ helpers
     @property
@@ -239,6 +251,10 @@ class Transform2d(object):
                 self._plans[key] = _Plan2d(self.ctx, batch, rows, cols, nlevels, self.biort, self.qshift)
             except NotImplementedError:
                 self._plans[key] = None
+            while len(self._plans) > self.MAX_PLANS:         # least recently used first
+                self._plans.popitem(last=False)
+        else:
+            self._plans.move_to_end(key)
         return self._plans[key]
 
     def plan(self, batch, rows, cols, nlevels):
@@ -368,6 +384,8 @@ class Transform2d(object):
         if isinstance(X, DeviceArray):
             if X.ndim != 2:
                 raise ValueError('Input array must be two-dimensional')
+            if X.dtype not in (np.float32, np.float64):
+                raise TypeError('device inputs must be float32 or float64, not %s' % X.dtype)
             Xd = X
         else:
             X = np.atleast_2d(np.asanyarray(X))
@@ -580,6 +598,8 @@ class Transform2d(object):
         if isinstance(X, DeviceArray):
             if not native or X.ndim != 3:
                 raise ValueError('device inputs must be in nhw/chw layout')
+            if X.dtype not in (np.float32, np.float64):
+                raise TypeError('device inputs must be float32 or float64, not %s' % X.dtype)
             Xd, info = X, None
         else:
             X = np.asanyarray(X)

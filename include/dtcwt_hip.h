@@ -311,6 +311,12 @@ int dtcwt_hip_plan2d_forward(dtcwt_hip_plan2d *plan, const float *X, float *Yl,
 int dtcwt_hip_plan2d_inverse(dtcwt_hip_plan2d *plan, const float *Yl, const void *const *Yh,
                              const double *gain_mask_host, float *Z);
 
+/* Which levels share a launch: bit 0 set = levels 1 and 2 of the FORWARD transform run as one kernel
+ * (the level-1 lowpass never leaves the chip: fused2d_l12.hpp; needs nlevels >= 2, an even-extended
+ * image whose sides are multiples of 4 and a tile program for the tap lengths); bit 1 = the same for the
+ * inverse.  Environment DTCWT_HIP_FUSE12=0 at plan creation keeps one launch per level. */
+int dtcwt_hip_plan2d_fused_levels(const dtcwt_hip_plan2d *plan);
+
 /* Band-pass ("_bp") wavelet sets: the third filter of a 6-vector biort (h2o, g2o; m_biort taps, 0:
  * none) and of a 12-vector q-shift (h2a, h2b, g2a, g2b; m_qshift taps, 0: none), used for the diagonal
  * subbands (dtcwt/numpy/transform2d.py:116-129, :145-155, :250-271, :283-291).  Call once after
@@ -337,6 +343,39 @@ int dtcwt_hip_plan2d_capture(dtcwt_hip_plan2d *plan, const float *X, float *Yl, 
                              dtcwt_hip_graph **graph);
 int dtcwt_hip_graph_launch(dtcwt_hip_graph *graph);
 int dtcwt_hip_graph_destroy(dtcwt_hip_graph *graph);
+
+/* ---------------------------------------------------------------- multi-GPU --------- */
+/* A batch of independent images sharded over the GPUs of one node from ONE process: contiguous
+ * split (shard d owns images [start_d, start_d + count_d), sizes differing by at most one), one
+ * context + stream + fused plan + host worker thread per shard, no data-path collective.  This is
+ * the scatter / transform / gather of the reference's only parallel code, the MPI frame groups of
+ * examples/register_video.py:125-156, with device-resident shards.  `devices` may name a device
+ * more than once (several shards on one GPU).
+ * flags: DTCWT_HIP_MGPU_BCAST_TAPS = the packed tap table travels from shard 0's device to every
+ * other device by ONE RCCL broadcast (single-process communicator over the shard devices, xGMI) and
+ * each shard builds its plan from the copy that arrived on its device; without it the host table
+ * is used directly.  Per-shard pointer arrays are indexed [shard] (X, Yl, Z) and
+ * [shard * nlevels + level] (Yh).  Calls return once every shard's launches are ENQUEUED;
+ * dtcwt_hip_mgpu_sync() waits for the devices. */
+#define DTCWT_HIP_MGPU_BCAST_TAPS 1
+typedef struct dtcwt_hip_mgpu dtcwt_hip_mgpu;
+int dtcwt_hip_mgpu_create(int ndev, const int *devices, int batch, int rows, int cols, int nlevels,
+                          const double *const *biort_host, const int *biort_len,
+                          const double *const *qshift_host, const int *qshift_len, int flags,
+                          dtcwt_hip_mgpu **mgpu);
+int dtcwt_hip_mgpu_destroy(dtcwt_hip_mgpu *mgpu);
+int dtcwt_hip_mgpu_ndev(const dtcwt_hip_mgpu *mgpu);
+int dtcwt_hip_mgpu_taps_broadcast(const dtcwt_hip_mgpu *mgpu);          /* 1: plans built from RCCL-delivered taps */
+int dtcwt_hip_mgpu_shard(const dtcwt_hip_mgpu *mgpu, int shard, int *device, int *start, int *count);
+dtcwt_hip_ctx *dtcwt_hip_mgpu_ctx(dtcwt_hip_mgpu *mgpu, int shard);     /* for allocations / copies on that shard */
+int dtcwt_hip_mgpu_shapes(const dtcwt_hip_mgpu *mgpu, int *shapes);     /* per image, as dtcwt_hip_plan2d_shapes */
+int dtcwt_hip_mgpu_forward2d(dtcwt_hip_mgpu *mgpu, const float *const *X, float *const *Yl, void *const *Yh);
+int dtcwt_hip_mgpu_inverse2d(dtcwt_hip_mgpu *mgpu, const float *const *Yl, const void *const *Yh,
+                             const double *gain_mask_host, float *const *Z);
+int dtcwt_hip_mgpu_sync(dtcwt_hip_mgpu *mgpu);
+/* host batch [batch][bytes_per_image] <-> the shards' device buffers (each shard copies its own slice from its thread) */
+int dtcwt_hip_mgpu_scatter(dtcwt_hip_mgpu *mgpu, const void *host, size_t bytes_per_image, void *const *dev);
+int dtcwt_hip_mgpu_gather(dtcwt_hip_mgpu *mgpu, const void *const *dev, size_t bytes_per_image, void *host);
 
 /* ---------------------------------------------------------------- re-sampling ------ */
 /* Replaces dtcwt/sampling.py.  An image is [H][W][ncomp] of the real
