@@ -68,6 +68,9 @@ def parse_args(argv=None):
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--config', choices=sorted(CONFIGS), default='c2')
     ap.add_argument('--sets', type=int, default=4, help='distinct buffer sets the steps rotate over')
+    ap.add_argument('--streams', type=int, default=1, help='HIP streams the steps alternate over (independent images: step k '
+                    'runs on stream k %% S, each with its own plan and buffer sets): the small coarse-level kernels of one '
+                    'image overlap the large level-1 kernels of the next')
     ap.add_argument('--mgpu', action='store_true', help='N > 1 from ONE process: dtcwt_hip_mgpu_* with a host '
                     'thread per device instead of one process per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -160,28 +163,35 @@ def main():
         bt, qt = broadcast_taps(bt, qt, dist, device=torch.device('cuda', local_rank), src=0)
 
     B, R, C, NL = cfg['batch'], cfg['rows'], cfg['cols'], cfg['nlevels']
-    t2 = dtcwt_amd.hip.Transform2d(tuple(bt), tuple(qt), ctx=ctx)
-    plan = t2.plan(B, R, C, NL)
-    rs = np.random.RandomState(cfg['seed'](rank))       # random, not zero: DVFS (SURVEY 8(d)); per-shard seed
+    nstreams = max(1, args.streams)
     nsets = max(1, args.sets)
+    if nsets % nstreams:
+        nsets = (nsets // nstreams + 1) * nstreams      # every buffer set belongs to exactly one stream
+    ctxs = [ctx] + [Context(ctx.device) for _ in range(nstreams - 1)]
+    t2s = [dtcwt_amd.hip.Transform2d(tuple(bt), tuple(qt), ctx=c) for c in ctxs]
+    plans = [t.plan(B, R, C, NL) for t in t2s]
+    t2, plan = t2s[0], plans[0]
+    rs = np.random.RandomState(cfg['seed'](rank))       # random, not zero: DVFS (SURVEY 8(d)); per-shard seed
     sets = []
-    for _ in range(nsets):
-        X = ctx.to_device(rs.standard_normal((B, R, C)).astype(np.float32))
-        Yl = DeviceArray(ctx, (B,) + plan.low, np.float32)
-        Yh = [DeviceArray(ctx, (B,) + plan.high[l] + (6,), np.complex64) for l in range(NL)]
-        Z = DeviceArray(ctx, (B,) + plan.ext, np.float32)
+    for k in range(nsets):
+        c = ctxs[k % nstreams]
+        X = c.to_device(rs.standard_normal((B, R, C)).astype(np.float32))
+        Yl = DeviceArray(c, (B,) + plan.low, np.float32)
+        Yh = [DeviceArray(c, (B,) + plan.high[l] + (6,), np.complex64) for l in range(NL)]
+        Z = DeviceArray(c, (B,) + plan.ext, np.float32)
         sets.append((X, Yl, Yh, Z))
     set_bytes = sum(a.nbytes for a in (sets[0][0], sets[0][1], sets[0][3])) + sum(a.nbytes for a in sets[0][2])
 
     # one step = the forward and the inverse level loops of one buffer set on one stream; --graph replays
     # them as one captured hipGraph per set instead (same kernels, same order)
-    graphs = [plan.capture(*s[:3], s[3]) for s in sets] if args.graph else None
+    graphs = [plans[k % nstreams].capture(*s[:3], s[3]) for k, s in enumerate(sets)] if args.graph else None
     counter = [0]
 
     def step_on(k):
         X, Yl, Yh, Z = sets[k]
-        plan.forward_into(X, Yl, Yh)
-        plan.inverse_into(Yl, Yh, None, Z)
+        pl = plans[k % nstreams]
+        pl.forward_into(X, Yl, Yh)
+        pl.inverse_into(Yl, Yh, None, Z)
 
     def step():
         k = counter[0] % nsets
@@ -192,7 +202,8 @@ def main():
             step_on(k)
 
     def fence():
-        ctx.sync()
+        for c in ctxs:
+            c.sync()
         if use_dist:
             dist.barrier()
         if torch is not None and torch.cuda.is_available():
@@ -206,7 +217,8 @@ def main():
         t_settle = time.perf_counter()
         for _ in range(20):
             step()
-        ctx.sync()
+        for c in ctxs:
+            c.sync()
         per_step = max((time.perf_counter() - t_settle) / 20, 1e-5)
         for _ in range(int(args.settle_ms * 1e-3 / per_step) + 1):     # no sync: the load stays continuous
             step()
@@ -226,7 +238,8 @@ def main():
     # sanity of the timed work: reconstruction equals the input, on every buffer set
     err = max(float(np.abs(s[3].get()[0, :64, :64] - s[0].get()[0, :64, :64]).max()) for s in sets)
 
-    # the same step on one buffer set only (input and pyramid may stay in the Infinity Cache)
+    # the same step on one buffer set and one stream only (input and pyramid may stay in the Infinity Cache)
+    fence()
     nres = max(5, min(args.steps, 100))
     for _ in range(5):
         step_on(0)
@@ -248,7 +261,7 @@ def main():
     kf = np.zeros(NL); ki = np.zeros(NL)
     nprof = max(5, min(args.steps, 50))
     for i in range(nprof):
-        step_on(i % nsets)     # per-kernel hipEvent pairs need the plain launches
+        step_on((i * nstreams) % nsets)     # sets of stream 0; per-kernel hipEvent pairs need the plain launches
         f, g = plan.kernel_ms()
         kf += f; ki += g
     plan.set_profiling(False)
@@ -289,7 +302,7 @@ def main():
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': '%s, %s/%s, %d image(s) per GPU per step' % (cfg['name'], BIORT, QSHIFT, B),
                    'sharding': 'independent images per GPU, no data-path collective',
-                   'buffer_sets': nsets, 'bytes_per_set': set_bytes,
+                   'buffer_sets': nsets, 'bytes_per_set': set_bytes, 'streams': nstreams,
                    'levels_1_2_fused_forward': fused12},
         'resident_ms_per_step': round(resident_ms, 5),
         'roofline': roofline, 'recon_max_abs_err': err,

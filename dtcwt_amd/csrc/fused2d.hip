@@ -159,94 +159,6 @@ __global__ void __launch_bounds__(C::NT, C::MIN_WAVES) k_fwd12(Fwd1Params p1, Fw
     }
 }
 
-// The same tile program as a PERSISTENT kernel over the tiles whose core lies wholly inside the image: a
-// workgroup walks a list of tiles and requests the next tile's input window right after the column pass has
-// consumed the current one, so that those loads are in flight while phases 2-4 compute and store, and a
-// workgroup never sits on a CU slot waiting for its last stores to be acknowledged.  (k_fwd12 alone leaves
-// arithmetic and HBM time un-overlapped: 113 us against a 55 us arithmetic floor and ~55 us of HBM traffic.)
-// vmcnt counts loads and stores in order: the wait for the prefetched window at the top of the loop must not
-// reach past the loads into the stores issued after them.  The compiler derives that count from the code
-// between the loads and the wait on EVERY path into the loop header, hence (a) the first tile is peeled (its
-// window comes from the prologue, with nothing after it), (b) the stores in the loop body are unconditional
-// (FULL tiles), so no path skips them.
-// Tile order: workgroup w runs on XCD w % 8 (observed dispatch rule); each XCD owns a contiguous run of
-// tiles, dealt round-robin to its workgroups, so neighbouring tiles share halo rows through one L2.
-template <class C>
-__device__ __forceinline__ void fwd12p_tile(const Fwd1Params &p1, const Fwd2Params &p2, float *sLo, float *sHi,
-                                            float *stage, int tid0, int b, int tr, int tc, int bn, int trn, int tcn,
-                                            Fwd12Win<C> &win) {
-    float *sLo2 = sHi, *sHi2 = sHi + C::S2;
-    // without this the compiler hoists every per-thread LDS address of every phase out of the tile loop
-    // (they do not depend on the tile) and spills them: 66 scratch accesses per tile
-    int tid = tid0;
-    DT_OPAQUE(tid);
-    const int tidp = lds128_perm(tid);
-    const int r2 = tr * C::T2R, c2 = tc * C::T2C, r1 = 2 * r2, c1 = 2 * c2;
-    fwd12_cols_compute<C>(p1, sLo, sHi, tid, win);
-    // the next tile's window (after the last tile: the same tile again, unused -- an unconditional load keeps
-    // the window in ONE set of registers; a conditional one makes the compiler copy it, and every copy is a wait)
-    fwd12_cols_load<C>(p1, tid, bn, 2 * trn * C::T2R, 2 * tcn * C::T2C, win);
-    __syncthreads();
-    Fwd12State<C> st;
-#pragma unroll
-    for (int round = 0; round < C::NCR; ++round) {
-        alignas(16) float rec[2][12];
-        fwd12_core_compute<C>(p1, sLo, sHi, tidp, round, st, rec);
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            fwd12_core_deposit<C, C::CORE_EXACT>(stage, tidp, round, half, rec);
-            fwd12_core_flush<C, C::CORE_EXACT>(p1, stage, tid, round, half, b, r1, c1);
-        }
-    }
-    fwd12_halo_compute<C>(p1, sLo, tidp, st);
-    __syncthreads();
-    fwd12_writeback<C>(p1, sLo, tidp, b, r1, c1, st);
-    __syncthreads();
-    if (fwd12_needs_fix<C>(p1, r1, c1)) {
-        fwd12_fix<C>(p1, sLo, tid, r1, c1);
-        __syncthreads();
-    }
-    fwd12_cols2<C>(p2, sLo, sLo2, sHi2, tid);
-    __syncthreads();
-    for (int base = 0; base < C::TI * C::TJ; base += C::NT) {
-        fwd2s_rows_compute<typename C::L2View>(p2, sLo2, sHi2, stage, tidp, base, b, r2, c2);
-        fwd2s_rows_flush<typename C::L2View>(p2, stage, tid, base, b, r2, c2);
-    }
-}
-
-template <class C, int SKIP = 0, int MW = (C::NT == 256 ? 3 : 2)>
-__global__ void __launch_bounds__(C::NT, MW) k_fwd12p(Fwd1Params p1, Fwd2Params p2) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    // full tiles only: tilesR / tilesC here count the tiles whose core is inside the image
-    const int ntile = p2.tilesR * p2.tilesC * p2.B;
-    const int per = (ntile + 7) / 8, nwx = gridDim.x / 8;          // tiles per XCD, workgroups per XCD
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int tend = min(ntile, (xcd + 1) * per);
-    int t = xcd * per + slot;
-    if (t >= tend) return;
-    float *sLo = smem, *sHi = sLo + C::SLO, *stage = sHi + C::SB;
-    Fwd12Win<C> win;
-    int tc = t % p2.tilesC, tr = (t / p2.tilesC) % p2.tilesR, b = t / (p2.tilesC * p2.tilesR);
-    fwd12_cols_load<C>(p1, threadIdx.x, b, 2 * tr * C::T2R, 2 * tc * C::T2C, win);
-    const int tid0 = threadIdx.x;
-    // first tile, peeled
-    {
-        const int tn = t + nwx, tl = tn < tend ? tn : t;
-        const int tcn = tl % p2.tilesC, trn = (tl / p2.tilesC) % p2.tilesR, bn = tl / (p2.tilesC * p2.tilesR);
-        fwd12p_tile<C>(p1, p2, sLo, sHi, stage, tid0, b, tr, tc, bn, trn, tcn, win);
-        if (tn >= tend) return;
-        t = tn; tc = tcn; tr = trn; b = bn;
-    }
-    for (;;) {
-        __syncthreads();                                // the planes are free for this tile's column pass
-        const int tn = t + nwx, tl = tn < tend ? tn : t;
-        const int tcn = tl % p2.tilesC, trn = (tl / p2.tilesC) % p2.tilesR, bn = tl / (p2.tilesC * p2.tilesR);
-        fwd12p_tile<C>(p1, p2, sLo, sHi, stage, tid0, b, tr, tc, bn, trn, tcn, win);
-        if (tn >= tend) break;
-        t = tn; tc = tcn; tr = trn; b = bn;
-    }
-}
-
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline unsigned grid_for(int ntile) { return (unsigned)(cdiv(ntile, 8) * 8); }
 
@@ -287,25 +199,6 @@ int launch_fwd12(Fwd1Params &p1, Fwd2Params &p2, hipStream_t s) {
         raised = true;
     }
     k_fwd12<C, SKIP><<<grid_for(p2.tilesR * p2.tilesC * p2.B), C::NT, lds, s>>>(p1, p2);
-    return 0;
-}
-
-template <class C, int SKIP = 0, int MW = (C::NT == 256 ? 3 : 2)>
-int launch_fwd12p(Fwd1Params &p1, Fwd2Params &p2, hipStream_t s, int wg_per_cu = 4, int cus = 256) {
-    // the persistent kernel takes the tiles that lie wholly inside the image (all of them when the level-2
-    // lowpass is a multiple of the tile: the caller checks that; otherwise it uses k_fwd12)
-    p2.tilesR = (p2.LR / 2) / C::T2R; p2.tilesC = (p2.LC / 2) / C::T2C;
-    constexpr size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
-    static bool raised = false;
-    if (lds > (48u << 10) && !raised) {
-        if (hipFuncSetAttribute((const void *)k_fwd12p<C, SKIP, MW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return -2;
-        raised = true;
-    }
-    const int ntile = p2.tilesR * p2.tilesC * p2.B;
-    int grid = cus * wg_per_cu;                       // a multiple of 8
-    if (grid > ((ntile + 7) / 8) * 8) grid = ((ntile + 7) / 8) * 8;
-    k_fwd12p<C, SKIP, MW><<<grid, C::NT, lds, s>>>(p1, p2);
     return 0;
 }
 
@@ -390,7 +283,8 @@ struct dtcwt_hip_plan2d {
     std::vector<hipEvent_t> ev;       // [fwd: 2 per level][inv: 2 per level]
     int xcd_order = -1;               // -1: per-kernel default, 0/1: forced (DTCWT_HIP_XCD_ORDER)
     int small_tiles = -1;             // -1: by size, 0/1: forced (DTCWT_HIP_SMALL_TILES)
-    int fuse12 = 1;                   // levels 1+2 in one launch where possible (DTCWT_HIP_FUSE12=0 disables)
+    int fuse12 = 0;                   // levels 1+2 of the forward in one launch (DTCWT_HIP_FUSE12=1): measured SLOWER than
+                                      // two launches on MI355X (114 vs 101 us at 4096^2), so opt-in
 };
 
 namespace {
@@ -425,7 +319,7 @@ int dtcwt_hip_plan2d_create(dtcwt_hip_ctx *ctx, int batch, int rows, int cols, i
     for (int i = 0; i < 8; ++i) p->qshift[i].assign(qshift_host[i], qshift_host[i] + qshift_len[i]);
     { const char *e = getenv("DTCWT_HIP_XCD_ORDER"); p->xcd_order = e ? (e[0] == '1' ? 1 : 0) : -1; }
     { const char *e = getenv("DTCWT_HIP_SMALL_TILES"); p->small_tiles = e ? (e[0] == '1' ? 1 : 0) : -1; }
-    { const char *e = getenv("DTCWT_HIP_FUSE12"); p->fuse12 = e ? (e[0] != '0') : 1; }
+    { const char *e = getenv("DTCWT_HIP_FUSE12"); p->fuse12 = e ? (e[0] != '0') : 0; }
     p->extR = rows + (rows & 1);
     p->extC = cols + (cols & 1);
     Level l0{rows, cols, 0, 0, p->extR, p->extC, p->extR, p->extC, p->extR / 2, p->extC / 2};
@@ -570,7 +464,7 @@ int dtcwt_hip_plan2d_forward(dtcwt_hip_plan2d *p, const float *X, float *Yl, voi
                 q2.LoLo = (nl == 2 && !Ys) ? Yl : (Ys ? Ys[1] : p->work[1]);
                 DT_REQUIRE(q2.LoLo && q2.Yh, "NULL output buffer at level 1");
                 q2.B = p->batch; q2.inR = L2.inR; q2.inC = L2.inC; q2.LR = L2.LR; q2.LC = L2.LC;
-                q2.xcd_order = p->xcd_order < 0 ? 0 : p->xcd_order;
+                q2.xcd_order = p->xcd_order < 0 ? 1 : p->xcd_order;     // measured: XCD-contiguous tiles 114 us, linear 122 us
                 q2.stream_records = (int64_t)p->batch * (L2.LR / 4) * (L2.LC / 4) * 48 >= ((int64_t)32 << 20);
                 put_taps(q2.l_a, p->qshift[1]); put_taps(q2.l_b, p->qshift[0]);
                 put_taps(q2.h_a, p->qshift[5]); put_taps(q2.h_b, p->qshift[4]);

@@ -131,6 +131,18 @@ SIGNATURES = {
     'dtcwt_hip_graph_destroy': (_i, [_vp]),
     'dtcwt_hip_plan2d_kernel_ms': (_i, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
     'dtcwt_hip_plan2d_fused_levels': (_i, [_vp]),
+    'dtcwt_hip_plan3d_create': (_i, [_vp, _i64, _i64, _i64, _i, _i, ctypes.POINTER(_pd), ctypes.POINTER(_i),
+                                     ctypes.POINTER(_pd), ctypes.POINTER(_i), ctypes.POINTER(_vp)]),
+    'dtcwt_hip_plan3d_destroy': (_i, [_vp]),
+    'dtcwt_hip_plan3d_shapes': (_i, [_vp, ctypes.POINTER(_i64)]),
+    'dtcwt_hip_plan3d_forward': (_i, [_vp, _vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _i]),
+    'dtcwt_hip_plan3d_inverse': (_i, [_vp, _vp, ctypes.POINTER(_vp), _vp, _i]),
+    'dtcwt_hip_plan1d_create': (_i, [_vp, _i, _i64, _i64, _i, ctypes.POINTER(_pd), ctypes.POINTER(_i),
+                                     ctypes.POINTER(_pd), ctypes.POINTER(_i), ctypes.POINTER(_vp)]),
+    'dtcwt_hip_plan1d_destroy': (_i, [_vp]),
+    'dtcwt_hip_plan1d_shapes': (_i, [_vp, ctypes.POINTER(_i64)]),
+    'dtcwt_hip_plan1d_forward': (_i, [_vp, _vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
+    'dtcwt_hip_plan1d_inverse': (_i, [_vp, _vp, ctypes.POINTER(_vp), _pd, _vp]),
     'dtcwt_hip_mgpu_create': (_i, [_i, ctypes.POINTER(_i), _i, _i, _i, _i, ctypes.POINTER(_pd), ctypes.POINTER(_i),
                                    ctypes.POINTER(_pd), ctypes.POINTER(_i), _i, ctypes.POINTER(_vp)]),
     'dtcwt_hip_mgpu_destroy': (_i, [_vp]),

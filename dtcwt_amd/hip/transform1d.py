@@ -3,13 +3,19 @@
 Interface, shapes, exceptions of dtcwt/numpy/transform1d.py:14-196.  A column vector (or
 the columns of a matrix) is filtered down axis 0 by the generic device filters; the
 real -> complex interleave (``Hi[::2] + 1j*Hi[1::2]``, :88,100) and its inverse ``c2q1d``
-(:186-196) are small device kernels.
+(:186-196) are small device kernels.  Where every level has a one-launch level kernel (odd-length
+biort filters, one signal or >= 32 side by side) the whole transform is ONE native call
+(``dtcwt_hip_plan1d_*``: geometry, workspaces and level sequencing inside the library).
 """
+import collections
+import ctypes
+import os
+
 import numpy as np
 
 from dtcwt_amd.coeffs import biort as _biort, qshift as _qshift
 from dtcwt_amd.defaults import DEFAULT_BIORT, DEFAULT_QSHIFT
-from dtcwt_amd.utils import asfarray
+from dtcwt_amd.utils import asfarray, flat_taps
 from dtcwt_amd.hip import _lib
 from dtcwt_amd.hip._lib import DeviceArray, check, dtype_code
 from dtcwt_amd.hip.common import Pyramid, nlevels_of
@@ -36,6 +42,66 @@ def _unpack(yh, gain):
     return out
 
 
+class _Plan1d(object):
+    """RAII wrapper of dtcwt_hip_plan1d: the whole 1-D transform in one native call."""
+
+    def __init__(self, ctx, dtype, n, k, nlevels, biort, qshift):
+        L = _lib.lib()
+        pd = ctypes.POINTER(ctypes.c_double)
+        self.ctx, self.dtype, self.n, self.k, self.nlevels = ctx, np.dtype(dtype), n, k, nlevels
+        self._keep = [flat_taps(h) for h in biort[:4]] + [flat_taps(h) for h in qshift[:8]]
+        bp = (pd * 4)(*[a.ctypes.data_as(pd) for a in self._keep[:4]])
+        bl = (ctypes.c_int * 4)(*[a.shape[0] for a in self._keep[:4]])
+        qp = (pd * 8)(*[a.ctypes.data_as(pd) for a in self._keep[4:]])
+        ql = (ctypes.c_int * 8)(*[a.shape[0] for a in self._keep[4:]])
+        h = ctypes.c_void_p()
+        rc = L.dtcwt_hip_plan1d_create(ctx.handle, dtype_code(dtype), n, k, nlevels, bp, bl, qp, ql, ctypes.byref(h))
+        if rc == -3:
+            raise NotImplementedError(L.dtcwt_hip_last_error().decode())
+        check(rc)
+        self._h, self._lib = h, L
+        s = (ctypes.c_int64 * (1 + 2 * nlevels))()
+        check(L.dtcwt_hip_plan1d_shapes(h, s))
+        self.low = int(s[0])
+        self.high = [int(s[1 + 2 * l]) for l in range(nlevels)]
+        self.scale = [int(s[2 + 2 * l]) for l in range(nlevels)]
+
+    def forward(self, Xd, include_scale):
+        ctx, nl, k = self.ctx, self.nlevels, self.k
+        cdt = np.complex64 if self.dtype == np.float32 else np.complex128
+        Yl = DeviceArray(ctx, (self.low, k), self.dtype)
+        Yh = [DeviceArray(ctx, (self.high[l], k), cdt) for l in range(nl)]
+        Ys = [DeviceArray(ctx, (self.scale[l], k), self.dtype) for l in range(nl)] if include_scale else None
+        vp = ctypes.c_void_p
+        yh_p = (vp * nl)(*[a.ptr for a in Yh])
+        ys_p = (vp * nl)(*[a.ptr for a in Ys]) if Ys else None
+        rc = self._lib.dtcwt_hip_plan1d_forward(self._h, Xd.ptr, Yl.ptr, yh_p, ys_p)
+        if rc == -3:
+            return None
+        check(rc)
+        return Yl, Yh, Ys
+
+    def inverse(self, Lo, Yh, gain_mask):
+        nl = self.nlevels
+        Z = DeviceArray(self.ctx, (self.n, self.k), self.dtype)
+        vp = ctypes.c_void_p
+        yh_p = (vp * nl)(*[a.ptr for a in Yh])
+        g = np.ascontiguousarray(np.asarray(gain_mask, dtype=np.float64).reshape(nl))
+        rc = self._lib.dtcwt_hip_plan1d_inverse(self._h, Lo.ptr, yh_p, g.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), Z.ptr)
+        if rc == -3:
+            return None
+        check(rc)
+        return Z
+
+    def __del__(self):
+        try:
+            if getattr(self, '_h', None) and getattr(self.ctx, '_h', None):
+                self._lib.dtcwt_hip_plan1d_destroy(self._h)
+            self._h = None
+        except Exception:
+            pass
+
+
 class Transform1d(object):
     """An implementation of the 1D DT-CWT on AMD GPUs via HIP.
 
@@ -47,6 +113,25 @@ class Transform1d(object):
         self.biort = biort
         self.qshift = qshift
         self._ctx = ctx
+        self._plans = collections.OrderedDict()
+
+    MAX_PLANS = 8
+
+    def _plan(self, dtype, n, k, nlevels, b, q):
+        """The native whole-transform plan (dtcwt_hip_plan1d_*) or None where some level has no one-launch kernel."""
+        if os.environ.get('DTCWT_HIP_PLAN1D', '1') == '0' or len(b) != 4 or len(q) != 8:
+            return None
+        key = (np.dtype(dtype).str, n, k, nlevels, tuple(np.asarray(h).tobytes() for h in tuple(b) + tuple(q)))
+        if key not in self._plans:
+            try:
+                self._plans[key] = _Plan1d(self.ctx, dtype, n, k, nlevels, b, q)
+            except (NotImplementedError, _lib.HipError):
+                self._plans[key] = None
+            while len(self._plans) > self.MAX_PLANS:
+                self._plans.popitem(last=False)
+        else:
+            self._plans.move_to_end(key)
+        return self._plans[key]
 
     @property
     def ctx(self):
@@ -89,6 +174,12 @@ class Transform1d(object):
             return Pyramid(Xh, (), ()) if include_scale else Pyramid(Xh, ())
         if Xd is None:
             Xd = self.ctx.to_device_float(X)     # asfarray semantics; integers are widened on the device
+        plan = self._plan(Xd.dtype, Xd.shape[0], Xd.shape[1], nlevels, (h0o, g0o, h1o, g1o),
+                          (h0a, h0b, g0a, g0b, h1a, h1b, g1a, g1b)) if Xd.dtype in (np.float32, np.float64) else None
+        done = plan.forward(Xd, include_scale) if plan is not None else None
+        if done is not None:            # the whole transform in one native call
+            Lo, Yh, Ys = done
+            return Pyramid(Lo, tuple(Yh), tuple(Ys)) if include_scale else Pyramid(Lo, tuple(Yh))
         Yh, Ys = [], []
         # a level = one launch with the highpass packing fused (dtcwt_hip_level1d_forward);
         # filters / shapes it declines go through the pair filter + pack kernels
@@ -135,6 +226,17 @@ class Transform1d(object):
         if Lo.ndim == 1:
             Lo = Lo.reshape(Lo.shape[0], 1)
         Yh = [y if y.ndim == 2 else y.reshape(y.shape[0], 1) for y in Yh]
+        n0, k = 2 * Yh[0].shape[0], Lo.shape[1]
+        plan = self._plan(Lo.dtype, n0, k, a, (h0o, g0o, h1o, g1o), (h0a, h0b, g0a, g0b, h1a, h1b, g1a, g1b)) \
+            if Lo.dtype in (np.float32, np.float64) else None
+        if plan is not None and plan.low == Lo.shape[0] and all(
+                tuple(Yh[l].shape) == (plan.high[l], k) for l in range(a)):
+            Z = plan.inverse(Lo, Yh, gain_mask)
+            if Z is not None:
+                if device_output:
+                    return Z
+                Zh = Z.get()
+                return Zh.flatten() if Zh.shape[1] == 1 else Zh
         level = a - 1
         while level >= 1:                                     # transform1d.py:150-160
             want = 2 * Yh[level - 1].shape[0]

@@ -8,10 +8,17 @@ the ``cube2c`` kernel into the reference's ``[d0/2, d1/2, d2/2, 28]`` complex la
 Edge padding (``ext_mode`` 4: one plane, 8: two planes per side, :322-335) and the
 inverse's cropping (:505-524) are index arithmetic inside the filters, never copies.
 
+float32 volumes whose every level has a fused level kernel run as ONE native call per
+transform (``dtcwt_hip_plan3d_*``: the plan owns the level geometry and the lowpass workspaces and
+sequences the level kernels in the library); everything else is sequenced here, level by level.
+
 One deliberate difference: the reference's highpass-free level-1 inverse
 (``_level1_ifm_no_highpass``, :442-458) forgets a transpose, so it swaps axes 0 and 2 of
-cubic volumes and raises on non-cubic ones; this backend returns the intended result.
+cubic volumes and raises on non-cubic ones; this backend returns the intended result unless the
+transform is built with ``reference_quirks=True``, which reproduces the reference literally
+(exchanged axes for cubic volumes, ``ValueError`` for the others).
 """
+import collections
 import ctypes
 import os
 
@@ -118,6 +125,67 @@ def _fused_inverse_level2(Yl, Yh, crops, g0b, g0a, g1b, g1a):
     return Z
 
 
+class _Plan3d(object):
+    """RAII wrapper of dtcwt_hip_plan3d: the whole 3-D transform in one native call."""
+
+    def __init__(self, ctx, shape, nlevels, ext_mode, biort, qshift):
+        L = _lib.lib()
+        pd = ctypes.POINTER(ctypes.c_double)
+        self.ctx = ctx
+        self._keep = [flat_taps(h) for h in biort[:4]] + [flat_taps(h) for h in qshift[:8]]
+        bp = (pd * 4)(*[a.ctypes.data_as(pd) for a in self._keep[:4]])
+        bl = (ctypes.c_int * 4)(*[a.shape[0] for a in self._keep[:4]])
+        qp = (pd * 8)(*[a.ctypes.data_as(pd) for a in self._keep[4:]])
+        ql = (ctypes.c_int * 8)(*[a.shape[0] for a in self._keep[4:]])
+        h = ctypes.c_void_p()
+        rc = L.dtcwt_hip_plan3d_create(ctx.handle, shape[0], shape[1], shape[2], nlevels, ext_mode, bp, bl, qp, ql,
+                                       ctypes.byref(h))
+        if rc == -3:
+            raise NotImplementedError(L.dtcwt_hip_last_error().decode())
+        check(rc)
+        self._h, self._lib, self.nlevels = h, L, nlevels
+        s = (ctypes.c_int64 * (3 + 6 * nlevels))()
+        check(L.dtcwt_hip_plan3d_shapes(h, s))
+        self.low = tuple(s[0:3])
+        self.high = [tuple(s[3 + 6 * l:6 + 6 * l]) for l in range(nlevels)]
+        self.scale = [tuple(s[6 + 6 * l:9 + 6 * l]) for l in range(nlevels)]
+
+    def forward(self, Xd, include_scale, discard_level_1):
+        """-> (Yl, [Yh], [Ys] | None) or None when a level turns out to have no fused kernel (tiny levels)."""
+        ctx, nl = self.ctx, self.nlevels
+        Yl = DeviceArray(ctx, self.low, np.float32)
+        Yh = [None if (l == 0 and discard_level_1) else DeviceArray(ctx, self.high[l] + (28,), np.complex64)
+              for l in range(nl)]
+        Ys = [DeviceArray(ctx, self.scale[l], np.float32) for l in range(nl)] if include_scale else None
+        vp = ctypes.c_void_p
+        yh_p = (vp * nl)(*[(a.ptr if a is not None else None) for a in Yh])
+        ys_p = (vp * nl)(*[a.ptr for a in Ys]) if Ys else None
+        rc = self._lib.dtcwt_hip_plan3d_forward(self._h, Xd.ptr, Yl.ptr, yh_p, ys_p, 1 if discard_level_1 else 0)
+        if rc == -3:
+            return None
+        check(rc)
+        return Yl, Yh, Ys
+
+    def inverse(self, Yl, Yh, out_shape):
+        nl = self.nlevels
+        Z = DeviceArray(self.ctx, out_shape, np.float32)
+        vp = ctypes.c_void_p
+        yh_p = (vp * nl)(*[(a.ptr if a is not None else None) for a in Yh])
+        rc = self._lib.dtcwt_hip_plan3d_inverse(self._h, Yl.ptr, yh_p, Z.ptr, 0)
+        if rc == -3:
+            return None
+        check(rc)
+        return Z
+
+    def __del__(self):
+        try:
+            if getattr(self, '_h', None) and getattr(self.ctx, '_h', None):
+                self._lib.dtcwt_hip_plan3d_destroy(self._h)
+            self._h = None
+        except Exception:
+            pass
+
+
 def _c2cube(Yh, octant):
     e0, e1, e2 = Yh.shape[:3]
     rdt = np.float32 if Yh.dtype == np.complex64 else np.float64
@@ -131,7 +199,9 @@ class Transform3d(object):
     """An implementation of the 3D DT-CWT on AMD GPUs via HIP.  *biort*/*qshift* as for
     :class:`Transform2d`; *ext_mode* 4 or 8 as in dtcwt/numpy/transform3d.py:22-35,:86-99."""
 
-    def __init__(self, biort=DEFAULT_BIORT, qshift=DEFAULT_QSHIFT, ext_mode=4, ctx=None):
+    def __init__(self, biort=DEFAULT_BIORT, qshift=DEFAULT_QSHIFT, ext_mode=4, ctx=None, reference_quirks=False):
+        self.reference_quirks = bool(reference_quirks)
+        self._plans = collections.OrderedDict()
         try:
             self.biort = _biort(biort)
         except TypeError:
@@ -158,6 +228,25 @@ class Transform3d(object):
         if self.ext_mode != 4 and self.ext_mode != 8:
             raise ValueError('ext_mode must be one of 4 or 8')
         return self.biort[:4], self.qshift[:8]
+
+    MAX_PLANS = 8
+
+    def _plan(self, shape, nlevels):
+        """The native whole-transform plan for float32 volumes of *shape*, or None (even-length biort,
+        q-shift lengths without a fused kernel, fused kernels switched off ...)."""
+        if not self.fused or nlevels < 1:
+            return None
+        key = (tuple(shape), nlevels, self.ext_mode)
+        if key not in self._plans:
+            try:
+                self._plans[key] = _Plan3d(self.ctx, shape, nlevels, self.ext_mode, self.biort, self.qshift)
+            except (NotImplementedError, _lib.HipError):
+                self._plans[key] = None
+            while len(self._plans) > self.MAX_PLANS:
+                self._plans.popitem(last=False)
+        else:
+            self._plans.move_to_end(key)
+        return self._plans[key]
 
     # ------------------------------------------------------------------ forward
     @staticmethod
@@ -219,6 +308,13 @@ class Transform3d(object):
             X = np.asanyarray(X)
             Xd = self.ctx.to_device_float(np.atleast_3d(asfarray(X) if np.issubdtype(X.dtype, np.complexfloating) else X))
         cdt = np.complex64 if Xd.dtype == np.float32 else np.complex128
+        if Xd.dtype == np.float32 and nlevels >= 1:
+            mult = 2 if self.ext_mode == 4 else 4
+            plan = self._plan(Xd.shape, nlevels) if not any(s % mult for s in Xd.shape) else None
+            done = plan.forward(Xd, include_scale, discard_level_1) if plan is not None else None
+            if done is not None:            # the whole transform in one native call
+                Yl, Yh, Ys = done
+                return Pyramid(Yl, tuple(Yh), tuple(Ys)) if include_scale else Pyramid(Yl, tuple(Yh))
         Yl = Xd
         Yh = [None] * nlevels
         Ys = [None] * nlevels
@@ -295,6 +391,31 @@ class Transform3d(object):
             p0[a2] = fsum(p1[(0, a2)], p1[(1, a2)], lo, hi, axis=0, crop=crops[0])
         return fsum(p0[0], p0[1], lo, hi, axis=2, crop=crops[2])
 
+    def _inverse_planned(self, Yl, Yh, nlevels):
+        """The whole inverse in one native call, or None when the pyramid does not fit a plan."""
+        if Yl.dtype != np.float32 or any(y is not None and y.dtype != np.complex64 for y in Yh):
+            return None
+        if any(y is None for y in Yh[1:]) or (Yh[0] is None and self.reference_quirks):
+            return None
+        if Yh[0] is not None:
+            shape = tuple(2 * s for s in Yh[0].shape[:3])
+        elif nlevels >= 2:
+            # no level-1 highpasses to read the extents from: the reference then takes level 2 as unpadded
+            # (prev_level_size = 2 x the level-2 highpass extents), i.e. the volume is 4 x Yh[1]
+            shape = tuple(4 * s for s in Yh[1].shape[:3])
+        else:
+            shape = tuple(Yl.shape)
+        try:
+            plan = self._plan(shape, nlevels)
+        except Exception:
+            plan = None
+        if plan is None or plan.low != tuple(Yl.shape):
+            return None
+        for l in range(nlevels):
+            if Yh[l] is not None and tuple(Yh[l].shape) != plan.high[l] + (28,):
+                return None
+        return plan.inverse(Yl, list(Yh), shape)
+
     def inverse(self, pyramid, device_output=False):
         """Perform an *n*-level dual-tree complex wavelet (DTCWT) 3D reconstruction
         (dtcwt/numpy/transform3d.py:133-206); ``highpasses[0]`` may be ``None``."""
@@ -313,6 +434,9 @@ class Transform3d(object):
                        for y in pyramid.highpasses)
         if nlevels == 0:
             return Yl if device_output else Yl.get()
+        Z = self._inverse_planned(Yl, Yh, nlevels)
+        if Z is not None:
+            return Z if device_output else Z.get()
         nocrop = ((0, 0),) * 3
         for level in range(nlevels):
             cur = Yh[-level - 1]
@@ -320,6 +444,14 @@ class Transform3d(object):
                 if cur is None:                                # :442-458 (see module docstring)
                     for axis in (1, 0, 2):
                         Yl = ll.axis_colfilter(Yl, g0o, axis=axis)
+                    if self.reference_quirks:
+                        # the reference filters "rows of each slice" through a transposed view twice and forgets
+                        # the third transpose: the result arrives with axes 0 and 2 exchanged, which only fits
+                        # the output array of a cubic volume
+                        if Yl.shape[0] != Yl.shape[2]:
+                            raise ValueError('could not broadcast: the reference cannot invert non-cubic volumes '
+                                             'without level-1 highpasses (dtcwt/numpy/transform3d.py:454-456)')
+                        Yl = self.ctx.to_device(np.ascontiguousarray(Yl.get().transpose(2, 1, 0)))
                 elif flat_taps(g0o).shape[0] % 2 == 0:
                     # even-length taps (:394-398, :437-438): first N samples of the lowpass
                     # block, N -> N+1 per axis, then drop sample 0 of every axis.

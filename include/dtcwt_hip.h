@@ -344,6 +344,46 @@ int dtcwt_hip_plan2d_capture(dtcwt_hip_plan2d *plan, const float *X, float *Yl, 
 int dtcwt_hip_graph_launch(dtcwt_hip_graph *graph);
 int dtcwt_hip_graph_destroy(dtcwt_hip_graph *graph);
 
+/* ---------------------------------------------------------------- 3-D / 1-D plans --- */
+/* Whole-transform entry points, as the reference's Transform3d.forward / .inverse
+ * (dtcwt/numpy/transform3d.py:37-131, :133-206) and Transform1d.forward / .inverse
+ * (dtcwt/numpy/transform1d.py:26-110, :112-180) are: the plan fixes every level's geometry (ext_mode
+ * 4 / 8 padding, :322-335; the replicated end samples of odd 1-D levels, transform1d.py:95-96), owns the
+ * lowpass workspaces between levels and sequences the level kernels on the context's stream.
+ * create returns -3 when some level has no one- or two-launch level kernel (even-length biort filters,
+ * q-shift lengths outside the table, k not 1 or >= 32 for 1-D): the host then sequences the generic
+ * filters itself.  forward / inverse return -3 in the same situations discovered late (tiny levels).
+ *
+ * plan3d: float32, X [n0][n1][n2] (multiples of 2, ext_mode 4, or 4, ext_mode 8).
+ *   shapes: s[0..2] = Yl extents; then per level l six values: Yh[l] extents (x 28 complex64), scale extents.
+ *   forward: Yh = nlevels device pointers (Yh[0] unused with discard_level_1 != 0, :291-315); Ys NULL or
+ *            nlevels pointers (include_scale).
+ *   inverse: Yh[0] may be NULL (pyramid of a discard_level_1 forward): level 1 is then the lowpass-only merge,
+ *            colfilter(., g0o) along axes 1, 0, 2.  The reference's `_level1_ifm_no_highpass` (:442-458) omits
+ *            a transpose there and returns cubic volumes with axes 0 and 2 exchanged; reference_quirks != 0 asks
+ *            for that literal behaviour, which only the host-sequenced path provides (returns -3 here).
+ * plan1d: dtype float32 / float64, X [n][k] (k signals side by side), gain_host: nlevels doubles or NULL.
+ *   shapes: s[0] = lowpass length; then per level: highpass length, scale length. */
+typedef struct dtcwt_hip_plan3d dtcwt_hip_plan3d;
+int dtcwt_hip_plan3d_create(dtcwt_hip_ctx *ctx, int64_t n0, int64_t n1, int64_t n2, int nlevels, int ext_mode,
+                            const double *const *biort_host, const int *biort_len,
+                            const double *const *qshift_host, const int *qshift_len, dtcwt_hip_plan3d **plan);
+int dtcwt_hip_plan3d_destroy(dtcwt_hip_plan3d *plan);
+int dtcwt_hip_plan3d_shapes(const dtcwt_hip_plan3d *plan, int64_t *shapes);
+int dtcwt_hip_plan3d_forward(dtcwt_hip_plan3d *plan, const float *X, float *Yl, void *const *Yh, float *const *Ys,
+                             int discard_level_1);
+int dtcwt_hip_plan3d_inverse(dtcwt_hip_plan3d *plan, const float *Yl, const void *const *Yh, float *Z,
+                             int reference_quirks);
+typedef struct dtcwt_hip_plan1d dtcwt_hip_plan1d;
+int dtcwt_hip_plan1d_create(dtcwt_hip_ctx *ctx, int dtype, int64_t n, int64_t k, int nlevels,
+                            const double *const *biort_host, const int *biort_len,
+                            const double *const *qshift_host, const int *qshift_len, dtcwt_hip_plan1d **plan);
+int dtcwt_hip_plan1d_destroy(dtcwt_hip_plan1d *plan);
+int dtcwt_hip_plan1d_shapes(const dtcwt_hip_plan1d *plan, int64_t *shapes);
+int dtcwt_hip_plan1d_forward(dtcwt_hip_plan1d *plan, const void *X, void *Yl, void *const *Yh, void *const *Ys);
+int dtcwt_hip_plan1d_inverse(dtcwt_hip_plan1d *plan, const void *Yl, const void *const *Yh, const double *gain_host,
+                             void *Z);
+
 /* ---------------------------------------------------------------- multi-GPU --------- */
 /* A batch of independent images sharded over the GPUs of one node from ONE process: contiguous
  * split (shard d owns images [start_d, start_d + count_d), sizes differing by at most one), one

@@ -32,7 +32,6 @@ def test_c2_whole_pyramid_vs_oracle_4096():
     rs = np.random.RandomState(4096)
     X = rs.standard_normal((4096, 4096)).astype(np.float32)
     t, to = Transform2d(B, Q), _oracle()
-    assert t.plan(1, 4096, 4096, 4).fused12                 # the headline path: levels 1+2 in one launch
     p = t.forward(X, nlevels=4, include_scale=False)
     want = to.forward(as_f64(X), nlevels=4)
     assert_close(p.lowpass, want.lowpass, XFM_TOL, 'Yl')
@@ -49,11 +48,26 @@ def test_c2_whole_pyramid_vs_oracle_4096():
     assert_close(z1, as_f64(X), INV_TOL, 'perfect reconstruction')
 
 
+def test_c2_fused_levels_whole_pyramid_4096(monkeypatch):
+    """The opt-in one-launch level-1+2 forward (DTCWT_HIP_FUSE12=1) at the headline size against the oracle."""
+    monkeypatch.setenv('DTCWT_HIP_FUSE12', '1')
+    rs = np.random.RandomState(4097)
+    X = rs.standard_normal((4096, 4096)).astype(np.float32)
+    t = Transform2d(B, Q)
+    assert t.plan(1, 4096, 4096, 4).fused12
+    p = t.forward(X, nlevels=4)
+    want = _oracle().forward(as_f64(X), nlevels=4)
+    assert_close(p.lowpass, want.lowpass, XFM_TOL, 'Yl')
+    for l in range(4):
+        assert_close(p.highpasses[l], want.highpasses[l], XFM_TOL, 'Yh[%d]' % l)
+
+
 def test_c2_fused_levels_equal_one_launch_per_level(monkeypatch):
-    """Levels 1+2 in one launch give the same pyramid as one launch per level (DTCWT_HIP_FUSE12=0),
+    """Levels 1+2 in one launch (DTCWT_HIP_FUSE12=1) give the same pyramid as one launch per level,
     include_scale (LoLo1 written out as well) included, on a size whose edge tiles hang over the image."""
     rs = np.random.RandomState(5)
     X = rs.standard_normal((1160, 1416)).astype(np.float32)
+    monkeypatch.setenv('DTCWT_HIP_FUSE12', '1')
     a = Transform2d(B, Q)
     assert a.plan(1, 1160, 1416, 3).fused12
     pa = a.forward(X, nlevels=3, include_scale=True)
@@ -71,16 +85,19 @@ def test_c2_fused_levels_equal_one_launch_per_level(monkeypatch):
 
 
 @pytest.mark.parametrize('shape', [(64, 64), (68, 132), (127, 256), (200, 64), (1023, 516)])
-def test_fused_levels_small_and_odd(shape):
+@pytest.mark.parametrize('bn', ['near_sym_a', 'antonini', 'legall'])
+def test_fused_levels_small_and_odd(shape, bn, monkeypatch):
     """The one-launch level-1+2 path on small / odd (bottom row replicated) images whose tiles mostly
     hang over the edge; sizes whose extension is not a multiple of 4 keep one launch per level."""
+    monkeypatch.setenv('DTCWT_HIP_FUSE12', '1')
+    B = bn
     rs = np.random.RandomState(sum(shape))
     X = rs.standard_normal(shape).astype(np.float32)
     t = Transform2d(B, Q)
     R, C = shape[0] + (shape[0] & 1), shape[1] + (shape[1] & 1)
     assert t.plan(1, shape[0], shape[1], 2).fused12 == (R % 4 == 0 and C % 4 == 0)
     p = t.forward(X, nlevels=2)
-    want = _oracle().forward(as_f64(X), nlevels=2)
+    want = o.Transform2d(biort(B), qshift(Q)).forward(as_f64(X), nlevels=2)
     assert_close(p.lowpass, want.lowpass, XFM_TOL)
     for l in range(2):
         assert_close(p.highpasses[l], want.highpasses[l], XFM_TOL)

@@ -109,7 +109,14 @@ def test_3d_golden():
         t = Transform3d(b, qn, ext_mode=ext)
         p = t.forward(_volume(s, xn).astype(dt), nlevels=nl, include_scale=True, discard_level_1=d)
         G.check_pyramid(s, case + '/fwd', p, tol)
-        G.check_stored(s, case + '/inv', t.inverse(p), tol * 10)
+        z = t.inverse(p)
+        if d:
+            # the fixture is the reference's literal output (axes 0 / 2 exchanged, transform3d.py:454-456):
+            # reference_quirks=True reproduces it, the default returns the intended volume = its transpose
+            tq = Transform3d(b, qn, ext_mode=ext, reference_quirks=True)
+            G.check_stored(s, case + '/inv', tq.inverse(p), tol * 10)
+            z = z.transpose(2, 1, 0)
+        G.check_stored(s, case + '/inv', z, tol * 10)
 
 
 @pytest.mark.parametrize('shape,ext', [((16, 24, 32), 4), ((30, 26, 22), 4), ((36, 28, 20), 8), ((8, 8, 8), 4)])
@@ -230,3 +237,79 @@ def test_3d_fused_vs_generic_random_sweep():
         assert zt.shape == zg.shape == X.shape
         assert_close(zt, zg, 2e-5, 'inverse %s %s %s ext%d nl%d' % (shape, bn, qn, ext, nl))
         assert_close(zt, X, 3e-5, 'PR')
+
+
+def test_native_plans_one_call_per_transform(monkeypatch):
+    """Transform3d / Transform1d run as ONE native call (dtcwt_hip_plan3d_* / plan1d_*) and give bit-identical
+    results to the level-by-level sequencing from Python (plans switched off)."""
+    from dtcwt_amd.hip import _lib
+    rs = np.random.RandomState(31)
+    V = rs.standard_normal((40, 48, 56)).astype(np.float32)
+    t = Transform3d(ext_mode=4)
+    assert t._plan(V.shape, 3) is not None
+    calls = []
+    real = _lib.lib().dtcwt_hip_fwd3_level2
+    p = t.forward(V, nlevels=3, include_scale=True)
+    z = t.inverse(p)
+    monkeypatch.setattr(Transform3d, '_plan', lambda self, shape, nlevels: None)
+    t2 = Transform3d(ext_mode=4)
+    q = t2.forward(V, nlevels=3, include_scale=True)
+    assert np.array_equal(p.lowpass, q.lowpass)
+    for l in range(3):
+        assert np.array_equal(p.highpasses[l], q.highpasses[l])
+        assert np.array_equal(p.scales[l], q.scales[l])
+    assert np.array_equal(z, t2.inverse(q))
+    monkeypatch.undo()
+    # discard_level_1 through the plan: level 1 lowpass only, Yh[0] None, inverse with the lowpass-only merge
+    t3 = Transform3d(ext_mode=4)
+    pd_ = t3.forward(V, nlevels=2, discard_level_1=True)
+    assert pd_.highpasses[0] is None
+    to = o.Transform3d(biort('near_sym_a'), qshift('qshift_a'), ext_mode=4)
+    want = to.forward(V.astype(np.float64), nlevels=2, discard_level_1=True)
+    assert_close(pd_.highpasses[1], want.highpasses[1], XFM_TOL)
+    assert_close(t3.inverse(pd_), to.inverse(want), 2e-5)
+    # 1-D: one vector and 64 signals side by side, float32 and float64
+    for shape, dt, tol in (((4096,), np.float64, F64_TOL), ((630 * 2, 64), np.float32, XFM_TOL)):
+        x = rs.standard_normal(shape).astype(dt)
+        t1 = Transform1d()
+        p1 = t1.forward(x, nlevels=4, include_scale=True)
+        assert len(t1._plans) == 1 and list(t1._plans.values())[0] is not None
+        gm = rs.uniform(0.5, 1.5, size=4)
+        z1 = t1.inverse(p1, gm)
+        monkeypatch.setenv('DTCWT_HIP_PLAN1D', '0')
+        t1b = Transform1d()
+        q1 = t1b.forward(x, nlevels=4, include_scale=True)
+        assert list(t1b._plans.values()) == []
+        assert np.array_equal(p1.lowpass, q1.lowpass)
+        for l in range(4):
+            assert np.array_equal(p1.highpasses[l], q1.highpasses[l])
+            assert np.array_equal(p1.scales[l], q1.scales[l])
+        assert np.array_equal(z1, t1b.inverse(q1, gm))
+        monkeypatch.delenv('DTCWT_HIP_PLAN1D')
+        w1 = o.Transform1d(biort('near_sym_a'), qshift('qshift_a')).forward(x.astype(np.float64), nlevels=4)
+        assert_close(p1.highpasses[3], w1.highpasses[3], tol)
+
+
+def test_c4_whole_pyramid_vs_oracle_256cubed():
+    """BASELINE config[3]: 256^3 float32, nlevels=3 -- every level and octant against the oracle evaluated in
+    float64 on the same samples (not just reconstruction, which any self-consistent pair passes), then
+    linearity and the inverse."""
+    rs = np.random.RandomState(256)
+    V = rs.standard_normal((256, 256, 256)).astype(np.float32)
+    t = Transform3d()
+    p = t.forward(V, nlevels=3)
+    want = o.Transform3d(biort('near_sym_a'), qshift('qshift_a')).forward(V.astype(np.float64), nlevels=3)
+    assert_close(p.lowpass, want.lowpass, XFM_TOL, 'Yl')
+    for l in range(3):
+        assert p.highpasses[l].shape == want.highpasses[l].shape
+        assert_close(p.highpasses[l], want.highpasses[l], XFM_TOL, 'Yh[%d]' % l)
+        for oct_ in range(7):
+            a, b = p.highpasses[l][..., 4 * oct_:4 * oct_ + 4], want.highpasses[l][..., 4 * oct_:4 * oct_ + 4]
+            assert_close(a, b, 2 * XFM_TOL, 'Yh[%d] octant %d' % (l, oct_))
+    z = t.inverse(p)
+    assert_close(z, V.astype(np.float64), 1e-5, 'reconstruction')
+    W = rs.standard_normal((256, 256, 256)).astype(np.float32)
+    q = t.forward(W, nlevels=3)
+    r = t.forward(1.5 * V - 0.25 * W, nlevels=3)
+    for l in range(3):
+        assert_close(r.highpasses[l], 1.5 * p.highpasses[l] - 0.25 * q.highpasses[l], 3e-6, 'linearity Yh[%d]' % l)

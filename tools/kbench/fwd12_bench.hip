@@ -57,13 +57,13 @@ static void run_variant(const char *name, int xcd) {
     // correctness on set 0 against the two-launch reference
     fill_params(q, q2, sets[0], B, N); q2.xcd_order = xcd;
     CK(hipMemsetAsync(sets[0].L2, 0xff, px, st)); CK(hipMemsetAsync(sets[0].Y0, 0xff, px * 12, st)); CK(hipMemsetAsync(sets[0].Y1, 0xff, px * 3, st));
-    if ((PERSIST ? launch_fwd12p<C, SKIP, MW>(q, q2, st, PERSIST) : launch_fwd12<C, SKIP>(q, q2, st))) { printf("%-28s launch failed\n", name); return; }
+    if (launch_fwd12<C, SKIP>(q, q2, st)) { printf("%-28s launch failed\n", name); return; }
     CK(hipStreamSynchronize(st)); CK(hipGetLastError());
     double e0 = maxdiff(sets[0].Y0, ref.Y0, px * 3), e1 = maxdiff(sets[0].Y1, ref.Y1, px * 3 / 4), e2 = maxdiff(sets[0].L2, ref.L2, px / 4);
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    for (int i = 0; i < 8; ++i) { fill_params(q, q2, sets[i % NSET], B, N); q2.xcd_order = xcd; (PERSIST ? launch_fwd12p<C, SKIP, MW>(q, q2, st, PERSIST) : launch_fwd12<C, SKIP>(q, q2, st)); }
+    for (int i = 0; i < 8; ++i) { fill_params(q, q2, sets[i % NSET], B, N); q2.xcd_order = xcd; launch_fwd12<C, SKIP>(q, q2, st); }
     CK(hipEventRecord(a, st));
-    for (int i = 0; i < REPS; ++i) { fill_params(q, q2, sets[i % NSET], B, N); q2.xcd_order = xcd; (PERSIST ? launch_fwd12p<C, SKIP, MW>(q, q2, st, PERSIST) : launch_fwd12<C, SKIP>(q, q2, st)); }
+    for (int i = 0; i < REPS; ++i) { fill_params(q, q2, sets[i % NSET], B, N); q2.xcd_order = xcd; launch_fwd12<C, SKIP>(q, q2, st); }
     CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms, a, b));
     const double us = ms * 1e3 / REPS;
@@ -123,19 +123,11 @@ int main(int argc, char **argv) {
     }
 #define V(...) run_variant<Fwd12Cfg<__VA_ARGS__>>(#__VA_ARGS__, 0); run_variant<Fwd12Cfg<__VA_ARGS__>>(#__VA_ARGS__, 1);
 #define K(S, ...) run_variant<Fwd12Cfg<__VA_ARGS__>, S>(#__VA_ARGS__, 1);
-#define P(W, ...) run_variant<Fwd12Cfg<__VA_ARGS__>, 0, W>(#__VA_ARGS__, 1);
     V(16, 32, 8, 4, 5, 7, 10, 256)
-    P(3, 16, 32, 8, 4, 5, 7, 10, 256)
     if (only) return 0;
-    P(4, 16, 32, 8, 4, 5, 7, 10, 256)
-    P(2, 16, 32, 8, 4, 5, 7, 10, 256)
-    P(8, 16, 32, 8, 4, 5, 7, 10, 256)
     V(32, 32, 8, 4, 5, 7, 10, 512)
-    run_variant<Fwd12Cfg<32, 32, 8, 4, 5, 7, 10, 512>, 0, 2, 2>("32,32,512 mw2", 1);
     V(16, 64, 8, 4, 5, 7, 10, 512)
-    run_variant<Fwd12Cfg<16, 64, 8, 4, 5, 7, 10, 512>, 0, 2, 2>("16,64,512 mw2", 1);
     V(8, 32, 8, 4, 5, 7, 10, 256)
-    run_variant<Fwd12Cfg<8, 32, 8, 4, 5, 7, 10, 256>, 0, 4, 3>("8,32 mw3", 1);
     // phase knock-outs (results wrong by construction; time only): 1 = level-1 column pass, 2 = core row pass,
     // 4 = halo LoLo1, 8 = level-2 column pass, 16 = level-2 row pass, 32 = Yh[0] record flush
     K(64, 16, 32, 8, 4, 5, 7, 10, 256)      // 64: all workgroups on 16 cache-resident tiles = the kernel without HBM
