@@ -68,7 +68,7 @@ def parse_args(argv=None):
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--config', choices=sorted(CONFIGS), default='c2')
     ap.add_argument('--sets', type=int, default=4, help='distinct buffer sets the steps rotate over')
-    ap.add_argument('--streams', type=int, default=1, help='HIP streams the steps alternate over (independent images: step k '
+    ap.add_argument('--streams', type=int, default=2, help='HIP streams the steps alternate over (independent images: step k '
                     'runs on stream k %% S, each with its own plan and buffer sets): the small coarse-level kernels of one '
                     'image overlap the large level-1 kernels of the next')
     ap.add_argument('--mgpu', action='store_true', help='N > 1 from ONE process: dtcwt_hip_mgpu_* with a host '
@@ -138,6 +138,9 @@ def main():
     if use_dist or os.environ.get('DTCWT_BENCH_TORCH', '0') == '1':
         import torch
     saved_stdout = None
+    if use_dist and 'RANK' not in os.environ:          # DTCWT_BENCH_FORCE_DIST=1 without a launcher: a one-rank group
+        os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1',
+                          MASTER_PORT=str(_free_port()))
     if use_dist:
         # RCCL prints its own banner lines on stdout at initialisation: keep stdout for the one
         # JSON line of the contract, send everything else to stderr

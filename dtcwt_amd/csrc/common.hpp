@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <functional>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -27,6 +28,8 @@ struct dtcwt_hip_ctx {
     // malloc / free / trim may come from different host threads: the Python layer shares one default context
     // per device, ctypes releases the GIL during calls and garbage collection frees arrays from any thread
     std::mutex pool_mu;
+    // things created on behalf of the context that must go before it (cached graphs and their buffers)
+    std::vector<std::function<void()>> on_destroy;
 };
 
 struct dtcwt_hip_event {

@@ -160,31 +160,35 @@ __global__ void __launch_bounds__(C::NT, C::MIN_WAVES) k_fwd12(Fwd1Params p1, Fw
 }
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
-inline unsigned grid_for(int ntile) { return (unsigned)(cdiv(ntile, 8) * 8); }
+// every tile order of tile_of() is a bijection on a grid that is a multiple of 8 x (group size)
+inline unsigned grid_for(int ntile, int order = 1) {
+    const int q = 8 * (order > 1 ? order : 1);
+    return (unsigned)(cdiv(ntile, q) * q);
+}
 
 // ------------------------------------------------------------------ launch dispatch
 template <class C>
 int launch_fwd1(Fwd1Params &p, hipStream_t s) {
     p.tilesR = cdiv(p.LR, C::TR); p.tilesC = cdiv(p.LC, C::TC);
-    k_fwd1<C><<<grid_for(p.tilesR * p.tilesC * p.B), DT_NT, 0, s>>>(p);
+    k_fwd1<C><<<grid_for(p.tilesR * p.tilesC * p.B, p.xcd_order), DT_NT, 0, s>>>(p);
     return 0;
 }
 template <class C>
 int launch_fwd2(Fwd2Params &p, hipStream_t s) {
     p.tilesR = cdiv(p.LR / 2, C::TR); p.tilesC = cdiv(p.LC / 2, C::TC);
-    k_fwd2<C><<<grid_for(p.tilesR * p.tilesC * p.B), DT_NT, 0, s>>>(p);
+    k_fwd2<C><<<grid_for(p.tilesR * p.tilesC * p.B, p.xcd_order), DT_NT, 0, s>>>(p);
     return 0;
 }
 template <class C>
 int launch_inv1(Inv1Params &p, hipStream_t s) {
     p.tilesR = cdiv(p.R, C::TR); p.tilesC = cdiv(p.C, C::TC);
-    k_inv1<C><<<grid_for(p.tilesR * p.tilesC * p.B), DT_NT, 0, s>>>(p);
+    k_inv1<C><<<grid_for(p.tilesR * p.tilesC * p.B, p.xcd_order), DT_NT, 0, s>>>(p);
     return 0;
 }
 template <class C>
 int launch_inv2(Inv2Params &p, hipStream_t s) {
     p.tilesR = cdiv(p.zr, C::TR); p.tilesC = cdiv(p.zc, C::TC);
-    k_inv2<C><<<grid_for(p.tilesR * p.tilesC * p.B), DT_NT, 0, s>>>(p);
+    k_inv2<C><<<grid_for(p.tilesR * p.tilesC * p.B, p.xcd_order), DT_NT, 0, s>>>(p);
     return 0;
 }
 
@@ -198,7 +202,7 @@ int launch_fwd12(Fwd1Params &p1, Fwd2Params &p2, hipStream_t s) {
             return -2;
         raised = true;
     }
-    k_fwd12<C, SKIP><<<grid_for(p2.tilesR * p2.tilesC * p2.B), C::NT, lds, s>>>(p1, p2);
+    k_fwd12<C, SKIP><<<grid_for(p2.tilesR * p2.tilesC * p2.B, p2.xcd_order), C::NT, lds, s>>>(p1, p2);
     return 0;
 }
 
@@ -283,6 +287,11 @@ struct dtcwt_hip_plan2d {
     std::vector<hipEvent_t> ev;       // [fwd: 2 per level][inv: 2 per level]
     int xcd_order = -1;               // -1: per-kernel default, 0/1: forced (DTCWT_HIP_XCD_ORDER)
     int small_tiles = -1;             // -1: by size, 0/1: forced (DTCWT_HIP_SMALL_TILES)
+    // tile order of the level-1 forward kernel (tile_of): 0 linear, 1 one contiguous run per XCD, g > 1 groups of g
+    // neighbouring tiles per XCD.  Measured at 4096^2 (profiles/r02): g = 8 fetches 74.6 MB for the 67.1 MB image
+    // (1.11 x; linear order: 133 MB, 1.99 x, every XCD's L2 fetching its own copy of the shared halo lines) in
+    // 60-62 us instead of 64-66; one run per XCD (order 1) is slower (79 us: the write streams thin out).
+    int fwd1_order = 8;
     int fuse12 = 0;                   // levels 1+2 of the forward in one launch (DTCWT_HIP_FUSE12=1): measured SLOWER than
                                       // two launches on MI355X (114 vs 101 us at 4096^2), so opt-in
 };
@@ -317,7 +326,8 @@ int dtcwt_hip_plan2d_create(dtcwt_hip_ctx *ctx, int batch, int rows, int cols, i
     p->ctx = ctx; p->batch = batch; p->rows = rows; p->cols = cols; p->nlevels = nlevels;
     for (int i = 0; i < 4; ++i) p->biort[i].assign(biort_host[i], biort_host[i] + biort_len[i]);
     for (int i = 0; i < 8; ++i) p->qshift[i].assign(qshift_host[i], qshift_host[i] + qshift_len[i]);
-    { const char *e = getenv("DTCWT_HIP_XCD_ORDER"); p->xcd_order = e ? (e[0] == '1' ? 1 : 0) : -1; }
+    { const char *e = getenv("DTCWT_HIP_XCD_ORDER"); p->xcd_order = e ? atoi(e) : -1; }
+    { const char *e = getenv("DTCWT_HIP_FWD1_ORDER"); p->fwd1_order = e ? atoi(e) : 8; }
     { const char *e = getenv("DTCWT_HIP_SMALL_TILES"); p->small_tiles = e ? (e[0] == '1' ? 1 : 0) : -1; }
     { const char *e = getenv("DTCWT_HIP_FUSE12"); p->fuse12 = e ? (e[0] != '0') : 0; }
     p->extR = rows + (rows & 1);
@@ -453,7 +463,7 @@ int dtcwt_hip_plan2d_forward(dtcwt_hip_plan2d *p, const float *X, float *Yl, voi
             Fwd1Params q{};
             q.X = in; q.LoLo = lo; q.Yh = (float *)Yh[l];
             q.B = p->batch; q.inR = L.inR; q.inC = L.inC; q.LR = L.LR; q.LC = L.LC;
-            q.xcd_order = p->xcd_order < 0 ? 0 : p->xcd_order;      // write-heavy: linear order
+            q.xcd_order = p->xcd_order < 0 ? p->fwd1_order : p->xcd_order;      // write-heavy: linear order unless told otherwise
             put_taps(q.h0, p->biort[0]); put_taps(q.h1, p->biort[2]); put_taps(q.h2, p->bp1[0]);
             if (f12) {
                 // one launch for levels 1 and 2: LoLo1 only leaves the chip when it is an output (Ys)

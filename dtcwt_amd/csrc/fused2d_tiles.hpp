@@ -256,8 +256,14 @@ DT_HD int xcd_tile(int bid, int ntiles) {
 // is FASTER than the XCD-contiguous one (82.6 vs 93.1 us for level-1 forward at 4096^2) --
 // neighbouring tiles in flight together keep the HBM write streams dense -- so linear is
 // the default and the remap stays selectable (DTCWT_HIP_XCD_ORDER=1) for experiments.
+// xcd_order > 1: groups of that many consecutive tiles share an XCD (and its L2) while the groups themselves
+// stay in linear order -- the halo columns two horizontally adjacent tiles both read are fetched once, and
+// the write streams stay as dense as in linear order.
 DT_HD int tile_of(int bid, int ntiles, int xcd_order) {
-    return xcd_order ? xcd_tile(bid, ntiles) : bid;
+    if (xcd_order <= 0) return bid;
+    if (xcd_order == 1) return xcd_tile(bid, ntiles);
+    const int g = xcd_order, x = bid % 8, i = bid / 8;
+    return ((i / g) * 8 + x) * g + i % g;       // may be >= ntiles: caller must skip
 }
 
 }  // namespace dt2d

@@ -320,19 +320,9 @@ int dtcwt_hip_fill_rows(dtcwt_hip_ctx *ctx, int64_t n, int K, const double *row,
 //   shapes: [nlevels][2] = (H_l, W_l);  groups: `ngroups` level lists, group g holds
 //   group_sizes[g] consecutive entries of group_levels (0-based); the first group gives the
 //   global estimate, the others refine it (:339-370);  avecs: [reg_h][reg_w][6] float64 out.
-int dtcwt_hip_estimatereg(dtcwt_hip_ctx *ctx, int dtype, int nlevels, const void *const *Yh_src,
-                          const void *const *Yh_ref, const int64_t *shapes, int64_t reg_h, int64_t reg_w,
-                          int ngroups, const int *group_sizes, const int *group_levels, double *avecs) {
-    DT_REQUIRE(ctx && Yh_src && Yh_ref && shapes && group_sizes && group_levels && avecs, "NULL argument");
-    DT_REQUIRE(nlevels > 0 && ngroups > 0 && reg_h > 0 && reg_w > 0, "bad extents");
-    DT_REQUIRE(dtype == DTCWT_HIP_F32 || dtype == DTCWT_HIP_F64, "bad dtype");
-    int total = 0;
-    for (int g = 0; g < ngroups; ++g) total += group_sizes[g];
-    for (int k = 0; k < total; ++k)
-        DT_REQUIRE(group_levels[k] >= 0 && group_levels[k] < nlevels && Yh_src[group_levels[k]] && Yh_ref[group_levels[k]],
-                   "level index out of range");
-    DT_CHECK_HIP(hipSetDevice(ctx->device));
-    Scratch sc(ctx);
+static int estimatereg_issue(dtcwt_hip_ctx *ctx, Scratch &sc, int dtype, int nlevels, const void *const *Yh_src,
+                             const void *const *Yh_ref, const int64_t *shapes, int64_t reg_h, int64_t reg_w,
+                             int ngroups, const int *group_sizes, const int *group_levels, double *avecs) {
     const double W0 = -3 * 3.14159265358979323846 / 2.15, W1 = -3.14159265358979323846 / 2.15;
     const double tdx[6] = {W1, W0, W0, W0, W0, W1}, tdy[6] = {W0, W0, W1, -W1, -W0, -W0};   // sampling.py:26-33
     const int ident[6] = {0, 1, 2, 3, 4, 5};
@@ -388,6 +378,103 @@ int dtcwt_hip_estimatereg(dtcwt_hip_ctx *ctx, int dtype, int nlevels, const void
         DT_TRY(dtcwt_hip_solve6(ctx, qts, nreg, da));
         DT_TRY(dtcwt_hip_axpy(ctx, nreg * 6, 1.0, da, avecs));
     }
+    return 0;
+}
+
+// About a hundred small dependent launches: at 288 x 352 the eager sequence is bound by the host's launch
+// rate (~6 us per launch, 0.61 ms), not by the device.  A call is therefore captured once as a hipGraph --
+// keyed by everything baked into its nodes: the pyramid pointers, shapes, groups and the output -- and
+// replayed when the same buffers come back (a registration loop over recycled pyramid buffers); up to four
+// graphs are kept per context, each owning its scratch buffers.  DTCWT_HIP_REG_GRAPH=0 keeps eager launches.
+namespace {
+struct RegGraph {
+    std::vector<int64_t> key;
+    Scratch *sc;
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
+struct RegCache {
+    std::vector<RegGraph> items;       // most recently used last
+    void drop(size_t i) {
+        (void)hipGraphExecDestroy(items[i].exec);
+        (void)hipGraphDestroy(items[i].graph);
+        delete items[i].sc;
+        items.erase(items.begin() + i);
+    }
+};
+std::mutex g_reg_mu;
+std::unordered_map<dtcwt_hip_ctx *, RegCache *> g_reg;
+}  // namespace
+
+int dtcwt_hip_estimatereg(dtcwt_hip_ctx *ctx, int dtype, int nlevels, const void *const *Yh_src,
+                          const void *const *Yh_ref, const int64_t *shapes, int64_t reg_h, int64_t reg_w,
+                          int ngroups, const int *group_sizes, const int *group_levels, double *avecs) {
+    DT_REQUIRE(ctx && Yh_src && Yh_ref && shapes && group_sizes && group_levels && avecs, "NULL argument");
+    DT_REQUIRE(nlevels > 0 && ngroups > 0 && reg_h > 0 && reg_w > 0, "bad extents");
+    DT_CHECK_HIP(hipSetDevice(ctx->device));
+    static const bool use_graph = [] { const char *e = getenv("DTCWT_HIP_REG_GRAPH"); return !(e && e[0] == '0'); }();
+    if (!use_graph) {
+        Scratch sc(ctx);
+        return estimatereg_issue(ctx, sc, dtype, nlevels, Yh_src, Yh_ref, shapes, reg_h, reg_w, ngroups, group_sizes,
+                                 group_levels, avecs);
+    }
+    int total = 0;
+    for (int g = 0; g < ngroups; ++g) total += group_sizes[g];
+    std::vector<int64_t> key = {dtype, nlevels, reg_h, reg_w, ngroups, (int64_t)(intptr_t)avecs};
+    for (int l = 0; l < nlevels; ++l) {
+        key.push_back((int64_t)(intptr_t)Yh_src[l]); key.push_back((int64_t)(intptr_t)Yh_ref[l]);
+        key.push_back(shapes[2 * l]); key.push_back(shapes[2 * l + 1]);
+    }
+    for (int g = 0; g < ngroups; ++g) key.push_back(group_sizes[g]);
+    for (int k = 0; k < total; ++k) key.push_back(group_levels[k]);
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    RegCache *&cache = g_reg[ctx];
+    if (!cache) {
+        cache = new RegCache();
+        ctx->on_destroy.push_back([ctx] {
+            std::lock_guard<std::mutex> lk2(g_reg_mu);
+            auto it = g_reg.find(ctx);
+            if (it == g_reg.end()) return;
+            while (!it->second->items.empty()) it->second->drop(0);
+            delete it->second;
+            g_reg.erase(it);
+        });
+    }
+    for (size_t i = 0; i < cache->items.size(); ++i)
+        if (cache->items[i].key == key) {
+            RegGraph g = cache->items[i];
+            cache->items.erase(cache->items.begin() + i);
+            cache->items.push_back(g);
+            DT_CHECK_HIP(hipGraphLaunch(g.exec, ctx->stream));
+            return 0;
+        }
+    // first call with these buffers: capture.  Relaxed mode: the scratch pool may have to hipMalloc meanwhile.
+    Scratch *sc = new Scratch(ctx);
+    hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) {
+        delete sc;
+        return dtcwt_set_error(-2, "hipStreamBeginCapture failed: %s", hipGetErrorString(e));
+    }
+    int rc = estimatereg_issue(ctx, *sc, dtype, nlevels, Yh_src, Yh_ref, shapes, reg_h, reg_w, ngroups, group_sizes,
+                               group_levels, avecs);
+    hipGraph_t graph = nullptr;
+    e = hipStreamEndCapture(ctx->stream, &graph);
+    hipGraphExec_t exec = nullptr;
+    if (!rc && e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (rc || e != hipSuccess) {
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        delete sc;
+        if (rc) return rc;
+        return dtcwt_set_error(-2, "capturing estimatereg as a graph failed: %s", hipGetErrorString(e));
+    }
+    while (cache->items.size() >= 4) {
+        // the evicted graph may still be running on this stream
+        DT_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+        cache->drop(0);
+    }
+    cache->items.push_back(RegGraph{key, sc, graph, exec});
+    DT_CHECK_HIP(hipGraphLaunch(exec, ctx->stream));
     return 0;
 }
 

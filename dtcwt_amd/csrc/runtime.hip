@@ -120,6 +120,8 @@ int dtcwt_hip_ctx_destroy(dtcwt_hip_ctx *c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    for (auto &fn : c->on_destroy) fn();
+    c->on_destroy.clear();
     for (auto &kv : c->pool)
         for (void *b : kv.second) (void)hipFree(b);
     c->pool.clear();

@@ -495,3 +495,60 @@ def test_integer_images_are_widened_on_the_device(dt):
     # strided / byte-swapped views still arrive right (host fallback or contiguous copy)
     Xs = np.asfortranarray(X)
     assert np.array_equal(t.forward(Xs, nlevels=1).lowpass, t.forward(X.astype(np.float64), nlevels=1).lowpass)
+
+
+def test_unpack_device_pyramid_and_env_backend():
+    """utils.unpack(p, 'hip') on a DEVICE pyramid hands out the resident buffers (no host copy), 'numpy' the
+    arrays (dtcwt/utils.py:9-42); DTCWT_BACKEND selects the backend of a fresh process and the transform
+    then runs on the GPU (dtcwt/__init__.py:133-143)."""
+    import os
+    import subprocess
+    import sys
+    from dtcwt_amd.utils import unpack
+    m = _mandrill()
+    t = Transform2d()
+    p = t.forward(m, nlevels=2, include_scale=True)
+    yl, yh, ys = unpack(p, 'hip')
+    assert isinstance(yl, DeviceArray) and all(isinstance(y, DeviceArray) for y in yh) and len(ys) == 2
+    assert p._host == {}                                   # nothing was copied to the host
+    nl, nh, ns = unpack(p, 'numpy')
+    assert isinstance(nl, np.ndarray) and np.array_equal(nl, yl.get()) and np.array_equal(nh[1], yh[1].get())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ('import numpy as np, dtcwt_amd as d; assert d.backend_name == "hip"; t = d.Transform2d(); '
+            'from dtcwt_amd.hip import Transform2d as T; assert isinstance(t, T); '
+            'p = t.forward(np.ones((64, 64), np.float32), nlevels=2); print(p.lowpass.shape)')
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, cwd=root,
+                       env=dict(os.environ, DTCWT_BACKEND='hip'), timeout=300)
+    assert r.returncode == 0 and '(32, 32)' in r.stdout, r.stderr[-1500:]
+
+
+def test_host_edit_of_device_pyramid_is_honoured():
+    """The reference's idiom p.highpasses[l][...] = 0 before inverse(): once a NumPy view has been handed out it
+    is the authoritative copy (the edit used to be ignored silently)."""
+    rs = np.random.RandomState(12)
+    X = rs.standard_normal((128, 192)).astype(np.float32)
+    t, to = Transform2d(), o.Transform2d(biort('near_sym_a'), qshift('qshift_a'))
+    p = t.forward(X, nlevels=3)
+    want = to.forward(as_f64(X), nlevels=3)
+    p.highpasses[1][:, :, 2] = 0
+    p.highpasses[0][10:40] *= 0.5
+    hp = list(want.highpasses)
+    hp[1] = hp[1].copy(); hp[1][:, :, 2] = 0
+    hp[0] = hp[0].copy(); hp[0][10:40] *= 0.5
+    z = t.inverse(p)
+    assert_close(z, to.inverse(o.Pyramid(want.lowpass, tuple(hp))), INV_TOL)
+    # untouched device pyramids keep running from HBM
+    q = t.forward(X, nlevels=3)
+    assert_close(t.inverse(q), as_f64(X), INV_TOL)
+    assert q._host == {}
+
+
+def test_plan_cache_is_bounded_and_complex_input_is_refused():
+    t = Transform2d()
+    for k in range(12):
+        t.forward(np.zeros((64 + 4 * k, 64), np.float32), nlevels=1)
+    assert len(t._plans) <= Transform2d.MAX_PLANS
+    t.clear_plans()
+    assert len(t._plans) == 0
+    with pytest.raises(TypeError):
+        t.forward(np.zeros((64, 64), np.complex64), nlevels=1)
