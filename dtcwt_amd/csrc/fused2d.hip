@@ -16,6 +16,10 @@
 
 using namespace dt2d;
 
+// the inverse kernels live in fused2d_inv.hip (built without SLP vectorisation: see the Makefile)
+int dtcwt_dispatch_inv1(int m0, int m1, int m2, dt2d::Inv1Params &p, hipStream_t s);
+int dtcwt_dispatch_inv2(int m, bool bp, dt2d::Inv2Params &p, hipStream_t s, bool small);
+
 namespace {
 
 // -------------------------------------------------------------------------- kernels
@@ -55,53 +59,6 @@ __global__ void __launch_bounds__(DT_NT) k_fwd2(Fwd2Params p) {
         fwd2s_rows_compute<C>(p, sLo, sHi, stage, threadIdx.x, base, b, r0, c0, sBa);
         fwd2s_rows_flush<C>(p, stage, threadIdx.x, base, b, r0, c0);
     }
-}
-
-// Level-1 inverse: records copied verbatim into LDS (coalesced 16-byte pieces, all requested
-// up front together with the lowpass window), quad-plane samples gathered from them with
-// c2q folded in (column parity uniform per wavefront), barrier, column FIR writing y1/y2
-// OVER the record buffer, barrier, row pass with 16-byte stores (fused2d_tiles_v2.hpp).
-template <class C>
-__global__ void __launch_bounds__(DT_NT) k_inv1(Inv1Params p) {
-    __shared__ __attribute__((aligned(16))) float smem[C::LDS_ALIASED];
-    const int ntile = p.tilesR * p.tilesC * p.B;
-    int t = tile_of(blockIdx.x, ntile, p.xcd_order);
-    if (t >= ntile) return;
-    int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
-    float *srec = smem, *y1 = smem, *y2 = y1 + C::SY, *y3 = y2 + C::SY;     // y3: band-pass variant only
-    int r0 = tr * C::TR, c0 = tc * C::TC;
-    const float *Yhb = p.Yh + (int64_t)b * (p.R / 2) * (p.C / 2) * 12;
-    float wz[C::WN], w1[C::WN], w2[C::WN], w3[C::WN];
-    inv1r_fetch<C>(p, wz, threadIdx.x, b, r0, c0);
-    inv_rec_stage<C::QR, C::QC>(Yhb, p.R, p.C, srec, r0 - C::HE, c0 - C::HE, threadIdx.x);
-    __syncthreads();
-    inv1r_gather<C>(p, srec, w1, w2, w3, threadIdx.x, r0, c0);
-    __syncthreads();
-    inv1r_fir<C>(p, wz, w1, w2, w3, y1, y2, threadIdx.x, y3);
-    __syncthreads();
-    inv1d_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0, y3);
-}
-
-// Level >= 2 inverse: same structure with the polyphase interpolating filters.
-template <class C>
-__global__ void __launch_bounds__(DT_NT) k_inv2(Inv2Params p) {
-    __shared__ __attribute__((aligned(16))) float smem[C::LDS_ALIASED];
-    const int ntile = p.tilesR * p.tilesC * p.B;
-    int t = tile_of(blockIdx.x, ntile, p.xcd_order);
-    if (t >= ntile) return;
-    int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
-    float *srec = smem, *y1 = smem, *y2 = y1 + C::SY, *y3 = y2 + C::SY;     // y3: band-pass variant only
-    int r0 = tr * C::TR, c0 = tc * C::TC;
-    const float *Yhb = p.Yh + (int64_t)b * (p.zr / 2) * (p.zc / 2) * 12;
-    float wz[C::WS], w1[C::WS], w2[C::WS], w3[C::WS];
-    inv2r_fetch<C>(p, wz, threadIdx.x, b, r0, c0);
-    inv_rec_stage<C::QR, C::QC>(Yhb, p.zr, p.zc, srec, r0 + C::ORG, c0 + C::ORG, threadIdx.x);
-    __syncthreads();
-    inv2r_gather<C>(p, srec, w1, w2, w3, threadIdx.x, r0, c0);
-    __syncthreads();
-    inv2r_fir<C>(p, wz, w1, w2, w3, y1, y2, threadIdx.x, y3);
-    __syncthreads();
-    inv2_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0, y3);
 }
 
 #define DT_WAIT_VMEM() __builtin_amdgcn_s_waitcnt(0x0F70)      /* s_waitcnt vmcnt(0), gfx9 encoding (expcnt 7, lgkmcnt 15 = no wait) */
@@ -179,25 +136,13 @@ int launch_fwd2(Fwd2Params &p, hipStream_t s) {
     k_fwd2<C><<<grid_for(p.tilesR * p.tilesC * p.B, p.xcd_order), DT_NT, 0, s>>>(p);
     return 0;
 }
-template <class C>
-int launch_inv1(Inv1Params &p, hipStream_t s) {
-    p.tilesR = cdiv(p.R, C::TR); p.tilesC = cdiv(p.C, C::TC);
-    k_inv1<C><<<grid_for(p.tilesR * p.tilesC * p.B, p.xcd_order), DT_NT, 0, s>>>(p);
-    return 0;
-}
-template <class C>
-int launch_inv2(Inv2Params &p, hipStream_t s) {
-    p.tilesR = cdiv(p.zr, C::TR); p.tilesC = cdiv(p.zc, C::TC);
-    k_inv2<C><<<grid_for(p.tilesR * p.tilesC * p.B, p.xcd_order), DT_NT, 0, s>>>(p);
-    return 0;
-}
-
+// extra_lds: bytes of LDS requested on top of what the tile needs (occupancy experiments of tools/kbench only)
 template <class C, int SKIP = 0>
-int launch_fwd12(Fwd1Params &p1, Fwd2Params &p2, hipStream_t s) {
+int launch_fwd12(Fwd1Params &p1, Fwd2Params &p2, hipStream_t s, size_t extra_lds = 0) {
     p2.tilesR = cdiv(p2.LR / 2, C::T2R); p2.tilesC = cdiv(p2.LC / 2, C::T2C);
-    constexpr size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
+    const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float) + extra_lds;
     static bool raised = false;         // per instantiation: allow more than the default 64 KiB of dynamic LDS
-    if (lds > (48u << 10) && !raised) {
+    if ((lds > (48u << 10) && !raised) || extra_lds) {
         if (hipFuncSetAttribute((const void *)k_fwd12<C, SKIP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -2;
         raised = true;
@@ -209,31 +154,18 @@ int launch_fwd12(Fwd1Params &p1, Fwd2Params &p2, hipStream_t s) {
 // Tile shapes and supported tap lengths live in fused2d_table.hpp (shared with the
 // test-only host emulator so both step through identical configurations).
 #define DT_CASE_FWD1(TR, TC, RS, A, B) if (m0 == A && m1 == B) return launch_fwd1<Fwd1DCfg<TR, TC, RS, A, B>>(p, s);
-#define DT_CASE_INV1(TR, TC, RS, A, B) if (m0 == A && m1 == B) return launch_inv1<Inv1RCfg<TR, TC, RS, A, B>>(p, s);
 #define DT_CASE_FWD2(TR, TC, PS, M) if (m == M) return launch_fwd2<Fwd2DCfg<TR, TC, PS, M>>(p, s);
-#define DT_CASE_INV2(TR, TC, JS, M) if (m == M) return launch_inv2<Inv2RCfg<TR, TC, JS, M>>(p, s);
 #define DT_CASE_FWD1_BP(TR, TC, RS, A, B, C2) if (m0 == A && m1 == B && m2 == C2) return launch_fwd1<Fwd1DCfg<TR, TC, RS, A, B, C2>>(p, s);
-#define DT_CASE_INV1_BP(TR, TC, RS, A, B, C2) if (m0 == A && m1 == B && m2 == C2) return launch_inv1<Inv1RCfg<TR, TC, RS, A, B, C2>>(p, s);
 #define DT_CASE_FWD2_BP(TR, TC, PS, M) if (m == M) return launch_fwd2<Fwd2DCfg<TR, TC, PS, M, true>>(p, s);
-#define DT_CASE_INV2_BP(TR, TC, JS, M) if (m == M) return launch_inv2<Inv2RCfg<TR, TC, JS, M, true>>(p, s);
 // m2 / bp: length of the band-pass filter of a 6-vector biort set / a 12-vector q-shift set (0 / false: none)
 int dispatch_fwd1(int m0, int m1, int m2, Fwd1Params &p, hipStream_t s) {
     if (m2) { DT_FWD1_BP_TABLE(DT_CASE_FWD1_BP) return -3; }
     DT_FWD1_TABLE(DT_CASE_FWD1) return -3;
 }
-int dispatch_inv1(int m0, int m1, int m2, Inv1Params &p, hipStream_t s) {
-    if (m2) { DT_INV1_BP_TABLE(DT_CASE_INV1_BP) return -3; }
-    DT_INV1_TABLE(DT_CASE_INV1) return -3;
-}
 int dispatch_fwd2(int m, bool bp, Fwd2Params &p, hipStream_t s, bool small) {
     if (bp) { DT_FWD2_BP_TABLE(DT_CASE_FWD2_BP) return -3; }
     if (small) { DT_FWD2_SMALL_TABLE(DT_CASE_FWD2) }
     DT_FWD2_TABLE(DT_CASE_FWD2) return -3;
-}
-int dispatch_inv2(int m, bool bp, Inv2Params &p, hipStream_t s, bool small) {
-    if (bp) { DT_INV2_BP_TABLE(DT_CASE_INV2_BP) return -3; }
-    if (small) { DT_INV2_SMALL_TABLE(DT_CASE_INV2) }
-    DT_INV2_TABLE(DT_CASE_INV2) return -3;
 }
 #define DT_CASE_FWD12(T2R, T2C, RS, PS, A, B, M) if (m0 == A && m1 == B && m == M) return launch_fwd12<Fwd12Cfg<T2R, T2C, RS, PS, A, B, M>>(p1, p2, s);
 int dispatch_fwd12(int m0, int m1, int m, Fwd1Params &p1, Fwd2Params &p2, hipStream_t s) {
@@ -540,7 +472,7 @@ int dtcwt_hip_plan2d_inverse(dtcwt_hip_plan2d *p, const float *Yl, const void *c
             q.B = p->batch; q.R = L.LR; q.C = L.LC; q.xcd_order = p->xcd_order < 0 ? 1 : p->xcd_order;
             for (int d = 0; d < 6; ++d) q.g[d] = g[d];
             put_taps(q.g0, p->biort[1]); put_taps(q.g1, p->biort[3]); put_taps(q.g2, p->bp1[1]);
-            rc = dispatch_inv1((int)p->biort[1].size(), (int)p->biort[3].size(), (int)p->bp1[1].size(), q, s);
+            rc = dtcwt_dispatch_inv1((int)p->biort[1].size(), (int)p->biort[3].size(), (int)p->bp1[1].size(), q, s);
         } else {
             Inv2Params q{};
             float *out = p->work[l - 1];          // size of LoLo_{l-1} = this level's input
@@ -560,7 +492,7 @@ int dtcwt_hip_plan2d_inverse(dtcwt_hip_plan2d *p, const float *Yl, const void *c
             }
             bool small = p->small_tiles >= 0 ? p->small_tiles != 0
                                              : (int64_t)cdiv(L.loR, 16) * cdiv(L.loC, 56) * p->batch < DT_SMALL_TILE_THRESHOLD;
-            rc = dispatch_inv2((int)p->qshift[0].size(), bp, q, s, small);
+            rc = dtcwt_dispatch_inv2((int)p->qshift[0].size(), bp, q, s, small);
             in = out;
         }
         if (rc) return dtcwt_set_error(rc, "no fused inverse kernel at level %d", l);

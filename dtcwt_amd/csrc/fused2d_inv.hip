@@ -1,0 +1,98 @@
+// The two inverse kernels of the float32 2-D plan (fused2d.hip) in a translation unit of their own: they
+// are built with -fno-slp-vectorize.  The SLP vectoriser turns the record -> quad-plane arithmetic of the
+// gather phase into v_pk_mul / v_pk_fma_f32 pairs, which have no throughput advantage on gfx950 and cost a
+// v_mov per operand to line the pairs up; measured in one run (profiles/r02/ab_noslp.txt): k_inv1 63.1 ->
+// 60.3 us, k_inv2 32.9 -> 31.9 us at 4096^2, the forward kernels unchanged or slightly slower -- they keep SLP.
+#include "common.hpp"
+#include "fused2d_tiles.hpp"
+#include "fused2d_tiles_v2.hpp"
+#include "fused2d_table.hpp"
+
+using namespace dt2d;
+
+namespace {
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+// every tile order of tile_of() is a bijection on a grid that is a multiple of 8 x (group size)
+inline unsigned grid_for(int ntile, int order = 1) {
+    const int q = 8 * (order > 1 ? order : 1);
+    return (unsigned)(cdiv(ntile, q) * q);
+}
+
+// Level-1 inverse: records copied verbatim into LDS (coalesced 16-byte pieces, all requested
+// up front together with the lowpass window), quad-plane samples gathered from them with
+// c2q folded in (column parity uniform per wavefront), barrier, column FIR writing y1/y2
+// OVER the record buffer, barrier, row pass with 16-byte stores (fused2d_tiles_v2.hpp).
+template <class C>
+__global__ void __launch_bounds__(DT_NT) k_inv1(Inv1Params p) {
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_ALIASED];
+    const int ntile = p.tilesR * p.tilesC * p.B;
+    int t = tile_of(blockIdx.x, ntile, p.xcd_order);
+    if (t >= ntile) return;
+    int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    float *srec = smem, *y1 = smem, *y2 = y1 + C::SY, *y3 = y2 + C::SY;     // y3: band-pass variant only
+    int r0 = tr * C::TR, c0 = tc * C::TC;
+    const float *Yhb = p.Yh + (int64_t)b * (p.R / 2) * (p.C / 2) * 12;
+    float wz[C::WN], w1[C::WN], w2[C::WN], w3[C::WN];
+    inv1r_fetch<C>(p, wz, threadIdx.x, b, r0, c0);
+    inv_rec_stage<C::QR, C::QC>(Yhb, p.R, p.C, srec, r0 - C::HE, c0 - C::HE, threadIdx.x);
+    __syncthreads();
+    inv1r_gather<C>(p, srec, w1, w2, w3, threadIdx.x, r0, c0);
+    __syncthreads();
+    inv1r_fir<C>(p, wz, w1, w2, w3, y1, y2, threadIdx.x, y3);
+    __syncthreads();
+    inv1d_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0, y3);
+}
+
+// Level >= 2 inverse: same structure with the polyphase interpolating filters.
+template <class C>
+__global__ void __launch_bounds__(DT_NT) k_inv2(Inv2Params p) {
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_ALIASED];
+    const int ntile = p.tilesR * p.tilesC * p.B;
+    int t = tile_of(blockIdx.x, ntile, p.xcd_order);
+    if (t >= ntile) return;
+    int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    float *srec = smem, *y1 = smem, *y2 = y1 + C::SY, *y3 = y2 + C::SY;     // y3: band-pass variant only
+    int r0 = tr * C::TR, c0 = tc * C::TC;
+    const float *Yhb = p.Yh + (int64_t)b * (p.zr / 2) * (p.zc / 2) * 12;
+    float wz[C::WS], w1[C::WS], w2[C::WS], w3[C::WS];
+    inv2r_fetch<C>(p, wz, threadIdx.x, b, r0, c0);
+    inv_rec_stage<C::QR, C::QC>(Yhb, p.zr, p.zc, srec, r0 + C::ORG, c0 + C::ORG, threadIdx.x);
+    __syncthreads();
+    inv2r_gather<C>(p, srec, w1, w2, w3, threadIdx.x, r0, c0);
+    __syncthreads();
+    inv2r_fir<C>(p, wz, w1, w2, w3, y1, y2, threadIdx.x, y3);
+    __syncthreads();
+    inv2_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0, y3);
+}
+
+template <class C>
+int launch_inv1(Inv1Params &p, hipStream_t s) {
+    p.tilesR = cdiv(p.R, C::TR); p.tilesC = cdiv(p.C, C::TC);
+    k_inv1<C><<<grid_for(p.tilesR * p.tilesC * p.B, p.xcd_order), DT_NT, 0, s>>>(p);
+    return 0;
+}
+template <class C>
+int launch_inv2(Inv2Params &p, hipStream_t s) {
+    p.tilesR = cdiv(p.zr, C::TR); p.tilesC = cdiv(p.zc, C::TC);
+    k_inv2<C><<<grid_for(p.tilesR * p.tilesC * p.B, p.xcd_order), DT_NT, 0, s>>>(p);
+    return 0;
+}
+
+#define DT_CASE_INV1(TR, TC, RS, A, B) if (m0 == A && m1 == B) return launch_inv1<Inv1RCfg<TR, TC, RS, A, B>>(p, s);
+#define DT_CASE_INV2(TR, TC, JS, M) if (m == M) return launch_inv2<Inv2RCfg<TR, TC, JS, M>>(p, s);
+#define DT_CASE_INV1_BP(TR, TC, RS, A, B, C2) if (m0 == A && m1 == B && m2 == C2) return launch_inv1<Inv1RCfg<TR, TC, RS, A, B, C2>>(p, s);
+#define DT_CASE_INV2_BP(TR, TC, JS, M) if (m == M) return launch_inv2<Inv2RCfg<TR, TC, JS, M, true>>(p, s);
+
+}  // namespace
+
+// m2 / bp: length of the band-pass filter of a 6-vector biort set / a 12-vector q-shift set (0 / false: none)
+int dtcwt_dispatch_inv1(int m0, int m1, int m2, Inv1Params &p, hipStream_t s) {
+    if (m2) { DT_INV1_BP_TABLE(DT_CASE_INV1_BP) return -3; }
+    DT_INV1_TABLE(DT_CASE_INV1) return -3;
+}
+int dtcwt_dispatch_inv2(int m, bool bp, Inv2Params &p, hipStream_t s, bool small) {
+    if (bp) { DT_INV2_BP_TABLE(DT_CASE_INV2_BP) return -3; }
+    if (small) { DT_INV2_SMALL_TABLE(DT_CASE_INV2) }
+    DT_INV2_TABLE(DT_CASE_INV2) return -3;
+}

@@ -249,6 +249,16 @@ DT_HD void fwd12_core_flush(const Fwd1Params &p, const float *stage, int tid, in
     const int HR = p.LR / 2, HCc = p.LC / 2;
     const int lane = tid & 63, wave = tid >> 6;
     const f4 *slab = reinterpret_cast<const f4 *>(stage + wave * STAGE_FLOATS_PER_WAVE);
+    if (32 % C::NV4 == 0) {         // the slab holds whole rows of 2 NV4 records: see flush_record_rows
+        const int t0 = DT_WAVE_UNIFORM_I(round * C::NT + wave * 64 + half * 32);
+        const int u0 = t0 / C::NV4;
+        const int rows = (p.LR - r1) / 2 - u0, recs = (p.LC - c1) / 2, rows_tile = C::NU - u0;
+        int rows_ok = rows < 32 / C::NV4 ? rows : 32 / C::NV4;
+        if (rows_tile < rows_ok) rows_ok = rows_tile;
+        float *row0 = p.Yh + (((int64_t)b * HR + r1 / 2 + u0) * HCc + c1 / 2) * 12;
+        flush_record_rows<2 * C::NV4, true>(row0, HCc * 12, rows_ok, recs < 2 * C::NV4 ? recs : 2 * C::NV4, slab, lane);
+        return;
+    }
     const int task0 = round * C::NT + wave * 64 + half * 32;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {

@@ -150,6 +150,34 @@ DT_HD void fwd1s_rows_compute(const Fwd1Params &p, const float *sLo, const float
     store_record(slab, hl, lh, hh);
 }
 
+// The 64 records a wavefront has staged are consecutive in tile order.  When the tile holds NVREC records per
+// row and NVREC divides 64 they are 64 / NVREC whole rows, each NVREC * 48 contiguous bytes of Yh, so the
+// address of 16-byte piece j is (row base, uniform per wavefront: scalar arithmetic) + 16 (j mod 3 NVREC):
+// a handful of vector instructions per piece instead of the ~20 of the general index algebra below (piece ->
+// record -> task -> (u, v) -> 64-bit address), which was a seventh of all vector instructions of k_fwd1.
+//   row0: first record of the wavefront's first row; row_stride: floats between record rows;
+//   rows_ok / recs_ok: rows / records per row of this wavefront that lie inside the image
+template <int NVREC, bool STREAM>
+DT_HD void flush_record_rows(float *row0, int row_stride, int rows_ok, int recs_ok, const f4 *slab, int lane) {
+    constexpr int PPR = 3 * NVREC;              // 16-byte pieces per record row
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int j = lane + 64 * k;
+        const int ul = j / PPR, off = j - ul * PPR;
+        if (ul < rows_ok && off < 3 * recs_ok) {
+            float *dst = row0 + ul * row_stride + 4 * off;
+            if (STREAM) DT_STREAM_STORE_F4(dst, slab[j]);
+            else *reinterpret_cast<f4 *>(dst) = slab[j];
+        }
+    }
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DT_WAVE_UNIFORM_I(x) __builtin_amdgcn_readfirstlane(x)
+#else
+#define DT_WAVE_UNIFORM_I(x) (x)
+#endif
+
 template <class C>
 DT_HD void fwd1s_rows_flush(const Fwd1Params &p, const float *stage, int tid, int base, int b, int r0,
                             int c0) {
@@ -157,6 +185,15 @@ DT_HD void fwd1s_rows_flush(const Fwd1Params &p, const float *stage, int tid, in
     const int HR = p.LR / 2, HCc = p.LC / 2;
     const int lane = tid & 63, wave = tid >> 6;
     const f4 *slab = reinterpret_cast<const f4 *>(stage + wave * STAGE_FLOATS_PER_WAVE);
+    if (64 % NV == 0 && (int64_t)p.B * HR * HCc * 12 < ((int64_t)1 << 31)) {       // whole record rows per wavefront
+        const int task0 = DT_WAVE_UNIFORM_I(base + wave * 64);
+        const int u0 = task0 / NV;                           // first record row of this wavefront in the tile
+        const int rows = (p.LR - r0) / 2 - u0, recs = (p.LC - c0) / 2;
+        const int rows_ok = rows < 64 / NV ? rows : 64 / NV, rows_tile = NU - u0;
+        float *row0 = p.Yh + (((int64_t)b * HR + r0 / 2 + u0) * HCc + c0 / 2) * 12;
+        flush_record_rows<NV, true>(row0, HCc * 12, rows_ok < rows_tile ? rows_ok : rows_tile, recs < NV ? recs : NV, slab, lane);
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         int j = lane + 64 * k;              // 16-byte piece of the wave's 64 records
@@ -288,17 +325,33 @@ DT_HD void fwd2s_rows_flush(const Fwd2Params &p, const float *stage, int tid, in
     const int HR = OR / 2, HCc = OC / 2;
     const int lane = tid & 63, wave = tid >> 6;
     const f4 *slab = reinterpret_cast<const f4 *>(stage + wave * STAGE_FLOATS_PER_WAVE);
+    if (64 % C::TJ == 0) {          // whole record rows per wavefront: see flush_record_rows
+        const int task0 = DT_WAVE_UNIFORM_I(base + wave * 64);
+        const int i0 = task0 / C::TJ;
+        const int rows = (OR - r0) / 2 - i0, recs = (OC - c0) / 2, rows_tile = C::TI - i0;
+        int rows_ok = rows < 64 / C::TJ ? rows : 64 / C::TJ;
+        if (rows_tile < rows_ok) rows_ok = rows_tile;
+        float *row0 = p.Yh + (((int64_t)b * HR + r0 / 2 + i0) * HCc + c0 / 2) * 12;
+        if (p.stream_records) flush_record_rows<C::TJ, true>(row0, HCc * 12, rows_ok, recs < C::TJ ? recs : C::TJ, slab, lane);
+        else flush_record_rows<C::TJ, false>(row0, HCc * 12, rows_ok, recs < C::TJ ? recs : C::TJ, slab, lane);
+        return;
+    }
+    // record rows of TJ records, 64 records of the wavefront spread over several of them: row and column of a
+    // record relative to the wavefront's first one, 32-bit offsets from a base that is uniform per wavefront
+    const int task0 = DT_WAVE_UNIFORM_I(base + wave * 64);
+    const int i0 = task0 / C::TJ, j0 = task0 - i0 * C::TJ;
+    const int rows = (OR - r0) / 2 - i0, recs = (OC - c0) / 2;
+    float *row0 = p.Yh + (((int64_t)b * HR + r0 / 2 + i0) * HCc + c0 / 2) * 12;
+    const int rstride = HCc * 12;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        int j = lane + 64 * k;
-        int rr = j / 3, part = j - 3 * rr;
-        int task = base + wave * 64 + rr;
-        int il = task / C::TJ, jl = task - il * C::TJ;
-        int R = r0 + 2 * il, Cc = c0 + 2 * jl;
-        if (task < C::TI * C::TJ && R < OR && Cc < OC) {
-            float *rec = p.Yh + (((int64_t)b * HR + R / 2) * HCc + Cc / 2) * 12;
-            if (p.stream_records) DT_STREAM_STORE_F4(reinterpret_cast<f4 *>(rec) + part, slab[j]);
-            else reinterpret_cast<f4 *>(rec)[part] = slab[j];
+        const int j = lane + 64 * k;
+        const int rr = j / 3, part = j - 3 * rr;
+        const int t = j0 + rr, il = t / C::TJ, jl = t - il * C::TJ;
+        if (task0 + rr < C::TI * C::TJ && il < rows && jl < recs) {
+            float *dst = row0 + il * rstride + jl * 12 + part * 4;
+            if (p.stream_records) DT_STREAM_STORE_F4(dst, slab[j]);
+            else *reinterpret_cast<f4 *>(dst) = slab[j];
         }
     }
 }
@@ -312,18 +365,23 @@ DT_HD void inv1d_rows(const Inv1Params &p, const float *y1, const float *y2, int
                       int c0, const float *y3 = nullptr) {
     constexpr int NQ = C::TC / 4;
     constexpr int WL = 4 + 2 * C::HE;
-    for (int task = tid; task < C::TR * NQ; task += DT_NT) {
-        int r = task / NQ, q = task - r * NQ;
-        int R = r0 + r, Cc = c0 + 4 * q;
-        if (R >= p.R || Cc >= p.C) continue;
-        float wa[WL], wb[WL];
-        const f2 *pa = reinterpret_cast<const f2 *>(y1 + r * C::NC + 4 * q);
-        const f2 *pb = reinterpret_cast<const f2 *>(y2 + r * C::NC + 4 * q);
+    static_assert(NQ <= 32 && WL % 4 == 0 && C::NC % 4 == 0 && C::TR % (DT_NT / 32) == 0, "row-pass task grid");
+    // 32 task slots to a row (NQ of them used): row and column group of a task are a shift and a mask of the
+    // thread index instead of a division by NQ = 30, 31, 27; the windows are read 16 bytes at a time
+    const int q = tid & 31;
 #pragma unroll
-        for (int j = 0; j < WL / 2; ++j) {
-            f2 a = pa[j], c = pb[j];
-            wa[2 * j] = a.x; wa[2 * j + 1] = a.y;
-            wb[2 * j] = c.x; wb[2 * j + 1] = c.y;
+    for (int round = 0; round < C::TR / (DT_NT / 32); ++round) {
+        const int r = (tid >> 5) + round * (DT_NT / 32);
+        int R = r0 + r, Cc = c0 + 4 * q;
+        if (q >= NQ || R >= p.R || Cc >= p.C) continue;
+        float wa[WL], wb[WL];
+        const f4 *pa = reinterpret_cast<const f4 *>(y1 + r * C::NC + 4 * q);
+        const f4 *pb = reinterpret_cast<const f4 *>(y2 + r * C::NC + 4 * q);
+#pragma unroll
+        for (int j = 0; j < WL / 4; ++j) {
+            f4 a = pa[j], c = pb[j];
+            wa[4 * j] = a.x; wa[4 * j + 1] = a.y; wa[4 * j + 2] = a.z; wa[4 * j + 3] = a.w;
+            wb[4 * j] = c.x; wb[4 * j + 1] = c.y; wb[4 * j + 2] = c.z; wb[4 * j + 3] = c.w;
         }
         float o[4];
 #pragma unroll
@@ -336,9 +394,9 @@ DT_HD void inv1d_rows(const Inv1Params &p, const float *y1, const float *y2, int
             o[e] = s;
         }
         if (C::BP) {
-            const f2 *pc = reinterpret_cast<const f2 *>(y3 + r * C::NC + 4 * q);
+            const f4 *pc = reinterpret_cast<const f4 *>(y3 + r * C::NC + 4 * q);
 #pragma unroll
-            for (int j = 0; j < WL / 2; ++j) { f2 a = pc[j]; wa[2 * j] = a.x; wa[2 * j + 1] = a.y; }
+            for (int j = 0; j < WL / 4; ++j) { f4 a = pc[j]; wa[4 * j] = a.x; wa[4 * j + 1] = a.y; wa[4 * j + 2] = a.z; wa[4 * j + 3] = a.w; }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float s = 0.f;
@@ -401,14 +459,40 @@ DT_HD void inv_rec_stage(const float *Yhb, int zr, int zc, float *srec, int ro, 
     const int hc = zc / 2;
     const bool interior = ro >= 0 && ro + 2 * QR <= zr && co >= 0 && co + 2 * QC <= zc;
     float px[NP], py[NP], pz[NP], pw[NP];       // scalar arrays: f4 arrays end up in scratch
+#ifdef DT_INV_STAGE_GENERIC                     /* A/B builds only: the general index algebra on every tile */
+    constexpr bool fast_rows = false;
+#else
+    constexpr bool fast_rows = true;
+#endif
+    if (interior && fast_rows) {
+        // interior tiles: a row of the window is 3 QC consecutive 16-byte pieces of Yh, so piece -> address is
+        // (row, offset in row) on a base that is uniform per workgroup -- the record / part / (uw, vw) / 64-bit
+        // index algebra of the general path below cost ~18 vector instructions per piece, 9 pieces per thread
+        constexpr int PPR = 3 * QC;
+        const float *base = Yhb + ((int64_t)(ro >> 1) * hc + (co >> 1)) * 12;       // ro, co are even
+        const int rstride = hc * 12;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            int piece = tid + k * DT_NT;
+            if (NP * DT_NT > NPIECE && piece >= NPIECE) piece = NPIECE - 1;
+            const int uw = piece / PPR, off = piece - uw * PPR;
+            const f4 *src = reinterpret_cast<const f4 *>(base + uw * rstride + 4 * off);
+            if (STREAM) {
+                const dt_v4f t = __builtin_nontemporal_load(reinterpret_cast<const dt_v4f *>(src));
+                px[k] = t.x; py[k] = t.y; pz[k] = t.z; pw[k] = t.w;
+            } else {
+                const dt_v4f t = *reinterpret_cast<const dt_v4f *>(src);     // vector-typed: stays ONE 16-byte load
+                px[k] = t.x; py[k] = t.y; pz[k] = t.z; pw[k] = t.w;
+            }
+        }
+    } else
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         int piece = tid + k * DT_NT;
         if (NP * DT_NT > NPIECE && piece >= NPIECE) piece = NPIECE - 1;      // clamp: no branch
         int rec = piece / 3, part = piece - 3 * rec;
         int uw = rec / QC, vw = rec - uw * QC;
-        int ur = ro + 2 * uw, vc = co + 2 * vw;
-        if (!interior) { ur = reflect_i(ur, zr); vc = reflect_i(vc, zc); }
+        int ur = reflect_i(ro + 2 * uw, zr), vc = reflect_i(co + 2 * vw, zc);
         const f4 *src = reinterpret_cast<const f4 *>(Yhb + ((int64_t)(ur >> 1) * hc + (vc >> 1)) * 12) + part;
         if (STREAM) {
             const dt_v4f t = __builtin_nontemporal_load(reinterpret_cast<const dt_v4f *>(src));

@@ -50,6 +50,7 @@ static Set sets[NSET], ref;
 static int N = 4096, REPS = 40, B = 1;
 static hipStream_t st;
 
+static size_t g_extra_lds = 0;
 template <class C, int SKIP = 0, int PERSIST = 0, int MW = 3>
 static void run_variant(const char *name, int xcd) {
     Fwd1Params q; Fwd2Params q2;
@@ -57,18 +58,18 @@ static void run_variant(const char *name, int xcd) {
     // correctness on set 0 against the two-launch reference
     fill_params(q, q2, sets[0], B, N); q2.xcd_order = xcd;
     CK(hipMemsetAsync(sets[0].L2, 0xff, px, st)); CK(hipMemsetAsync(sets[0].Y0, 0xff, px * 12, st)); CK(hipMemsetAsync(sets[0].Y1, 0xff, px * 3, st));
-    if (launch_fwd12<C, SKIP>(q, q2, st)) { printf("%-28s launch failed\n", name); return; }
+    if (launch_fwd12<C, SKIP>(q, q2, st, g_extra_lds)) { printf("%-28s launch failed\n", name); return; }
     CK(hipStreamSynchronize(st)); CK(hipGetLastError());
     double e0 = maxdiff(sets[0].Y0, ref.Y0, px * 3), e1 = maxdiff(sets[0].Y1, ref.Y1, px * 3 / 4), e2 = maxdiff(sets[0].L2, ref.L2, px / 4);
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    for (int i = 0; i < 8; ++i) { fill_params(q, q2, sets[i % NSET], B, N); q2.xcd_order = xcd; launch_fwd12<C, SKIP>(q, q2, st); }
+    for (int i = 0; i < 8; ++i) { fill_params(q, q2, sets[i % NSET], B, N); q2.xcd_order = xcd; launch_fwd12<C, SKIP>(q, q2, st, g_extra_lds); }
     CK(hipEventRecord(a, st));
-    for (int i = 0; i < REPS; ++i) { fill_params(q, q2, sets[i % NSET], B, N); q2.xcd_order = xcd; launch_fwd12<C, SKIP>(q, q2, st); }
+    for (int i = 0; i < REPS; ++i) { fill_params(q, q2, sets[i % NSET], B, N); q2.xcd_order = xcd; launch_fwd12<C, SKIP>(q, q2, st, g_extra_lds); }
     CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms, a, b));
     const double us = ms * 1e3 / REPS;
     if (SKIP) printf("skip=%2d ", SKIP);
-    if (PERSIST) printf("persistent %d/CU mw%d ", PERSIST, MW);
+    if (g_extra_lds) printf("extra LDS %zu KB ", g_extra_lds >> 10);
     printf("%-28s xcd=%d lds=%6zu B  %8.2f us  %6.2f TB/s(20 B/px)  err Yh0 %.2e Yh1 %.2e LoLo2 %.2e\n", name, xcd,
            (size_t)C::LDS_FLOATS * 4, us, 20.0 * px / us / 1e6, e0, e1, e2);
     fflush(stdout);
@@ -125,6 +126,13 @@ int main(int argc, char **argv) {
 #define K(S, ...) run_variant<Fwd12Cfg<__VA_ARGS__>, S>(#__VA_ARGS__, 1);
     V(16, 32, 8, 4, 5, 7, 10, 256)
     if (only) return 0;
+    // occupancy: 39 KB -> 4 workgroups per CU; + 14 KB -> 3; + 40 KB -> 2; + 100 KB -> 1
+    for (size_t extra : {(size_t)14 << 10, (size_t)40 << 10, (size_t)100 << 10}) {
+        g_extra_lds = extra;
+        run_variant<Fwd12Cfg<16, 32, 8, 4, 5, 7, 10, 256>>("16,32 occupancy", 1);
+        run_variant<Fwd12Cfg<16, 32, 8, 4, 5, 7, 10, 256>, 96>("16,32 occupancy", 1);
+    }
+    g_extra_lds = 0;
     V(32, 32, 8, 4, 5, 7, 10, 512)
     V(16, 64, 8, 4, 5, 7, 10, 512)
     V(8, 32, 8, 4, 5, 7, 10, 256)
