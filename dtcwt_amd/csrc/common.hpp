@@ -83,3 +83,9 @@ int dtcwt_g2_sum(dtcwt_hip_ctx *ctx, int dtype, int kind, const void *X0, const 
                  int64_t outer, int64_t n, int64_t inner, int crop, const double *lo_a,
                  const double *lo_b, const double *hi_a, const double *hi_b, int m_lo, int m_hi,
                  int packed_x1, double gain1);
+
+// would the fused 3-D level kernels take this level? (fused3d.hip; used by the whole-transform plan)
+bool dtcwt_fwd3_level1_ok(int64_t n0, int64_t n1, int64_t n2, int m0, int m1);
+bool dtcwt_fwd3_level2_ok(int64_t n0, int64_t n1, int64_t n2, int pad0, int pad1, int pad2, int m);
+bool dtcwt_inv3_level1_ok(int64_t n0, int64_t n1, int64_t n2, int m0, int m1);
+bool dtcwt_inv3_level2_ok(int64_t n0, int64_t n1, int64_t n2, int crop0, int m);

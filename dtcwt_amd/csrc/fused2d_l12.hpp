@@ -79,10 +79,11 @@ struct Fwd12Cfg {
 // A wave's ds_read_b128 is served in four groups of 16 lanes -- {0-3,12-15,20-27}, {4-11,16-19,28-31} and
 // the same again + 32 (MI355X_MICROARCH.md, LDS) -- conflict-free when the 16 lanes of a group read 256
 // consecutive bytes.  Tasks are dealt in row-major order, 16 (or 20, 32) to a row of the tile, so giving
-// lane l the task of index perm(l) makes every hardware group a run of 16 consecutive tasks.  MEASURED:
-// SQ_LDS_BANK_CONFLICT of this kernel is the same with and without the permutation (1.38e7 of 3.0e7 LDS
-// cycles, profiles/r02/pmc_fwd12_*.txt), and the same permutation left the 3-D level-1 kernel's 38 %
-// unchanged too, so the conflicts of these kernels are not where the documented grouping puts them; the
+// lane l the task of index perm(l) makes every hardware group a run of 16 consecutive tasks.  In isolation
+// (tools/kbench/lds_probe, profiles/r02/lds_probe.txt) such reads at row strides of 72-96 floats cost 3.38 ns
+// per wave-instruction in lane order and 1.82 ns -- the conflict-free rate -- permuted.  The kernel's time and
+// its SQ_LDS_BANK_CONFLICT count do not move (that counter also charges the 13-cycle transfer of every wide
+// ds_write: 5.7 ns per ds_write_b128 against 1.9 ns per ds_read_b128), LDS is not what bounds it; the
 // permutation is kept because it is free and the staged record order depends on it.
 DT_HD int lds128_perm(int tid) {
     const int l = tid & 31;

@@ -28,6 +28,8 @@
     X(16, 34, 2, 32)        /* qshift_32 */
 /* level >= 2 inverse: X(tile rows, tile cols (INPUT samples), j's per column-pass strip,
  * q-shift length); tile cols + window - 2 = 64 columns */
+/* measured and dropped (profiles/r02/ab_inv2_tiles.txt): 32 x 56 and 16 x 120 tiles (record window 1.43 x /
+ * 1.6 x the compulsory records instead of 1.71 x): level 2 unchanged at 32.5 us, levels 3-4 slower */
 #define DT_INV2_TABLE(X) \
     X(16, 56, 2, 10) \
     X(16, 52, 2, 14) \

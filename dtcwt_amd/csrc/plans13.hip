@@ -36,6 +36,7 @@ struct dtcwt_hip_plan3d {
     std::vector<double> qshift[8];    // h0a h0b g0a g0b h1a h1b g1a g1b
     std::vector<float *> work;        // lowpass of level l (l < nlevels - 1), also the inverse's intermediate
     float *tmp[2] = {nullptr, nullptr};   // highpass-free level 1 (discard_level_1 / Yh[0] == NULL): axis passes
+    bool fwd_ok = false, inv_ok = false;  // every level of that direction has a fused level kernel
 };
 
 struct dtcwt_hip_plan1d {
@@ -86,6 +87,19 @@ int dtcwt_hip_plan3d_create(dtcwt_hip_ctx *ctx, int64_t n0, int64_t n1, int64_t 
             L.lo[a] = ext / 2; L.hi[a] = ext / 4;
         }
         p->lv.push_back(L);
+    }
+    // which directions run natively at every level (the conditions of the level entry points, fused3d.hip)
+    const int mq = qshift_len[0];
+    p->fwd_ok = dtcwt_fwd3_level1_ok(n0, n1, n2, biort_len[0], biort_len[2]);
+    p->inv_ok = dtcwt_inv3_level1_ok(n0, n1, n2, biort_len[1], biort_len[3]);
+    for (int l = 1; l < nlevels; ++l) {
+        const Lv3 &L = p->lv[l];
+        p->fwd_ok = p->fwd_ok && dtcwt_fwd3_level2_ok(L.in[0], L.in[1], L.in[2], L.pad[0], L.pad[1], L.pad[2], mq);
+        p->inv_ok = p->inv_ok && dtcwt_inv3_level2_ok(L.lo[0], L.lo[1], L.lo[2], L.pad[0], mq);
+    }
+    if (!p->fwd_ok && !p->inv_ok) {
+        delete p;
+        return dtcwt_set_error(-3, "some level of this volume has no fused 3-D level kernel in either direction");
     }
     p->work.assign(nlevels, nullptr);
     for (int l = 0; l < nlevels; ++l) {
@@ -147,6 +161,7 @@ static int lowpass_only_level1(dtcwt_hip_plan3d *p, const float *X, float *Y, co
 int dtcwt_hip_plan3d_forward(dtcwt_hip_plan3d *p, const float *X, float *Yl, void *const *Yh, float *const *Ys,
                              int discard_level_1) {
     DT_REQUIRE(p && X && Yl && Yh, "NULL argument");
+    if (!p->fwd_ok) return dtcwt_set_error(-3, "a level of the forward transform has no fused kernel for this volume");
     const int nl = p->nlevels;
     const float *in = X;
     for (int l = 0; l < nl; ++l) {
@@ -185,6 +200,7 @@ int dtcwt_hip_plan3d_forward(dtcwt_hip_plan3d *p, const float *X, float *Yl, voi
 // volume comes back with axes 0 and 2 exchanged (non-cubic volumes raise in the reference; here: error).
 int dtcwt_hip_plan3d_inverse(dtcwt_hip_plan3d *p, const float *Yl, const void *const *Yh, float *Z, int quirks) {
     DT_REQUIRE(p && Yl && Yh && Z, "NULL argument");
+    if (!p->inv_ok) return dtcwt_set_error(-3, "a level of the inverse transform has no fused kernel for this volume");
     const int nl = p->nlevels;
     const float *in = Yl;
     for (int l = nl - 1; l >= 0; --l) {

@@ -200,6 +200,110 @@ __global__ void __launch_bounds__(256) k_broadcast_rows(int64_t n, int K, const 
     if (id < n * K) out[id] = row[id % K];
 }
 
+// ---- fused steps of the refinement loop of estimatereg ------------------------------------------------
+// One launch for `warphighpass(Yh_src[l], avecs, 'bilinear')` (registration.py:397-415 over sampling.py:
+// 192-278): velocity field of the affine parameters at their own grid (k_affine_velocity) -> bilinear rescale of
+// vx and vy to the level (k_rescale<double>) -> sample positions (k_warp_coords) -> phase unroll of the subbands
+// at the integer grid (k_phase_roll_tab) -> bilinear sample at the positions (k_sample<T>) -> phase re-roll at the
+// positions (k_phase_roll<T, false>), each of which used to be a launch of its own on arrays of a few thousand
+// elements.  Same arithmetic, same association and the same rounding to T between the steps.
+__device__ inline int refl_near(int64_t u, int n) { return (int)dt_reflect(u, n); }
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_warp_level(const T *__restrict__ Yh, int H, int W, const double *__restrict__ av,
+                                                    int rh, int rw, T *__restrict__ out) {
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (int64_t)H * W * 6) return;
+    const int64_t p = id / 6;
+    const int ch = (int)(id - p * 6);
+    const int py = (int)(p / W), px = (int)(p - (int64_t)py * W);
+    const double W0 = -3 * 3.14159265358979323846 / 2.15, W1 = -3.14159265358979323846 / 2.15;
+    const double tdx[6] = {W1, W0, W0, W0, W0, W1}, tdy[6] = {W0, W0, W1, -W1, -W0, -W0};   // sampling.py:26-33
+    // velocity at this pixel: (vx, vy) of the reg grid, bilinear (dtcwt_hip_rescale, float64)
+    double vxs, vys;
+    {
+        const double x = ((double)rw / (double)W) * ((double)px + 0.5) - 0.5;
+        const double y = ((double)rh / (double)H) * ((double)py + 0.5) - 0.5;
+        const double fx0 = floor(x), fy0 = floor(y);
+        const double wx1 = x - fx0, wx0 = 1.0 - wx1, wy1 = y - fy0, wy0 = 1.0 - wy1;
+        const int xa = refl_near((int64_t)fx0, rw), xb = refl_near((int64_t)fx0 + 1, rw);
+        const int ya = refl_near((int64_t)fy0, rh), yb = refl_near((int64_t)fy0 + 1, rh);
+        double v[2][2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int yy = j ? yb : ya, xx = i ? xb : xa;
+                const double pxn = (double)((float)xx / (float)rw), pyn = (double)((float)yy / (float)rh);
+                const double *a = av + ((int64_t)yy * rw + xx) * 6;
+                v[j][i][0] = a[0] + a[2] * pxn + a[4] * pyn;
+                v[j][i][1] = a[1] + a[3] * pxn + a[5] * pyn;
+            }
+        vxs = wy0 * (wx0 * v[0][0][0] + wx1 * v[0][1][0]) + wy1 * (wx0 * v[1][0][0] + wx1 * v[1][1][0]);
+        vys = wy0 * (wx0 * v[0][0][1] + wx1 * v[0][1][1]) + wy1 * (wx0 * v[1][0][1] + wx1 * v[1][1][1]);
+    }
+    const double xs = ((double)((float)px / (float)W) + vxs) * W;
+    const double ys = ((double)((float)py / (float)H) + vys) * H;
+    // bilinear sample of the unrolled subband at (xs, ys); the reference's association: x first, then y
+    const double fx0 = floor(xs), fy0 = floor(ys);
+    const T fx = (T)(xs - fx0), fy = (T)(ys - fy0);
+    const int xi[2] = {refl_near((int64_t)fx0, W), refl_near((int64_t)fx0 + 1, W)};
+    const int yi[2] = {refl_near((int64_t)fy0, H), refl_near((int64_t)fy0 + 1, H)};
+    T ur[2][2], ui[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const T *q = Yh + (((int64_t)yi[j] * W + xi[i]) * 6 + ch) * 2;
+            double sn, cs;
+            sincos(-(tdx[ch] * (double)xi[i] + tdy[ch] * (double)yi[j]), &sn, &cs);
+            ur[j][i] = (T)((double)q[0] * cs - (double)q[1] * sn);
+            ui[j][i] = (T)((double)q[0] * sn + (double)q[1] * cs);
+        }
+    const T lr = ((T)1 - fx) * ur[0][0] + fx * ur[0][1], hr = ((T)1 - fx) * ur[1][0] + fx * ur[1][1];
+    const T li = ((T)1 - fx) * ui[0][0] + fx * ui[0][1], hi = ((T)1 - fx) * ui[1][0] + fx * ui[1][1];
+    const T sr = ((T)1 - fy) * lr + fy * hr, si = ((T)1 - fy) * li + fy * hi;
+    double sn, cs;
+    sincos(tdx[ch] * xs + tdy[ch] * ys, &sn, &cs);
+    out[id * 2] = (T)((double)sr * cs - (double)si * sn);
+    out[id * 2 + 1] = (T)((double)sr * sn + (double)si * cs);
+}
+
+// One launch for `_boxfilter(qtilde, 3)` (registration.py:417-446) -> bilinear rescale onto the reg grid
+// (sampling.py:131-165) -> accumulation over the levels of a group (:362-368):
+//   acc[r][c] (+)= rescale(boxfilter(q))[r][c],   q: [H][W][27], acc: [rh][rw][27], float64
+__global__ void __launch_bounds__(256) k_box_rescale_acc(const double *__restrict__ q, int H, int W, int rh, int rw,
+                                                         int accumulate, double *__restrict__ acc) {
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (int64_t)rh * rw * 27) return;
+    const int c = (int)(id % 27);
+    const int64_t r = id / 27;
+    const int ry = (int)(r / rw), rx = (int)(r - (int64_t)ry * rw);
+    const double x = ((double)W / (double)rw) * ((double)rx + 0.5) - 0.5;
+    const double y = ((double)H / (double)rh) * ((double)ry + 0.5) - 0.5;
+    const double fx0 = floor(x), fy0 = floor(y);
+    const double wx1 = x - fx0, wx0 = 1.0 - wx1, wy1 = y - fy0, wy0 = 1.0 - wy1;
+    const int xt[2] = {refl_near((int64_t)fx0, W), refl_near((int64_t)fx0 + 1, W)};
+    const int yt[2] = {refl_near((int64_t)fy0, H), refl_near((int64_t)fy0 + 1, H)};
+    const double inv = 1.0 / 3.0;
+    double b[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            double s = 0.0;
+            for (int dy = -1; dy <= 1; ++dy) {
+                const double *row = q + (int64_t)refl_i(yt[j] + dy, H) * W * 27 + c;
+                double t = 0.0;
+                for (int dx = -1; dx <= 1; ++dx) t += row[(int64_t)refl_i(xt[i] + dx, W) * 27];
+                s += t * inv;
+            }
+            b[j][i] = s * inv;
+        }
+    const double v = wy0 * (wx0 * b[0][0] + wx1 * b[0][1]) + wy1 * (wx0 * b[1][0] + wx1 * b[1][1]);
+    acc[id] = accumulate ? acc[id] + v : v;
+}
+
 inline unsigned blocks_for(int64_t total) { return (unsigned)((total + 255) / 256); }
 
 // pooled scratch buffers of one estimatereg call, released (stream-ordered) on every exit path
@@ -323,9 +427,6 @@ int dtcwt_hip_fill_rows(dtcwt_hip_ctx *ctx, int64_t n, int K, const double *row,
 static int estimatereg_issue(dtcwt_hip_ctx *ctx, Scratch &sc, int dtype, int nlevels, const void *const *Yh_src,
                              const void *const *Yh_ref, const int64_t *shapes, int64_t reg_h, int64_t reg_w,
                              int ngroups, const int *group_sizes, const int *group_levels, double *avecs) {
-    const double W0 = -3 * 3.14159265358979323846 / 2.15, W1 = -3.14159265358979323846 / 2.15;
-    const double tdx[6] = {W1, W0, W0, W0, W0, W1}, tdy[6] = {W0, W0, W1, -W1, -W0, -W0};   // sampling.py:26-33
-    const int ident[6] = {0, 1, 2, 3, 4, 5};
     const size_t esz = dtype == DTCWT_HIP_F32 ? sizeof(float) : sizeof(double);
     const int64_t nreg = reg_h * reg_w;
 
@@ -348,32 +449,30 @@ static int estimatereg_issue(dtcwt_hip_ctx *ctx, Scratch &sc, int dtype, int nle
     DT_LAUNCH_CHECK();
     lv += group_sizes[0];
 
-    double *vx = sc.get<double>(nreg), *vy = sc.get<double>(nreg);
-    double *qts = sc.get<double>(nreg * 27), *qr = sc.get<double>(nreg * 27), *da = sc.get<double>(nreg * 6);
-    DT_REQUIRE(vx && vy && qts && qr && da, "out of device memory");
+    double *qts = sc.get<double>(nreg * 27), *da = sc.get<double>(nreg * 6);
+    DT_REQUIRE(qts && da, "out of device memory");
     for (int g = 1; g < ngroups; lv += group_sizes[g], ++g) {
         if (group_sizes[g] < 1) continue;
         for (int k = 0; k < group_sizes[g]; ++k) {
             const int l = lv[k];
             const int64_t H = shapes[2 * l], W = shapes[2 * l + 1], n = H * W;
-            double *vxs = sc.get<double>(n), *vys = sc.get<double>(n), *xs = sc.get<double>(n), *ys = sc.get<double>(n);
-            void *un = sc.get<char>(n * 12 * esz), *smp = sc.get<char>(n * 12 * esz), *wrp = sc.get<char>(n * 12 * esz);
-            double *q = sc.get<double>(n * 27), *qb = sc.get<double>(n * 27);
-            DT_REQUIRE(vxs && vys && xs && ys && un && smp && wrp && q && qb, "out of device memory");
-            // warphighpass(Yh_src[l], avecs, 'bilinear')   (:397-408)
-            DT_TRY(dtcwt_hip_affine_velocity(ctx, avecs, reg_h, reg_w, vx, vy));
-            DT_TRY(dtcwt_hip_rescale(ctx, DTCWT_HIP_F64, vx, reg_h, reg_w, 1, H, W, DTCWT_HIP_SAMPLE_BILINEAR, vxs));
-            DT_TRY(dtcwt_hip_rescale(ctx, DTCWT_HIP_F64, vy, reg_h, reg_w, 1, H, W, DTCWT_HIP_SAMPLE_BILINEAR, vys));
-            DT_TRY(dtcwt_hip_warp_coords(ctx, vxs, vys, H, W, xs, ys));
-            DT_TRY(dtcwt_hip_phase_roll_grid(ctx, dtype, Yh_src[l], H, W, 6, 6, ident, tdx, tdy, 1.0, 1.0, -1.0, un));
-            DT_TRY(dtcwt_hip_sample(ctx, dtype, un, H, W, 12, xs, ys, n, DTCWT_HIP_SAMPLE_BILINEAR, smp));
-            DT_TRY(dtcwt_hip_phase_roll_points(ctx, dtype, smp, n, 6, 6, ident, tdx, tdy, xs, ys, 1.0, wrp));
+            void *wrp = sc.get<char>(n * 12 * esz);
+            double *q = sc.get<double>(n * 27);
+            DT_REQUIRE(wrp && q, "out of device memory");
+            DT_REQUIRE(n * 27 < ((int64_t)1 << 31), "level too large");
+            // warphighpass(Yh_src[l], avecs, 'bilinear')   (:397-408), one launch
+            if (dtype == DTCWT_HIP_F32)
+                k_warp_level<float><<<blocks_for(n * 6), 256, 0, ctx->stream>>>((const float *)Yh_src[l], (int)H, (int)W, avecs,
+                                                                              (int)reg_h, (int)reg_w, (float *)wrp);
+            else
+                k_warp_level<double><<<blocks_for(n * 6), 256, 0, ctx->stream>>>((const double *)Yh_src[l], (int)H, (int)W, avecs,
+                                                                               (int)reg_h, (int)reg_w, (double *)wrp);
+            DT_LAUNCH_CHECK();
             // Q-tilde of the warped level, box filtered and resampled onto the block grid (:362-368)
             DT_TRY(dtcwt_hip_qtilde(ctx, dtype, wrp, Yh_ref[l], H, W, 1e-6, q));
-            DT_TRY(dtcwt_hip_boxfilter(ctx, q, H, W, 27, 3, qb));
-            DT_TRY(dtcwt_hip_rescale(ctx, DTCWT_HIP_F64, qb, H, W, 27, reg_h, reg_w, DTCWT_HIP_SAMPLE_BILINEAR,
-                                     k == 0 ? qts : qr));
-            if (k > 0) DT_TRY(dtcwt_hip_axpy(ctx, nreg * 27, 1.0, qr, qts));
+            k_box_rescale_acc<<<blocks_for(nreg * 27), 256, 0, ctx->stream>>>(q, (int)H, (int)W, (int)reg_h, (int)reg_w,
+                                                                               k > 0, qts);
+            DT_LAUNCH_CHECK();
         }
         DT_TRY(dtcwt_hip_solve6(ctx, qts, nreg, da));
         DT_TRY(dtcwt_hip_axpy(ctx, nreg * 6, 1.0, da, avecs));
