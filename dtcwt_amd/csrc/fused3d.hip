@@ -43,10 +43,11 @@ __global__ void __launch_bounds__(C::NT, 2) k_fwd3_l1(Fwd3L1Params p) {
         f3l1_rotate<C>(st);
         float od[8][4];
         f3l1_axis1<C>(p, od, S1, tid, i + 1, j0, k0);
-        f3l1_pack_stage<C>(st.ev, od, stage, tid, 0);
-        f3l1_pack_flush<C>(p, stage, tid, 0, i + 1, j0, k0);
-        f3l1_pack_stage<C>(st.ev, od, stage, tid, 1);
-        f3l1_pack_flush<C>(p, stage, tid, 1, i + 1, j0, k0);
+#pragma unroll
+        for (int pass = 0; pass < C::SP; ++pass) {
+            f3l1_pack_stage<C>(st.ev, od, stage, tid, pass);
+            f3l1_pack_flush<C>(p, stage, tid, pass, i + 1, j0, k0);
+        }
     }
 }
 

@@ -72,7 +72,15 @@ struct Fwd3L1Cfg {
     static constexpr int NPOS = PJ * PK;
     static constexpr int NPT = (NPOS + NT - 1) / NT;      // ring positions per thread
     static constexpr int S0F = 2 * PJ * S0S, S1F = 4 * PJ * TK;
-    static constexpr int STAGE_W = 32 * REC_LDS;          // floats: 32 records per wavefront
+#ifndef DT_F3L1_STAGE_PASSES
+#define DT_F3L1_STAGE_PASSES 2
+#endif
+    // the records of a wavefront's 64 cells leave through its slab in SP passes of 64 / SP records: 2 passes need
+    // 30 KB of slabs per workgroup (66 KB of LDS in all: two workgroups per CU), 4 passes 15 KB (51 KB: three) --
+    // but the kernel needs ~250 VGPRs (register rings of 7 slices x 6 positions + 8 x 4 octant cells), i.e. two
+    // waves per SIMD whatever the LDS says: at the 168-register cap of three it spills 84-194 VGPRs.  So 2.
+    static constexpr int SP = DT_F3L1_STAGE_PASSES, SREC = 64 / SP;
+    static constexpr int STAGE_W = SREC * REC_LDS;        // floats: SREC records per wavefront
     static constexpr int LDS_FLOATS = S0F + S1F + (NT / 64) * STAGE_W;
     static constexpr int NT2 = 2 * PJ * (TK / 4);         // axis-2 tasks (4 outputs each)
     static constexpr int WK = 4 + 2 * H;                  // axis-2 window (<= 12)
@@ -245,10 +253,10 @@ DT_HD void f3l1_axis1(const Fwd3L1Params &p, float (&out)[8][4], const float *S1
 // passes; on the device they are called back to back (LDS operations of one wavefront
 // execute in order, no barrier needed).
 template <class C>
-DT_HD void f3l1_pack_stage(const float (&ev)[8][4], const float (&od)[8][4], float *stage, int tid, int half) {
+DT_HD void f3l1_pack_stage(const float (&ev)[8][4], const float (&od)[8][4], float *stage, int tid, int pass) {
     const int lane = tid & 63, wave = tid >> 6;
-    if ((lane >> 5) != half) return;
-    float *rec = stage + wave * C::STAGE_W + (lane & 31) * REC_LDS;
+    if (lane / C::SREC != pass) return;
+    float *rec = stage + wave * C::STAGE_W + (lane % C::SREC) * REC_LDS;
     // record slots in the reference's concatenation order (transform3d.py:278-289):
     // (a0,a1,a2) = 010, 100, 110, 001, 011, 101, 111
     cube2c_record(rec + 0, ev[2], od[2]);
@@ -260,18 +268,22 @@ DT_HD void f3l1_pack_stage(const float (&ev)[8][4], const float (&od)[8][4], flo
     cube2c_record(rec + 48, ev[7], od[7]);
 }
 
+// pass: which SREC consecutive cells of the wavefront's 64 (two rows of 32) are in the slab
 template <class C>
-DT_HD void f3l1_pack_flush(const Fwd3L1Params &p, const float *stage, int tid, int half, int i, int j0,
+DT_HD void f3l1_pack_flush(const Fwd3L1Params &p, const float *stage, int tid, int pass, int i, int j0,
                            int k0) {
     const int lane = tid & 63, wave = tid >> 6;
-    const int j = j0 + 2 * (2 * wave + half);            // the half wavefront's cell row
+    const int cell0 = pass * C::SREC;                    // first cell of the pass within the wavefront
+    const int half = cell0 >> 5, c0 = cell0 & 31;        // its cell row (half wavefront) and first cell in the row
+    const int j = j0 + 2 * (2 * wave + half);
     if (j >= p.n1) return;
     const f4 *slab = reinterpret_cast<const f4 *>(stage + wave * C::STAGE_W);
-    f4 *row = reinterpret_cast<f4 *>(p.Yh + (((int64_t)(i >> 1) * (p.n1 / 2) + (j >> 1)) * (p.n2 / 2) + (k0 >> 1)) * 56);
-    const int ncell = (p.n2 - k0) / 2 < 32 ? (p.n2 - k0) / 2 : 32;
+    f4 *row = reinterpret_cast<f4 *>(p.Yh + (((int64_t)(i >> 1) * (p.n1 / 2) + (j >> 1)) * (p.n2 / 2) + (k0 >> 1) + c0) * 56);
+    int ncell = (p.n2 - k0) / 2 - c0;
+    if (ncell > C::SREC) ncell = C::SREC;
 #pragma unroll
-    for (int it = 0; it < 7; ++it) {
-        int piece = it * 64 + lane;                      // 16-byte piece of the row's 32 records
+    for (int it = 0; it < (C::SREC * 14 + 63) / 64; ++it) {
+        int piece = it * 64 + lane;                      // 16-byte piece of the pass's records
         if (piece < ncell * 14) DT_STREAM_STORE_F4(row + piece, slab[slab_f4(piece)]);
     }
 }

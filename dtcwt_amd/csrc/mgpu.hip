@@ -155,6 +155,9 @@ int broadcast_taps(dtcwt_hip_mgpu *m, const std::vector<double> &flat, std::vect
     }
     const int nr = (int)devs.size();
     std::vector<ncclComm_t> comms(nr);
+    int caller_device = 0;                  // this function walks the devices: put the caller's back at the end
+    (void)hipGetDevice(&caller_device);
+    struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{caller_device};
     ncclResult_t r = R.CommInitAll(comms.data(), nr, devs.data());
     if (r != 0) return dtcwt_set_error(-2, "ncclCommInitAll failed: %s", R.GetErrorString ? R.GetErrorString(r) : "?");
     std::vector<double *> buf(nr, nullptr);

@@ -175,9 +175,9 @@ static int run_fwd3_l1(dt3d::Fwd3L1Params p, int chunk) {
                     for (int t = 0; t < C::NT; ++t) f3l1_axis0<C>(p, st[t], S0, i + 1, i + 2 < iend);
                     for (int t = 0; t < C::NT; ++t) f3l1_axis2<C>(p, S0, S1, t);
                     for (int t = 0; t < C::NT; ++t) { f3l1_rotate<C>(st[t]); f3l1_axis1<C>(p, od[t], S1, t, i + 1, j0, k0); }
-                    for (int half = 0; half < 2; ++half) {
-                        for (int t = 0; t < C::NT; ++t) f3l1_pack_stage<C>(st[t].ev, od[t], stage, t, half);
-                        for (int t = 0; t < C::NT; ++t) f3l1_pack_flush<C>(p, stage, t, half, i + 1, j0, k0);
+                    for (int pass = 0; pass < C::SP; ++pass) {
+                        for (int t = 0; t < C::NT; ++t) f3l1_pack_stage<C>(st[t].ev, od[t], stage, t, pass);
+                        for (int t = 0; t < C::NT; ++t) f3l1_pack_flush<C>(p, stage, t, pass, i + 1, j0, k0);
                     }
                 }
             }
