@@ -47,12 +47,18 @@ DT_HD void fwd1d_cols(const Fwd1Params &p, float *sLo, float *sHi, int tid, int 
                       float *sBa = nullptr) {
     const float *Xb = p.X + (int64_t)b * p.inR * p.inC;
     const int ro = r0 - C::HH, co = c0 - C::HC;
-    const bool interior = ro >= 0 && ro + C::TR + 2 * C::HH <= p.inR && co >= 0 && co + C::W <= p.inC;
+    const bool rows_in = ro >= 0 && ro + C::TR + 2 * C::HH <= p.inR;
+    const bool interior = rows_in && co >= 0 && co + C::W <= p.inC;
     for (int task = tid; task < C::NS * C::W; task += DT_NT) {
         int strip = task / C::W, cc = task - strip * C::W;
         float w[C::WN];
         if (interior) {
             const float *src = Xb + (int64_t)(ro + strip * C::RS) * p.inC + (co + cc);
+#pragma unroll
+            for (int j = 0; j < C::WN; ++j) w[j] = src[(int64_t)j * p.inC];
+        } else if (rows_in) {       // left / right edge tiles: the column is reflected once, the rows run straight
+            int gc = reflect_i(co + cc, p.LC); if (gc > p.inC - 1) gc = p.inC - 1;
+            const float *src = Xb + (int64_t)(ro + strip * C::RS) * p.inC + gc;
 #pragma unroll
             for (int j = 0; j < C::WN; ++j) w[j] = src[(int64_t)j * p.inC];
         } else {
@@ -232,14 +238,19 @@ DT_HD void fwd2d_cols(const Fwd2Params &p, float *sLo, float *sHi, int tid, int 
     const float *Xb = p.X + (int64_t)b * p.inR * p.inC;
     const int ro = 2 * r0 - C::M + 2, co = 2 * c0 - C::M + 2;      // logical origin of the window
     const int NRI = 2 * C::TR + 2 * C::M - 4;
-    const bool interior = ro - p.padR >= 0 && ro + NRI - p.padR <= p.inR &&
-                          co - p.padC >= 0 && co + C::NCI - p.padC <= p.inC;
+    const bool rows_in = ro - p.padR >= 0 && ro + NRI - p.padR <= p.inR;
+    const bool interior = rows_in && co - p.padC >= 0 && co + C::NCI - p.padC <= p.inC;
     for (int task = tid; task < C::NS * C::NCI; task += DT_NT) {
         int strip = task / C::NCI, cc = task - strip * C::NCI;
         float w[C::WN];
         const int rs = ro + 4 * C::PS * strip;
         if (interior) {
             const float *src = Xb + (int64_t)(rs - p.padR) * p.inC + (co + cc - p.padC);
+#pragma unroll
+            for (int j = 0; j < C::WN; ++j) w[j] = src[(int64_t)j * p.inC];
+        } else if (rows_in) {       // left / right edge tiles: the column is reflected once, the rows run straight
+            const int gc = clamp_i(reflect_i(co + cc, p.LC) - p.padC, 0, p.inC - 1);
+            const float *src = Xb + (int64_t)(rs - p.padR) * p.inC + gc;
 #pragma unroll
             for (int j = 0; j < C::WN; ++j) w[j] = src[(int64_t)j * p.inC];
         } else {
@@ -485,6 +496,22 @@ DT_HD void inv_rec_stage(const float *Yhb, int zr, int zc, float *srec, int ro, 
                 px[k] = t.x; py[k] = t.y; pz[k] = t.z; pw[k] = t.w;
             }
         }
+    } else if (ro >= 0 && ro + 2 * QR <= zr && fast_rows) {
+        // left / right edge tiles: rows run straight, only the record column is reflected
+        constexpr int PPR = 3 * QC;
+        const float *base = Yhb + (int64_t)(ro >> 1) * hc * 12;
+        const int rstride = hc * 12;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            int piece = tid + k * DT_NT;
+            if (NP * DT_NT > NPIECE && piece >= NPIECE) piece = NPIECE - 1;
+            const int uw = piece / PPR, off = piece - uw * PPR;
+            const int vw = off / 3, part = off - 3 * vw;
+            const int vc = reflect_i(co + 2 * vw, zc);
+            const f4 *src = reinterpret_cast<const f4 *>(base + uw * rstride + (vc >> 1) * 12 + 4 * part);
+            const dt_v4f t = *reinterpret_cast<const dt_v4f *>(src);
+            px[k] = t.x; py[k] = t.y; pz[k] = t.z; pw[k] = t.w;
+        }
     } else
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
@@ -578,10 +605,15 @@ DT_HD void inv1r_fetch_from(const Inv1Params &p, const float *Z, float (&w0)[C::
     if (!t.valid) return;
     const float *Zb = Z + (int64_t)b * p.R * p.C;
     const int ro = r0 - C::HE, co = c0 - C::HE;
-    const bool interior = ro >= 0 && ro + C::NR <= p.R && co >= 0 && co + C::NC <= p.C;
+    const bool rows_in = ro >= 0 && ro + C::NR <= p.R;
+    const bool interior = rows_in && co >= 0 && co + C::NC <= p.C;
     const int cc = 2 * t.i + t.e;
     if (interior) {
         const float *src = Zb + (int64_t)(ro + t.strip * C::RS) * p.C + (co + cc);
+#pragma unroll
+        for (int j = 0; j < C::WN; ++j) w0[j] = src[(int64_t)j * p.C];
+    } else if (rows_in) {           // left / right edge tiles: the column is reflected once, the rows run straight
+        const float *src = Zb + (int64_t)(ro + t.strip * C::RS) * p.C + reflect_i(co + cc, p.C);
 #pragma unroll
         for (int j = 0; j < C::WN; ++j) w0[j] = src[(int64_t)j * p.C];
     } else {
@@ -699,10 +731,15 @@ DT_HD void inv2r_fetch_from(const Inv2Params &p, const float *Z, float (&w0)[C::
     if (!t.valid) return;
     const float *Zb = Z + (int64_t)b * p.zr * p.zc;
     const int ro = r0 + C::ORG, co = c0 + C::ORG;
-    const bool interior = ro >= 0 && ro + C::NR <= p.zr && co >= 0 && co + C::NC <= p.zc;
+    const bool rows_in = ro >= 0 && ro + C::NR <= p.zr;
+    const bool interior = rows_in && co >= 0 && co + C::NC <= p.zc;
     const int cc = 2 * t.i + t.e, rs = C::RS * t.strip;
     if (interior) {
         const float *src = Zb + (int64_t)(ro + rs) * p.zc + (co + cc);
+#pragma unroll
+        for (int j = 0; j < C::WS; ++j) w0[j] = src[(int64_t)j * p.zc];
+    } else if (rows_in) {           // left / right edge tiles: the column is reflected once, the rows run straight
+        const float *src = Zb + (int64_t)(ro + rs) * p.zc + reflect_i(co + cc, p.zc);
 #pragma unroll
         for (int j = 0; j < C::WS; ++j) w0[j] = src[(int64_t)j * p.zc];
     } else {
