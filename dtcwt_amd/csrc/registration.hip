@@ -31,19 +31,23 @@ __device__ inline c2 ld(const T *__restrict__ Yh, int W, int y, int x, int sb) {
 // registration.py:29
 __constant__ double c_shift[6][2] = {{-1, -3}, {-3, -3}, {-3, -1}, {-3, 1}, {-3, 3}, {-1, 3}};
 
-// One pixel of one level of `qtildematrices` (registration.py:166-212):
+// One level of `qtildematrices` (registration.py:166-212):
 //   out[y][x][0..26] = sum over the six subbands of C^2 * (t_r t_c over triu(6x6), then t_r t_6)
+// One thread per (pixel, subband): a subband's confidence and phase gradients are a chain of float64 hypot /
+// atan2 / sincos calls, and with one thread doing the six subbands of a pixel in turn the kernel took 15-21 us
+// whatever the level size (half of estimatereg).  The six contributions of a pixel meet in LDS and are summed
+// in subband order, i.e. exactly as the serial loop accumulated them.
+constexpr int QT_PIX = 32;                 // pixels per workgroup (x 6 subbands = 192 threads)
+
 template <typename T>
-__global__ void __launch_bounds__(256) k_qtilde(const T *__restrict__ A, const T *__restrict__ B, int H, int W,
-                                                double eps, double *__restrict__ out) {
-    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (id >= (int64_t)H * W) return;
-    const int y = (int)(id / W), x = (int)(id - (int64_t)y * W);
-    const double xs = x * (1.0 / W), ys = y * (1.0 / H);          // np.arange(0, 1, 1/W)  (:168-169)
-    double q[27];
-#pragma unroll
-    for (int e = 0; e < 27; ++e) q[e] = 0.0;
-    for (int sb = 0; sb < 6; ++sb) {
+__global__ void __launch_bounds__(QT_PIX * 6) k_qtilde(const T *__restrict__ A, const T *__restrict__ B, int H, int W,
+                                                       double eps, double *__restrict__ out) {
+    __shared__ double part[QT_PIX][6][27];
+    const int pl = threadIdx.x / 6, sb = threadIdx.x - 6 * pl;
+    const int64_t id = (int64_t)blockIdx.x * QT_PIX + pl;
+    if (id < (int64_t)H * W) {
+        const int y = (int)(id / W), x = (int)(id - (int64_t)y * W);
+        const double xs = x * (1.0 / W), ys = y * (1.0 / H);          // np.arange(0, 1, 1/W)  (:168-169)
         const double wx = c_shift[sb][0] * (3.14159265358979323846 / 2.15);
         const double wy = c_shift[sb][1] * (3.14159265358979323846 / 2.15);
         // confidence (:83-137): the four diagonal neighbours, edges replicated
@@ -87,17 +91,25 @@ __global__ void __launch_bounds__(256) k_qtilde(const T *__restrict__ A, const T
         const double dt = ang(mulconj(b0, a0));                     // angle(b conj a)
         const double t[7] = {dx, dy, xs * dx, xs * dy, ys * dx, ys * dy, -dt};
         const double c2w = C * C;
+        double *q = part[pl][sb];
         int e = 0;
 #pragma unroll
         for (int r = 0; r < 6; ++r)
 #pragma unroll
-            for (int c = r; c < 6; ++c) q[e++] += c2w * (t[r] * t[c]);
+            for (int c = r; c < 6; ++c) q[e++] = c2w * (t[r] * t[c]);
 #pragma unroll
-        for (int r = 0; r < 6; ++r) q[21 + r] += c2w * (t[r] * t[6]);
+        for (int r = 0; r < 6; ++r) q[21 + r] = c2w * (t[r] * t[6]);
     }
-    double *o = out + id * 27;
+    __syncthreads();
+    for (int k = threadIdx.x; k < QT_PIX * 27; k += QT_PIX * 6) {
+        const int p2 = k / 27, e = k - 27 * p2;
+        const int64_t id2 = (int64_t)blockIdx.x * QT_PIX + p2;
+        if (id2 >= (int64_t)H * W) continue;
+        double acc = 0.0;
 #pragma unroll
-    for (int e = 0; e < 27; ++e) o[e] = q[e];
+        for (int s6 = 0; s6 < 6; ++s6) acc += part[p2][s6][e];
+        out[id2 * 27 + e] = acc;
+    }
 }
 
 // a = -Q^{-1} q with the Q the reference builds -- upper triangle only (registration.py:231-232),
@@ -333,9 +345,9 @@ int dtcwt_hip_qtilde(dtcwt_hip_ctx *ctx, int dtype, const void *Yh_ref, const vo
     DT_REQUIRE(H >= 2 && W >= 2 && H * W < ((int64_t)1 << 31), "subbands must be at least 2 x 2");
     DT_CHECK_HIP(hipSetDevice(ctx->device));
     if (dtype == DTCWT_HIP_F32)
-        k_qtilde<float><<<blocks_for(H * W), 256, 0, ctx->stream>>>((const float *)Yh_ref, (const float *)Yh_target, (int)H, (int)W, epsilon, out);
+        k_qtilde<float><<<(unsigned)((H * W + QT_PIX - 1) / QT_PIX), QT_PIX * 6, 0, ctx->stream>>>((const float *)Yh_ref, (const float *)Yh_target, (int)H, (int)W, epsilon, out);
     else if (dtype == DTCWT_HIP_F64)
-        k_qtilde<double><<<blocks_for(H * W), 256, 0, ctx->stream>>>((const double *)Yh_ref, (const double *)Yh_target, (int)H, (int)W, epsilon, out);
+        k_qtilde<double><<<(unsigned)((H * W + QT_PIX - 1) / QT_PIX), QT_PIX * 6, 0, ctx->stream>>>((const double *)Yh_ref, (const double *)Yh_target, (int)H, (int)W, epsilon, out);
     else
         return dtcwt_set_error(-1, "bad dtype %d", dtype);
     DT_LAUNCH_CHECK();
