@@ -38,6 +38,67 @@ __constant__ double c_shift[6][2] = {{-1, -3}, {-3, -3}, {-3, -1}, {-3, 1}, {-3,
 // whatever the level size (half of estimatereg).  The six contributions of a pixel meet in LDS and are summed
 // in subband order, i.e. exactly as the serial loop accumulated them.
 constexpr int QT_PIX = 32;                 // pixels per workgroup (x 6 subbands = 192 threads)
+constexpr int QT_TW = 8, QT_TH = 4;        // the tile of the batched kernels
+
+// subband `sb` of pixel (y, x) from records in memory
+template <typename T>
+struct LdGlobal {
+    const T *p; int W, sb;
+    __device__ c2 operator()(int y, int x) const { return ld(p, W, y, x, sb); }
+};
+
+// q[0..26] = the contribution of subband sb at (y, x); A(y, x) / B(y, x) load that subband of the two pyramids
+template <typename LA, typename LB>
+__device__ inline void qtilde_contrib(const LA &A, const LB &B, int H, int W, int y, int x, int sb, double eps,
+                                      double *__restrict__ q) {
+    const double xs = x * (1.0 / W), ys = y * (1.0 / H);          // np.arange(0, 1, 1/W)  (:168-169)
+    const double wx = c_shift[sb][0] * (3.14159265358979323846 / 2.15);
+    const double wy = c_shift[sb][1] * (3.14159265358979323846 / 2.15);
+    // confidence (:83-137): the four diagonal neighbours, edges replicated
+    c2 num = mk(0, 0);
+    double den = eps;
+#pragma unroll
+    for (int oy = -1; oy <= 1; oy += 2)
+#pragma unroll
+        for (int ox = -1; ox <= 1; ox += 2) {
+            const int yy = min(max(y + oy, 0), H - 1), xx = min(max(x + ox, 0), W - 1);
+            const c2 u = A(yy, xx), v = B(yy, xx);
+            num = num + mulconj(v, u);                         // conj(u) v
+            const double au = hypot(u.re, u.im), av = hypot(v.re, v.im);
+            den += au * au * au + av * av * av;
+        }
+    const double an = hypot(num.re, num.im);
+    const double C = an * an / den;
+    // phase gradients (:31-75)
+    const c2 a0 = A(y, x), b0 = B(y, x);
+    const c2 ex = mk(cos(wx), -sin(wx)), ey = mk(cos(wy), -sin(wy));
+    // S(i) = (a[i+1] conj a[i] + b[i+1] conj b[i]) exp(-j w) between samples i and i+1
+    c2 Sx;
+    {
+        const int xl = x > 0 ? x - 1 : 0, xr = x < W - 1 ? x : W - 2;    // pairs (xl, xl+1), (xr, xr+1)
+        const c2 s1 = mul(mulconj(A(y, xl + 1), A(y, xl)) + mulconj(B(y, xl + 1), B(y, xl)), ex);
+        const c2 s2 = mul(mulconj(A(y, xr + 1), A(y, xr)) + mulconj(B(y, xr + 1), B(y, xr)), ex);
+        Sx = (x == 0) ? s1 : (x == W - 1 ? s2 : mk(0.5 * (s1.re + s2.re), 0.5 * (s1.im + s2.im)));
+    }
+    c2 Sy;
+    {
+        const int yl = y > 0 ? y - 1 : 0, yr = y < H - 1 ? y : H - 2;
+        const c2 s1 = mul(mulconj(A(yl + 1, x), A(yl, x)) + mulconj(B(yl + 1, x), B(yl, x)), ey);
+        const c2 s2 = mul(mulconj(A(yr + 1, x), A(yr, x)) + mulconj(B(yr + 1, x), B(yr, x)), ey);
+        Sy = (y == 0) ? s1 : (y == H - 1 ? s2 : mk(0.5 * (s1.re + s2.re), 0.5 * (s1.im + s2.im)));
+    }
+    const double dx = (ang(Sx) + wx) * W, dy = (ang(Sy) + wy) * H;
+    const double dt = ang(mulconj(b0, a0));                     // angle(b conj a)
+    const double t[7] = {dx, dy, xs * dx, xs * dy, ys * dx, ys * dy, -dt};
+    const double c2w = C * C;
+    int e = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = r; c < 6; ++c) q[e++] = c2w * (t[r] * t[c]);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) q[21 + r] = c2w * (t[r] * t[6]);
+}
 
 template <typename T>
 __global__ void __launch_bounds__(QT_PIX * 6) k_qtilde(const T *__restrict__ A, const T *__restrict__ B, int H, int W,
@@ -47,58 +108,7 @@ __global__ void __launch_bounds__(QT_PIX * 6) k_qtilde(const T *__restrict__ A, 
     const int64_t id = (int64_t)blockIdx.x * QT_PIX + pl;
     if (id < (int64_t)H * W) {
         const int y = (int)(id / W), x = (int)(id - (int64_t)y * W);
-        const double xs = x * (1.0 / W), ys = y * (1.0 / H);          // np.arange(0, 1, 1/W)  (:168-169)
-        const double wx = c_shift[sb][0] * (3.14159265358979323846 / 2.15);
-        const double wy = c_shift[sb][1] * (3.14159265358979323846 / 2.15);
-        // confidence (:83-137): the four diagonal neighbours, edges replicated
-        c2 num = mk(0, 0);
-        double den = eps;
-#pragma unroll
-        for (int oy = -1; oy <= 1; oy += 2)
-#pragma unroll
-            for (int ox = -1; ox <= 1; ox += 2) {
-                const int yy = min(max(y + oy, 0), H - 1), xx = min(max(x + ox, 0), W - 1);
-                const c2 u = ld(A, W, yy, xx, sb), v = ld(B, W, yy, xx, sb);
-                num = num + mulconj(v, u);                         // conj(u) v
-                const double au = hypot(u.re, u.im), av = hypot(v.re, v.im);
-                den += au * au * au + av * av * av;
-            }
-        const double an = hypot(num.re, num.im);
-        const double C = an * an / den;
-        // phase gradients (:31-75)
-        const c2 a0 = ld(A, W, y, x, sb), b0 = ld(B, W, y, x, sb);
-        const c2 ex = mk(cos(wx), -sin(wx)), ey = mk(cos(wy), -sin(wy));
-        // S(i) = (a[i+1] conj a[i] + b[i+1] conj b[i]) exp(-j w) between samples i and i+1
-        c2 Sx;
-        {
-            const int xl = x > 0 ? x - 1 : 0, xr = x < W - 1 ? x : W - 2;    // pairs (xl, xl+1), (xr, xr+1)
-            const c2 s1 = mul(mulconj(ld(A, W, y, xl + 1, sb), ld(A, W, y, xl, sb)) +
-                              mulconj(ld(B, W, y, xl + 1, sb), ld(B, W, y, xl, sb)), ex);
-            const c2 s2 = mul(mulconj(ld(A, W, y, xr + 1, sb), ld(A, W, y, xr, sb)) +
-                              mulconj(ld(B, W, y, xr + 1, sb), ld(B, W, y, xr, sb)), ex);
-            Sx = (x == 0) ? s1 : (x == W - 1 ? s2 : mk(0.5 * (s1.re + s2.re), 0.5 * (s1.im + s2.im)));
-        }
-        c2 Sy;
-        {
-            const int yl = y > 0 ? y - 1 : 0, yr = y < H - 1 ? y : H - 2;
-            const c2 s1 = mul(mulconj(ld(A, W, yl + 1, x, sb), ld(A, W, yl, x, sb)) +
-                              mulconj(ld(B, W, yl + 1, x, sb), ld(B, W, yl, x, sb)), ey);
-            const c2 s2 = mul(mulconj(ld(A, W, yr + 1, x, sb), ld(A, W, yr, x, sb)) +
-                              mulconj(ld(B, W, yr + 1, x, sb), ld(B, W, yr, x, sb)), ey);
-            Sy = (y == 0) ? s1 : (y == H - 1 ? s2 : mk(0.5 * (s1.re + s2.re), 0.5 * (s1.im + s2.im)));
-        }
-        const double dx = (ang(Sx) + wx) * W, dy = (ang(Sy) + wy) * H;
-        const double dt = ang(mulconj(b0, a0));                     // angle(b conj a)
-        const double t[7] = {dx, dy, xs * dx, xs * dy, ys * dx, ys * dy, -dt};
-        const double c2w = C * C;
-        double *q = part[pl][sb];
-        int e = 0;
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int c = r; c < 6; ++c) q[e++] = c2w * (t[r] * t[c]);
-#pragma unroll
-        for (int r = 0; r < 6; ++r) q[21 + r] = c2w * (t[r] * t[6]);
+        qtilde_contrib(LdGlobal<T>{A, W, sb}, LdGlobal<T>{B, W, sb}, H, W, y, x, sb, eps, part[pl][sb]);
     }
     __syncthreads();
     for (int k = threadIdx.x; k < QT_PIX * 27; k += QT_PIX * 6) {
@@ -114,11 +124,8 @@ __global__ void __launch_bounds__(QT_PIX * 6) k_qtilde(const T *__restrict__ A, 
 
 // a = -Q^{-1} q with the Q the reference builds -- upper triangle only (registration.py:231-232),
 // so the solve is a back substitution.  Qt: [n][27], a: [n][6].
-__global__ void __launch_bounds__(256) k_solve6(const double *__restrict__ Qt, int64_t n, double *__restrict__ a) {
-    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (id >= n) return;
-    const double *q = Qt + id * 27;
-    double U[6][6], s[6];
+__device__ inline void solve6(const double *q, double *s) {
+    double U[6][6];
     int e = 0;
 #pragma unroll
     for (int r = 0; r < 6; ++r)
@@ -131,6 +138,13 @@ __global__ void __launch_bounds__(256) k_solve6(const double *__restrict__ Qt, i
         for (int c = r + 1; c < 6; ++c) acc -= U[r][c] * s[c];
         s[r] = acc / U[r][r];
     }
+}
+
+__global__ void __launch_bounds__(256) k_solve6(const double *__restrict__ Qt, int64_t n, double *__restrict__ a) {
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= n) return;
+    double s[6];
+    solve6(Qt + id * 27, s);
 #pragma unroll
     for (int r = 0; r < 6; ++r) a[id * 6 + r] = s[r];
 }
@@ -222,13 +236,8 @@ __global__ void __launch_bounds__(256) k_broadcast_rows(int64_t n, int K, const 
 __device__ inline int refl_near(int64_t u, int n) { return (int)dt_reflect(u, n); }
 
 template <typename T>
-__global__ void __launch_bounds__(256) k_warp_level(const T *__restrict__ Yh, int H, int W, const double *__restrict__ av,
-                                                    int rh, int rw, T *__restrict__ out) {
-    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (id >= (int64_t)H * W * 6) return;
-    const int64_t p = id / 6;
-    const int ch = (int)(id - p * 6);
-    const int py = (int)(p / W), px = (int)(p - (int64_t)py * W);
+__device__ inline void warp_sample(const T *__restrict__ Yh, int H, int W, const double *__restrict__ av, int rh, int rw,
+                                   int py, int px, int ch, T *__restrict__ o_re, T *__restrict__ o_im) {
     const double W0 = -3 * 3.14159265358979323846 / 2.15, W1 = -3.14159265358979323846 / 2.15;
     const double tdx[6] = {W1, W0, W0, W0, W0, W1}, tdy[6] = {W0, W0, W1, -W1, -W0, -W0};   // sampling.py:26-33
     // velocity at this pixel: (vx, vy) of the reg grid, bilinear (dtcwt_hip_rescale, float64)
@@ -277,20 +286,25 @@ __global__ void __launch_bounds__(256) k_warp_level(const T *__restrict__ Yh, in
     const T sr = ((T)1 - fy) * lr + fy * hr, si = ((T)1 - fy) * li + fy * hi;
     double sn, cs;
     sincos(tdx[ch] * xs + tdy[ch] * ys, &sn, &cs);
-    out[id * 2] = (T)((double)sr * cs - (double)si * sn);
-    out[id * 2 + 1] = (T)((double)sr * sn + (double)si * cs);
+    *o_re = (T)((double)sr * cs - (double)si * sn);
+    *o_im = (T)((double)sr * sn + (double)si * cs);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_warp_level(const T *__restrict__ Yh, int H, int W, const double *__restrict__ av,
+                                                    int rh, int rw, T *__restrict__ out) {
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (int64_t)H * W * 6) return;
+    const int64_t p = id / 6;
+    const int ch = (int)(id - p * 6);
+    const int py = (int)(p / W), px = (int)(p - (int64_t)py * W);
+    warp_sample(Yh, H, W, av, rh, rw, py, px, ch, out + id * 2, out + id * 2 + 1);
 }
 
 // One launch for `_boxfilter(qtilde, 3)` (registration.py:417-446) -> bilinear rescale onto the reg grid
 // (sampling.py:131-165) -> accumulation over the levels of a group (:362-368):
 //   acc[r][c] (+)= rescale(boxfilter(q))[r][c],   q: [H][W][27], acc: [rh][rw][27], float64
-__global__ void __launch_bounds__(256) k_box_rescale_acc(const double *__restrict__ q, int H, int W, int rh, int rw,
-                                                         int accumulate, double *__restrict__ acc) {
-    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (id >= (int64_t)rh * rw * 27) return;
-    const int c = (int)(id % 27);
-    const int64_t r = id / 27;
-    const int ry = (int)(r / rw), rx = (int)(r - (int64_t)ry * rw);
+__device__ inline double box_rescale(const double *__restrict__ q, int H, int W, int rh, int rw, int ry, int rx, int c) {
     const double x = ((double)W / (double)rw) * ((double)rx + 0.5) - 0.5;
     const double y = ((double)H / (double)rh) * ((double)ry + 0.5) - 0.5;
     const double fx0 = floor(x), fy0 = floor(y);
@@ -312,8 +326,158 @@ __global__ void __launch_bounds__(256) k_box_rescale_acc(const double *__restric
             }
             b[j][i] = s * inv;
         }
-    const double v = wy0 * (wx0 * b[0][0] + wx1 * b[0][1]) + wy1 * (wx0 * b[1][0] + wx1 * b[1][1]);
+    return wy0 * (wx0 * b[0][0] + wx1 * b[0][1]) + wy1 * (wx0 * b[1][0] + wx1 * b[1][1]);
+}
+
+__global__ void __launch_bounds__(256) k_box_rescale_acc(const double *__restrict__ q, int H, int W, int rh, int rw,
+                                                         int accumulate, double *__restrict__ acc) {
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (int64_t)rh * rw * 27) return;
+    const int c = (int)(id % 27);
+    const int64_t r = id / 27;
+    const int ry = (int)(r / rw), rx = (int)(r - (int64_t)ry * rw);
+    const double v = box_rescale(q, H, W, rh, rw, ry, rx, c);
     acc[id] = accumulate ? acc[id] + v : v;
+}
+
+// ---- the levels of one group of estimatereg in one launch per step ----------------------------------------
+// A refinement pass used to be warp -> qtilde -> box-filter/resample/accumulate per level, then solve and axpy:
+// 3 x levels + 2 dependent launches of a few thousand threads, each costing the ~4 us a dependent dispatch
+// takes however little it does.  The levels of a group only depend on the parameters of the previous group, so
+//   k_warp_qtilde_levels   warps a tile (+1 halo) of a level into LDS and forms its Q-tilde from there, for all
+//                          levels of the group at once (blocks are assigned to levels by `blk0`);
+//   k_box_solve_levels     box-filters / resamples / accumulates the levels in order, solves the 6 x 6 system
+//                          of each block of the grid and adds the update to avecs.
+// Same arithmetic and the same order of accumulation as the per-level kernels above.
+constexpr int REG_MAXL = 12;
+struct RegLevel {
+    const void *src, *ref;     // records [H][W][6] complex
+    double *q;                 // [H][W][27]
+    int H, W, blk0, tw;        // first block of this level in the launch, tiles per row
+};
+struct RegBatch {
+    RegLevel lv[REG_MAXL];
+    int n, nblk;
+};
+
+// A warped in LDS: tile (QT_TH + 2) x (QT_TW + 2) around (y0, x0), records of T
+template <typename T>
+struct LdTile {
+    const T *t; int y0, x0, sb;
+    __device__ c2 operator()(int y, int x) const {
+        const T *p = t + (((y - y0 + 1) * (QT_TW + 2) + (x - x0 + 1)) * 6 + sb) * 2;
+        return mk((double)p[0], (double)p[1]);
+    }
+};
+
+// MODE 0: A = src warped by the parameters `av`, q written per pixel
+// MODE 1: A = src as it is, the block's pixels summed (in pixel order) into partial[block][27]
+template <typename T, int MODE>
+__global__ void __launch_bounds__(QT_PIX * 6) k_warp_qtilde_levels(RegBatch b, const double *__restrict__ av, int rh, int rw,
+                                                                   double eps, double *__restrict__ partial) {
+    __shared__ double part[QT_PIX][6][27];
+    __shared__ double pix[MODE == 1 ? QT_PIX : 1][27];
+    __shared__ T tile[MODE == 0 ? (QT_TH + 2) * (QT_TW + 2) * 12 : 2];
+    int li = 0;
+#pragma unroll 1
+    for (int k = 1; k < b.n; ++k)
+        if ((int)blockIdx.x >= b.lv[k].blk0) li = k;
+    const RegLevel L = b.lv[li];
+    const int tb = (int)blockIdx.x - L.blk0;
+    const int y0 = (tb / L.tw) * QT_TH, x0 = (tb % L.tw) * QT_TW;
+    const int H = L.H, W = L.W;
+    if (MODE == 0) {
+        for (int i = threadIdx.x; i < (QT_TH + 2) * (QT_TW + 2) * 6; i += QT_PIX * 6) {
+            const int hp = i / 6, ch = i - 6 * hp;
+            const int hy = hp / (QT_TW + 2), hx = hp - hy * (QT_TW + 2);
+            const int py = y0 - 1 + hy, px = x0 - 1 + hx;
+            if (py >= 0 && py < H && px >= 0 && px < W)
+                warp_sample((const T *)L.src, H, W, av, rh, rw, py, px, ch, &tile[i * 2], &tile[i * 2 + 1]);
+        }
+        __syncthreads();
+    }
+    const int pl = threadIdx.x / 6, sb = threadIdx.x - 6 * pl;
+    {
+        const int y = y0 + pl / QT_TW, x = x0 + pl % QT_TW;
+        if (y < H && x < W) {
+            if (MODE == 0)
+                qtilde_contrib(LdTile<T>{tile, y0, x0, sb}, LdGlobal<T>{(const T *)L.ref, W, sb}, H, W, y, x, sb, eps, part[pl][sb]);
+            else
+                qtilde_contrib(LdGlobal<T>{(const T *)L.src, W, sb}, LdGlobal<T>{(const T *)L.ref, W, sb}, H, W, y, x, sb, eps,
+                               part[pl][sb]);
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < QT_PIX * 27; k += QT_PIX * 6) {
+        const int p2 = k / 27, e = k - 27 * p2;
+        const int y = y0 + p2 / QT_TW, x = x0 + p2 % QT_TW;
+        double acc = 0.0;
+        if (y < H && x < W) {
+#pragma unroll
+            for (int s6 = 0; s6 < 6; ++s6) acc += part[p2][s6][e];
+            if (MODE == 0) L.q[((int64_t)y * W + x) * 27 + e] = acc;
+        }
+        if (MODE == 1) pix[p2][e] = acc;          // 0 outside the image
+    }
+    if (MODE == 1) {
+        __syncthreads();
+        if (threadIdx.x < 27) {
+            double acc = 0.0;
+            for (int p2 = 0; p2 < QT_PIX; ++p2) acc += pix[p2][threadIdx.x];
+            partial[(int64_t)blockIdx.x * 27 + threadIdx.x] = acc;
+        }
+    }
+}
+
+// global estimate: Qt = sum of the block partials (fixed order), a0 = solve(Qt), and -- when the grid is small
+// enough for one workgroup -- avecs[:] = a0
+__global__ void __launch_bounds__(1024) k_sum_solve(const double *__restrict__ partial, int nblk, double *__restrict__ a0,
+                                                    int64_t nfill, double *__restrict__ avecs) {
+    __shared__ double red[32][27];
+    __shared__ double a[6];
+    const int j = threadIdx.x / 27, c = threadIdx.x - 27 * j;
+    if (j < 32) {
+        double acc = 0.0;
+        for (int p = j; p < nblk; p += 32) acc += partial[(int64_t)p * 27 + c];
+        red[j][c] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 27) {
+        double acc = 0.0;
+        for (int k = 0; k < 32; ++k) acc += red[k][threadIdx.x];
+        red[0][threadIdx.x] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s[6];
+        solve6(red[0], s);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) { a[r] = s[r]; a0[r] = s[r]; }
+    }
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < nfill; i += 1024) avecs[i] = a[i % 6];
+}
+
+constexpr int BS_PIX = 8;                  // blocks of the grid per workgroup (x 27 entries = 216 threads)
+__global__ void __launch_bounds__(256) k_box_solve_levels(RegBatch b, int rh, int rw, double *__restrict__ avecs) {
+    __shared__ double qs[BS_PIX][27];
+    const int rp = threadIdx.x / 27, c = threadIdx.x - 27 * rp;
+    const int64_t r = (int64_t)blockIdx.x * BS_PIX + rp;
+    if (rp < BS_PIX && r < (int64_t)rh * rw) {
+        const int ry = (int)(r / rw), rx = (int)(r - (int64_t)ry * rw);
+        double acc = box_rescale(b.lv[0].q, b.lv[0].H, b.lv[0].W, rh, rw, ry, rx, c);
+#pragma unroll 1
+        for (int k = 1; k < b.n; ++k) acc = acc + box_rescale(b.lv[k].q, b.lv[k].H, b.lv[k].W, rh, rw, ry, rx, c);
+        qs[rp][c] = acc;
+    }
+    __syncthreads();
+    const int64_t r2 = (int64_t)blockIdx.x * BS_PIX + threadIdx.x;
+    if (threadIdx.x < BS_PIX && r2 < (int64_t)rh * rw) {
+        double s[6];
+        solve6(qs[threadIdx.x], s);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) avecs[r2 * 6 + k] += 1.0 * s[k];
+    }
 }
 
 inline unsigned blocks_for(int64_t total) { return (unsigned)((total + 255) / 256); }
@@ -436,11 +600,79 @@ int dtcwt_hip_fill_rows(dtcwt_hip_ctx *ctx, int64_t n, int K, const double *row,
 //   shapes: [nlevels][2] = (H_l, W_l);  groups: `ngroups` level lists, group g holds
 //   group_sizes[g] consecutive entries of group_levels (0-based); the first group gives the
 //   global estimate, the others refine it (:339-370);  avecs: [reg_h][reg_w][6] float64 out.
+// the levels of a group as one batch of tiles; q buffers only when `want_q`
+static int reg_batch(Scratch &sc, const void *const *Yh_src, const void *const *Yh_ref, const int64_t *shapes,
+                     const int *lv, int n, bool want_q, RegBatch *b) {
+    b->n = n;
+    int blk = 0;
+    for (int k = 0; k < n; ++k) {
+        const int l = lv[k];
+        const int64_t H = shapes[2 * l], W = shapes[2 * l + 1];
+        DT_REQUIRE(H >= 2 && W >= 2 && H * W * 27 < ((int64_t)1 << 31), "level too small or too large");
+        RegLevel &L = b->lv[k];
+        L.src = Yh_src[l]; L.ref = Yh_ref[l];
+        L.H = (int)H; L.W = (int)W;
+        L.tw = (int)((W + QT_TW - 1) / QT_TW);
+        L.blk0 = blk;
+        blk += L.tw * (int)((H + QT_TH - 1) / QT_TH);
+        L.q = nullptr;
+        if (want_q) {
+            L.q = sc.get<double>(H * W * 27);
+            DT_REQUIRE(L.q, "out of device memory");
+        }
+    }
+    b->nblk = blk;
+    return 0;
+}
+
+// one launch per step and group (see k_warp_qtilde_levels)
+static int estimatereg_issue_batched(dtcwt_hip_ctx *ctx, Scratch &sc, int dtype, const void *const *Yh_src,
+                                     const void *const *Yh_ref, const int64_t *shapes, int64_t reg_h, int64_t reg_w,
+                                     int ngroups, const int *group_sizes, const int *group_levels, double *avecs) {
+    const int64_t nreg = reg_h * reg_w;
+    const bool f32 = dtype == DTCWT_HIP_F32;
+    const int *lv = group_levels;
+    RegBatch b;
+    {
+        DT_TRY(reg_batch(sc, Yh_src, Yh_ref, shapes, lv, group_sizes[0], false, &b));
+        double *partial = sc.get<double>((int64_t)b.nblk * 27), *a0 = sc.get<double>(6);
+        DT_REQUIRE(partial && a0, "out of device memory");
+        if (f32) k_warp_qtilde_levels<float, 1><<<b.nblk, QT_PIX * 6, 0, ctx->stream>>>(b, nullptr, 0, 0, 1e-6, partial);
+        else k_warp_qtilde_levels<double, 1><<<b.nblk, QT_PIX * 6, 0, ctx->stream>>>(b, nullptr, 0, 0, 1e-6, partial);
+        DT_LAUNCH_CHECK();
+        const bool fold = nreg * 6 <= 16384;
+        k_sum_solve<<<1, 1024, 0, ctx->stream>>>(partial, b.nblk, a0, fold ? nreg * 6 : 0, avecs);
+        DT_LAUNCH_CHECK();
+        if (!fold) {
+            k_broadcast_rows<<<blocks_for(nreg * 6), 256, 0, ctx->stream>>>(nreg, 6, a0, avecs);
+            DT_LAUNCH_CHECK();
+        }
+        lv += group_sizes[0];
+    }
+    for (int g = 1; g < ngroups; lv += group_sizes[g], ++g) {
+        if (group_sizes[g] < 1) continue;
+        DT_TRY(reg_batch(sc, Yh_src, Yh_ref, shapes, lv, group_sizes[g], true, &b));
+        if (f32) k_warp_qtilde_levels<float, 0><<<b.nblk, QT_PIX * 6, 0, ctx->stream>>>(b, avecs, (int)reg_h, (int)reg_w, 1e-6, nullptr);
+        else k_warp_qtilde_levels<double, 0><<<b.nblk, QT_PIX * 6, 0, ctx->stream>>>(b, avecs, (int)reg_h, (int)reg_w, 1e-6, nullptr);
+        DT_LAUNCH_CHECK();
+        k_box_solve_levels<<<(unsigned)((nreg + BS_PIX - 1) / BS_PIX), 256, 0, ctx->stream>>>(b, (int)reg_h, (int)reg_w, avecs);
+        DT_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 static int estimatereg_issue(dtcwt_hip_ctx *ctx, Scratch &sc, int dtype, int nlevels, const void *const *Yh_src,
                              const void *const *Yh_ref, const int64_t *shapes, int64_t reg_h, int64_t reg_w,
                              int ngroups, const int *group_sizes, const int *group_levels, double *avecs) {
     const size_t esz = dtype == DTCWT_HIP_F32 ? sizeof(float) : sizeof(double);
     const int64_t nreg = reg_h * reg_w;
+    // DTCWT_HIP_REG_BATCH=0 keeps one launch per level and step (the A/B switch of the batched kernels)
+    static const bool batch = [] { const char *e = getenv("DTCWT_HIP_REG_BATCH"); return !(e && e[0] == '0'); }();
+    bool fits = group_sizes[0] >= 1 && nreg * 27 < ((int64_t)1 << 31);
+    for (int g = 0; g < ngroups; ++g) fits = fits && group_sizes[g] <= REG_MAXL;
+    if (batch && fits)
+        return estimatereg_issue_batched(ctx, sc, dtype, Yh_src, Yh_ref, shapes, reg_h, reg_w, ngroups, group_sizes,
+                                         group_levels, avecs);
 
     // global estimate: Q-tilde summed over every pixel of the first group's levels
     double *Qt = sc.get<double>(27), *part = sc.get<double>(27), *a0 = sc.get<double>(6);
