@@ -45,7 +45,9 @@ __global__ void __launch_bounds__(DT_NT) k_inv1(Inv1Params p) {
 }
 
 // Level >= 2 inverse: same structure with the polyphase interpolating filters.
-template <class C>
+// STD: compile-time filter phases + packed FMAs (ifilt4_acc).  112 VGPRs (the scalar form: 72); bounding the
+// registers to get the occupancy back spills (5 waves per SIMD: 50 us instead of 31) and buys nothing at 4.
+template <class C, bool STD>
 __global__ void __launch_bounds__(DT_NT) k_inv2(Inv2Params p) {
     __shared__ __attribute__((aligned(16))) float smem[C::LDS_ALIASED];
     const int ntile = p.tilesR * p.tilesC * p.B;
@@ -61,9 +63,9 @@ __global__ void __launch_bounds__(DT_NT) k_inv2(Inv2Params p) {
     __syncthreads();
     inv2r_gather<C>(p, srec, w1, w2, w3, threadIdx.x, r0, c0);
     __syncthreads();
-    inv2r_fir<C>(p, wz, w1, w2, w3, y1, y2, threadIdx.x, y3);
+    inv2r_fir<C, false, STD>(p, wz, w1, w2, w3, y1, y2, threadIdx.x, y3);
     __syncthreads();
-    inv2_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0, y3);
+    inv2_rows<C, STD>(p, y1, y2, threadIdx.x, b, r0, c0, y3);
 }
 
 template <class C>
@@ -75,7 +77,11 @@ int launch_inv1(Inv1Params &p, hipStream_t s) {
 template <class C>
 int launch_inv2(Inv2Params &p, hipStream_t s) {
     p.tilesR = cdiv(p.zr, C::TR); p.tilesC = cdiv(p.zc, C::TC);
-    k_inv2<C><<<grid_for(p.tilesR * p.tilesC * p.B, p.xcd_order), DT_NT, 0, s>>>(p);
+    // every shipped q-shift set: sum(g0a g0b) > 0 > sum(g1a g1b) (and the band-pass pair like g1) -- compile-time
+    // filter phases; anything else takes the run-time flags
+    const bool std_set = p.lo_pos && !p.hi_pos && (!C::BP || !p.bp_pos);
+    if (std_set) k_inv2<C, true><<<grid_for(p.tilesR * p.tilesC * p.B, p.xcd_order), DT_NT, 0, s>>>(p);
+    else k_inv2<C, false><<<grid_for(p.tilesR * p.tilesC * p.B, p.xcd_order), DT_NT, 0, s>>>(p);
     return 0;
 }
 

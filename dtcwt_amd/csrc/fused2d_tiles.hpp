@@ -201,10 +201,39 @@ DT_HD void ifilt4(const float *w, const float *ha, const float *hb, int pos, flo
     y[0] = y0; y[1] = y1; y[2] = y2; y[3] = y3;
 }
 
-template <class C>
+// The same four phases ACCUMULATED into two packed pairs, P = (y0, y2) and Q = (y1, y3): with an odd half
+// length the two outputs of a pair multiply the SAME window sample by two neighbouring taps, which is one
+// v_pk_fma_f32 (taps as a scalar register pair, the sample broadcast) instead of two v_fma_f32 -- the level >= 2
+// inverse kernels are bound by VALU issue (761 VALU instructions per wavefront, a third of them FMAs, = 27 us of
+// the 32 us of k_inv2 at 4096^2).  POS >= 0: sum(ha * hb) > 0 known at compile time (every shipped q-shift set
+// has it 1 for the g0 pair and 0 for the g1 pair), which also removes the per-sample selects; POS < 0: `pos`.
+typedef float dt_pk2 __attribute__((ext_vector_type(2)));
+template <class C, int POS>
+DT_HD void ifilt4_acc(const float *w, const float *ha, const float *hb, int pos, dt_pk2 &P, dt_pk2 &Q) {
+    const bool ps = POS < 0 ? pos != 0 : POS != 0;
+    if (C::ODD) {
+#pragma unroll
+        for (int k = 0; k < C::M2; ++k) {
+            const float hi = w[C::M - 1 - 2 * k], lo = w[C::M - 2 - 2 * k];
+            const float xa = ps ? hi : lo, xb = ps ? lo : hi;
+            P += dt_pk2{ha[2 * k], ha[2 * k + 1]} * dt_pk2{xb, xb};
+            Q += dt_pk2{hb[2 * k], hb[2 * k + 1]} * dt_pk2{xa, xa};
+        }
+    } else {
+        float y[4];
+        ifilt4<C>(w, ha, hb, ps, y);
+        P += dt_pk2{y[0], y[2]};
+        Q += dt_pk2{y[1], y[3]};
+    }
+}
+
+// STD: the g0 pair has sum(ha*hb) > 0 and the g1 (and band-pass) pair < 0 -- true of every shipped q-shift set --
+// known at compile time (see ifilt4_acc); otherwise the flags of the parameter block decide at run time
+template <class C, bool STD = false>
 DT_HD void inv2_rows(const Inv2Params &p, const float *y1, const float *y2, int tid, int b,
                      int r0, int c0, const float *y3 = nullptr) {
     constexpr int NJ = C::TC / 2;
+    constexpr int LP = STD ? 1 : -1, HP = STD ? 0 : -1;
     const int OR = 2 * p.zr - 2 * p.cropR, OC = 2 * p.zc - 2 * p.cropC;
     for (int task = tid; task < 2 * C::TR * NJ; task += DT_NT) {
         int r = task / NJ, jl = task - r * NJ;
@@ -214,31 +243,30 @@ DT_HD void inv2_rows(const Inv2Params &p, const float *y1, const float *y2, int 
         int Rw = Rl - p.cropR;
         if (Rw < 0 || Rw >= OR) continue;
         float w[C::WN];
-        float a[4], t[4];
+        dt_pk2 P = {0.f, 0.f}, Q = {0.f, 0.f};
         const f2 *pa = reinterpret_cast<const f2 *>(y1 + r * C::NC + 2 * jl);
         const f2 *pb = reinterpret_cast<const f2 *>(y2 + r * C::NC + 2 * jl);
 #pragma unroll
         for (int j = 0; j < C::WN / 2; ++j) { f2 v = pa[j]; w[2 * j] = v.x; w[2 * j + 1] = v.y; }
-        ifilt4<C>(w, p.l_a, p.l_b, p.lo_pos, a);
+        ifilt4_acc<C, LP>(w, p.l_a, p.l_b, p.lo_pos, P, Q);
 #pragma unroll
         for (int j = 0; j < C::WN / 2; ++j) { f2 v = pb[j]; w[2 * j] = v.x; w[2 * j + 1] = v.y; }
-        ifilt4<C>(w, p.h_a, p.h_b, p.hi_pos, t);
+        ifilt4_acc<C, HP>(w, p.h_a, p.h_b, p.hi_pos, P, Q);
         if (C::BP) {            // third row filter on the band-pass plane
             const f2 *pc = reinterpret_cast<const f2 *>(y3 + r * C::NC + 2 * jl);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) a[e] += t[e];
-#pragma unroll
             for (int j = 0; j < C::WN / 2; ++j) { f2 v = pc[j]; w[2 * j] = v.x; w[2 * j + 1] = v.y; }
-            ifilt4<C>(w, p.b_a, p.b_b, p.bp_pos, t);
+            ifilt4_acc<C, HP>(w, p.b_a, p.b_b, p.bp_pos, P, Q);
         }
+        const float a[4] = {P.x, Q.x, P.y, Q.y};
         float *O = p.Out + ((int64_t)b * OR + Rw) * OC;
         if (p.cropC == 0 && (OC & 3) == 0) {
-            *reinterpret_cast<f4 *>(O + Cl) = f4{a[0] + t[0], a[1] + t[1], a[2] + t[2], a[3] + t[3]};
+            *reinterpret_cast<f4 *>(O + Cl) = f4{a[0], a[1], a[2], a[3]};
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 int cw = Cl + e - p.cropC;
-                if (cw >= 0 && cw < OC) O[cw] = a[e] + t[e];
+                if (cw >= 0 && cw < OC) O[cw] = a[e];
             }
         }
     }

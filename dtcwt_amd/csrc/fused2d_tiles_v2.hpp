@@ -793,31 +793,32 @@ DT_HD void inv2r_gather(const Inv2Params &p, const float *srec, float (&w1)[C::W
     if (DT_WAVE_UNIFORM((tid >> 6) & 1)) inv2r_gather_e<C, 1>(p, srec, w1, w2, w3, tid, r0, c0);
     else inv2r_gather_e<C, 0>(p, srec, w1, w2, w3, tid, r0, c0);
 }
-template <class C, bool LIN = false>
+template <class C, bool LIN = false, bool STD = false>
 DT_HD void inv2r_fir(const Inv2Params &p, const float (&w0)[C::WS], const float (&w1)[C::WS],
                      const float (&w2)[C::WS], const float (&w3)[C::WS], float *y1, float *y2, int tid,
                      float *y3 = nullptr) {
     const ColTask t = LIN ? inv_col_task_lin<C>(tid) : inv_col_task<C>(tid);
     if (!t.valid) return;
+    constexpr int LP = STD ? 1 : -1, HP = STD ? 0 : -1;
     const int cc = 2 * t.i + t.e;
-    float a[4], tt[4];
 #pragma unroll
     for (int q = 0; q < C::JS; ++q) {
-        ifilt4<C>(w0 + 2 * q, p.l_a, p.l_b, p.lo_pos, a);
-        ifilt4<C>(w1 + 2 * q, p.h_a, p.h_b, p.hi_pos, tt);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) y1[(4 * (t.strip * C::JS + q) + e) * C::NC + cc] = a[e] + tt[e];
-        ifilt4<C>(w2 + 2 * q, p.l_a, p.l_b, p.lo_pos, a);
+        float *o1 = y1 + 4 * (t.strip * C::JS + q) * C::NC + cc, *o2 = y2 + 4 * (t.strip * C::JS + q) * C::NC + cc;
+        dt_pk2 P = {0.f, 0.f}, Q = {0.f, 0.f};
+        ifilt4_acc<C, LP>(w0 + 2 * q, p.l_a, p.l_b, p.lo_pos, P, Q);
+        ifilt4_acc<C, HP>(w1 + 2 * q, p.h_a, p.h_b, p.hi_pos, P, Q);
+        o1[0] = P.x; o1[C::NC] = Q.x; o1[2 * C::NC] = P.y; o1[3 * C::NC] = Q.y;
+        P = dt_pk2{0.f, 0.f}; Q = dt_pk2{0.f, 0.f};
+        ifilt4_acc<C, LP>(w2 + 2 * q, p.l_a, p.l_b, p.lo_pos, P, Q);
         if (C::BP) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y2[(4 * (t.strip * C::JS + q) + e) * C::NC + cc] = a[e];
-            ifilt4<C>(w3 + 2 * q, p.b_a, p.b_b, p.bp_pos, tt);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y3[(4 * (t.strip * C::JS + q) + e) * C::NC + cc] = tt[e];
+            o2[0] = P.x; o2[C::NC] = Q.x; o2[2 * C::NC] = P.y; o2[3 * C::NC] = Q.y;
+            float *o3 = y3 + 4 * (t.strip * C::JS + q) * C::NC + cc;
+            P = dt_pk2{0.f, 0.f}; Q = dt_pk2{0.f, 0.f};
+            ifilt4_acc<C, HP>(w3 + 2 * q, p.b_a, p.b_b, p.bp_pos, P, Q);
+            o3[0] = P.x; o3[C::NC] = Q.x; o3[2 * C::NC] = P.y; o3[3 * C::NC] = Q.y;
         } else {
-            ifilt4<C>(w3 + 2 * q, p.h_a, p.h_b, p.hi_pos, tt);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y2[(4 * (t.strip * C::JS + q) + e) * C::NC + cc] = a[e] + tt[e];
+            ifilt4_acc<C, HP>(w3 + 2 * q, p.h_a, p.h_b, p.hi_pos, P, Q);
+            o2[0] = P.x; o2[C::NC] = Q.x; o2[2 * C::NC] = P.y; o2[3 * C::NC] = Q.y;
         }
     }
 }

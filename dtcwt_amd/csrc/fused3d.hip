@@ -14,41 +14,55 @@ using namespace dt3d;
 
 namespace {
 
+// the march of one workgroup; FULL: the tile lies inside the volume
+template <class C, bool FULL>
+__device__ __forceinline__ void fwd3_l1_march(const Fwd3L1Params &p, float *smem, int j0, int k0, int i0, int iend) {
+    float *S0 = smem, *S1 = smem + C::S0F, *stage = S1 + C::S1F, *XR = smem + C::XR0;
+    const int tid = threadIdx.x;
+    Fwd3L1State<C> st;
+    f3l1_init<C>(p, st, tid, j0, k0);
+    f3l1_prologue<C>(p, st, XR, tid, i0);
+    f3l1_prefetch<C>(p, st, tid, i0);
+    // settle the prologue loads here so that no wait on them lands inside the march (where
+    // it would also drain the stores in flight): s_waitcnt vmcnt(0)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    int rot = 0;
+    for (int i = i0; i < iend; i += 2) {             // chunks start and end on even slices
+        f3l1_axis0<C>(p, st, S0, XR, tid, rot);
+        __syncthreads();
+        f3l1_axis2<C>(p, S0, S1, tid);
+        __syncthreads();
+        f3l1_rotate<C>(st, XR, tid, rot, false);
+        rot = rot + 1 == C::MR ? 0 : rot + 1;
+        f3l1_axis1<C, FULL>(p, st.ev, S1, tid, i, j0, k0);
+        f3l1_axis0<C>(p, st, S0, XR, tid, rot);
+        __syncthreads();
+        f3l1_axis2<C>(p, S0, S1, tid);
+        __syncthreads();
+        f3l1_rotate<C>(st, XR, tid, rot, true);
+        rot = rot + 1 == C::MR ? 0 : rot + 1;
+        f3l1_prefetch<C>(p, st, tid, i + 2);         // ahead of this pair's stores (reflected past the end: harmless)
+        float od[8][4];
+        f3l1_axis1<C, FULL>(p, od, S1, tid, i + 1, j0, k0);
+#pragma unroll
+        for (int pass = 0; pass < C::SP; ++pass) {
+            f3l1_pack_stage<C>(st.ev, od, stage, tid, pass);
+            f3l1_pack_flush<C, FULL>(p, stage, tid, pass, i + 1, j0, k0);
+        }
+    }
+}
+
 template <class C>
 __global__ void __launch_bounds__(C::NT, 2) k_fwd3_l1(Fwd3L1Params p) {
     __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
-    float *S0 = smem, *S1 = smem + C::S0F, *stage = S1 + C::S1F;
     const int bid = blockIdx.x;
     const int tk = bid % p.tilesK, tj = (bid / p.tilesK) % p.tilesJ, ch = bid / (p.tilesK * p.tilesJ);
     const int j0 = tj * C::TJ, k0 = tk * C::TK, i0 = ch * p.chunk;
     const int iend = min(i0 + p.chunk, p.n0);
-    const int tid = threadIdx.x;
-    Fwd3L1State<C> st;
-    f3l1_init<C>(p, st, tid, j0, k0);
-    f3l1_prologue<C>(p, st, i0);
-    // settle the prologue loads here so that no wait on them lands inside the march (where
-    // it would also drain the stores in flight): s_waitcnt vmcnt(0)
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    for (int i = i0; i < iend; i += 2) {             // chunks start and end on even slices
-        f3l1_axis0<C>(p, st, S0, i, true);
-        __syncthreads();
-        f3l1_axis2<C>(p, S0, S1, tid);
-        __syncthreads();
-        f3l1_rotate<C>(st);
-        f3l1_axis1<C>(p, st.ev, S1, tid, i, j0, k0);
-        f3l1_axis0<C>(p, st, S0, i + 1, i + 2 < iend);
-        __syncthreads();
-        f3l1_axis2<C>(p, S0, S1, tid);
-        __syncthreads();
-        f3l1_rotate<C>(st);
-        float od[8][4];
-        f3l1_axis1<C>(p, od, S1, tid, i + 1, j0, k0);
-#pragma unroll
-        for (int pass = 0; pass < C::SP; ++pass) {
-            f3l1_pack_stage<C>(st.ev, od, stage, tid, pass);
-            f3l1_pack_flush<C>(p, stage, tid, pass, i + 1, j0, k0);
-        }
-    }
+    if (j0 + C::TJ <= p.n1 && k0 + C::TK <= p.n2)
+        fwd3_l1_march<C, true>(p, smem, j0, k0, i0, iend);
+    else
+        fwd3_l1_march<C, false>(p, smem, j0, k0, i0, iend);
 }
 
 // Level >= 2, pass A: the 2-D level-2 tile program over every slice, four planes out.

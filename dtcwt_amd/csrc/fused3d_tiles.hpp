@@ -35,6 +35,22 @@
 #define DT_PIN_HERE(x) (void)(x)
 #endif
 
+// Lanes of ONE wavefront hand data to each other through a wave-private LDS slab without a workgroup barrier
+// (LDS operations of a wavefront execute in order).  The compiler still has to be told: a wavefront-scope
+// release / acquire pair around a convergent no-op, which costs no instruction but stops it from moving the
+// reads of all lanes into the divergent block in which some lanes wrote (it did, once the stores that follow
+// became unconditional: the lanes outside the block then stored stale registers).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DT_WAVE_LDS_SYNC()                                  \
+    do {                                                    \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                    \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+#else
+#define DT_WAVE_LDS_SYNC() (void)0
+#endif
+
 namespace dt3d {
 
 using dt2d::cmax;
@@ -60,6 +76,8 @@ struct Fwd3L1Params {
     float h0[DT_MAXT], h1[DT_MAXT];
 };
 
+typedef float f3_v2f __attribute__((ext_vector_type(2)));
+
 template <int M0_, int M1_>
 struct Fwd3L1Cfg {
     static constexpr int M0 = M0_, M1 = M1_;
@@ -70,7 +88,13 @@ struct Fwd3L1Cfg {
     static constexpr int S0S = TK + 8;                    // S0 row stride: 16-byte aligned windows
     static constexpr int NT = 256;                        // threads per workgroup (4 wavefronts)
     static constexpr int NPOS = PJ * PK;
-    static constexpr int NPT = (NPOS + NT - 1) / NT;      // ring positions per thread
+    // The ring lives in registers as PAIRS of k-adjacent positions (one v_pk_fma_f32 filters both); every thread
+    // holds NPP pairs, and the NLEFT pairs that do not divide evenly (2 for H = 3, 96 for H = 4) belong to the
+    // first NLEFT threads, which keep their raw slices in a small LDS ring (XR) instead of a fourth register slot.
+    static constexpr int NPAIR = NPOS / 2;
+    static constexpr int NPP = NPAIR / NT;
+    static constexpr int NLEFT = NPAIR - NPP * NT;
+    static constexpr int XRF = 2 * NLEFT * MR;            // floats of the leftover ring
     static constexpr int S0F = 2 * PJ * S0S, S1F = 4 * PJ * TK;
 #ifndef DT_F3L1_STAGE_PASSES
 #define DT_F3L1_STAGE_PASSES 2
@@ -81,85 +105,137 @@ struct Fwd3L1Cfg {
     // waves per SIMD whatever the LDS says: at the 168-register cap of three it spills 84-194 VGPRs.  So 2.
     static constexpr int SP = DT_F3L1_STAGE_PASSES, SREC = 64 / SP;
     static constexpr int STAGE_W = SREC * REC_LDS;        // floats: SREC records per wavefront
-    static constexpr int LDS_FLOATS = S0F + S1F + (NT / 64) * STAGE_W;
+    static constexpr int XR0 = S0F + S1F + (NT / 64) * STAGE_W;
+    static constexpr int LDS_FLOATS = XR0 + ((XRF + 3) & ~3);
     static constexpr int NT2 = 2 * PJ * (TK / 4);         // axis-2 tasks (4 outputs each)
     static constexpr int WK = 4 + 2 * H;                  // axis-2 window (<= 12)
     static_assert(M0 % 2 == 1 && M1 % 2 == 1, "biort filters must have odd length");
     static_assert(H <= 4, "axis-2 window must fit three float4");
+    static_assert(PK % 2 == 0 && NLEFT <= NT, "position pairs must not straddle rows");
     static constexpr int NCELL = (TJ / 2) * (TK / 2);
     static_assert(NCELL == NT && TK / 2 == 32, "one 2x2 cell per thread, one cell row per half wavefront");
 };
 
+// The lowpass and the highpass filter of axis 2 and axis 1 run as ONE chain of packed FMAs: window element d of
+// 2H+1 meets the pair (h0, h1) of taps that multiply it, the shorter filter padded with zeros -- 7 v_pk_fma_f32
+// per output pair instead of 5 + 7 scalar FMAs for near_sym_a.  (The kernel is bound by instruction issue and
+// LDS latency at two waves per SIMD, not by HBM: 590 VALU instructions per thread and slice before this.)
+template <class C>
+DT_HD f3_v2f f3l1_tap_pair(const Fwd3L1Params &p, int d) {
+    const int k0 = C::H + C::H0 - d, k1 = C::H + C::H1 - d;
+    return f3_v2f{(k0 >= 0 && k0 < C::M0) ? p.h0[k0] : 0.f, (k1 >= 0 && k1 < C::M1) ? p.h1[k1] : 0.f};
+}
+
 // per-thread registers carried across the steps of the march
 template <class C>
 struct Fwd3L1State {
-    float ring[C::NPT][C::MR];
-    float nxt[C::NPT];
-    int goff[C::NPT];         // j*n2 + k of the position (reflected), constant over slices
-    int soff[C::NPT];         // pj*S0S + pk, or -1 for the unused tail
+    f3_v2f ring[C::NPP][C::MR];
+    f3_v2f nxa[C::NPP], nxb[C::NPP];      // the next two slices, loaded one slice pair ahead
+    int goff[C::NPP][2];                  // j*n2 + k of the two positions (reflected), constant over slices
+    int soff[C::NPP];                     // pj*S0S + pk of the pair
+    f3_v2f exa, exb;                      // leftover pair (threads < NLEFT)
+    int egoff[2], esoff;
     float ev[8][4];           // [a0*4 + a1*2 + a2][dj*2 + dk] of the even slice of the pair
 };
 
 template <class C>
+DT_HD void f3l1_pair_offsets(const Fwd3L1Params &p, int qp, int j0, int k0, int (&goff)[2], int &soff) {
+    const int q = 2 * qp;
+    const int pj = q / C::PK, pk = q - pj * C::PK;
+    const int j = reflect_i(j0 - C::H + pj, p.n1);
+    goff[0] = j * p.n2 + reflect_i(k0 - C::H + pk, p.n2);
+    goff[1] = j * p.n2 + reflect_i(k0 - C::H + pk + 1, p.n2);
+    soff = pj * C::S0S + pk;
+}
+
+template <class C>
 DT_HD void f3l1_init(const Fwd3L1Params &p, Fwd3L1State<C> &st, int tid, int j0, int k0) {
 #pragma unroll
-    for (int s = 0; s < C::NPT; ++s) {
-        int q = tid + C::NT * s;
-        int pj = q / C::PK, pk = q - pj * C::PK;
-        bool ok = q < C::NPOS;
-        if (!ok) { pj = 0; pk = 0; }
-        int j = reflect_i(j0 - C::H + pj, p.n1), k = reflect_i(k0 - C::H + pk, p.n2);
-        st.goff[s] = j * p.n2 + k;
-        st.soff[s] = ok ? pj * C::S0S + pk : -1;
+    for (int s = 0; s < C::NPP; ++s) f3l1_pair_offsets<C>(p, tid + C::NT * s, j0, k0, st.goff[s], st.soff[s]);
+    if (tid < C::NLEFT) f3l1_pair_offsets<C>(p, tid + C::NT * C::NPP, j0, k0, st.egoff, st.esoff);
+}
+
+// slices i+H+1 and i+H+2 -> nxa / nxb.  Called BEFORE the stores of a slice pair are issued: s_waitcnt vmcnt
+// counts loads and stores in order, so a load issued after the record stores cannot be waited for without
+// draining them, while one issued before them only has to let `the stores issued since` stay in flight.
+template <class C>
+DT_HD void f3l1_prefetch(const Fwd3L1Params &p, Fwd3L1State<C> &st, int tid, int i) {
+    const int64_t ss = (int64_t)p.n1 * p.n2;
+    const float *sa = p.X + ss * reflect_i(i + C::H + 1, p.n0), *sb = p.X + ss * reflect_i(i + C::H + 2, p.n0);
+#pragma unroll
+    for (int s = 0; s < C::NPP; ++s) {
+        st.nxa[s] = f3_v2f{sa[st.goff[s][0]], sa[st.goff[s][1]]};
+        st.nxb[s] = f3_v2f{sb[st.goff[s][0]], sb[st.goff[s][1]]};
+    }
+    if (tid < C::NLEFT) {
+        st.exa = f3_v2f{sa[st.egoff[0]], sa[st.egoff[1]]};
+        st.exb = f3_v2f{sb[st.egoff[0]], sb[st.egoff[1]]};
     }
 }
 
-// ring <- slices i0-H .. i0+H: all loads in one batch
+// ring <- slices i0-H .. i0+H (all loads in one batch), leftover pairs into XR[slice][thread]
 template <class C>
-DT_HD void f3l1_prologue(const Fwd3L1Params &p, Fwd3L1State<C> &st, int i0) {
+DT_HD void f3l1_prologue(const Fwd3L1Params &p, Fwd3L1State<C> &st, float *XR, int tid, int i0) {
     const int64_t ss = (int64_t)p.n1 * p.n2;
 #pragma unroll
     for (int t = 0; t < C::MR; ++t) {
         const float *sl = p.X + ss * reflect_i(i0 - C::H + t, p.n0);
 #pragma unroll
-        for (int s = 0; s < C::NPT; ++s) st.ring[s][t] = sl[st.goff[s]];
+        for (int s = 0; s < C::NPP; ++s) st.ring[s][t] = f3_v2f{sl[st.goff[s][0]], sl[st.goff[s][1]]};
     }
-}
-
-// prefetch slice i+1+H, filter the ring (slices i-H .. i+H) along axis 0 into S0.
-// The prefetched values are only touched by f3l1_rotate two barriers later: a wait on them
-// here would also wait for the record stores of the previous step (vmcnt counts both).
-template <class C>
-DT_HD void f3l1_axis0(const Fwd3L1Params &p, Fwd3L1State<C> &st, float *S0, int i, bool more) {
-    if (more) {
-        const float *sl = p.X + (int64_t)p.n1 * p.n2 * reflect_i(i + 1 + C::H, p.n0);
+    if (tid < C::NLEFT) {
+        f3_v2f e[C::MR];                                 // all loads first, then the LDS writes (one wait)
 #pragma unroll
-        for (int s = 0; s < C::NPT; ++s) st.nxt[s] = sl[st.goff[s]];
-    }
-#pragma unroll
-    for (int s = 0; s < C::NPT; ++s) {
-        float lo = 0.f, hi = 0.f;
-#pragma unroll
-        for (int k = 0; k < C::M0; ++k) lo += p.h0[k] * st.ring[s][C::H + C::H0 - k];
-#pragma unroll
-        for (int k = 0; k < C::M1; ++k) hi += p.h1[k] * st.ring[s][C::H + C::H1 - k];
-        if (st.soff[s] >= 0) {
-            S0[st.soff[s]] = lo;
-            S0[C::PJ * C::S0S + st.soff[s]] = hi;
+        for (int t = 0; t < C::MR; ++t) {
+            const float *sl = p.X + ss * reflect_i(i0 - C::H + t, p.n0);
+            e[t] = f3_v2f{sl[st.egoff[0]], sl[st.egoff[1]]};
         }
+#pragma unroll
+        for (int t = 0; t < C::MR; ++t) *reinterpret_cast<f3_v2f *>(XR + 2 * (t * C::NLEFT + tid)) = e[t];
     }
 }
 
-// ring <- slices i+1-H .. i+1+H (called before the stores of step i are issued)
+// both filters of axis 0 over a k-adjacent position pair: M0 + M1 packed FMAs, lo / hi pairs to S0
 template <class C>
-DT_HD void f3l1_rotate(Fwd3L1State<C> &st) {
+DT_HD void f3l1_axis0_pair(const Fwd3L1Params &p, const f3_v2f (&r)[C::MR], float *S0, int soff) {
+    f3_v2f lo = {0.f, 0.f}, hi = {0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < C::NPT; ++s) {
+    for (int k = 0; k < C::M0; ++k) lo += p.h0[k] * r[C::H + C::H0 - k];
+#pragma unroll
+    for (int k = 0; k < C::M1; ++k) hi += p.h1[k] * r[C::H + C::H1 - k];
+    *reinterpret_cast<f3_v2f *>(S0 + soff) = lo;
+    *reinterpret_cast<f3_v2f *>(S0 + C::PJ * C::S0S + soff) = hi;
+}
+
+// filter the ring (slices i-H .. i+H) along axis 0 into S0; rot = slices rotated so far (mod MR): the oldest
+// slice of the leftover ring sits in slot rot
+template <class C>
+DT_HD void f3l1_axis0(const Fwd3L1Params &p, Fwd3L1State<C> &st, float *S0, const float *XR, int tid, int rot) {
+#pragma unroll
+    for (int s = 0; s < C::NPP; ++s) f3l1_axis0_pair<C>(p, st.ring[s], S0, st.soff[s]);
+    if (tid < C::NLEFT) {
+        f3_v2f r[C::MR];
+#pragma unroll
+        for (int t = 0; t < C::MR; ++t) {
+            int slot = rot + t;
+            if (slot >= C::MR) slot -= C::MR;
+            r[t] = *reinterpret_cast<const f3_v2f *>(XR + 2 * (slot * C::NLEFT + tid));
+        }
+        f3l1_axis0_pair<C>(p, r, S0, st.esoff);
+    }
+}
+
+// ring <- slices one further, the new one from nxa (second == false) or nxb
+template <class C>
+DT_HD void f3l1_rotate(Fwd3L1State<C> &st, float *XR, int tid, int rot, bool second) {
+#pragma unroll
+    for (int s = 0; s < C::NPP; ++s) {
 #pragma unroll
         for (int t = 0; t < C::MR - 1; ++t) st.ring[s][t] = st.ring[s][t + 1];
-        st.ring[s][C::MR - 1] = st.nxt[s];
+        st.ring[s][C::MR - 1] = second ? st.nxb[s] : st.nxa[s];
         DT_PIN_HERE(st.ring[s][C::MR - 1]);
     }
+    if (tid < C::NLEFT) *reinterpret_cast<f3_v2f *>(XR + 2 * (rot * C::NLEFT + tid)) = second ? st.exb : st.exa;
 }
 
 // S1[2*a0 + a2][pj][k] = (axis-2 filter a2) of S0[a0][pj][.]
@@ -182,12 +258,10 @@ DT_HD void f3l1_axis2(const Fwd3L1Params &p, const float *S0, float *S1, int tid
         float lo[4], hi[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float a = 0.f, b = 0.f;
+            f3_v2f a = {0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < C::M0; ++k) a += p.h0[k] * w[e + C::H + C::H0 - k];
-#pragma unroll
-            for (int k = 0; k < C::M1; ++k) b += p.h1[k] * w[e + C::H + C::H1 - k];
-            lo[e] = a; hi[e] = b;
+            for (int d = 0; d < C::MR; ++d) a += f3l1_tap_pair<C>(p, d) * f3_v2f{w[e + d], w[e + d]};
+            lo[e] = a.x; hi[e] = a.y;
         }
         float *d = S1 + ((2 * vol) * C::PJ + pj) * C::TK + 4 * c;
         *reinterpret_cast<f4 *>(d) = f4{lo[0], lo[1], lo[2], lo[3]};
@@ -208,8 +282,10 @@ DT_HD void cube2c_record(float *rec, const float (&ev)[4], const float (&od)[4])
 // record slot of octant idx = a0*4 + a1*2 + a2 (reference order 010 100 110 001 011 101 111)
 DT_HD int octant_slot(int idx) { return (idx & 1) ? 3 + (idx >> 1) : (idx >> 1) - 1; }
 
-// axis-1 filters for the thread's 2x2 (j, k) cell -> out[a0*4 + a1*2 + a2][dj*2 + dk], LLL store
-template <class C>
+// axis-1 filters for the thread's 2x2 (j, k) cell -> out[a0*4 + a1*2 + a2][dj*2 + dk], LLL store.
+// FULL: the tile lies inside the volume (stores without conditions: the compiler can then count them when it
+// waits for the prefetched slices, see f3l1_prefetch)
+template <class C, bool FULL>
 DT_HD void f3l1_axis1(const Fwd3L1Params &p, float (&out)[8][4], const float *S1, int tid, int i, int j0,
                       int k0) {
     const int cj = tid / (C::TK / 2), ck = tid - cj * (C::TK / 2);
@@ -227,16 +303,14 @@ DT_HD void f3l1_axis1(const Fwd3L1Params &p, float (&out)[8][4], const float *S1
         for (int e = 0; e < 2; ++e)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                float lo = 0.f, hi = 0.f;
+                f3_v2f a = {0.f, 0.f};
 #pragma unroll
-                for (int t = 0; t < C::M0; ++t) lo += p.h0[t] * u[e + C::H + C::H0 - t][c];
-#pragma unroll
-                for (int t = 0; t < C::M1; ++t) hi += p.h1[t] * u[e + C::H + C::H1 - t][c];
-                out[a0 * 4 + a2][e * 2 + c] = lo;
-                out[a0 * 4 + 2 + a2][e * 2 + c] = hi;
+                for (int d = 0; d < C::MR; ++d) a += f3l1_tap_pair<C>(p, d) * f3_v2f{u[e + d][c], u[e + d][c]};
+                out[a0 * 4 + a2][e * 2 + c] = a.x;
+                out[a0 * 4 + 2 + a2][e * 2 + c] = a.y;
             }
     }
-    if (j < p.n1 && k < p.n2) {
+    if (FULL || (j < p.n1 && k < p.n2)) {
         float *L = p.LLL + ((int64_t)i * p.n1 + j) * p.n2 + k;
         *reinterpret_cast<f2 *>(L) = f2{out[0][0], out[0][1]};
         *reinterpret_cast<f2 *>(L + p.n2) = f2{out[0][2], out[0][3]};
@@ -255,6 +329,7 @@ DT_HD void f3l1_axis1(const Fwd3L1Params &p, float (&out)[8][4], const float *S1
 template <class C>
 DT_HD void f3l1_pack_stage(const float (&ev)[8][4], const float (&od)[8][4], float *stage, int tid, int pass) {
     const int lane = tid & 63, wave = tid >> 6;
+    DT_WAVE_LDS_SYNC();                                  // the previous pass has read its records out of the slab
     if (lane / C::SREC != pass) return;
     float *rec = stage + wave * C::STAGE_W + (lane % C::SREC) * REC_LDS;
     // record slots in the reference's concatenation order (transform3d.py:278-289):
@@ -269,22 +344,27 @@ DT_HD void f3l1_pack_stage(const float (&ev)[8][4], const float (&od)[8][4], flo
 }
 
 // pass: which SREC consecutive cells of the wavefront's 64 (two rows of 32) are in the slab
-template <class C>
+template <class C, bool FULL>
 DT_HD void f3l1_pack_flush(const Fwd3L1Params &p, const float *stage, int tid, int pass, int i, int j0,
                            int k0) {
     const int lane = tid & 63, wave = tid >> 6;
     const int cell0 = pass * C::SREC;                    // first cell of the pass within the wavefront
     const int half = cell0 >> 5, c0 = cell0 & 31;        // its cell row (half wavefront) and first cell in the row
     const int j = j0 + 2 * (2 * wave + half);
-    if (j >= p.n1) return;
+    DT_WAVE_LDS_SYNC();                                  // the records other lanes staged
+    if (!FULL && j >= p.n1) return;
     const f4 *slab = reinterpret_cast<const f4 *>(stage + wave * C::STAGE_W);
     f4 *row = reinterpret_cast<f4 *>(p.Yh + (((int64_t)(i >> 1) * (p.n1 / 2) + (j >> 1)) * (p.n2 / 2) + (k0 >> 1) + c0) * 56);
-    int ncell = (p.n2 - k0) / 2 - c0;
-    if (ncell > C::SREC) ncell = C::SREC;
+    int ncell = C::SREC;
+    if (!FULL) {
+        ncell = (p.n2 - k0) / 2 - c0;
+        if (ncell > C::SREC) ncell = C::SREC;
+    }
 #pragma unroll
     for (int it = 0; it < (C::SREC * 14 + 63) / 64; ++it) {
         int piece = it * 64 + lane;                      // 16-byte piece of the pass's records
-        if (piece < ncell * 14) DT_STREAM_STORE_F4(row + piece, slab[slab_f4(piece)]);
+        if (FULL ? (C::SREC * 14 % 64 == 0 || piece < C::SREC * 14) : piece < ncell * 14)
+            DT_STREAM_STORE_F4(row + piece, slab[slab_f4(piece)]);
     }
 }
 

@@ -145,8 +145,15 @@ static int run_inv2(Inv2Params p) {
                 for (int t = 0; t < DT_NT; ++t)
                     inv_rec_stage<C::QR, C::QC>(Yhb, p.zr, p.zc, srec, r0 + C::ORG, c0 + C::ORG, t);
                 for (int t = 0; t < DT_NT; ++t) inv2r_gather<C>(p, srec, w1[t], w2[t], w3[t], t, r0, c0);
-                for (int t = 0; t < DT_NT; ++t) inv2r_fir<C>(p, wz[t], w1[t], w2[t], w3[t], y1, y2, t, y3);
-                for (int t = 0; t < DT_NT; ++t) inv2_rows<C>(p, y1, y2, t, b, r0, c0, y3);
+                const bool std_set = p.lo_pos && !p.hi_pos && (!C::BP || !p.bp_pos);     // as launch_inv2 decides
+                for (int t = 0; t < DT_NT; ++t) {
+                    if (std_set) inv2r_fir<C, false, true>(p, wz[t], w1[t], w2[t], w3[t], y1, y2, t, y3);
+                    else inv2r_fir<C, false, false>(p, wz[t], w1[t], w2[t], w3[t], y1, y2, t, y3);
+                }
+                for (int t = 0; t < DT_NT; ++t) {
+                    if (std_set) inv2_rows<C, true>(p, y1, y2, t, b, r0, c0, y3);
+                    else inv2_rows<C, false>(p, y1, y2, t, b, r0, c0, y3);
+                }
             }
     return 0;
 }
@@ -159,25 +166,43 @@ static int run_fwd3_l1(dt3d::Fwd3L1Params p, int chunk) {
     std::vector<float> smem(C::LDS_FLOATS + 4);
     float *base = smem.data();
     while (((uintptr_t)base) & 15) ++base;
-    float *S0 = base, *S1 = base + C::S0F, *stage = S1 + C::S1F;
+    float *S0 = base, *S1 = base + C::S0F, *stage = S1 + C::S1F, *XR = base + C::XR0;
     static Fwd3L1State<C> st[C::NT];
     for (int ch = 0; ch < p.chunks; ++ch)
         for (int tj = 0; tj < p.tilesJ; ++tj)
             for (int tk = 0; tk < p.tilesK; ++tk) {
                 int j0 = tj * C::TJ, k0 = tk * C::TK, i0 = ch * p.chunk;
                 int iend = i0 + p.chunk < p.n0 ? i0 + p.chunk : p.n0;
-                for (int t = 0; t < C::NT; ++t) { f3l1_init<C>(p, st[t], t, j0, k0); f3l1_prologue<C>(p, st[t], i0); }
+                const bool full = j0 + C::TJ <= p.n1 && k0 + C::TK <= p.n2;
+                for (int t = 0; t < C::NT; ++t) {
+                    f3l1_init<C>(p, st[t], t, j0, k0); f3l1_prologue<C>(p, st[t], XR, t, i0); f3l1_prefetch<C>(p, st[t], t, i0);
+                }
                 static float od[C::NT][8][4];
+                int rot = 0;
                 for (int i = i0; i < iend; i += 2) {
-                    for (int t = 0; t < C::NT; ++t) f3l1_axis0<C>(p, st[t], S0, i, true);
+                    for (int t = 0; t < C::NT; ++t) f3l1_axis0<C>(p, st[t], S0, XR, t, rot);
                     for (int t = 0; t < C::NT; ++t) f3l1_axis2<C>(p, S0, S1, t);
-                    for (int t = 0; t < C::NT; ++t) { f3l1_rotate<C>(st[t]); f3l1_axis1<C>(p, st[t].ev, S1, t, i, j0, k0); }
-                    for (int t = 0; t < C::NT; ++t) f3l1_axis0<C>(p, st[t], S0, i + 1, i + 2 < iend);
+                    for (int t = 0; t < C::NT; ++t) {
+                        f3l1_rotate<C>(st[t], XR, t, rot, false);
+                        if (full) f3l1_axis1<C, true>(p, st[t].ev, S1, t, i, j0, k0);
+                        else f3l1_axis1<C, false>(p, st[t].ev, S1, t, i, j0, k0);
+                    }
+                    rot = rot + 1 == C::MR ? 0 : rot + 1;
+                    for (int t = 0; t < C::NT; ++t) f3l1_axis0<C>(p, st[t], S0, XR, t, rot);
                     for (int t = 0; t < C::NT; ++t) f3l1_axis2<C>(p, S0, S1, t);
-                    for (int t = 0; t < C::NT; ++t) { f3l1_rotate<C>(st[t]); f3l1_axis1<C>(p, od[t], S1, t, i + 1, j0, k0); }
+                    for (int t = 0; t < C::NT; ++t) {
+                        f3l1_rotate<C>(st[t], XR, t, rot, true);
+                        f3l1_prefetch<C>(p, st[t], t, i + 2);
+                        if (full) f3l1_axis1<C, true>(p, od[t], S1, t, i + 1, j0, k0);
+                        else f3l1_axis1<C, false>(p, od[t], S1, t, i + 1, j0, k0);
+                    }
+                    rot = rot + 1 == C::MR ? 0 : rot + 1;
                     for (int pass = 0; pass < C::SP; ++pass) {
                         for (int t = 0; t < C::NT; ++t) f3l1_pack_stage<C>(st[t].ev, od[t], stage, t, pass);
-                        for (int t = 0; t < C::NT; ++t) f3l1_pack_flush<C>(p, stage, t, pass, i + 1, j0, k0);
+                        for (int t = 0; t < C::NT; ++t) {
+                            if (full) f3l1_pack_flush<C, true>(p, stage, t, pass, i + 1, j0, k0);
+                            else f3l1_pack_flush<C, false>(p, stage, t, pass, i + 1, j0, k0);
+                        }
                     }
                 }
             }

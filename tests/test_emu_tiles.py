@@ -254,7 +254,7 @@ def emu_fwd3_l1(emu, X, h0o, h1o, chunk):
     return LLL, Yh.view(np.complex64)
 
 
-@pytest.mark.parametrize('shape,chunk', [((8, 8, 8), 8), ((12, 20, 70), 4), ((10, 34, 130), 6), ((16, 16, 64), 16)])
+@pytest.mark.parametrize('shape,chunk', [((8, 8, 8), 8), ((12, 20, 70), 4), ((10, 34, 130), 6), ((16, 16, 64), 16), ((12, 32, 128), 6)])
 @pytest.mark.parametrize('bname', ['near_sym_a', 'antonini', 'legall'])
 def test_fwd3_level1_tiles(emu, shape, chunk, bname):
     X = np.random.RandomState(11).standard_normal(shape).astype(np.float32)

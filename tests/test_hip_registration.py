@@ -64,6 +64,28 @@ def test_float32_pyramids_and_device_outputs():
     assert dtcwt_amd.registration.estimatereg is reg.estimatereg
 
 
+def test_estimatereg_ragged_levels_vs_oracle():
+    """Levels whose sides are not multiples of the 8 x 4 tile of the batched kernels (41 x 53 ... 6 x 7; level indices are 0-based), a
+    group of three levels, and a grid larger than one workgroup's fold (regshape 60 x 60)."""
+    from oracle import dtcwt_oracle as o
+    from dtcwt_amd.coeffs import biort, qshift
+    yy, xx = np.mgrid[0:164, 0:212]
+    rs = np.random.RandomState(5)
+    ims = []
+    for sx, sy in ((0.0, 0.0), (0.9, -0.6)):
+        im = np.zeros(yy.shape)
+        for _ in range(16):
+            fx, fy, ph = rs.uniform(0.01, 0.12, 2).tolist() + [rs.uniform(0, 6.28)]
+            im += np.cos(6.283 * (fx * (xx + sx) + fy * (yy + sy)) + ph)
+        ims.append(im)
+        rs = np.random.RandomState(5)
+    t, to = Transform2d(), o.Transform2d(biort('near_sym_a'), qshift('qshift_a'))
+    p1, p2 = t.forward(ims[0], nlevels=5), t.forward(ims[1], nlevels=5)
+    o1, o2 = to.forward(ims[0], nlevels=5), to.forward(ims[1], nlevels=5)
+    for kw in (dict(), dict(levels=[[4, 3], [4, 3, 2], [3, 2, 1]]), dict(regshape=(60, 60), levels=[[4, 3], [3, 2]])):
+        assert rel(reg.estimatereg(p1, p2, **kw), ro.estimatereg(o1, o2, **kw)) < 1e-6, kw
+
+
 def test_argument_errors():
     g = golden()
     p1, p2 = hip_pyramids(g)
