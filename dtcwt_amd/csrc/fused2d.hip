@@ -39,7 +39,9 @@ __global__ void __launch_bounds__(DT_NT) k_fwd1(Fwd1Params p) {
     constexpr int NQ = (C::TR / 2) * (C::TC / 2);
     for (int base = 0; base < NQ; base += DT_NT) {
         fwd1s_rows_compute<C>(p, sLo, sHi, stage, threadIdx.x, base, b, r0, c0, sBa);
+        DT_WAVE_LDS_SYNC();
         fwd1s_rows_flush<C>(p, stage, threadIdx.x, base, b, r0, c0);
+        DT_WAVE_LDS_SYNC();
     }
 }
 
@@ -57,7 +59,9 @@ __global__ void __launch_bounds__(DT_NT) k_fwd2(Fwd2Params p) {
     __syncthreads();
     for (int base = 0; base < C::TI * C::TJ; base += DT_NT) {
         fwd2s_rows_compute<C>(p, sLo, sHi, stage, threadIdx.x, base, b, r0, c0, sBa);
+        DT_WAVE_LDS_SYNC();
         fwd2s_rows_flush<C>(p, stage, threadIdx.x, base, b, r0, c0);
+        DT_WAVE_LDS_SYNC();
     }
 }
 
@@ -96,7 +100,9 @@ __global__ void __launch_bounds__(C::NT, C::MIN_WAVES) k_fwd12(Fwd1Params p1, Fw
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             fwd12_core_deposit<C>(stage, tidp, round, half, rec);
+            DT_WAVE_LDS_SYNC();
             fwd12_core_flush<C>(p1, stage, tid, round, half, b, r1, c1);
+            DT_WAVE_LDS_SYNC();
         }
     }
     if (!(SKIP & 4)) fwd12_halo_compute<C>(p1, sLo, tidp, st);
@@ -112,7 +118,9 @@ __global__ void __launch_bounds__(C::NT, C::MIN_WAVES) k_fwd12(Fwd1Params p1, Fw
     if (!(SKIP & 16))
     for (int base = 0; base < C::TI * C::TJ; base += C::NT) {
         fwd2s_rows_compute<typename C::L2View>(p2, sLo2, sHi2, stage, tidp, base, b, r2, c2);
+        DT_WAVE_LDS_SYNC();
         fwd2s_rows_flush<typename C::L2View>(p2, stage, tid, base, b, r2, c2);
+        DT_WAVE_LDS_SYNC();
     }
 }
 

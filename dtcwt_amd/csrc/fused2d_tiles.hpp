@@ -21,6 +21,23 @@
 // (colfilter :47-80, coldfilt :82-154, colifilt :156-260) and
 // dtcwt/numpy/transform2d.py (level loops :112-160, :242-293; q2c :301-322; c2q :324-350).
 #pragma once
+
+// Lanes of ONE wavefront hand data to each other through a wave-private LDS slab without a workgroup barrier
+// (LDS operations of a wavefront execute in order).  The compiler still has to be told: a wavefront-scope
+// release / acquire pair around a convergent no-op, which costs no instruction but stops it from moving the
+// reads of all lanes into the divergent block in which some lanes wrote (it did, once the stores that follow
+// became unconditional: the lanes outside the block then stored stale registers).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DT_WAVE_LDS_SYNC()                                  \
+    do {                                                    \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                    \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+#else
+#define DT_WAVE_LDS_SYNC() (void)0
+#endif
+
 #include <hip/hip_runtime.h>
 
 #include <cstdint>

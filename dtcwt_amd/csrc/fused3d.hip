@@ -87,6 +87,7 @@ __global__ void __launch_bounds__(NT) k_fwd3_l2_axis0(Fwd3L2Params p) {
     const int id = (int)(blockIdx.x * NT + threadIdx.x);
     float *ws = slab + wave * 64 * REC_LDS;
     f3l2_axis0_stage<M>(p, id, ws + lane * REC_LDS);
+    DT_WAVE_LDS_SYNC();
     f3l2_axis0_flush(p, id - lane, lane, ws);
 }
 

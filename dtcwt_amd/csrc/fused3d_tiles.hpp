@@ -35,21 +35,6 @@
 #define DT_PIN_HERE(x) (void)(x)
 #endif
 
-// Lanes of ONE wavefront hand data to each other through a wave-private LDS slab without a workgroup barrier
-// (LDS operations of a wavefront execute in order).  The compiler still has to be told: a wavefront-scope
-// release / acquire pair around a convergent no-op, which costs no instruction but stops it from moving the
-// reads of all lanes into the divergent block in which some lanes wrote (it did, once the stores that follow
-// became unconditional: the lanes outside the block then stored stale registers).
-#if defined(__HIP_DEVICE_COMPILE__)
-#define DT_WAVE_LDS_SYNC()                                  \
-    do {                                                    \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
-        __builtin_amdgcn_wave_barrier();                    \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
-    } while (0)
-#else
-#define DT_WAVE_LDS_SYNC() (void)0
-#endif
 
 namespace dt3d {
 
