@@ -141,6 +141,7 @@ int launch_fwd1(Fwd1Params &p, hipStream_t s) {
 template <class C>
 int launch_fwd2(Fwd2Params &p, hipStream_t s) {
     p.tilesR = cdiv(p.LR / 2, C::TR); p.tilesC = cdiv(p.LC / 2, C::TC);
+    dt_pack_lh(p);
     k_fwd2<C><<<grid_for(p.tilesR * p.tilesC * p.B, p.xcd_order), DT_NT, 0, s>>>(p);
     return 0;
 }
@@ -148,6 +149,7 @@ int launch_fwd2(Fwd2Params &p, hipStream_t s) {
 template <class C, int SKIP = 0>
 int launch_fwd12(Fwd1Params &p1, Fwd2Params &p2, hipStream_t s, size_t extra_lds = 0) {
     p2.tilesR = cdiv(p2.LR / 2, C::T2R); p2.tilesC = cdiv(p2.LC / 2, C::T2C);
+    dt_pack_lh(p2);
     const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float) + extra_lds;
     static bool raised = false;         // per instantiation: allow more than the default 64 KiB of dynamic LDS
     if ((lds > (48u << 10) && !raised) || extra_lds) {

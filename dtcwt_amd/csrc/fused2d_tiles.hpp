@@ -122,6 +122,9 @@ struct Fwd2Params {
     // coldfilt(X, ha, hb) is called as (h0b, h0a) and (h1b, h1a): "a" arrays hold the
     // first argument, "b" the second.
     float l_a[DT_MAXT], l_b[DT_MAXT], h_a[DT_MAXT], h_b[DT_MAXT];
+    // (l_a[i], h_a[i]) and (l_b[i], h_b[i]) interleaved, 8-byte aligned: the tap pairs of dfilt_pair2, filled by
+    // dt_pack_lh() in the launch functions
+    float lh_a[2 * DT_MAXT] __attribute__((aligned(8))), lh_b[2 * DT_MAXT] __attribute__((aligned(8)));
     // band-pass q-shift (12-vector sets): coldfilt(X, h2b, h2a) for the diagonal subbands (:145-155)
     int bp_a_first;
     float b_a[DT_MAXT], b_b[DT_MAXT];
@@ -130,6 +133,37 @@ struct Fwd2Params {
 // One (A, B) pair from a 2M window w[0..2M) whose element j is logical sample
 // 4i - M + 2 + j (A.2):  A = sum_k ha[2k] w[2M-2-4k] + ha[2k+1] w[2M-4-4k]
 //                        B = sum_k hb[2k] w[2M-1-4k] + hb[2k+1] w[2M-3-4k]
+typedef float dt_pk2 __attribute__((ext_vector_type(2)));
+
+// The lowpass and the highpass pair of a level >= 2 forward filter over the SAME window as packed FMAs: lane 0
+// of a v_pk_fma_f32 carries the l_a / l_b chain, lane 1 the h_a / h_b chain, the window sample is broadcast.
+// Half the FMA instructions of two dfilt_pair calls (the forward q-shift kernels spend 75-85 % of their time
+// with the VALU busy: profiles/r02/pmc_valu_2d.txt).
+// The (lowpass, highpass) tap pairs come INTERLEAVED from the parameter block (lh_a / lh_b: one aligned 8-byte
+// scalar load per pair).  Forming the pairs in the kernel from the separate l_* / h_* kernel-argument arrays made
+// the compiler copy those arrays to scratch and fetch the pairs from there (k_fwd2: 21.6 -> 66 us).
+template <class P>
+inline void dt_pack_lh(P &p) {
+    for (int i = 0; i < DT_MAXT; ++i) {
+        p.lh_a[2 * i] = p.l_a[i]; p.lh_a[2 * i + 1] = p.h_a[i];
+        p.lh_b[2 * i] = p.l_b[i]; p.lh_b[2 * i + 1] = p.h_b[i];
+    }
+}
+
+template <int M>
+DT_HD void dfilt_pair2(const float *w, const float *lha, const float *lhb, float &Al, float &Bl, float &Ah, float &Bh) {
+    const dt_pk2 *ta = reinterpret_cast<const dt_pk2 *>(lha), *tb = reinterpret_cast<const dt_pk2 *>(lhb);
+    dt_pk2 a = {0.f, 0.f}, b = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < M / 2; ++k) {
+        a += ta[2 * k] * w[2 * M - 2 - 4 * k];
+        a += ta[2 * k + 1] * w[2 * M - 4 - 4 * k];
+        b += tb[2 * k] * w[2 * M - 1 - 4 * k];
+        b += tb[2 * k + 1] * w[2 * M - 3 - 4 * k];
+    }
+    Al = a.x; Ah = a.y; Bl = b.x; Bh = b.y;
+}
+
 template <int M>
 DT_HD void dfilt_pair(const float *w, const float *ha, const float *hb, float &A, float &B) {
     float a = 0.f, b = 0.f;
@@ -224,7 +258,6 @@ DT_HD void ifilt4(const float *w, const float *ha, const float *hb, int pos, flo
 // inverse kernels are bound by VALU issue (761 VALU instructions per wavefront, a third of them FMAs, = 27 us of
 // the 32 us of k_inv2 at 4096^2).  POS >= 0: sum(ha * hb) > 0 known at compile time (every shipped q-shift set
 // has it 1 for the g0 pair and 0 for the g1 pair), which also removes the per-sample selects; POS < 0: `pos`.
-typedef float dt_pk2 __attribute__((ext_vector_type(2)));
 template <class C, int POS>
 DT_HD void ifilt4_acc(const float *w, const float *ha, const float *hb, int pos, dt_pk2 &P, dt_pk2 &Q) {
     const bool ps = POS < 0 ? pos != 0 : POS != 0;

@@ -263,14 +263,13 @@ DT_HD void fwd2d_cols(const Fwd2Params &p, float *sLo, float *sHi, int tid, int 
         }
 #pragma unroll
         for (int q = 0; q < C::PS; ++q) {
-            float A, Bv;
+            float A, Bv, Ah, Bh;
             int row = 2 * (strip * C::PS + q);
-            dfilt_pair<C::M>(w + 4 * q, p.l_a, p.l_b, A, Bv);
+            dfilt_pair2<C::M>(w + 4 * q, p.lh_a, p.lh_b, A, Bv, Ah, Bh);
             sLo[row * C::NCI + cc] = p.lo_a_first ? A : Bv;
             sLo[(row + 1) * C::NCI + cc] = p.lo_a_first ? Bv : A;
-            dfilt_pair<C::M>(w + 4 * q, p.h_a, p.h_b, A, Bv);
-            sHi[row * C::NCI + cc] = p.hi_a_first ? A : Bv;
-            sHi[(row + 1) * C::NCI + cc] = p.hi_a_first ? Bv : A;
+            sHi[row * C::NCI + cc] = p.hi_a_first ? Ah : Bh;
+            sHi[(row + 1) * C::NCI + cc] = p.hi_a_first ? Bh : Ah;
             if (C::BP) {
                 dfilt_pair<C::M>(w + 4 * q, p.b_a, p.b_b, A, Bv);
                 sBa[row * C::NCI + cc] = p.bp_a_first ? A : Bv;
@@ -302,14 +301,13 @@ DT_HD void fwd2s_rows_compute(const Fwd2Params &p, const float *sLo, const float
             wl[4 * j] = a.x; wl[4 * j + 1] = a.y; wl[4 * j + 2] = a.z; wl[4 * j + 3] = a.w;
             wh[4 * j] = c.x; wh[4 * j + 1] = c.y; wh[4 * j + 2] = c.z; wh[4 * j + 3] = c.w;
         }
-        float A, Bv;
-        dfilt_pair<C::M>(wl, p.l_a, p.l_b, A, Bv);
+        float A, Bv, Ah, Bh;
+        dfilt_pair2<C::M>(wl, p.lh_a, p.lh_b, A, Bv, Ah, Bh);
         ll[er][0] = p.lo_a_first ? A : Bv; ll[er][1] = p.lo_a_first ? Bv : A;
-        dfilt_pair<C::M>(wh, p.l_a, p.l_b, A, Bv);
-        hl[er][0] = p.lo_a_first ? A : Bv; hl[er][1] = p.lo_a_first ? Bv : A;
-        dfilt_pair<C::M>(wl, p.h_a, p.h_b, A, Bv);
-        lh[er][0] = p.hi_a_first ? A : Bv; lh[er][1] = p.hi_a_first ? Bv : A;
-        if (C::BP) {            // diagonal subbands: Ba rows through the band-pass pair
+        lh[er][0] = p.hi_a_first ? Ah : Bh; lh[er][1] = p.hi_a_first ? Bh : Ah;
+        if (C::BP) {
+            dfilt_pair<C::M>(wh, p.l_a, p.l_b, A, Bv);
+            hl[er][0] = p.lo_a_first ? A : Bv; hl[er][1] = p.lo_a_first ? Bv : A;            // diagonal subbands: Ba rows through the band-pass pair
             const f4 *pb = reinterpret_cast<const f4 *>(sBa + (2 * il + er) * C::NCI + 4 * jl);
 #pragma unroll
             for (int j = 0; j < C::M / 2; ++j) {
@@ -319,8 +317,9 @@ DT_HD void fwd2s_rows_compute(const Fwd2Params &p, const float *sLo, const float
             dfilt_pair<C::M>(wh, p.b_a, p.b_b, A, Bv);
             hh[er][0] = p.bp_a_first ? A : Bv; hh[er][1] = p.bp_a_first ? Bv : A;
         } else {
-            dfilt_pair<C::M>(wh, p.h_a, p.h_b, A, Bv);
-            hh[er][0] = p.hi_a_first ? A : Bv; hh[er][1] = p.hi_a_first ? Bv : A;
+            dfilt_pair2<C::M>(wh, p.lh_a, p.lh_b, A, Bv, Ah, Bh);
+            hl[er][0] = p.lo_a_first ? A : Bv; hl[er][1] = p.lo_a_first ? Bv : A;
+            hh[er][0] = p.hi_a_first ? Ah : Bh; hh[er][1] = p.hi_a_first ? Bh : Ah;
         }
     }
     float *L = p.LoLo + ((int64_t)b * OR + R) * OC + Cc;

@@ -121,6 +121,7 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 template <class C>
 int launch_l2_planes(dt2d::Fwd2Params &p, float *planes, int64_t pstride, hipStream_t s) {
     p.tilesR = cdiv(p.LR / 2, C::TR); p.tilesC = cdiv(p.LC / 2, C::TC);
+    dt2d::dt_pack_lh(p);
     const int ntile = p.tilesR * p.tilesC * p.B;
     k_fwd3_l2_planes<C><<<xcd3_grid(ntile, XCD3_FWD_PLANES), DT_NT, 0, s>>>(p, planes, pstride, xcd3_arg(ntile, XCD3_FWD_PLANES));
     return 0;
@@ -143,6 +144,7 @@ void launch_l2_planes_best(dt2d::Fwd2Params &p, float *planes, int64_t pstride, 
 
 template <class C>
 int launch_l2_axis0(Fwd3L2Params &p, int cus, hipStream_t s) {
+    dt2d::dt_pack_lh(p);
     int cells = (p.O0 / 2) * (p.O1 / 2) * (p.O2 / 2);
     // coarse levels: single-wavefront workgroups so that every CU gets work
     if (cdiv(cells, DT_NT) < 4 * cus)

@@ -389,16 +389,14 @@ DT_HD void fwd2p_rows(const dt2d::Fwd2Params &p, const float *sLo, const float *
             wl[4 * j] = a.x; wl[4 * j + 1] = a.y; wl[4 * j + 2] = a.z; wl[4 * j + 3] = a.w;
             wh[4 * j] = c.x; wh[4 * j + 1] = c.y; wh[4 * j + 2] = c.z; wh[4 * j + 3] = c.w;
         }
-        float A, Bv;
+        float A, Bv, Ah, Bh;
         float *q = o + (int64_t)er * OC;
-        dfilt_pair<C::M>(wl, p.l_a, p.l_b, A, Bv);      // a1 = 0, a2 = 0
+        dt2d::dfilt_pair2<C::M>(wl, p.lh_a, p.lh_b, A, Bv, Ah, Bh);      // a1 = 0; a2 = 0, 1
         *reinterpret_cast<f2 *>(q) = p.lo_a_first ? f2{A, Bv} : f2{Bv, A};
-        dfilt_pair<C::M>(wl, p.h_a, p.h_b, A, Bv);      // a1 = 0, a2 = 1
-        *reinterpret_cast<f2 *>(q + pstride) = p.hi_a_first ? f2{A, Bv} : f2{Bv, A};
-        dfilt_pair<C::M>(wh, p.l_a, p.l_b, A, Bv);      // a1 = 1, a2 = 0
+        *reinterpret_cast<f2 *>(q + pstride) = p.hi_a_first ? f2{Ah, Bh} : f2{Bh, Ah};
+        dt2d::dfilt_pair2<C::M>(wh, p.lh_a, p.lh_b, A, Bv, Ah, Bh);      // a1 = 1; a2 = 0, 1
         *reinterpret_cast<f2 *>(q + 2 * pstride) = p.lo_a_first ? f2{A, Bv} : f2{Bv, A};
-        dfilt_pair<C::M>(wh, p.h_a, p.h_b, A, Bv);      // a1 = 1, a2 = 1
-        *reinterpret_cast<f2 *>(q + 3 * pstride) = p.hi_a_first ? f2{A, Bv} : f2{Bv, A};
+        *reinterpret_cast<f2 *>(q + 3 * pstride) = p.hi_a_first ? f2{Ah, Bh} : f2{Bh, Ah};
     }
 }
 
@@ -411,6 +409,7 @@ struct Fwd3L2Params {
     int O0, O1, O2;       // octant extents (L/2, all even)
     int lo_a_first, hi_a_first;
     float l_a[DT_MAXT], l_b[DT_MAXT], h_a[DT_MAXT], h_b[DT_MAXT];
+    float lh_a[2 * DT_MAXT] __attribute__((aligned(8))), lh_b[2 * DT_MAXT] __attribute__((aligned(8)));   // dt_pack_lh()
 };
 
 // One thread per output cell; the 56-float record goes to the thread's slot of a
@@ -446,11 +445,10 @@ DT_HD void f3l2_axis0_stage(const Fwd3L2Params &p, int id, float *rec) {
         float lev[4], lod[4], hev[4], hod[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float A, Bv;
-            dfilt_pair<M>(w[q], p.l_a, p.l_b, A, Bv);
+            float A, Bv, Ah, Bh;
+            dt2d::dfilt_pair2<M>(w[q], p.lh_a, p.lh_b, A, Bv, Ah, Bh);
             lev[q] = p.lo_a_first ? A : Bv; lod[q] = p.lo_a_first ? Bv : A;
-            dfilt_pair<M>(w[q], p.h_a, p.h_b, A, Bv);
-            hev[q] = p.hi_a_first ? A : Bv; hod[q] = p.hi_a_first ? Bv : A;
+            hev[q] = p.hi_a_first ? Ah : Bh; hod[q] = p.hi_a_first ? Bh : Ah;
         }
         if (v == 0) {
             float *L = p.LLL + (int64_t)(2 * c0) * ss + base;

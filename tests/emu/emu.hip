@@ -52,6 +52,7 @@ static int run_fwd1(Fwd1Params p) {
 template <class C>
 static int run_fwd2(Fwd2Params p) {
     p.tilesR = cdiv(p.LR / 2, C::TR); p.tilesC = cdiv(p.LC / 2, C::TC);
+    dt_pack_lh(p);
     std::vector<float> smem(C::LDS_FLOATS + 4 * STAGE_FLOATS_PER_WAVE + 4);
     float *base = smem.data();
     while (((uintptr_t)base) & 15) ++base;
@@ -72,6 +73,7 @@ static int run_fwd2(Fwd2Params p) {
 template <class C>
 static int run_fwd12(Fwd1Params p1, Fwd2Params p2) {
     p2.tilesR = cdiv(p2.LR / 2, C::T2R); p2.tilesC = cdiv(p2.LC / 2, C::T2C);
+    dt_pack_lh(p2);
     std::vector<float> smem(C::LDS_FLOATS + 4);
     float *base = smem.data();
     while (((uintptr_t)base) & 15) ++base;
@@ -212,6 +214,7 @@ static int run_fwd3_l1(dt3d::Fwd3L1Params p, int chunk) {
 template <class C>
 static int run_fwd3_l2(Fwd2Params a, dt3d::Fwd3L2Params b, float *planes) {
     a.tilesR = cdiv(a.LR / 2, C::TR); a.tilesC = cdiv(a.LC / 2, C::TC);
+    dt_pack_lh(a); dt_pack_lh(b);
     std::vector<float> smem(C::LDS_FLOATS + 4);
     float *base = smem.data();
     while (((uintptr_t)base) & 15) ++base;
