@@ -104,16 +104,18 @@ __global__ void __launch_bounds__(DT_NT) k_fwd3_l2_planes(dt2d::Fwd2Params p, fl
         fwd2p_rows<C>(p, sLo, sHi, planes, pstride, threadIdx.x, base, b, r0, c0);
 }
 
-// Level >= 2, pass B: axis-0 decimating filters + cube2c, one thread per output cell.
-template <int M, int NT>
+// Level >= 2, pass B: axis-0 decimating filters + cube2c; CPW cells per wavefront (f3l2_axis0_stage).
+template <int M, int NT, int CPW>
 __global__ void __launch_bounds__(NT) k_fwd3_l2_axis0(Fwd3L2Params p) {
-    __shared__ __attribute__((aligned(16))) float slab[(NT / 64) * 64 * REC_LDS];
+    __shared__ __attribute__((aligned(16))) float slab[(NT / 64) * CPW * REC_LDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int id = (int)(blockIdx.x * NT + threadIdx.x);
-    float *ws = slab + wave * 64 * REC_LDS;
-    f3l2_axis0_stage<M>(p, id, ws + lane * REC_LDS);
+    float *ws = slab + wave * CPW * REC_LDS;
+    const int cl = lane & (CPW - 1);                               // the lane's cell within the wavefront
+    const int first = ((int)blockIdx.x * (NT / 64) + wave) * CPW;
+    if (CPW == 64) f3l2_axis0_stage<M>(p, first + cl, ws + cl * REC_LDS);
+    else f3l2_axis0_stage<M>(p, first + cl, ws + cl * REC_LDS, 2 * (lane >> 5), 2);
     DT_WAVE_LDS_SYNC();
-    f3l2_axis0_flush(p, id - lane, lane, ws);
+    f3l2_axis0_flush<CPW>(p, first, lane, ws);
 }
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -145,12 +147,16 @@ void launch_l2_planes_best(dt2d::Fwd2Params &p, float *planes, int64_t pstride, 
 template <class C>
 int launch_l2_axis0(Fwd3L2Params &p, int cus, hipStream_t s) {
     dt2d::dt_pack_lh(p);
+
     int cells = (p.O0 / 2) * (p.O1 / 2) * (p.O2 / 2);
     // coarse levels: single-wavefront workgroups so that every CU gets work
+    // coarse levels: single-wavefront workgroups and two lanes per cell (half the dependent loads per thread: 64^3
+    // cells 8.1 -> 7.4 us), so that every CU gets work; large levels are not latency-bound (no gain from the split:
+    // a knock-out build runs 19 of their 31 us without any load or store) and keep one lane per cell
     if (cdiv(cells, DT_NT) < 4 * cus)
-        k_fwd3_l2_axis0<C::M, 64><<<(unsigned)cdiv(cells, 64), 64, 0, s>>>(p);
+        k_fwd3_l2_axis0<C::M, 64, 32><<<(unsigned)cdiv(cells, 32), 64, 0, s>>>(p);
     else
-        k_fwd3_l2_axis0<C::M, DT_NT><<<(unsigned)cdiv(cells, DT_NT), DT_NT, 0, s>>>(p);
+        k_fwd3_l2_axis0<C::M, DT_NT, 64><<<(unsigned)cdiv(cells, DT_NT), DT_NT, 0, s>>>(p);
     return 0;
 }
 

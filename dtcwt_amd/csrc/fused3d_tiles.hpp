@@ -412,34 +412,37 @@ struct Fwd3L2Params {
     float lh_a[2 * DT_MAXT] __attribute__((aligned(8))), lh_b[2 * DT_MAXT] __attribute__((aligned(8)));   // dt_pack_lh()
 };
 
-// One thread per output cell; the 56-float record goes to the thread's slot of a
-// wave-private LDS slab (64 x 56 floats) and f3l2_axis0_flush writes the wavefront's 64
-// consecutive records (cell ids are record indices) as fourteen 1 KiB runs.
-template <int M>
-DT_HD void f3l2_axis0_stage(const Fwd3L2Params &p, int id, float *rec) {
-    using dt2d::dfilt_pair;
-    const int e2 = p.O2 / 2, e1 = p.O1 / 2, e0 = p.O0 / 2;
-    if (id >= e0 * e1 * e2) return;
-    const int c2 = id % e2, t = id / e2, c1 = t % e1, c0 = t / e1;
+// Planes v0 .. v0 + nv - 1 (of the four (a1, a2) planes) of output cell `id`: their octants go to the cell's
+// 56-float record in a wave-private LDS slab, and f3l2_axis0_flush writes the wavefront's consecutive records
+// (cell ids are record indices) as 1 KiB runs.  Two lanes share a cell (two planes each: 32 cells and a 7.7 KB
+// slab per wavefront, five workgroups per CU, 80 dependent loads per thread) or one lane does all four (64
+// cells, 15 KB: two workgroups per CU, 160 loads per thread).
+// INNER: the 2M slices of the window are slices r0 .. r0 + 2M - 1 of the planes as they are (no reflection, no
+// replicated planes): one multiply-add per address instead of a table of 2M reflected offsets
+template <int M, bool INNER>
+DT_HD void f3l2_axis0_planes(const Fwd3L2Params &p, int c0, int base, int r0, float *rec, int v0, int nv) {
     const int ss = p.O1 * p.O2;
-    int soff[2 * M];
+    int soff[INNER ? 1 : 2 * M];
+    if (!INNER) {
 #pragma unroll
-    for (int j = 0; j < 2 * M; ++j) {
-        int r = 4 * c0 - M + 2 + j;                      // logical slice (A.2)
-        while ((unsigned)r >= (unsigned)p.L0) r = r < 0 ? -1 - r : 2 * p.L0 - 1 - r;
-        r -= p.pad0;
-        r = r < 0 ? 0 : (r > p.n0 - 1 ? p.n0 - 1 : r);
-        soff[j] = r * ss;
+        for (int j = 0; j < 2 * M; ++j) {
+            int r = r0 + p.pad0 + j;                         // logical slice (A.2)
+            while ((unsigned)r >= (unsigned)p.L0) r = r < 0 ? -1 - r : 2 * p.L0 - 1 - r;
+            r -= p.pad0;
+            r = r < 0 ? 0 : (r > p.n0 - 1 ? p.n0 - 1 : r);
+            soff[j] = r * ss;
+        }
     }
-    const int base = (2 * c1) * p.O2 + 2 * c2;
 #pragma unroll 1
-    for (int v = 0; v < 4; ++v) {
+    for (int v = v0; v < v0 + nv; ++v) {
         const float *Pv = p.P + v * p.pstride + base;
+        const float *P0 = Pv + (int64_t)r0 * ss;
         float w[4][2 * M];                               // [dj*2 + dk][slice]
 #pragma unroll
         for (int j = 0; j < 2 * M; ++j) {
-            f2 a = *reinterpret_cast<const f2 *>(Pv + soff[j]);
-            f2 b = *reinterpret_cast<const f2 *>(Pv + soff[j] + p.O2);
+            const float *src = INNER ? P0 + j * ss : Pv + soff[j];
+            f2 a = *reinterpret_cast<const f2 *>(src);
+            f2 b = *reinterpret_cast<const f2 *>(src + p.O2);
             w[0][j] = a.x; w[1][j] = a.y; w[2][j] = b.x; w[3][j] = b.y;
         }
         float lev[4], lod[4], hev[4], hod[4];
@@ -463,14 +466,26 @@ DT_HD void f3l2_axis0_stage(const Fwd3L2Params &p, int id, float *rec) {
     }
 }
 
-// first: cell id of the wavefront's lane 0
+template <int M>
+DT_HD void f3l2_axis0_stage(const Fwd3L2Params &p, int id, float *rec, int v0 = 0, int nv = 4) {
+    const int e2 = p.O2 / 2, e1 = p.O1 / 2, e0 = p.O0 / 2;
+    if (id >= e0 * e1 * e2) return;
+    const int c2 = id % e2, t = id / e2, c1 = t % e1, c0 = t / e1;
+    const int base = (2 * c1) * p.O2 + 2 * c2;
+    const int r0 = 4 * c0 - M + 2 - p.pad0;              // first slice of the window in the unpadded planes
+    if (r0 >= 0 && r0 + 2 * M <= p.n0) f3l2_axis0_planes<M, true>(p, c0, base, r0, rec, v0, nv);
+    else f3l2_axis0_planes<M, false>(p, c0, base, r0, rec, v0, nv);
+}
+
+// first: id of the wavefront's first cell, CPW: cells per wavefront (64 or 32)
+template <int CPW = 64>
 DT_HD void f3l2_axis0_flush(const Fwd3L2Params &p, int first, int lane, const float *slab) {
     const int ncell = (p.O0 / 2) * (p.O1 / 2) * (p.O2 / 2);
-    const int n = ncell - first < 64 ? ncell - first : 64;
+    const int n = ncell - first < CPW ? ncell - first : CPW;
     f4 *dst = reinterpret_cast<f4 *>(p.Yh + (int64_t)first * 56);
     const f4 *src = reinterpret_cast<const f4 *>(slab);
 #pragma unroll
-    for (int it = 0; it < 14; ++it) {
+    for (int it = 0; it < 14 * CPW / 64; ++it) {
         int piece = it * 64 + lane;
         if (piece < n * 14) DT_STREAM_STORE_F4(dst + piece, src[slab_f4(piece)]);
     }

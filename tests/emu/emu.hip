@@ -231,9 +231,10 @@ static int run_fwd3_l2(Fwd2Params a, dt3d::Fwd3L2Params b, float *planes) {
     std::vector<float> slab(64 * dt3d::REC_LDS + 4);
     float *ws = slab.data();
     while (((uintptr_t)ws) & 15) ++ws;
-    for (int first = 0; first < cells; first += 64) {
-        for (int l = 0; l < 64; ++l) dt3d::f3l2_axis0_stage<C::M>(b, first + l, ws + l * dt3d::REC_LDS);
-        for (int l = 0; l < 64; ++l) dt3d::f3l2_axis0_flush(b, first, l, ws);
+    for (int first = 0; first < cells; first += 32) {      // two lanes per cell, as the kernel runs coarse levels
+        for (int l = 0; l < 64; ++l)
+            dt3d::f3l2_axis0_stage<C::M>(b, first + (l & 31), ws + (l & 31) * dt3d::REC_LDS, 2 * (l >> 5), 2);
+        for (int l = 0; l < 64; ++l) dt3d::f3l2_axis0_flush<32>(b, first, l, ws);
     }
     return 0;
 }
