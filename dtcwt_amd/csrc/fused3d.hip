@@ -366,6 +366,10 @@ void launch_inv3_axis0(Inv3AParams &p, int cus, hipStream_t s) {
     const int pairs = p.n0 / 2;
     int chunk = 64;             // long marches amortise the 2 HP + 1 warm-up steps
     while (chunk > 8 && (int64_t)p.tilesJ * p.tilesK * cdiv(pairs, chunk) < 4 * (int64_t)cus) chunk /= 2;
+    // coarse levels: fewer workgroups than CUs even at 8 pairs per march -- shorter marches (more warm-up steps in
+    // all, but the level is a latency chain: 32^3 cells 22.6 -> 14.2 us); with a workgroup per CU or more, 8 stays
+    // (64^3 cells: 35 us at 8, 45 us at 4)
+    while (chunk > 2 && (int64_t)p.tilesJ * p.tilesK * cdiv(pairs, chunk) < (int64_t)cus) chunk /= 2;
     if (const char *e = getenv("DTCWT_HIP_CHUNK3D_INV")) {
         int v = atoi(e);
         if (v >= 1) chunk = v;
