@@ -160,12 +160,21 @@ def test_emu_level1_forward_inverse(emu, bn, shape):
         assert rel(Z[i], want) < TOL
 
 
-@pytest.mark.parametrize('qn', QSHIFTS)
+def _flipped(qn):
+    """qshift_a with the signs of g0b, g1b, h0b and h1b flipped: sum(ha hb) of every pair changes sign, so the level
+    >= 2 tile programs take their run-time filter phases instead of the compile-time ones of the shipped sets"""
+    q = [np.array(v, dtype=np.float64) for v in qshift(qn.split(':')[0])]
+    for k in (1, 3, 5, 7):
+        q[k] = -q[k]
+    return tuple(q)
+
+
+@pytest.mark.parametrize('qn', QSHIFTS + ['qshift_a:flipped'])
 @pytest.mark.parametrize('shape', [(64, 64), (44, 52), (42, 74), (40, 40), (130, 66)])
 def test_emu_level2_forward_inverse(emu, qn, shape):
     rs = np.random.RandomState(5)
     X = rs.standard_normal((2,) + shape).astype(np.float32)
-    q = qshift(qn)
+    q = _flipped(qn) if ':' in qn else qshift(qn)
     lolo, yh = emu_fwd2(emu, X, q)
     h0a, h0b, g0a, g0b, h1a, h1b, g1a, g1b = q[:8]
     rows = lambda fn, A, *h: fn(A.T, *h).T

@@ -552,3 +552,26 @@ def test_plan_cache_is_bounded_and_complex_input_is_refused():
     assert len(t._plans) == 0
     with pytest.raises(TypeError):
         t.forward(np.zeros((64, 64), np.complex64), nlevels=1)
+
+
+@pytest.mark.parametrize('flip', ['g0', 'g1', 'both', 'h'])
+def test_user_taps_with_other_filter_phases(flip):
+    """Every shipped q-shift set has sum(g0a g0b) > 0 > sum(g1a g1b) (and the analysis pairs likewise), which the
+    fused level >= 2 kernels take as compile-time constants; user-supplied taps with the other signs must take the
+    run-time path and still agree with the oracle (no perfect reconstruction: the transform is linear either way)."""
+    q = [np.array(v, dtype=np.float64) for v in qshift('qshift_a')]
+    # (h0a, h0b, g0a, g0b, h1a, h1b, g1a, g1b)
+    if flip in ('g0', 'both'):
+        q[3] = -q[3]
+    if flip in ('g1', 'both'):
+        q[7] = -q[7]
+    if flip == 'h':
+        q[1] = -q[1]; q[5] = -q[5]
+    q = tuple(q)
+    rs = np.random.RandomState(23)
+    X = rs.standard_normal((192, 256)).astype(np.float32)
+    t, to = Transform2d('near_sym_a', q), o.Transform2d(biort('near_sym_a'), q)
+    assert t.plan(1, 192, 256, 3) is not None
+    want = to.forward(as_f64(X), nlevels=3)
+    assert_pyramids_close(t.forward(X, nlevels=3), want, XFM_TOL, same_dtype=False)
+    assert_close(t.inverse(cast_pyramid(want, np.float32)), to.inverse(want), INV_TOL, 'inverse, user taps ' + flip)
