@@ -135,6 +135,7 @@ inline unsigned grid_for(int ntile, int order = 1) {
 template <class C>
 int launch_fwd1(Fwd1Params &p, hipStream_t s) {
     p.tilesR = cdiv(p.LR, C::TR); p.tilesC = cdiv(p.LC, C::TC);
+    dt_pack_c01<C::M0, C::M1>(p);
     k_fwd1<C><<<grid_for(p.tilesR * p.tilesC * p.B, p.xcd_order), DT_NT, 0, s>>>(p);
     return 0;
 }

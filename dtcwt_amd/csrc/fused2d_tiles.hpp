@@ -45,6 +45,7 @@
 #define DT_HD __host__ __device__ __forceinline__
 #define DT_NT 256                       // threads per workgroup
 #define DT_MAXT 40                      // == DTCWT_HIP_MAX_TAPS
+typedef float dt_pk2 __attribute__((ext_vector_type(2)));   // one v_pk_fma_f32 operand
 
 namespace dt2d {
 
@@ -81,7 +82,20 @@ struct Fwd1Params {
     int xcd_order;        // 1: XCD-contiguous tile runs, 0: linear order
     float h0[DT_MAXT], h1[DT_MAXT];
     float h2[DT_MAXT];    // band-pass biort (6-vector sets): the diagonal subbands (transform2d.py:116-129)
+    // (h0, h1) pairs by window offset, the shorter filter zero-padded: element d of a window of 2 HH + 1 samples
+    // meets c01[2d] (lowpass) and c01[2d + 1] (highpass) in one packed FMA; filled by dt_pack_c01 in the launch
+    float c01[2 * DT_MAXT] __attribute__((aligned(8)));
 };
+
+template <int M0, int M1>
+inline void dt_pack_c01(Fwd1Params &p) {
+    constexpr int H0 = M0 / 2, H1 = M1 / 2, HH = H0 > H1 ? H0 : H1;
+    for (int d = 0; d < DT_MAXT; ++d) {
+        const int k0 = HH + H0 - d, k1 = HH + H1 - d;
+        p.c01[2 * d] = (k0 >= 0 && k0 < M0) ? p.h0[k0] : 0.f;
+        p.c01[2 * d + 1] = (k1 >= 0 && k1 < M1) ? p.h1[k1] : 0.f;
+    }
+}
 
 // q2c of quad (a b / c d): z0 = s((a-d) + j(b+c)), z1 = s((a+d) + j(b-c))   (A.4)
 DT_HD void q2c_pair(float a, float b, float c, float d, float &z0r, float &z0i, float &z1r,
@@ -133,8 +147,6 @@ struct Fwd2Params {
 // One (A, B) pair from a 2M window w[0..2M) whose element j is logical sample
 // 4i - M + 2 + j (A.2):  A = sum_k ha[2k] w[2M-2-4k] + ha[2k+1] w[2M-4-4k]
 //                        B = sum_k hb[2k] w[2M-1-4k] + hb[2k+1] w[2M-3-4k]
-typedef float dt_pk2 __attribute__((ext_vector_type(2)));
-
 // The lowpass and the highpass pair of a level >= 2 forward filter over the SAME window as packed FMAs: lane 0
 // of a v_pk_fma_f32 carries the l_a / l_b chain, lane 1 the h_a / h_b chain, the window sample is broadcast.
 // Half the FMA instructions of two dfilt_pair calls (the forward q-shift kernels spend 75-85 % of their time

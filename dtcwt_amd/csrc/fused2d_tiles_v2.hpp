@@ -69,15 +69,14 @@ DT_HD void fwd1d_cols(const Fwd1Params &p, float *sLo, float *sHi, int tid, int 
                 w[j] = Xb[(int64_t)gr * p.inC + gc];
             }
         }
+        const dt_pk2 *cp = reinterpret_cast<const dt_pk2 *>(p.c01);
 #pragma unroll
         for (int q = 0; q < C::RS; ++q) {
-            float lo = 0.f, hi = 0.f;
+            dt_pk2 a = {0.f, 0.f};                  // (lowpass, highpass) of row q: one packed chain
 #pragma unroll
-            for (int k = 0; k < C::M0; ++k) lo += p.h0[k] * w[q + C::HH + C::H0 - k];
-#pragma unroll
-            for (int k = 0; k < C::M1; ++k) hi += p.h1[k] * w[q + C::HH + C::H1 - k];
-            sLo[(strip * C::RS + q) * C::W + cc] = lo;
-            sHi[(strip * C::RS + q) * C::W + cc] = hi;
+            for (int d = 0; d < 2 * C::HH + 1; ++d) a += cp[d] * w[q + d];
+            sLo[(strip * C::RS + q) * C::W + cc] = a.x;
+            sHi[(strip * C::RS + q) * C::W + cc] = a.y;
             if (C::BP) {
                 float ba = 0.f;
 #pragma unroll
@@ -121,20 +120,16 @@ DT_HD void fwd1s_rows_compute(const Fwd1Params &p, const float *sLo, const float
             wl[2 * j] = a.x; wl[2 * j + 1] = a.y;
             wh[2 * j] = c.x; wh[2 * j + 1] = c.y;
         }
+        const dt_pk2 *cp = reinterpret_cast<const dt_pk2 *>(p.c01);
 #pragma unroll
         for (int ec = 0; ec < 2; ++ec) {
-            float s_ll = 0.f, s_hl = 0.f, s_lh = 0.f, s_hh = 0.f;
+            dt_pk2 al = {0.f, 0.f}, ah = {0.f, 0.f};       // (h0, h1) over the Lo row: (ll, lh); over the Hi row: (hl, hh)
 #pragma unroll
-            for (int k = 0; k < C::M0; ++k) {
-                s_ll += p.h0[k] * wl[ec + C::HC + C::H0 - k];
-                s_hl += p.h0[k] * wh[ec + C::HC + C::H0 - k];
+            for (int d = 0; d < 2 * C::HH + 1; ++d) {
+                al += cp[d] * wl[ec + C::HC - C::HH + d];
+                ah += cp[d] * wh[ec + C::HC - C::HH + d];
             }
-#pragma unroll
-            for (int k = 0; k < C::M1; ++k) {
-                s_lh += p.h1[k] * wl[ec + C::HC + C::H1 - k];
-                if (!C::BP) s_hh += p.h1[k] * wh[ec + C::HC + C::H1 - k];
-            }
-            ll[er][ec] = s_ll; hl[er][ec] = s_hl; lh[er][ec] = s_lh; hh[er][ec] = s_hh;
+            ll[er][ec] = al.x; lh[er][ec] = al.y; hl[er][ec] = ah.x; hh[er][ec] = ah.y;   // hh: h2 below when BP
         }
         if (C::BP) {            // diagonal subbands: Ba rows through h2
             float wb[WL];

@@ -31,6 +31,7 @@ static double dotd(const double *a, const double *b, int m) {
 template <class C>
 static int run_fwd1(Fwd1Params p) {
     p.tilesR = cdiv(p.LR, C::TR); p.tilesC = cdiv(p.LC, C::TC);
+    dt_pack_c01<C::M0, C::M1>(p);
     std::vector<float> smem(C::LDS_FLOATS + 4 * STAGE_FLOATS_PER_WAVE + 4);
     float *base = smem.data();
     while (((uintptr_t)base) & 15) ++base;
