@@ -71,6 +71,7 @@ __global__ void __launch_bounds__(DT_NT) k_inv2(Inv2Params p) {
 template <class C>
 int launch_inv1(Inv1Params &p, hipStream_t s) {
     p.tilesR = cdiv(p.R, C::TR); p.tilesC = cdiv(p.C, C::TC);
+    dt_pack_g01<C::M0, C::M1>(p);
     k_inv1<C><<<grid_for(p.tilesR * p.tilesC * p.B, p.xcd_order), DT_NT, 0, s>>>(p);
     return 0;
 }

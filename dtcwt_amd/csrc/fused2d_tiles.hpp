@@ -204,7 +204,20 @@ struct Inv1Params {
     float g[6];           // gain_mask column * sqrt(1/2)
     float g0[DT_MAXT], g1[DT_MAXT];
     float g2[DT_MAXT];    // band-pass biort: y2bp = colfilter(hh, g2), third row filter (:283-291)
+    // (g0, g1) pairs by window offset for the row pass (dt_pack_g01 in the launch functions): sample d of a window
+    // of 2 HH + 1 interleaved (y1, y2) pairs meets (g01[2d], g01[2d + 1]) in one packed FMA
+    float g01[2 * DT_MAXT] __attribute__((aligned(8)));
 };
+
+template <int M0, int M1>
+inline void dt_pack_g01(Inv1Params &p) {
+    constexpr int H0 = M0 / 2, H1 = M1 / 2, HH = H0 > H1 ? H0 : H1;
+    for (int d = 0; d < DT_MAXT; ++d) {
+        const int k0 = HH + H0 - d, k1 = HH + H1 - d;
+        p.g01[2 * d] = (k0 >= 0 && k0 < M0) ? p.g0[k0] : 0.f;
+        p.g01[2 * d + 1] = (k1 >= 0 && k1 < M1) ? p.g1[k1] : 0.f;
+    }
+}
 
 // ======================================================================================
 // Level >= 2 inverse: even-length q-shift pairs, interpolation by 2 per axis (colifilt).

@@ -379,26 +379,26 @@ DT_HD void inv1d_rows(const Inv1Params &p, const float *y1, const float *y2, int
         const int r = (tid >> 5) + round * (DT_NT / 32);
         int R = r0 + r, Cc = c0 + 4 * q;
         if (q >= NQ || R >= p.R || Cc >= p.C) continue;
-        float wa[WL], wb[WL];
-        const f4 *pa = reinterpret_cast<const f4 *>(y1 + r * C::NC + 4 * q);
-        const f4 *pb = reinterpret_cast<const f4 *>(y2 + r * C::NC + 4 * q);
+        // y1 and y2 are interleaved in LDS ((y1, y2) pairs, written by inv1r_fir): a 16-byte read is two window
+        // positions ready as packed operands, and (g0 over y1, g1 over y2) of an output is one packed chain
+        dt_pk2 wab[WL];
+        const f4 *pa = reinterpret_cast<const f4 *>(y1 + 2 * (r * C::NC + 4 * q));
 #pragma unroll
-        for (int j = 0; j < WL / 4; ++j) {
-            f4 a = pa[j], c = pb[j];
-            wa[4 * j] = a.x; wa[4 * j + 1] = a.y; wa[4 * j + 2] = a.z; wa[4 * j + 3] = a.w;
-            wb[4 * j] = c.x; wb[4 * j + 1] = c.y; wb[4 * j + 2] = c.z; wb[4 * j + 3] = c.w;
+        for (int j = 0; j < WL / 2; ++j) {
+            f4 a = pa[j];
+            wab[2 * j] = dt_pk2{a.x, a.y}; wab[2 * j + 1] = dt_pk2{a.z, a.w};
         }
+        const dt_pk2 *gp = reinterpret_cast<const dt_pk2 *>(p.g01);
         float o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float s = 0.f;
+            dt_pk2 s2 = {0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < C::M0; ++k) s += p.g0[k] * wa[e + C::HE + C::H0 - k];
-#pragma unroll
-            for (int k = 0; k < C::M1; ++k) s += p.g1[k] * wb[e + C::HE + C::H1 - k];
-            o[e] = s;
+            for (int d = 0; d < 2 * C::HH + 1; ++d) s2 += gp[d] * wab[e + C::HE - C::HH + d];
+            o[e] = s2.x + s2.y;
         }
         if (C::BP) {
+            float wa[WL];
             const f4 *pc = reinterpret_cast<const f4 *>(y3 + r * C::NC + 4 * q);
 #pragma unroll
             for (int j = 0; j < WL / 4; ++j) { f4 a = pc[j]; wa[4 * j] = a.x; wa[4 * j + 1] = a.y; wa[4 * j + 2] = a.z; wa[4 * j + 3] = a.w; }
@@ -670,21 +670,20 @@ DT_HD void inv1r_fir(const Inv1Params &p, const float (&w0)[C::WN], const float 
     const ColTask t = LIN ? inv_col_task_lin<C>(tid) : inv_col_task<C>(tid);
     if (!t.valid) return;
     const int cc = 2 * t.i + t.e;
+    // (y1, y2) of a row as one packed chain: g0 over (w0, w2), g1 over (w1, w3); the pair goes to LDS interleaved
+    // (one 8-byte write; y2 is not a plane of its own any more: y1 holds [TR][NC] pairs = the same 2 SY floats)
+    dt_pk2 u[C::WN], v[C::WN];
+#pragma unroll
+    for (int j = 0; j < C::WN; ++j) { u[j] = dt_pk2{w0[j], w2[j]}; v[j] = dt_pk2{w1[j], C::BP ? 0.f : w3[j]}; }
+    dt_pk2 *y12 = reinterpret_cast<dt_pk2 *>(y1);
 #pragma unroll
     for (int q = 0; q < C::RS; ++q) {
-        float a = 0.f, bq = 0.f;
+        dt_pk2 a = {0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < C::M0; ++k) {
-            a += p.g0[k] * w0[q + C::HE + C::H0 - k];
-            bq += p.g0[k] * w2[q + C::HE + C::H0 - k];
-        }
+        for (int k = 0; k < C::M0; ++k) a += p.g0[k] * u[q + C::HE + C::H0 - k];
 #pragma unroll
-        for (int k = 0; k < C::M1; ++k) {
-            a += p.g1[k] * w1[q + C::HE + C::H1 - k];
-            if (!C::BP) bq += p.g1[k] * w3[q + C::HE + C::H1 - k];
-        }
-        y1[(t.strip * C::RS + q) * C::NC + cc] = a;
-        y2[(t.strip * C::RS + q) * C::NC + cc] = bq;
+        for (int k = 0; k < C::M1; ++k) a += p.g1[k] * v[q + C::HE + C::H1 - k];
+        y12[(t.strip * C::RS + q) * C::NC + cc] = a;
         if (C::BP) {
             float c = 0.f;
 #pragma unroll

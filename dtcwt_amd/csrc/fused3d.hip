@@ -350,6 +350,7 @@ __global__ void __launch_bounds__(DT_NT) k_inv3_l2_planes(dt2d::Inv2Params p, co
 template <class C>
 void launch_inv3_l1_planes(dt2d::Inv1Params &b, const float *planes, int64_t ps, hipStream_t s) {
     b.tilesR = cdiv(b.R, C::TR); b.tilesC = cdiv(b.C, C::TC);
+    dt2d::dt_pack_g01<C::M0, C::M1>(b);
     const int ntile = b.tilesR * b.tilesC * b.B;
     k_inv3_l1_planes<C><<<xcd3_grid(ntile, XCD3_INV_L1_PLANES), DT_NT, 0, s>>>(b, planes, ps, xcd3_arg(ntile, XCD3_INV_L1_PLANES));
 }

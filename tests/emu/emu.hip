@@ -111,6 +111,7 @@ static int run_fwd12(Fwd1Params p1, Fwd2Params p2) {
 template <class C>
 static int run_inv1(Inv1Params p) {
     p.tilesR = cdiv(p.R, C::TR); p.tilesC = cdiv(p.C, C::TC);
+    dt_pack_g01<C::M0, C::M1>(p);
     std::vector<float> smem(C::LDS_ALIASED + 4);
     float *base = smem.data();
     while (((uintptr_t)base) & 15) ++base;
@@ -284,6 +285,7 @@ static void run_inv3_axis0(dt3d::Inv3AParams p, int chunk) {
 template <class C>
 static void run_inv3_l1_planes(Inv1Params p, const float *planes, int64_t ps) {
     p.tilesR = cdiv(p.R, C::TR); p.tilesC = cdiv(p.C, C::TC);
+    dt_pack_g01<C::M0, C::M1>(p);
     std::vector<float> smem(2 * C::SY + 4);
     float *base = smem.data();
     while (((uintptr_t)base) & 15) ++base;
