@@ -1,5 +1,6 @@
-"""Time dtcwt_hip_fwd3_level1 alone (256^3 float32 by default); DTCWT_HIP_F3_KNOCK selects knock-outs in
-experiment builds (tools/build_variant.sh knock fused3d.hip -DDT_F3L1_KNOCK)."""
+"""Time dtcwt_hip_fwd3_level1 alone (256^3 float32 by default; N3D=<n> for n^3).  KNOCKS=a,b,... repeats the
+measurement with DTCWT_HIP_F3_KNOCK set to each value -- only meaningful with an experiment build that reads it
+(the phase knock-outs quoted in DESIGN.md section 4 were such builds, made with tools/build_variant.sh)."""
 import ctypes, os, sys, time
 import numpy as np
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
