@@ -173,6 +173,7 @@ int launch_fwd3_l1(Fwd3L1Params &p, int cus, hipStream_t s) {
     }
     p.chunk = chunk;
     p.chunks = cdiv(p.n0, chunk);
+    f3l1_pack_taps<C>(p);
     const int ntile = p.tilesJ * p.tilesK * p.chunks;
     k_fwd3_l1<C><<<xcd3_grid(ntile, XCD3_FWD_L1), C::NT, 0, s>>>(p, xcd3_arg(ntile, XCD3_FWD_L1));
     return 0;

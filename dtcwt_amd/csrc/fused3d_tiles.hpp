@@ -59,7 +59,25 @@ struct Fwd3L1Params {
     int chunk;           // slices marched by one workgroup (even)
     int tilesJ, tilesK, chunks;
     float h0[DT_MAXT], h1[DT_MAXT];
+    // axis-1 taps with cube2c's factor 1/2 folded in (exact: a power of two), filled by f3l1_pack_taps():
+    // h0s = h0 / 2, h1s = h1 / 2, and h0p = (h0, h0 / 2) pairs for the one lowpass chain whose first lane is the
+    // unscaled LLL octant
+    float h1s[DT_MAXT];
+    float h0p[2 * DT_MAXT] __attribute__((aligned(8)));
+    // (h0, h1) by window offset d = 0 .. 2H (the shorter filter zero-padded): the pairs of the axis-2 chains, and
+    // the scalars of the axis-0 chains, from one table (scalar registers are short in this kernel)
+    float c01[2 * DT_MAXT] __attribute__((aligned(8)));
 };
+template <class C>
+inline void f3l1_pack_taps(Fwd3L1Params &p) {
+    for (int k = 0; k < DT_MAXT; ++k) {
+        p.h1s[k] = 0.5f * p.h1[k];
+        p.h0p[2 * k] = p.h0[k]; p.h0p[2 * k + 1] = 0.5f * p.h0[k];
+        const int k0 = C::H + C::H0 - k, k1 = C::H + C::H1 - k;       // k as window offset d
+        p.c01[2 * k] = (k0 >= 0 && k0 < C::M0) ? p.h0[k0] : 0.f;
+        p.c01[2 * k + 1] = (k1 >= 0 && k1 < C::M1) ? p.h1[k1] : 0.f;
+    }
+}
 
 typedef float f3_v2f __attribute__((ext_vector_type(2)));
 
@@ -107,8 +125,7 @@ struct Fwd3L1Cfg {
 // LDS latency at two waves per SIMD, not by HBM: 590 VALU instructions per thread and slice before this.)
 template <class C>
 DT_HD f3_v2f f3l1_tap_pair(const Fwd3L1Params &p, int d) {
-    const int k0 = C::H + C::H0 - d, k1 = C::H + C::H1 - d;
-    return f3_v2f{(k0 >= 0 && k0 < C::M0) ? p.h0[k0] : 0.f, (k1 >= 0 && k1 < C::M1) ? p.h1[k1] : 0.f};
+    return reinterpret_cast<const f3_v2f *>(p.c01)[d];
 }
 
 // per-thread registers carried across the steps of the march
@@ -185,9 +202,9 @@ template <class C>
 DT_HD void f3l1_axis0_pair(const Fwd3L1Params &p, const f3_v2f (&r)[C::MR], float *S0, int soff) {
     f3_v2f lo = {0.f, 0.f}, hi = {0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < C::M0; ++k) lo += p.h0[k] * r[C::H + C::H0 - k];
+    for (int d = C::H - C::H0; d <= C::H + C::H0; ++d) lo += p.c01[2 * d] * r[d];
 #pragma unroll
-    for (int k = 0; k < C::M1; ++k) hi += p.h1[k] * r[C::H + C::H1 - k];
+    for (int d = C::H - C::H1; d <= C::H + C::H1; ++d) hi += p.c01[2 * d + 1] * r[d];
     *reinterpret_cast<f3_v2f *>(S0 + soff) = lo;
     *reinterpret_cast<f3_v2f *>(S0 + C::PJ * C::S0S + soff) = hi;
 }
@@ -240,17 +257,18 @@ DT_HD void f3l1_axis2(const Fwd3L1Params &p, const float *S0, float *S1, int tid
             f4 v = src[q];
             w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
         }
-        float lo[4], hi[4];
+        f3_v2f a[4];                                      // (a2 = 0, a2 = 1) of outputs k = 4c .. 4c + 3
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            f3_v2f a = {0.f, 0.f};
+            a[e] = f3_v2f{0.f, 0.f};
 #pragma unroll
-            for (int d = 0; d < C::MR; ++d) a += f3l1_tap_pair<C>(p, d) * f3_v2f{w[e + d], w[e + d]};
-            lo[e] = a.x; hi[e] = a.y;
+            for (int d = 0; d < C::MR; ++d) a[e] += f3l1_tap_pair<C>(p, d) * f3_v2f{w[e + d], w[e + d]};
         }
-        float *d = S1 + ((2 * vol) * C::PJ + pj) * C::TK + 4 * c;
-        *reinterpret_cast<f4 *>(d) = f4{lo[0], lo[1], lo[2], lo[3]};
-        *reinterpret_cast<f4 *>(d + C::PJ * C::TK) = f4{hi[0], hi[1], hi[2], hi[3]};
+        // S1[a0][pj][k parity][k / 2] pairs: the even and the odd outputs of the task are 16 bytes each, at a 16-byte
+        // lane stride (conflict-free), and stay packed for the axis-1 chains
+        float *d = S1 + (((vol * C::PJ + pj) * 2) * (C::TK / 2) + 2 * c) * 2;
+        *reinterpret_cast<f4 *>(d) = f4{a[0].x, a[0].y, a[2].x, a[2].y};
+        *reinterpret_cast<f4 *>(d + C::TK) = f4{a[1].x, a[1].y, a[3].x, a[3].y};
     }
 }
 
@@ -264,6 +282,14 @@ DT_HD void cube2c_record(float *rec, const float (&ev)[4], const float (&od)[4])
     o[1] = f4{(A + G + D - F) * h, (B + Hh - Cc + E) * h, (A + G - D + F) * h, (-B - Hh - Cc + E) * h};
 }
 
+// the same for octants that already carry the factor 1/2 (f3l1_axis1)
+DT_HD void cube2c_record_scaled(float *rec, const float (&ev)[4], const float (&od)[4]) {
+    const float A = ev[0], B = ev[2], Cc = od[0], D = od[2], E = ev[1], F = ev[3], G = od[1], Hh = od[3];
+    f4 *o = reinterpret_cast<f4 *>(rec);
+    o[0] = f4{A - G - D - F, B - Hh + Cc + E, A - G + D + F, -B + Hh + Cc + E};
+    o[1] = f4{A + G + D - F, B + Hh - Cc + E, A + G - D + F, -B - Hh - Cc + E};
+}
+
 // record slot of octant idx = a0*4 + a1*2 + a2 (reference order 010 100 110 001 011 101 111)
 DT_HD int octant_slot(int idx) { return (idx & 1) ? 3 + (idx >> 1) : (idx >> 1) - 1; }
 
@@ -275,24 +301,33 @@ DT_HD void f3l1_axis1(const Fwd3L1Params &p, float (&out)[8][4], const float *S1
                       int k0) {
     const int cj = tid / (C::TK / 2), ck = tid - cj * (C::TK / 2);
     const int j = j0 + 2 * cj, k = k0 + 2 * ck;
+    // per a0: the rows of the cell's two columns as (a2 = 0, a2 = 1) pairs; the lowpass chain of a position gives
+    // octants (a1 = 0; a2 = 0, 1), the highpass chain (a1 = 1; a2 = 0, 1): M0 + M1 packed FMAs for four values.
+    // Taps carry cube2c's 1/2 -- except the lane of (0, 0, 0), which is the lowpass volume itself.
+    const f3_v2f *t0p = reinterpret_cast<const f3_v2f *>(p.h0p);
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        float u[2 * C::H + 2][2];
+    for (int a0 = 0; a0 < 2; ++a0) {
+        f3_v2f u[2 * C::H + 2][2];
 #pragma unroll
         for (int r = 0; r < 2 * C::H + 2; ++r) {
-            f2 t = *reinterpret_cast<const f2 *>(S1 + (v * C::PJ + 2 * cj + r) * C::TK + 2 * ck);
-            u[r][0] = t.x; u[r][1] = t.y;
+            const float *q = S1 + ((((a0 * C::PJ + 2 * cj + r) * 2) * (C::TK / 2)) + ck) * 2;
+            u[r][0] = *reinterpret_cast<const f3_v2f *>(q);
+            u[r][1] = *reinterpret_cast<const f3_v2f *>(q + C::TK);
         }
-        const int a0 = v >> 1, a2 = v & 1;
 #pragma unroll
         for (int e = 0; e < 2; ++e)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                f3_v2f a = {0.f, 0.f};
+                f3_v2f lo = {0.f, 0.f}, hi = {0.f, 0.f};
 #pragma unroll
-                for (int d = 0; d < C::MR; ++d) a += f3l1_tap_pair<C>(p, d) * f3_v2f{u[e + d][c], u[e + d][c]};
-                out[a0 * 4 + a2][e * 2 + c] = a.x;
-                out[a0 * 4 + 2 + a2][e * 2 + c] = a.y;
+                for (int t = 0; t < C::M0; ++t) {
+                    if (a0 == 0) lo += t0p[t] * u[e + C::H + C::H0 - t][c];
+                    else lo += t0p[t].y * u[e + C::H + C::H0 - t][c];
+                }
+#pragma unroll
+                for (int t = 0; t < C::M1; ++t) hi += p.h1s[t] * u[e + C::H + C::H1 - t][c];
+                out[a0 * 4 + 0][e * 2 + c] = lo.x; out[a0 * 4 + 1][e * 2 + c] = lo.y;
+                out[a0 * 4 + 2][e * 2 + c] = hi.x; out[a0 * 4 + 3][e * 2 + c] = hi.y;
             }
     }
     if (FULL || (j < p.n1 && k < p.n2)) {
@@ -319,13 +354,13 @@ DT_HD void f3l1_pack_stage(const float (&ev)[8][4], const float (&od)[8][4], flo
     float *rec = stage + wave * C::STAGE_W + (lane % C::SREC) * REC_LDS;
     // record slots in the reference's concatenation order (transform3d.py:278-289):
     // (a0,a1,a2) = 010, 100, 110, 001, 011, 101, 111
-    cube2c_record(rec + 0, ev[2], od[2]);
-    cube2c_record(rec + 8, ev[4], od[4]);
-    cube2c_record(rec + 16, ev[6], od[6]);
-    cube2c_record(rec + 24, ev[1], od[1]);
-    cube2c_record(rec + 32, ev[3], od[3]);
-    cube2c_record(rec + 40, ev[5], od[5]);
-    cube2c_record(rec + 48, ev[7], od[7]);
+    cube2c_record_scaled(rec + 0, ev[2], od[2]);
+    cube2c_record_scaled(rec + 8, ev[4], od[4]);
+    cube2c_record_scaled(rec + 16, ev[6], od[6]);
+    cube2c_record_scaled(rec + 24, ev[1], od[1]);
+    cube2c_record_scaled(rec + 32, ev[3], od[3]);
+    cube2c_record_scaled(rec + 40, ev[5], od[5]);
+    cube2c_record_scaled(rec + 48, ev[7], od[7]);
 }
 
 // pass: which SREC consecutive cells of the wavefront's 64 (two rows of 32) are in the slab

@@ -167,6 +167,7 @@ static int run_fwd3_l1(dt3d::Fwd3L1Params p, int chunk) {
     using namespace dt3d;
     p.tilesJ = cdiv(p.n1, C::TJ); p.tilesK = cdiv(p.n2, C::TK);
     p.chunk = chunk; p.chunks = cdiv(p.n0, chunk);
+    dt3d::f3l1_pack_taps<C>(p);
     std::vector<float> smem(C::LDS_FLOATS + 4);
     float *base = smem.data();
     while (((uintptr_t)base) & 15) ++base;
