@@ -85,3 +85,16 @@ def test_device_resident_pyramid_is_resampled_in_place():
     lo = sampling.upsample(p.hip_lowpass, 'lanczos', device_output=True)
     close(lo.get(), so.upsample(p.lowpass, 'lanczos'), F32_TOL)
     assert dtcwt_amd.sampling.sample is sampling.sample
+
+
+def test_nearest_at_exact_ties_follows_numpy_rounding():
+    """Output pixel centres that fall exactly half-way between two source pixels (4 rows -> 210: row 52 sits at
+    y = 0.5) must round like NumPy does on the coordinate NumPy computes: scale * (i + 1/2) - 1/2 in two rounded
+    steps, half to even -- a fused multiply-add differs in the last bit and picks the other row (found by
+    tools/soak.py, seed 11)."""
+    rs = np.random.RandomState(3)
+    for shape, out in (((4, 106), (210, 31)), ((6, 10), (300, 25)), ((3, 3), (6, 6)), ((5, 7), (50, 70))):
+        im = rs.standard_normal(shape)
+        assert np.array_equal(sampling.rescale(im, out, 'nearest'), so.rescale(im, out, 'nearest')), (shape, out)
+        hi = (rs.standard_normal(shape + (6,)) + 1j * rs.standard_normal(shape + (6,))).astype(np.complex64)
+        close(sampling.rescale_highpass(hi, out, 'nearest'), so.rescale_highpass(hi, out, 'nearest'), 5e-6)
