@@ -512,7 +512,13 @@ int emu_inv3_l2(int m, const float *LLL, const float *Yh, float *planes, float *
     b.Out = Z; b.B = a.S; b.zr = n1; b.zc = n2; b.cropR = crop1; b.cropC = crop2;
     b.lo_pos = a.lo_pos; b.hi_pos = a.hi_pos;
     put_taps(b.l_a, g0b, m); put_taps(b.l_b, g0a, m); put_taps(b.h_a, g1b, m); put_taps(b.h_b, g1a, m);
-    if (m == 10) { run_inv3_axis0<dt3d::Inv3L2<10>>(a, chunk); run_inv3_l2_planes<Inv2RCfg<16, 56, 2, 10>>(b, planes, a.pstride); return 0; }
+    if (m == 10) {
+        run_inv3_axis0<dt3d::Inv3L2<10>>(a, chunk);
+        // planes whose width is a multiple of 64 go through the 8 x 64 tiles the library uses at coarse levels
+        if (n2 % 64 == 0) run_inv3_l2_planes<Inv2RCfg<8, 64, 2, 10>>(b, planes, a.pstride);
+        else run_inv3_l2_planes<Inv2RCfg<16, 56, 2, 10>>(b, planes, a.pstride);
+        return 0;
+    }
     if (m == 14) { run_inv3_axis0<dt3d::Inv3L2<14>>(a, chunk); run_inv3_l2_planes<Inv2RCfg<16, 52, 2, 14>>(b, planes, a.pstride); return 0; }
     return -3;
 }
