@@ -501,8 +501,10 @@ int dtcwt_hip_plan2d_inverse(dtcwt_hip_plan2d *p, const float *Yl, const void *c
                 put_taps(q.b_a, p->bp2[3]); put_taps(q.b_b, p->bp2[2]);
                 q.bp_pos = dotd(p->bp2[3], p->bp2[2]) > 0;
             }
+            // the coarsest levels of a single image (fewer than two 16 x 56 tiles per CU): 8 x 64 tiles, twice the
+            // workgroups of half the rows each (fused2d_table.hpp)
             bool small = p->small_tiles >= 0 ? p->small_tiles != 0
-                                             : (int64_t)cdiv(L.loR, 16) * cdiv(L.loC, 56) * p->batch < DT_SMALL_TILE_THRESHOLD;
+                                             : (int64_t)cdiv(L.loR, 16) * cdiv(L.loC, 56) * p->batch < DT_INV2_SMALL_BELOW;
             rc = dtcwt_dispatch_inv2((int)p->qshift[0].size(), bp, q, s, small);
             in = out;
         }

@@ -378,6 +378,21 @@ int emu_inv2(int m, const float *Z, const float *Yh, float *Out, int B, int zr, 
     for (int d = 0; d < 6; ++d) p.g[d] = (float)(0.70710678118654752440 * gain6[d]);
     put_taps(p.l_a, la, m); put_taps(p.l_b, lb, m); put_taps(p.h_a, ha, m); put_taps(p.h_b, hb, m);
     p.lo_pos = dotd(la, lb, m) > 0; p.hi_pos = dotd(ha, hb, m) > 0;
+    // the library's choice: the small tiles where the level has fewer than two 16 x 56 tiles per CU of an MI355X
+    if ((int64_t)cdiv(zr, 16) * cdiv(zc, 56) * B < DT_INV2_SMALL_BELOW) { DT_INV2_SMALL_TABLE(EMU_INV2) }
+    DT_INV2_TABLE(EMU_INV2)
+    return -3;
+}
+
+// the same level with the large tiles whatever the size
+int emu_inv2_large(int m, const float *Z, const float *Yh, float *Out, int B, int zr, int zc, int cropR,
+                   int cropC, const double *gain6, const double *la, const double *lb, const double *ha,
+                   const double *hb) {
+    Inv2Params p{};
+    p.Z = Z; p.Yh = Yh; p.Out = Out; p.B = B; p.zr = zr; p.zc = zc; p.cropR = cropR; p.cropC = cropC;
+    for (int d = 0; d < 6; ++d) p.g[d] = (float)(0.70710678118654752440 * gain6[d]);
+    put_taps(p.l_a, la, m); put_taps(p.l_b, lb, m); put_taps(p.h_a, ha, m); put_taps(p.h_b, hb, m);
+    p.lo_pos = dotd(la, lb, m) > 0; p.hi_pos = dotd(ha, hb, m) > 0;
     DT_INV2_TABLE(EMU_INV2)
     return -3;
 }
