@@ -22,6 +22,12 @@ int dtcwt_dispatch_inv2(int m, bool bp, dt2d::Inv2Params &p, hipStream_t s, bool
 
 namespace {
 
+// record arrays at least this big leave with the non-temporal hint (DTCWT_HIP_STREAM_RECORDS_MB; default 32)
+inline int64_t stream_records_bytes() {
+    static const int64_t b = [] { const char *e = getenv("DTCWT_HIP_STREAM_RECORDS_MB"); return (int64_t)(e ? atoi(e) : 32) << 20; }();
+    return b;
+}
+
 // -------------------------------------------------------------------------- kernels
 // Level-1 forward: column pass straight from global memory into two LDS planes, one
 // barrier, row pass + q2c with wave-staged coalesced record stores (fused2d_tiles_v2.hpp).
@@ -418,7 +424,7 @@ int dtcwt_hip_plan2d_forward(dtcwt_hip_plan2d *p, const float *X, float *Yl, voi
                 DT_REQUIRE(q2.LoLo && q2.Yh, "NULL output buffer at level 1");
                 q2.B = p->batch; q2.inR = L2.inR; q2.inC = L2.inC; q2.LR = L2.LR; q2.LC = L2.LC;
                 q2.xcd_order = p->xcd_order < 0 ? 1 : p->xcd_order;     // measured: XCD-contiguous tiles 114 us, linear 122 us
-                q2.stream_records = (int64_t)p->batch * (L2.LR / 4) * (L2.LC / 4) * 48 >= ((int64_t)32 << 20);
+                q2.stream_records = (int64_t)p->batch * (L2.LR / 4) * (L2.LC / 4) * 48 >= stream_records_bytes();
                 put_taps(q2.l_a, p->qshift[1]); put_taps(q2.l_b, p->qshift[0]);
                 put_taps(q2.h_a, p->qshift[5]); put_taps(q2.h_b, p->qshift[4]);
                 q2.lo_a_first = dotd(p->qshift[1], p->qshift[0]) > 0;
@@ -433,7 +439,7 @@ int dtcwt_hip_plan2d_forward(dtcwt_hip_plan2d *p, const float *X, float *Yl, voi
             q.LR = L.LR; q.LC = L.LC; q.xcd_order = p->xcd_order < 0 ? 1 : p->xcd_order;
             // record arrays of 32 MiB and more cannot wait in the caches for whoever reads them next:
             // stream them past, so that they do not evict the lowpass plane the next level reads
-            q.stream_records = (int64_t)p->batch * (L.LR / 4) * (L.LC / 4) * 48 >= ((int64_t)32 << 20);
+            q.stream_records = (int64_t)p->batch * (L.LR / 4) * (L.LC / 4) * 48 >= stream_records_bytes();
             // coldfilt(X, h0b, h0a) / coldfilt(X, h1b, h1a)   (transform2d.py:143-157)
             put_taps(q.l_a, p->qshift[1]); put_taps(q.l_b, p->qshift[0]);
             put_taps(q.h_a, p->qshift[5]); put_taps(q.h_b, p->qshift[4]);
