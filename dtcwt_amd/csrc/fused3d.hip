@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(DT_NT) k_inv3_axis0(Inv3AParams p, int ntile_x
     __shared__ __attribute__((aligned(16))) float slab[2][I3_SLAB];
     const int bid = xcd_tile3(ntile_xcd), tid = threadIdx.x;
     if (bid < 0) return;
-    const int tk = bid % p.tilesK, tj = (bid / p.tilesK) % p.tilesJ, ch = bid / (p.tilesK * p.tilesJ);
+    const int tk = bid % p.tilesK, tj = (bid / p.tilesK) % p.tilesJ, ch = bid / (p.tilesK * p.tilesJ) + p.ch0;
     const int cj0 = tj * I3_CJ, ck0 = tk * I3_CK, c0 = ch * p.chunk;
     const int c1 = min(c0 + p.chunk, p.n0 / 2);
     const int cs = c0 - (2 * F::HP + 1);            // warm-up steps fill the rings
@@ -362,8 +362,9 @@ void launch_inv3_l2_planes(dt2d::Inv2Params &b, const float *planes, int64_t ps,
     k_inv3_l2_planes<C><<<xcd3_grid(ntile, XCD3_INV_L2_PLANES), DT_NT, 0, s>>>(b, planes, ps, xcd3_arg(ntile, XCD3_INV_L2_PLANES));
 }
 
+// ch0, nch: the chunks of this launch (nch < 0: all of them); sets p.chunk / p.chunks either way
 template <class F>
-void launch_inv3_axis0(Inv3AParams &p, int cus, hipStream_t s) {
+void launch_inv3_axis0(Inv3AParams &p, int cus, hipStream_t s, int ch0 = 0, int nch = -1) {
     p.tilesJ = cdiv(p.n1 / 2, I3_CJ); p.tilesK = cdiv(p.n2 / 2, I3_CK);
     const int pairs = p.n0 / 2;
     int chunk = 64;             // long marches amortise the 2 HP + 1 warm-up steps
@@ -377,7 +378,10 @@ void launch_inv3_axis0(Inv3AParams &p, int cus, hipStream_t s) {
         if (v >= 1) chunk = v;
     }
     p.chunk = chunk; p.chunks = cdiv(pairs, chunk);
-    const int ntile = p.tilesJ * p.tilesK * p.chunks;
+    if (nch < 0) { ch0 = 0; nch = p.chunks; }
+    p.ch0 = ch0;
+    if (nch == 0) return;
+    const int ntile = p.tilesJ * p.tilesK * nch;
     k_inv3_axis0<F><<<xcd3_grid(ntile, XCD3_INV_AXIS0), DT_NT, 0, s>>>(p, xcd3_arg(ntile, XCD3_INV_AXIS0));
 }
 
@@ -419,13 +423,34 @@ extern "C" int dtcwt_hip_inv3_level1(dtcwt_hip_ctx *ctx, const float *LLL, const
     if (int rc = dtcwt_hip_malloc(ctx, (size_t)(4 * a.pstride) * sizeof(float), &planes)) return rc;
     a.P = (float *)planes;
     DT_CHECK_HIP(hipSetDevice(ctx->device));
+    // Slabs along axis 0: pass A of a slab, then pass B of the same slab, the four planes of ONE slab in a buffer
+    // that the next slab reuses.  Measured at 256^3 (268 MB of planes): two slabs 345 us per inverse, one 355 us --
+    // pass A gains (2 x 75 instead of 162 us), pass B does not (the planes do not survive in the Infinity Cache
+    // next to the 537 MB pass A streams through).  DTCWT_HIP_INV3_SLABS: number of slabs (default: planes of at
+    // most 96 MB per slab, and never less than one march per slab).
+    int nslab = 1;
+    {
+        const char *e = getenv("DTCWT_HIP_INV3_SLABS");          // read per call: the tests switch it
+        const int forced = e ? atoi(e) : 0;
+        const int64_t plane_bytes = 4 * a.pstride * (int64_t)sizeof(float);
+        nslab = forced > 0 ? forced : (int)((plane_bytes + ((int64_t)96 << 20) - 1) / ((int64_t)96 << 20));
+    }
 #define X_(TR_, TC_, RS_, MA_, MB_)                                                         \
     if (m0 == MA_ && m1 == MB_) {                                                           \
-        launch_inv3_axis0<Inv3L1<MA_, MB_>>(a, ctx->cus, ctx->stream);                      \
-        if (narrow_wins(b.C, TC_, 56))                                                      \
-            launch_inv3_l1_planes<dt2d::Inv1RCfg<32, 56, 8, MA_, MB_>>(b, (const float *)planes, a.pstride, ctx->stream); \
-        else                                                                                \
-            launch_inv3_l1_planes<dt2d::Inv1RCfg<TR_, TC_, RS_, MA_, MB_>>(b, (const float *)planes, a.pstride, ctx->stream); \
+        launch_inv3_axis0<Inv3L1<MA_, MB_>>(a, ctx->cus, ctx->stream, 0, 0);   /* sets a.chunk / a.chunks only */ \
+        const int per = cdiv(a.chunks, nslab < a.chunks ? nslab : a.chunks);                \
+        for (int c0 = 0; c0 < a.chunks; c0 += per) {                                        \
+            const int nch = a.chunks - c0 < per ? a.chunks - c0 : per;                      \
+            a.so0 = 2 * c0 * a.chunk;                                                       \
+            a.slabS = 2 * nch * a.chunk < a.S - a.so0 ? 2 * nch * a.chunk : a.S - a.so0;    \
+            a.pstride = (int64_t)(2 * per * a.chunk < a.S ? 2 * per * a.chunk : a.S) * n1 * n2;   \
+            launch_inv3_axis0<Inv3L1<MA_, MB_>>(a, ctx->cus, ctx->stream, c0, nch);         \
+            b.B = a.slabS; b.X = Z + (int64_t)a.so0 * n1 * n2;                              \
+            if (narrow_wins(b.C, TC_, 56))                                                  \
+                launch_inv3_l1_planes<dt2d::Inv1RCfg<32, 56, 8, MA_, MB_>>(b, (const float *)planes, a.pstride, ctx->stream); \
+            else                                                                            \
+                launch_inv3_l1_planes<dt2d::Inv1RCfg<TR_, TC_, RS_, MA_, MB_>>(b, (const float *)planes, a.pstride, ctx->stream); \
+        }                                                                                   \
     }
     DT_INV3_L1_TABLE(X_)
 #undef X_

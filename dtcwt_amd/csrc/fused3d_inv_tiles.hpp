@@ -34,6 +34,10 @@ struct Inv3AParams {
     int crop0;
     int chunk;            // records (slice pairs) marched by one workgroup
     int tilesJ, tilesK, chunks;
+    // slab launches (level 1 of large volumes: the planes of one slab stay in the Infinity Cache for pass B and the
+    // buffer is reused by the next slab): this launch marches chunks ch0 .. ch0 + gridDim / tiles - 1 and P holds
+    // output slices so0 .. so0 + slabS - 1 only.  slabS == 0: one launch, P holds all S slices.
+    int ch0, so0, slabS;
     int lo_pos, hi_pos;   // level >= 2: sum(ha*hb) > 0 of the g0 / g1 pair (lowlevel.py:205,232)
     // level 1: l_a = g0o, h_a = g1o.  level >= 2: colifilt(., g0b, g0a) + colifilt(., g1b, g1a):
     // l_a = g0b, l_b = g0a, h_a = g1b, h_b = g1a
@@ -216,6 +220,10 @@ DT_HD void i3a_store(const Inv3AParams &p, const float (&out)[F::NOUT][4], int t
     for (int e = 0; e < F::NOUT; ++e) {
         int so = F::NOUT * c + e - p.crop0;
         if (so < 0 || so >= p.S) continue;
+        if (p.slabS) {
+            so -= p.so0;
+            if (so < 0 || so >= p.slabS) continue;
+        }
         float *o = p.P + v * p.pstride + ((int64_t)so * p.n1 + j) * p.n2 + k;
         *reinterpret_cast<f2 *>(o) = f2{out[e][0], out[e][1]};
         *reinterpret_cast<f2 *>(o + p.n2) = f2{out[e][2], out[e][3]};
