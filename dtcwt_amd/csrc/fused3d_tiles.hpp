@@ -59,20 +59,19 @@ struct Fwd3L1Params {
     int chunk;           // slices marched by one workgroup (even)
     int tilesJ, tilesK, chunks;
     float h0[DT_MAXT], h1[DT_MAXT];
-    // axis-1 taps with cube2c's factor 1/2 folded in (exact: a power of two), filled by f3l1_pack_taps():
-    // h0s = h0 / 2, h1s = h1 / 2, and h0p = (h0, h0 / 2) pairs for the one lowpass chain whose first lane is the
-    // unscaled LLL octant
+    // cube2c's factor 1/2 rides on the filter taps (exact: a power of two), set up by f3l1_pack_taps(): the a0 = 1
+    // half-volume takes it at axis 0 (h1s = h1 / 2 there), the a1 = 1 octants of the a0 = 0 half at axis 1 (h1s
+    // again); only octant (0, 0, 1), which shares its axis-1 chain with the unscaled lowpass volume, is halved in
+    // cube2c itself.  One scaled table instead of three: the kernel is short of scalar registers.
     float h1s[DT_MAXT];
-    float h0p[2 * DT_MAXT] __attribute__((aligned(8)));
     // (h0, h1) by window offset d = 0 .. 2H (the shorter filter zero-padded): the pairs of the axis-2 chains, and
-    // the scalars of the axis-0 chains, from one table (scalar registers are short in this kernel)
+    // the scalars of the axis-0 / axis-1 chains, from one table
     float c01[2 * DT_MAXT] __attribute__((aligned(8)));
 };
 template <class C>
 inline void f3l1_pack_taps(Fwd3L1Params &p) {
     for (int k = 0; k < DT_MAXT; ++k) {
         p.h1s[k] = 0.5f * p.h1[k];
-        p.h0p[2 * k] = p.h0[k]; p.h0p[2 * k + 1] = 0.5f * p.h0[k];
         const int k0 = C::H + C::H0 - k, k1 = C::H + C::H1 - k;       // k as window offset d
         p.c01[2 * k] = (k0 >= 0 && k0 < C::M0) ? p.h0[k0] : 0.f;
         p.c01[2 * k + 1] = (k1 >= 0 && k1 < C::M1) ? p.h1[k1] : 0.f;
@@ -204,7 +203,7 @@ DT_HD void f3l1_axis0_pair(const Fwd3L1Params &p, const f3_v2f (&r)[C::MR], floa
 #pragma unroll
     for (int d = C::H - C::H0; d <= C::H + C::H0; ++d) lo += p.c01[2 * d] * r[d];
 #pragma unroll
-    for (int d = C::H - C::H1; d <= C::H + C::H1; ++d) hi += p.c01[2 * d + 1] * r[d];
+    for (int k = 0; k < C::M1; ++k) hi += p.h1s[k] * r[C::H + C::H1 - k];      // the a0 = 1 half carries cube2c's 1/2 from here
     *reinterpret_cast<f3_v2f *>(S0 + soff) = lo;
     *reinterpret_cast<f3_v2f *>(S0 + C::PJ * C::S0S + soff) = hi;
 }
@@ -303,8 +302,7 @@ DT_HD void f3l1_axis1(const Fwd3L1Params &p, float (&out)[8][4], const float *S1
     const int j = j0 + 2 * cj, k = k0 + 2 * ck;
     // per a0: the rows of the cell's two columns as (a2 = 0, a2 = 1) pairs; the lowpass chain of a position gives
     // octants (a1 = 0; a2 = 0, 1), the highpass chain (a1 = 1; a2 = 0, 1): M0 + M1 packed FMAs for four values.
-    // Taps carry cube2c's 1/2 -- except the lane of (0, 0, 0), which is the lowpass volume itself.
-    const f3_v2f *t0p = reinterpret_cast<const f3_v2f *>(p.h0p);
+    // cube2c's 1/2: see Fwd3L1Params::h1s.
 #pragma unroll
     for (int a0 = 0; a0 < 2; ++a0) {
         f3_v2f u[2 * C::H + 2][2];
@@ -320,12 +318,12 @@ DT_HD void f3l1_axis1(const Fwd3L1Params &p, float (&out)[8][4], const float *S1
             for (int c = 0; c < 2; ++c) {
                 f3_v2f lo = {0.f, 0.f}, hi = {0.f, 0.f};
 #pragma unroll
-                for (int t = 0; t < C::M0; ++t) {
-                    if (a0 == 0) lo += t0p[t] * u[e + C::H + C::H0 - t][c];
-                    else lo += t0p[t].y * u[e + C::H + C::H0 - t][c];
-                }
+                for (int t = 0; t < C::M0; ++t) lo += p.c01[2 * (C::H + C::H0 - t)] * u[e + C::H + C::H0 - t][c];
 #pragma unroll
-                for (int t = 0; t < C::M1; ++t) hi += p.h1s[t] * u[e + C::H + C::H1 - t][c];
+                for (int t = 0; t < C::M1; ++t) {
+                    if (a0 == 0) hi += p.h1s[t] * u[e + C::H + C::H1 - t][c];
+                    else hi += p.c01[2 * (C::H + C::H1 - t) + 1] * u[e + C::H + C::H1 - t][c];
+                }
                 out[a0 * 4 + 0][e * 2 + c] = lo.x; out[a0 * 4 + 1][e * 2 + c] = lo.y;
                 out[a0 * 4 + 2][e * 2 + c] = hi.x; out[a0 * 4 + 3][e * 2 + c] = hi.y;
             }
@@ -357,7 +355,7 @@ DT_HD void f3l1_pack_stage(const float (&ev)[8][4], const float (&od)[8][4], flo
     cube2c_record_scaled(rec + 0, ev[2], od[2]);
     cube2c_record_scaled(rec + 8, ev[4], od[4]);
     cube2c_record_scaled(rec + 16, ev[6], od[6]);
-    cube2c_record_scaled(rec + 24, ev[1], od[1]);
+    cube2c_record(rec + 24, ev[1], od[1]);               // (0, 0, 1): not scaled yet
     cube2c_record_scaled(rec + 32, ev[3], od[3]);
     cube2c_record_scaled(rec + 40, ev[5], od[5]);
     cube2c_record_scaled(rec + 48, ev[7], od[7]);
