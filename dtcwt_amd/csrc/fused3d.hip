@@ -28,10 +28,11 @@ __device__ __forceinline__ int xcd_tile3(int ntile_xcd) {
 }
 // bit mask of the kernels that take the XCD order (DTCWT_HIP_XCD3D): 1 k_fwd3_l1, 2 k_fwd3_l2_planes,
 // 4 k_inv3_axis0, 8 k_inv3_l1_planes, 16 k_inv3_l2_planes.  Measured at 256^3 (profiles/r02/xcd3d.txt): the
-// forward kernels gain (pass A of level 2: 46 -> 34 us; the transform 252 -> 240 us), the inverse ones do not.
+// forward kernels gain (pass A of level 2: 46 -> 34 us; the transform 252 -> 240 us); so do the plane passes of
+// the inverse once its level 1 runs in slabs (345 -> 322 us); the inverse march (4) does not.
 enum { XCD3_FWD_L1 = 1, XCD3_FWD_PLANES = 2, XCD3_INV_AXIS0 = 4, XCD3_INV_L1_PLANES = 8, XCD3_INV_L2_PLANES = 16 };
 inline bool xcd3_enabled(int bit) {
-    static const int mask = [] { const char *e = getenv("DTCWT_HIP_XCD3D"); return e ? atoi(e) : (XCD3_FWD_L1 | XCD3_FWD_PLANES); }();
+    static const int mask = [] { const char *e = getenv("DTCWT_HIP_XCD3D"); return e ? atoi(e) : (XCD3_FWD_L1 | XCD3_FWD_PLANES | XCD3_INV_L1_PLANES | XCD3_INV_L2_PLANES); }();
     return (mask & bit) != 0;
 }
 inline unsigned xcd3_grid(int ntile, int bit) { return xcd3_enabled(bit) ? (unsigned)(8 * ((ntile + 7) / 8)) : (unsigned)ntile; }
