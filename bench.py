@@ -2,7 +2,7 @@
 """Benchmark of the hot path: 2-D DT-CWT forward + inverse, 4096x4096 float32, nlevels=4,
 near_sym_a / qshift_a (BASELINE.json metric, configs[1]) on N MI355X GPUs of one node.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c5|c5full]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one forward + one inverse of one batch per GPU, input and pyramid resident in
@@ -18,10 +18,18 @@ Steps rotate over `--sets` (default 4) distinct sets of input / pyramid / output
 pyramid in the 256 MiB Infinity Cache; `resident_ms_per_step` in the JSON line is the same
 step on ONE buffer set (what round 1 reported), for comparison.
 
-The roofline object is for the dominant kernel (the slowest level kernel of a step), its
-duration measured with hipEvent pairs on the library's stream minus the duration of an empty
-event pair; cpu_baseline times the NumPy oracle (a port of the reference's algorithm) on the
-host, rank 0 only.
+`ms_per_step` / `value` are throughput over `--streams` (default 2) HIP streams of independent
+images (the coarse-level kernels of one image overlap the level-1 kernels of the next); it is not
+the latency of one forward + inverse: `one_stream_ms_per_step` in the same line is the same
+rotating-buffer protocol on ONE stream.
+
+The roofline object is for the dominant kernel (the level kernel with the longest median
+duration, k_inv1 or k_fwd1): `kernel_ms` is the MEDIAN over the profiled steps of the raw
+hipEvent-pair time around that kernel on the library's stream (an empty pair costs
+`event_pair_overhead_ms`, reported, not subtracted); `rocprof_kernel_ms` next to it is the median of
+the same kernel under `rocprofv3 --kernel-trace` of this command (tools/profile_round.sh ->
+profiles/traffic.json), as is `traffic`.  cpu_baseline times the NumPy oracle (a port of the
+reference's algorithm) on the host, rank 0 only, after the process group is gone.
 """
 import argparse
 import json
@@ -50,7 +58,22 @@ CONFIGS = {
                name='batched 2D 64x1024x1024 f32, nlevels=5'),
     'c5': dict(rows=2048, cols=2048, batch=64, nlevels=4, seed=lambda rank: 3 + 1000 * rank,
                name='batched 2D 512x2048x2048 f32 nlevels=4 sharded over 8 GPUs: 64 images per GPU'),
+    # the WHOLE C5 batch on one GPU: 2.1 G pixels, Yh[0] 6.4 G floats (> 2^31 elements), 58 GB per buffer set
+    'c5full': dict(rows=2048, cols=2048, batch=512, nlevels=4, seed=lambda rank: 3 + 1000 * rank, sets=1, streams=1,
+                   name='batched 2D 512x2048x2048 f32 nlevels=4, the whole batch on ONE GPU'),
 }
+
+
+def shard_plan(cfg, world):
+    """Weak scaling over independent images: what each of `world` ranks transforms per step, as
+    [(seed of its synthetic images, images per step)], and the global batch (the reference's shape:
+    examples/register_video.py:125-156 hands a contiguous run of frames to each worker)."""
+    return [(cfg['seed'](r), cfg['batch']) for r in range(world)], world * cfg['batch']
+
+
+def aggregate_value(world, px_per_rank, steps, dt_max):
+    """Whole-job Mpixels/s: the pixels ALL ranks processed in `steps` steps over the slowest rank's time."""
+    return world * px_per_rank * steps / dt_max / 1e6
 
 
 def _free_port():
@@ -95,6 +118,20 @@ def respawn_under_launcher(args):
            '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
     raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def upload_random(ctx, rs, B, R, C, chunk=64):
+    """[B][R][C] float32 standard-normal samples in HBM, generated and uploaded `chunk` images at a time."""
+    from dtcwt_amd.hip import DeviceArray
+    if B <= chunk:
+        return ctx.to_device(rs.standard_normal((B, R, C)).astype(np.float32))
+    X = DeviceArray(ctx, (B, R, C), np.float32)
+    per = R * C * 4
+    for b0 in range(0, B, chunk):
+        n = min(chunk, B - b0)
+        DeviceArray(ctx, (n, R, C), np.float32, ptr=X.ptr + b0 * per, owner=X).set(
+            rs.standard_normal((n, R, C)).astype(np.float32))
+    return X
 
 
 def cpu_baseline(cfg, Xh):
@@ -166,19 +203,19 @@ def main():
         bt, qt = broadcast_taps(bt, qt, dist, device=torch.device('cuda', local_rank), src=0)
 
     B, R, C, NL = cfg['batch'], cfg['rows'], cfg['cols'], cfg['nlevels']
-    nstreams = max(1, args.streams)
-    nsets = max(1, args.sets)
+    nstreams = max(1, cfg.get('streams', args.streams))
+    nsets = max(1, cfg.get('sets', args.sets))
     if nsets % nstreams:
         nsets = (nsets // nstreams + 1) * nstreams      # every buffer set belongs to exactly one stream
     ctxs = [ctx] + [Context(ctx.device) for _ in range(nstreams - 1)]
     t2s = [dtcwt_amd.hip.Transform2d(tuple(bt), tuple(qt), ctx=c) for c in ctxs]
     plans = [t.plan(B, R, C, NL) for t in t2s]
     t2, plan = t2s[0], plans[0]
-    rs = np.random.RandomState(cfg['seed'](rank))       # random, not zero: DVFS; per-shard seed
+    rs = np.random.RandomState(shard_plan(cfg, world)[0][rank][0])   # random, not zero: DVFS; per-shard seed
     sets = []
     for k in range(nsets):
         c = ctxs[k % nstreams]
-        X = c.to_device(rs.standard_normal((B, R, C)).astype(np.float32))
+        X = upload_random(c, rs, B, R, C)
         Yl = DeviceArray(c, (B,) + plan.low, np.float32)
         Yh = [DeviceArray(c, (B,) + plan.high[l] + (6,), np.complex64) for l in range(NL)]
         Z = DeviceArray(c, (B,) + plan.ext, np.float32)
@@ -233,17 +270,27 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
+    rank_ms = [dt / args.steps * 1e3]
+    nccl_ranks = 1
     if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        nccl_ranks = dist.get_world_size()
+        mine = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        every = [torch.zeros_like(mine) for _ in range(nccl_ranks)]
+        dist.all_gather(every, mine)                    # every rank's own time: min / max in the JSON line
+        rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
+        tt = mine.clone()
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
     # sanity of the timed work: reconstruction equals the input, on every buffer set
-    err = max(float(np.abs(s[3].get()[0, :64, :64] - s[0].get()[0, :64, :64]).max()) for s in sets)
+    def first_image(a, shape):      # image 0 of a batch without downloading the whole batch
+        return DeviceArray(a.ctx, (1,) + tuple(shape), np.float32, ptr=a.ptr, owner=a).get()[0]
+    err = max(float(np.abs(first_image(s[3], plan.ext)[:64, :64] - first_image(s[0], (R, C))[:64, :64]).max()) for s in sets)
 
     # the same step on one buffer set and one stream only (input and pyramid may stay in the Infinity Cache)
     fence()
-    nres = max(5, min(args.steps, 100))
+    px_step = B * R * C
+    nres = 100 if px_step <= 2 ** 25 else max(5, min(args.steps, 100))      # short timed regions carry ~0.5 ms of start / drain cost
     for _ in range(5):
         step_on(0)
     ctx.sync()
@@ -253,34 +300,43 @@ def main():
     ctx.sync()
     resident_ms = (time.perf_counter() - r0) / nres * 1e3
 
+    # ... and rotating over the buffer sets of stream 0 on that ONE stream: what a single forward + inverse
+    # costs end to end, without the overlap of independent images
+    own = [k for k in range(nsets) if k % nstreams == 0]
+    for i in range(5):
+        step_on(own[i % len(own)])
+    ctx.sync()
+    r0 = time.perf_counter()
+    for i in range(nres):
+        step_on(own[i % len(own)])
+    ctx.sync()
+    one_stream_ms = (time.perf_counter() - r0) / nres * 1e3
+
     # ---- roofline of the dominant kernel: hipEvent pair around every level kernel -------
     ev0, ev1 = ctx.event(), ctx.event()
     null_ms = []
     for _ in range(20):
         ev0.record(); ev1.record()
         null_ms.append(ev0.elapsed_ms(ev1))
-    null_ms = float(np.median(null_ms))                 # an event pair with nothing in between
+    null_ms = float(np.median(null_ms))                 # an event pair with nothing in between: reported, NOT subtracted
     plan.set_profiling(True)
-    kf = np.zeros(NL); ki = np.zeros(NL)
     nprof = max(5, min(args.steps, 50))
+    kf = np.zeros((nprof, NL)); ki = np.zeros((nprof, NL))
     for i in range(nprof):
-        step_on((i * nstreams) % nsets)     # sets of stream 0; per-kernel hipEvent pairs need the plain launches
-        f, g = plan.kernel_ms()
-        kf += f; ki += g
+        step_on(own[i % len(own)])          # per-kernel hipEvent pairs need the plain launches, on stream 0
+        kf[i], ki[i] = plan.kernel_ms()
     plan.set_profiling(False)
-    kf = np.maximum(kf / nprof - null_ms, 0.0); ki = np.maximum(ki / nprof - null_ms, 0.0)
+    kf = np.median(kf, axis=0); ki = np.median(ki, axis=0)
     px = float(B) * R * C
-    fused12 = bool(getattr(plan, 'fused12', False))
     # algorithmic bytes per launch of the level-1 kernels (SURVEY 8(d) per-unit figures x pixels):
-    #   one launch per level:   X 4 + LoLo1 4 + Yh[0] 12          = 20 B/px (inverse mirrored)
-    #   levels 1+2 in one launch: X 4 + Yh[0] 12 + LoLo2 1 + Yh[1] 3 = 20 B/px (LoLo1 stays on chip)
-    cand = [('k_fwd12 (levels 1+2 forward)' if fused12 else 'k_fwd1 (level-1 forward)', kf[0], 20.0),
-            ('k_inv1 (level-1 inverse)', ki[0], 20.0)]
+    #   X 4 + LoLo1 4 + Yh[0] 12 = 20 B/px (inverse mirrored)
+    cand = [('k_fwd1 (level-1 forward)', kf[0], 20.0), ('k_inv1 (level-1 inverse)', ki[0], 20.0)]
     name, ms, bpp = max(cand, key=lambda c: c[1])
     achieved = bpp * px / (ms * 1e-3) / 1e9       # GB/s
     roofline = {'bound': 'hbm', 'kernel': name, 'achieved': round(achieved, 1), 'peak': HBM_PEAK / 1e9,
                 'unit': 'GB/s', 'frac': round(achieved * 1e9 / HBM_PEAK, 4), 'traffic': None,
-                'kernel_ms': round(float(ms), 5), 'algorithmic_bytes_per_launch': bpp * px,
+                'kernel_ms': round(float(ms), 5), 'kernel_ms_is': 'median raw hipEvent pair, %d steps' % nprof,
+                'rocprof_kernel_ms': None, 'algorithmic_bytes_per_launch': bpp * px,
                 'fwd_kernel_ms': [round(float(x), 5) for x in kf],
                 'inv_kernel_ms': [round(float(x), 5) for x in ki],
                 'sum_kernel_ms': round(float(kf.sum() + ki.sum()), 5), 'event_pair_overhead_ms': round(null_ms, 5),
@@ -289,12 +345,16 @@ def main():
     if os.path.exists(tr) and args.config == 'c2':
         try:
             tj = json.load(open(tr))
-            roofline['traffic'] = tj.get(name.split(' ')[0])
+            short = name.split(' ')[0]
+            roofline['traffic'] = tj.get(short)
+            for key, src in (('rocprof_kernel_ms', 'rocprof_median_us_one_stream'), ('rocprof_kernel_ms_two_streams', 'rocprof_median_us')):
+                v = (tj.get(src) or {}).get(short, None)
+                roofline[key] = None if v is None else round(v / 1e3, 5)
             roofline['traffic_source'] = tj.get('source')
         except Exception:
             pass
 
-    value = world * px * args.steps / dt / 1e6
+    value = aggregate_value(world, px, args.steps, dt)
     out = {
         'metric': 'Mpixels/s 2D DT-CWT fwd+inv, 4096^2 f32 nlevels=4' if args.config == 'c2' else
                   'Mpixels/s 2D DT-CWT fwd+inv, %s' % cfg['name'],
@@ -306,16 +366,27 @@ def main():
         'config': {'workload': '%s, %s/%s, %d image(s) per GPU per step' % (cfg['name'], BIORT, QSHIFT, B),
                    'sharding': 'independent images per GPU, no data-path collective',
                    'buffer_sets': nsets, 'bytes_per_set': set_bytes, 'streams': nstreams,
-                   'levels_1_2_fused_forward': fused12},
-        'resident_ms_per_step': round(resident_ms, 5),
+                   'ms_per_step_is': 'throughput over %d overlapped stream(s) of independent images' % nstreams},
+        'one_stream_ms_per_step': round(one_stream_ms, 5), 'resident_ms_per_step': round(resident_ms, 5),
         'roofline': roofline, 'recon_max_abs_err': err,
     }
 
+    out['nccl_ranks'] = nccl_ranks
+    out['rank_ms_per_step'] = {'min': round(min(rank_ms), 5), 'max': round(max(rank_ms), 5)}
+    Xh0 = Zh0 = None
+    if rank == 0 and not args.no_cpu_baseline:
+        Xh0, Zh0 = first_image(sets[0][0], (R, C)), first_image(sets[0][3], plan.ext)
+    # the collective library goes first: the other ranks must not sit in a RCCL barrier while rank 0 spends
+    # ~13 s in the single-core CPU baseline
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
     # ---- CPU baseline: the oracle (a NumPy port of the reference's algorithm), rank 0 ----
     if rank == 0 and not args.no_cpu_baseline:
-        out['cpu_baseline'], zc = cpu_baseline(cfg, sets[0][0].get()[0])
+        out['cpu_baseline'], zc = cpu_baseline(cfg, Xh0)
         # the timed GPU output against the CPU port on the same input
-        out['gpu_vs_cpu_recon_max_abs_diff'] = float(np.abs(sets[0][3].get()[0] - zc).max())
+        out['gpu_vs_cpu_recon_max_abs_diff'] = float(np.abs(Zh0 - zc).max())
     elif rank == 0:
         out['cpu_baseline'] = None
     if rank == 0:
@@ -323,11 +394,6 @@ def main():
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
-        if saved_stdout is not None:
-            os.dup2(2, 1)           # teardown chatter of the collective library, if any
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 def main_mgpu(args):

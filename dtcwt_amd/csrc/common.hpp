@@ -30,6 +30,10 @@ struct dtcwt_hip_ctx {
     std::mutex pool_mu;
     // things created on behalf of the context that must go before it (cached graphs and their buffers)
     std::vector<std::function<void()>> on_destroy;
+    // downloads that overlap the kernels issued after them (dtcwt_hip_memcpy_d2h_overlapped): a second stream that
+    // waits, per copy, for an event recorded on `stream`; created on first use
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copy_event = nullptr;
 };
 
 struct dtcwt_hip_event {

@@ -11,7 +11,6 @@
 #include "common.hpp"
 #include "fused2d_tiles.hpp"
 #include "fused2d_tiles_v2.hpp"
-#include "fused2d_l12.hpp"
 #include "fused2d_table.hpp"
 
 using namespace dt2d;
@@ -71,65 +70,6 @@ __global__ void __launch_bounds__(DT_NT) k_fwd2(Fwd2Params p) {
     }
 }
 
-#define DT_WAIT_VMEM() __builtin_amdgcn_s_waitcnt(0x0F70)      /* s_waitcnt vmcnt(0), gfx9 encoding (expcnt 7, lgkmcnt 15 = no wait) */
-#define DT_OPAQUE(v_) asm volatile("" : "+v"(v_))             /* the value may have changed: nothing derived from it is loop-invariant */
-
-// Levels 1 and 2 forward in one launch (fused2d_l12.hpp): LoLo1 stays in LDS.
-// SKIP: phase knock-out bits for tools/kbench/fwd12_bench (timing experiments only; always 0 in the library)
-template <class C, int SKIP = 0>
-__global__ void __launch_bounds__(C::NT, C::MIN_WAVES) k_fwd12(Fwd1Params p1, Fwd2Params p2) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];       // C::LDS_FLOATS (may exceed 64 KiB)
-    const int ntile = p2.tilesR * p2.tilesC * p2.B;
-    int t = tile_of(blockIdx.x, ntile, p2.xcd_order);
-    if (t >= ntile) return;
-    int tc = t % p2.tilesC, tr = (t / p2.tilesC) % p2.tilesR, b = t / (p2.tilesC * p2.tilesR);
-    float *sLo = smem, *sHi = sLo + C::SLO, *stage = sHi + C::SB;
-    float *sLo2 = sHi, *sHi2 = sHi + C::S2;            // level-2 planes over the (dead) Hi plane
-    const int tid = threadIdx.x;
-    const int tidp = lds128_perm(tid);              // task index of this lane in the phases that read LDS 16 bytes at a time
-    if (SKIP & 64) { tr = 2 + (tr & 3); tc = 2 + (tc & 3); }     // timing experiment: every workgroup on the same few (cache-resident) tiles
-    const int r2 = tr * C::T2R, c2 = tc * C::T2C, r1 = 2 * r2, c1 = 2 * c2;
-    if (!(SKIP & 1)) fwd12_cols<C>(p1, sLo, sHi, tid, b, r1, c1);
-    // Every load of this workgroup has been consumed by now.  Saying so keeps the compiler from guarding later
-    // re-uses of the window registers with s_waitcnt vmcnt(0) -- which, further down, would also wait for the
-    // record STORES issued in between (vmcnt counts loads and stores in order) and put the HBM write latency
-    // on the critical path of the tile.
-    DT_WAIT_VMEM();
-    __syncthreads();
-    Fwd12State<C> st;
-    if (!(SKIP & 2))
-#pragma unroll
-    for (int round = 0; round < C::NCR; ++round) {
-        alignas(16) float rec[2][12];
-        fwd12_core_compute<C>(p1, sLo, sHi, tidp, round, st, rec);
-        if (!(SKIP & 32))
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            fwd12_core_deposit<C>(stage, tidp, round, half, rec);
-            DT_WAVE_LDS_SYNC();
-            fwd12_core_flush<C>(p1, stage, tid, round, half, b, r1, c1);
-            DT_WAVE_LDS_SYNC();
-        }
-    }
-    if (!(SKIP & 4)) fwd12_halo_compute<C>(p1, sLo, tidp, st);
-    __syncthreads();                                // every read of the Lo plane is done: LoLo1 goes over it
-    if (!(SKIP & 6)) fwd12_writeback<C>(p1, sLo, tidp, b, r1, c1, st);
-    __syncthreads();
-    if (fwd12_needs_fix<C>(p1, r1, c1)) {           // uniform per workgroup
-        fwd12_fix<C>(p1, sLo, tid, r1, c1);
-        __syncthreads();
-    }
-    if (!(SKIP & 8)) fwd12_cols2<C>(p2, sLo, sLo2, sHi2, tid);
-    __syncthreads();
-    if (!(SKIP & 16))
-    for (int base = 0; base < C::TI * C::TJ; base += C::NT) {
-        fwd2s_rows_compute<typename C::L2View>(p2, sLo2, sHi2, stage, tidp, base, b, r2, c2);
-        DT_WAVE_LDS_SYNC();
-        fwd2s_rows_flush<typename C::L2View>(p2, stage, tid, base, b, r2, c2);
-        DT_WAVE_LDS_SYNC();
-    }
-}
-
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // every tile order of tile_of() is a bijection on a grid that is a multiple of 8 x (group size)
 inline unsigned grid_for(int ntile, int order = 1) {
@@ -152,22 +92,6 @@ int launch_fwd2(Fwd2Params &p, hipStream_t s) {
     k_fwd2<C><<<grid_for(p.tilesR * p.tilesC * p.B, p.xcd_order), DT_NT, 0, s>>>(p);
     return 0;
 }
-// extra_lds: bytes of LDS requested on top of what the tile needs (occupancy experiments of tools/kbench only)
-template <class C, int SKIP = 0>
-int launch_fwd12(Fwd1Params &p1, Fwd2Params &p2, hipStream_t s, size_t extra_lds = 0) {
-    p2.tilesR = cdiv(p2.LR / 2, C::T2R); p2.tilesC = cdiv(p2.LC / 2, C::T2C);
-    dt_pack_lh(p2);
-    const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float) + extra_lds;
-    static bool raised = false;         // per instantiation: allow more than the default 64 KiB of dynamic LDS
-    if ((lds > (48u << 10) && !raised) || extra_lds) {
-        if (hipFuncSetAttribute((const void *)k_fwd12<C, SKIP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return -2;
-        raised = true;
-    }
-    k_fwd12<C, SKIP><<<grid_for(p2.tilesR * p2.tilesC * p2.B, p2.xcd_order), C::NT, lds, s>>>(p1, p2);
-    return 0;
-}
-
 // Tile shapes and supported tap lengths live in fused2d_table.hpp (shared with the
 // test-only host emulator so both step through identical configurations).
 #define DT_CASE_FWD1(TR, TC, RS, A, B) if (m0 == A && m1 == B) return launch_fwd1<Fwd1DCfg<TR, TC, RS, A, B>>(p, s);
@@ -184,12 +108,6 @@ int dispatch_fwd2(int m, bool bp, Fwd2Params &p, hipStream_t s, bool small) {
     if (small) { DT_FWD2_SMALL_TABLE(DT_CASE_FWD2) }
     DT_FWD2_TABLE(DT_CASE_FWD2) return -3;
 }
-#define DT_CASE_FWD12(T2R, T2C, RS, PS, A, B, M) if (m0 == A && m1 == B && m == M) return launch_fwd12<Fwd12Cfg<T2R, T2C, RS, PS, A, B, M>>(p1, p2, s);
-int dispatch_fwd12(int m0, int m1, int m, Fwd1Params &p1, Fwd2Params &p2, hipStream_t s) {
-    DT_FWD12_TABLE(DT_CASE_FWD12) return -3;
-}
-#define DT_HAS12(T2R, T2C, RS, PS, A, B, M) if (m0 == A && m1 == B && m == M) return true;
-bool fwd12_supported(int m0, int m1, int m) { DT_FWD12_TABLE(DT_HAS12) return false; }
 #define DT_HAS3(TR, TC, RS, A, B, C2) if (m0 == A && m1 == B && m2 == C2) return true;
 bool fwd1_bp_supported(int m0, int m1, int m2) { DT_FWD1_BP_TABLE(DT_HAS3) return false; }
 bool inv1_bp_supported(int m0, int m1, int m2) { DT_INV1_BP_TABLE(DT_HAS3) return false; }
@@ -241,19 +159,7 @@ struct dtcwt_hip_plan2d {
     // (1.11 x; linear order: 133 MB, 1.99 x, every XCD's L2 fetching its own copy of the shared halo lines) in
     // 60-62 us instead of 64-66; one run per XCD (order 1) is slower (79 us: the write streams thin out).
     int fwd1_order = 8;
-    int fuse12 = 0;                   // levels 1+2 of the forward in one launch (DTCWT_HIP_FUSE12=1): measured SLOWER than
-                                      // two launches on MI355X (114 vs 101 us at 4096^2), so opt-in
 };
-
-namespace {
-// levels 1 and 2 of the forward transform can run as one launch (fused2d_l12.hpp)
-bool can_fuse12_fwd(const dtcwt_hip_plan2d *p) {
-    if (!p->fuse12 || p->nlevels < 2 || !p->bp1[0].empty() || !p->bp2[0].empty()) return false;
-    const Level &L = p->lv[1];
-    if (L.padR || L.padC || L.LR < DT_MIN_FUSE12_DIM || L.LC < DT_MIN_FUSE12_DIM) return false;
-    return fwd12_supported((int)p->biort[0].size(), (int)p->biort[2].size(), (int)p->qshift[0].size());
-}
-}  // namespace
 
 extern "C" {
 
@@ -278,7 +184,6 @@ int dtcwt_hip_plan2d_create(dtcwt_hip_ctx *ctx, int batch, int rows, int cols, i
     { const char *e = getenv("DTCWT_HIP_XCD_ORDER"); p->xcd_order = e ? atoi(e) : -1; }
     { const char *e = getenv("DTCWT_HIP_FWD1_ORDER"); p->fwd1_order = e ? atoi(e) : 8; }
     { const char *e = getenv("DTCWT_HIP_SMALL_TILES"); p->small_tiles = e ? (e[0] == '1' ? 1 : 0) : -1; }
-    { const char *e = getenv("DTCWT_HIP_FUSE12"); p->fuse12 = e ? (e[0] != '0') : 0; }
     p->extR = rows + (rows & 1);
     p->extC = cols + (cols & 1);
     Level l0{rows, cols, 0, 0, p->extR, p->extC, p->extR, p->extC, p->extR / 2, p->extC / 2};
@@ -348,11 +253,6 @@ int dtcwt_hip_plan2d_set_bandpass(dtcwt_hip_plan2d *p, const double *h2o, const 
     return 0;
 }
 
-int dtcwt_hip_plan2d_fused_levels(const dtcwt_hip_plan2d *p) {
-    if (!p) return 0;
-    return (can_fuse12_fwd(p) ? 1 : 0);
-}
-
 int dtcwt_hip_plan2d_set_profiling(dtcwt_hip_plan2d *p, int enable) {
     DT_REQUIRE(p, "NULL plan");
     if (enable && p->ev.empty()) {
@@ -393,19 +293,10 @@ int dtcwt_hip_plan2d_forward(dtcwt_hip_plan2d *p, const float *X, float *Yl, voi
     hipStream_t s = p->ctx->stream;
     const int nl = p->nlevels;
     const float *in = X;
-    const bool f12 = can_fuse12_fwd(p);
     for (int l = 0; l < nl; ++l) {
         const Level &L = p->lv[l];
         float *lo = (l == nl - 1 && !Ys) ? Yl : (Ys ? Ys[l] : p->work[l]);
         DT_REQUIRE(lo && Yh[l], "NULL output buffer at level %d", l);
-        if (f12 && l == 1) {            // done by the level-1 launch
-            if (p->profiling) {
-                DT_CHECK_HIP(hipEventRecord(p->ev[2], s));
-                DT_CHECK_HIP(hipEventRecord(p->ev[3], s));
-            }
-            in = lo;
-            continue;
-        }
         int rc;
         if (p->profiling) DT_CHECK_HIP(hipEventRecord(p->ev[2 * l], s));
         if (l == 0) {
@@ -414,23 +305,6 @@ int dtcwt_hip_plan2d_forward(dtcwt_hip_plan2d *p, const float *X, float *Yl, voi
             q.B = p->batch; q.inR = L.inR; q.inC = L.inC; q.LR = L.LR; q.LC = L.LC;
             q.xcd_order = p->xcd_order < 0 ? p->fwd1_order : p->xcd_order;      // write-heavy: linear order unless told otherwise
             put_taps(q.h0, p->biort[0]); put_taps(q.h1, p->biort[2]); put_taps(q.h2, p->bp1[0]);
-            if (f12) {
-                // one launch for levels 1 and 2: LoLo1 only leaves the chip when it is an output (Ys)
-                const Level &L2 = p->lv[1];
-                Fwd2Params q2{};
-                q.LoLo = Ys ? Ys[0] : nullptr;
-                q2.X = nullptr; q2.Yh = (float *)Yh[1];
-                q2.LoLo = (nl == 2 && !Ys) ? Yl : (Ys ? Ys[1] : p->work[1]);
-                DT_REQUIRE(q2.LoLo && q2.Yh, "NULL output buffer at level 1");
-                q2.B = p->batch; q2.inR = L2.inR; q2.inC = L2.inC; q2.LR = L2.LR; q2.LC = L2.LC;
-                q2.xcd_order = p->xcd_order < 0 ? 1 : p->xcd_order;     // measured: XCD-contiguous tiles 114 us, linear 122 us
-                q2.stream_records = (int64_t)p->batch * (L2.LR / 4) * (L2.LC / 4) * 48 >= stream_records_bytes();
-                put_taps(q2.l_a, p->qshift[1]); put_taps(q2.l_b, p->qshift[0]);
-                put_taps(q2.h_a, p->qshift[5]); put_taps(q2.h_b, p->qshift[4]);
-                q2.lo_a_first = dotd(p->qshift[1], p->qshift[0]) > 0;
-                q2.hi_a_first = dotd(p->qshift[5], p->qshift[4]) > 0;
-                rc = dispatch_fwd12((int)p->biort[0].size(), (int)p->biort[2].size(), (int)p->qshift[0].size(), q, q2, s);
-            } else
             rc = dispatch_fwd1((int)p->biort[0].size(), (int)p->biort[2].size(), (int)p->bp1[0].size(), q, s);
         } else {
             Fwd2Params q{};

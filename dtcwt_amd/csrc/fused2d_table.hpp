@@ -70,12 +70,3 @@
     X(8, 16, 2, 16) \
     X(8, 16, 2, 18) \
     X(16, 32, 2, 32)
-
-/* Levels 1 + 2 forward in one launch (fused2d_l12.hpp):
- * X(level-2 tile rows, cols, level-1 column-pass strip, level-2 (A,B) pairs per strip,
- *   len h0o, len h1o, q-shift length).  Smallest image side for this path: DT_MIN_FUSE12_DIM. */
-#define DT_MIN_FUSE12_DIM 64
-#define DT_FWD12_TABLE(X) \
-    X(16, 32, 8, 4, 5, 7, 10)     /* near_sym_a + qshift_a / qshift_06 */ \
-    X(16, 28, 8, 4, 9, 7, 10)     /* antonini (9-tap lowpass: a wider halo, so a narrower core keeps one column-pass task per thread) */ \
-    X(16, 32, 8, 4, 5, 3, 10)     /* legall */

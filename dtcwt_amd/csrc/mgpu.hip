@@ -216,6 +216,11 @@ int dtcwt_hip_mgpu_create(int ndev, const int *devices, int batch, int rows, int
     DT_REQUIRE(out && devices && biort_host && biort_len && qshift_host && qshift_len, "NULL argument");
     DT_REQUIRE(ndev >= 1 && ndev <= 64, "bad device count %d", ndev);
     DT_REQUIRE(batch >= 1 && rows >= 1 && cols >= 1 && nlevels >= 1, "bad extents");
+    // the tables are copied below, before any plan looks at them: lengths first
+    for (int i = 0; i < 4; ++i)
+        DT_REQUIRE(biort_host[i] && biort_len[i] >= 1 && biort_len[i] <= DTCWT_HIP_MAX_TAPS, "biort vector %d: NULL or length %d out of range", i, biort_len[i]);
+    for (int i = 0; i < 8; ++i)
+        DT_REQUIRE(qshift_host[i] && qshift_len[i] >= 1 && qshift_len[i] <= DTCWT_HIP_MAX_TAPS, "q-shift vector %d: NULL or length %d out of range", i, qshift_len[i]);
     int nvis = 0;
     DT_CHECK_HIP(hipGetDeviceCount(&nvis));
     for (int d = 0; d < ndev; ++d)
@@ -299,14 +304,19 @@ int dtcwt_hip_mgpu_shapes(const dtcwt_hip_mgpu *m, int *shapes) {
     return dtcwt_set_error(-1, "no shard holds an image");
 }
 
-int dtcwt_hip_mgpu_forward2d(dtcwt_hip_mgpu *m, const float *const *X, float *const *Yl, void *const *Yh) {
+int dtcwt_hip_mgpu_forward2d_scales(dtcwt_hip_mgpu *m, const float *const *X, float *const *Yl, void *const *Yh,
+                                    float *const *Ys) {
     DT_REQUIRE(m && X && Yl && Yh, "NULL argument");
     const int nl = m->nlevels;
     return on_all(m, [&](int d) -> int {
         Shard &s = m->sh[d];
         if (!s.plan) return 0;
-        return dtcwt_hip_plan2d_forward(s.plan, X[d], Yl[d], Yh + (size_t)d * nl, nullptr);
+        return dtcwt_hip_plan2d_forward(s.plan, X[d], Yl[d], Yh + (size_t)d * nl, Ys ? Ys + (size_t)d * nl : nullptr);
     });
+}
+
+int dtcwt_hip_mgpu_forward2d(dtcwt_hip_mgpu *m, const float *const *X, float *const *Yl, void *const *Yh) {
+    return dtcwt_hip_mgpu_forward2d_scales(m, X, Yl, Yh, nullptr);
 }
 
 int dtcwt_hip_mgpu_inverse2d(dtcwt_hip_mgpu *m, const float *const *Yl, const void *const *Yh,

@@ -54,6 +54,8 @@ _dbl = ctypes.c_double
 _pd = ctypes.POINTER(ctypes.c_double)
 
 # name -> (restype, argtypes); every symbol include/dtcwt_hip.h declares
+ABI_VERSION = 2          # == DTCWT_HIP_ABI_VERSION of include/dtcwt_hip.h (checked in load_library)
+
 SIGNATURES = {
     'dtcwt_hip_abi_version': (_i, []),
     'dtcwt_hip_last_error': (ctypes.c_char_p, []),
@@ -71,6 +73,11 @@ SIGNATURES = {
     'dtcwt_hip_memcpy_d2h': (_i, [_vp, _vp, _vp, _sz]),
     'dtcwt_hip_memcpy_d2d': (_i, [_vp, _vp, _vp, _sz]),
     'dtcwt_hip_to_float': (_i, [_vp, _i, _vp, _i, _vp, _i64]),
+    'dtcwt_hip_host_alloc': (_i, [_sz, ctypes.POINTER(_vp)]),
+    'dtcwt_hip_host_free': (_i, [_vp]),
+    'dtcwt_hip_memcpy_h2d_async': (_i, [_vp, _vp, _vp, _sz]),
+    'dtcwt_hip_memcpy_d2h_overlapped': (_i, [_vp, _vp, _vp, _sz]),
+    'dtcwt_hip_copy_sync': (_i, [_vp]),
     'dtcwt_hip_memset': (_i, [_vp, _vp, _i, _sz]),
     'dtcwt_hip_event_create': (_i, [_vp, ctypes.POINTER(_vp)]),
     'dtcwt_hip_event_record': (_i, [_vp, _vp]),
@@ -130,7 +137,6 @@ SIGNATURES = {
     'dtcwt_hip_graph_launch': (_i, [_vp]),
     'dtcwt_hip_graph_destroy': (_i, [_vp]),
     'dtcwt_hip_plan2d_kernel_ms': (_i, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
-    'dtcwt_hip_plan2d_fused_levels': (_i, [_vp]),
     'dtcwt_hip_plan3d_create': (_i, [_vp, _i64, _i64, _i64, _i, _i, ctypes.POINTER(_pd), ctypes.POINTER(_i),
                                      ctypes.POINTER(_pd), ctypes.POINTER(_i), ctypes.POINTER(_vp)]),
     'dtcwt_hip_plan3d_destroy': (_i, [_vp]),
@@ -152,6 +158,7 @@ SIGNATURES = {
     'dtcwt_hip_mgpu_ctx': (_vp, [_vp, _i]),
     'dtcwt_hip_mgpu_shapes': (_i, [_vp, ctypes.POINTER(_i)]),
     'dtcwt_hip_mgpu_forward2d': (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
+    'dtcwt_hip_mgpu_forward2d_scales': (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
     'dtcwt_hip_mgpu_inverse2d': (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _pd, ctypes.POINTER(_vp)]),
     'dtcwt_hip_mgpu_sync': (_i, [_vp]),
     'dtcwt_hip_mgpu_scatter': (_i, [_vp, _vp, _sz, ctypes.POINTER(_vp)]),
@@ -198,6 +205,20 @@ def load_library(path=None):
             handle = ctypes.CDLL(path)
         except OSError as e:
             _lib_error = 'cannot load %s: %s' % (path, e)
+            raise NoHIPPresentError(_lib_error)
+        # a stale build would otherwise surface as an AttributeError on the first missing entry point
+        try:
+            handle.dtcwt_hip_abi_version.restype = _i
+            have = handle.dtcwt_hip_abi_version()
+        except AttributeError:
+            have = None
+        if have != ABI_VERSION:
+            _lib_error = ('%s has ABI version %r, this package needs %d: rebuild it with `make -C dtcwt_amd/csrc`'
+                          % (path, have, ABI_VERSION))
+            raise NoHIPPresentError(_lib_error)
+        missing = [name for name in SIGNATURES if not hasattr(handle, name)]
+        if missing:
+            _lib_error = '%s lacks %s: rebuild it with `make -C dtcwt_amd/csrc`' % (path, ', '.join(missing[:4]))
             raise NoHIPPresentError(_lib_error)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)

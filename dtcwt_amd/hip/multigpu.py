@@ -50,8 +50,8 @@ class _ShardCtx(object):
 class ShardedBuffers(object):
     """Device buffers of one batch: per shard X, Yl, Yh[level], Z (``DeviceArray``; None for empty shards)."""
 
-    def __init__(self, X, Yl, Yh, Z):
-        self.X, self.Yl, self.Yh, self.Z = X, Yl, Yh, Z
+    def __init__(self, X, Yl, Yh, Z, Ys=None):
+        self.X, self.Yl, self.Yh, self.Z, self.Ys = X, Yl, Yh, Z, Ys
 
 
 class MultiGPUTransform2d(object):
@@ -89,6 +89,7 @@ class MultiGPUTransform2d(object):
         check(L.dtcwt_hip_mgpu_shapes(h, s))
         self.ext, self.low = (s[0], s[1]), (s[2], s[3])
         self.high = [(s[4 + 4 * l], s[5 + 4 * l]) for l in range(nlevels)]
+        self.scale = [(s[6 + 4 * l], s[7 + 4 * l]) for l in range(nlevels)]
         self.shards = []
         self.ctxs = []
         for d in range(self.ndev):
@@ -109,7 +110,7 @@ class MultiGPUTransform2d(object):
             out.append(_lib.DeviceArray(self.ctxs[d], (cnt,) + tuple(shape_tail), dtype) if cnt else None)
         return out
 
-    def alloc(self, with_input=True):
+    def alloc(self, with_input=True, include_scale=False):
         X = self._per_shard((self.rows, self.cols), np.float32) if with_input else None
         Yl = self._per_shard(self.low, np.float32)
         Yh = [[None] * self.nlevels for _ in range(self.ndev)]
@@ -118,7 +119,15 @@ class MultiGPUTransform2d(object):
             for d in range(self.ndev):
                 Yh[d][l] = col[d]
         Z = self._per_shard(self.ext, np.float32)
-        return ShardedBuffers(X, Yl, Yh, Z)
+        bufs = ShardedBuffers(X, Yl, Yh, Z)
+        bufs.Ys = None
+        if include_scale:       # the lowpass image of every level (transform2d.py:96-99, :160-163)
+            bufs.Ys = [[None] * self.nlevels for _ in range(self.ndev)]
+            for l in range(self.nlevels):
+                col = self._per_shard(self.scale[l], np.float32)
+                for d in range(self.ndev):
+                    bufs.Ys[d][l] = col[d]
+        return bufs
 
     @staticmethod
     def _ptrs(arrs):
@@ -140,7 +149,13 @@ class MultiGPUTransform2d(object):
     # ---- transforms ------------------------------------------------------------------
     def forward_into(self, bufs):
         flat = [bufs.Yh[d][l] for d in range(self.ndev) for l in range(self.nlevels)]
-        check(self._lib.dtcwt_hip_mgpu_forward2d(self._h, self._ptrs(bufs.X), self._ptrs(bufs.Yl), self._ptrs(flat)))
+        Ys = getattr(bufs, 'Ys', None)
+        if Ys is None:
+            check(self._lib.dtcwt_hip_mgpu_forward2d(self._h, self._ptrs(bufs.X), self._ptrs(bufs.Yl), self._ptrs(flat)))
+        else:
+            flat_s = [Ys[d][l] for d in range(self.ndev) for l in range(self.nlevels)]
+            check(self._lib.dtcwt_hip_mgpu_forward2d_scales(self._h, self._ptrs(bufs.X), self._ptrs(bufs.Yl),
+                                                            self._ptrs(flat), self._ptrs(flat_s)))
 
     def inverse_into(self, bufs, gain_mask=None):
         flat = [bufs.Yh[d][l] for d in range(self.ndev) for l in range(self.nlevels)]
@@ -153,12 +168,13 @@ class MultiGPUTransform2d(object):
     def sync(self):
         check(self._lib.dtcwt_hip_mgpu_sync(self._h))
 
-    def forward(self, X):
-        """Host batch [batch, rows, cols] float32 -> :class:`ShardedBuffers` (pyramids resident per device)."""
+    def forward(self, X, include_scale=False):
+        """Host batch [batch, rows, cols] float32 -> :class:`ShardedBuffers` (pyramids resident per device);
+        *include_scale*: also keep the lowpass image of every level (``bufs.Ys[shard][level]``)."""
         X = np.asarray(X)
         if X.shape != (self.batch, self.rows, self.cols):
             raise ValueError('expected a batch of shape %r' % ((self.batch, self.rows, self.cols),))
-        bufs = self.alloc()
+        bufs = self.alloc(include_scale=include_scale)
         self.scatter(X.astype(np.float32, copy=False), bufs.X)
         self.forward_into(bufs)
         return bufs
@@ -173,6 +189,11 @@ class MultiGPUTransform2d(object):
         high = [self.gather([bufs.Yh[d][l] for d in range(self.ndev)], self.high[l] + (6,), np.complex64)
                 for l in range(self.nlevels)]
         return low, high
+
+    def gather_scales(self, bufs):
+        """[scales[l] [B, lo_r, lo_c]] on the host (forward(..., include_scale=True))."""
+        return [self.gather([bufs.Ys[d][l] for d in range(self.ndev)], self.scale[l], np.float32)
+                for l in range(self.nlevels)]
 
     def __del__(self):
         try:

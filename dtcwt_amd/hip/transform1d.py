@@ -86,7 +86,8 @@ class _Plan1d(object):
         Z = DeviceArray(self.ctx, (self.n, self.k), self.dtype)
         vp = ctypes.c_void_p
         yh_p = (vp * nl)(*[a.ptr for a in Yh])
-        g = np.ascontiguousarray(np.asarray(gain_mask, dtype=np.float64).reshape(nl))
+        # the reference indexes gain_mask[level] (transform1d.py:150-176): longer masks are allowed, extra entries unused
+        g = np.ascontiguousarray(np.asarray(gain_mask, dtype=np.float64).ravel()[:nl])
         rc = self._lib.dtcwt_hip_plan1d_inverse(self._h, Lo.ptr, yh_p, g.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), Z.ptr)
         if rc == -3:
             return None
@@ -125,8 +126,10 @@ class Transform1d(object):
         if key not in self._plans:
             try:
                 self._plans[key] = _Plan1d(self.ctx, dtype, n, k, nlevels, b, q)
-            except (NotImplementedError, _lib.HipError):
+            except NotImplementedError:         # -3: no one-launch kernel for some level; permanent for this key
                 self._plans[key] = None
+            except _lib.HipError:               # transient (e.g. out of memory): level-by-level now, retry next time
+                return None
             while len(self._plans) > self.MAX_PLANS:
                 self._plans.popitem(last=False)
         else:
@@ -229,8 +232,9 @@ class Transform1d(object):
         n0, k = 2 * Yh[0].shape[0], Lo.shape[1]
         plan = self._plan(Lo.dtype, n0, k, a, (h0o, g0o, h1o, g1o), (h0a, h0b, g0a, g0b, h1a, h1b, g1a, g1b)) \
             if Lo.dtype in (np.float32, np.float64) else None
-        if plan is not None and plan.low == Lo.shape[0] and all(
-                tuple(Yh[l].shape) == (plan.high[l], k) for l in range(a)):
+        cdt = np.complex64 if Lo.dtype == np.float32 else np.complex128
+        if plan is not None and plan.low == Lo.shape[0] and np.size(gain_mask) >= a and all(
+                tuple(Yh[l].shape) == (plan.high[l], k) and Yh[l].dtype == cdt for l in range(a)):
             Z = plan.inverse(Lo, Yh, gain_mask)
             if Z is not None:
                 if device_output:

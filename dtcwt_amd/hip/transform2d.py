@@ -79,11 +79,6 @@ class _Plan2d(object):
         self.high = [(s[4 + 4 * l], s[5 + 4 * l]) for l in range(nlevels)]
         self.scale = [(s[6 + 4 * l], s[7 + 4 * l]) for l in range(nlevels)]
 
-    @property
-    def fused12(self):
-        """True when levels 1 and 2 of the forward transform run as one launch (LoLo1 stays on chip)."""
-        return bool(self._lib.dtcwt_hip_plan2d_fused_levels(self._h) & 1)
-
     def forward(self, Xd, include_scale):
         ctx, B, nl = self.ctx, self.batch, self.nlevels
         Yl = DeviceArray(ctx, (B,) + self.low, np.float32)

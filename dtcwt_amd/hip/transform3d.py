@@ -199,7 +199,11 @@ class Transform3d(object):
     """An implementation of the 3D DT-CWT on AMD GPUs via HIP.  *biort*/*qshift* as for
     :class:`Transform2d`; *ext_mode* 4 or 8 as in dtcwt/numpy/transform3d.py:22-35,:86-99."""
 
-    def __init__(self, biort=DEFAULT_BIORT, qshift=DEFAULT_QSHIFT, ext_mode=4, ctx=None, reference_quirks=False):
+    def __init__(self, biort=DEFAULT_BIORT, qshift=DEFAULT_QSHIFT, ext_mode=4, ctx=None, reference_quirks=None):
+        # None: taken from the environment, so that users of dtcwt.push_backend('hip') -- who never see this
+        # constructor -- can ask for the reference's literal behaviour (DTCWT_HIP_REFERENCE_QUIRKS=1)
+        if reference_quirks is None:
+            reference_quirks = os.environ.get('DTCWT_HIP_REFERENCE_QUIRKS', '0') not in ('', '0')
         self.reference_quirks = bool(reference_quirks)
         self._plans = collections.OrderedDict()
         try:
@@ -240,8 +244,10 @@ class Transform3d(object):
         if key not in self._plans:
             try:
                 self._plans[key] = _Plan3d(self.ctx, shape, nlevels, self.ext_mode, self.biort, self.qshift)
-            except (NotImplementedError, _lib.HipError):
+            except NotImplementedError:         # -3: permanent for this key
                 self._plans[key] = None
+            except _lib.HipError:               # transient (e.g. out of memory): level-by-level now, retry next time
+                return None
             while len(self._plans) > self.MAX_PLANS:
                 self._plans.popitem(last=False)
         else:

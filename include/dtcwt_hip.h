@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define DTCWT_HIP_ABI_VERSION 1
+/* 2: plan1d_*, plan3d_*, mgpu_* (round 2), mgpu_forward2d_scales, host_alloc / host_free / memcpy_*_async (round 3) */
+#define DTCWT_HIP_ABI_VERSION 2
 
 #define DTCWT_HIP_F32 0
 #define DTCWT_HIP_F64 1
@@ -70,6 +71,15 @@ int dtcwt_hip_memcpy_h2d(dtcwt_hip_ctx *ctx, void *dst, const void *src_host, si
 int dtcwt_hip_memcpy_d2h(dtcwt_hip_ctx *ctx, void *dst_host, const void *src, size_t bytes);
 int dtcwt_hip_memcpy_d2d(dtcwt_hip_ctx *ctx, void *dst, const void *src, size_t bytes);
 int dtcwt_hip_memset(dtcwt_hip_ctx *ctx, void *dst, int value, size_t bytes);
+/* Page-locked host buffers and asynchronous copies (the lazy host copies of dtcwt/opencl/transform2d.py:30-84):
+ * h2d_async only enqueues on the context's stream; d2h_overlapped is ordered after everything enqueued so far but
+ * runs on a second stream, so kernels enqueued after it are not held up (a level's subbands go down the host link
+ * while the next levels are computed); copy_sync waits for the overlapped downloads. */
+int dtcwt_hip_host_alloc(size_t bytes, void **hptr);
+int dtcwt_hip_host_free(void *hptr);
+int dtcwt_hip_memcpy_h2d_async(dtcwt_hip_ctx *ctx, void *dst, const void *src_host, size_t bytes);
+int dtcwt_hip_memcpy_d2h_overlapped(dtcwt_hip_ctx *ctx, void *dst_host, const void *src, size_t bytes);
+int dtcwt_hip_copy_sync(dtcwt_hip_ctx *ctx);
 /* Integer / bool samples -> float32 / float64 on the device: `asfarray` of dtcwt/utils.py:98-105 (every
  * non-float input becomes float64) done after the upload, so that an 8-bit image crosses the host link
  * as 1 byte per sample.  src_kind: 0 u8, 1 i8, 2 u16, 3 i16, 4 u32, 5 i32, 6 u64, 7 i64, 8 bool. */
@@ -311,11 +321,6 @@ int dtcwt_hip_plan2d_forward(dtcwt_hip_plan2d *plan, const float *X, float *Yl,
 int dtcwt_hip_plan2d_inverse(dtcwt_hip_plan2d *plan, const float *Yl, const void *const *Yh,
                              const double *gain_mask_host, float *Z);
 
-/* Which levels share a launch: bit 0 set = levels 1 and 2 of the FORWARD transform run as one kernel
- * (the level-1 lowpass never leaves the chip: fused2d_l12.hpp; needs nlevels >= 2, an even-extended
- * image whose sides are multiples of 4 and a tile program for the tap lengths); bit 1 = the same for the
- * inverse.  Environment DTCWT_HIP_FUSE12=0 at plan creation keeps one launch per level. */
-int dtcwt_hip_plan2d_fused_levels(const dtcwt_hip_plan2d *plan);
 
 /* Band-pass ("_bp") wavelet sets: the third filter of a 6-vector biort (h2o, g2o; m_biort taps, 0:
  * none) and of a 12-vector q-shift (h2a, h2b, g2a, g2b; m_qshift taps, 0: none), used for the diagonal
@@ -410,6 +415,10 @@ int dtcwt_hip_mgpu_shard(const dtcwt_hip_mgpu *mgpu, int shard, int *device, int
 dtcwt_hip_ctx *dtcwt_hip_mgpu_ctx(dtcwt_hip_mgpu *mgpu, int shard);     /* for allocations / copies on that shard */
 int dtcwt_hip_mgpu_shapes(const dtcwt_hip_mgpu *mgpu, int *shapes);     /* per image, as dtcwt_hip_plan2d_shapes */
 int dtcwt_hip_mgpu_forward2d(dtcwt_hip_mgpu *mgpu, const float *const *X, float *const *Yl, void *const *Yh);
+/* the same with include_scale (transform2d.py:96-99, :160-163): Ys[shard * nlevels + level] receives the lowpass
+ * image of every level, [count][lo_r][lo_c] as dtcwt_hip_plan2d_shapes reports them; Ys == NULL: no scales */
+int dtcwt_hip_mgpu_forward2d_scales(dtcwt_hip_mgpu *mgpu, const float *const *X, float *const *Yl, void *const *Yh,
+                                    float *const *Ys);
 int dtcwt_hip_mgpu_inverse2d(dtcwt_hip_mgpu *mgpu, const float *const *Yl, const void *const *Yh,
                              const double *gain_mask_host, float *const *Z);
 int dtcwt_hip_mgpu_sync(dtcwt_hip_mgpu *mgpu);

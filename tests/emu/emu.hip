@@ -11,7 +11,7 @@
 
 #include "fused2d_tiles.hpp"
 #include "fused2d_tiles_v2.hpp"
-#include "fused2d_l12.hpp"
+#include "../../tools/kbench/fused2d_l12.hpp"      /* measurement-only tile program (not in the library) */
 #include "fused2d_table.hpp"
 #include "fused3d_tiles.hpp"
 #include "fused3d_inv_tiles.hpp"
@@ -398,6 +398,7 @@ int emu_inv2_large(int m, const float *Z, const float *Yh, float *Out, int B, in
 }
 
 // levels 1 + 2 forward in one tile program (fused2d_l12.hpp); LoLo1 may be NULL
+#define DT_FWD12_TABLE(X) X(16, 32, 8, 4, 5, 7, 10) X(16, 28, 8, 4, 9, 7, 10) X(16, 32, 8, 4, 5, 3, 10)      /* == tools/kbench/fwd12_kernel.hpp */
 #define EMU_FWD12(T2R, T2C, RS, PS, A, B, M) if (m0 == A && m1 == B && m == M) return run_fwd12<Fwd12Cfg<T2R, T2C, RS, PS, A, B, M>>(p1, p2);
 int emu_fwd12(int m0, int m1, int m, const float *X, float *LoLo1, float *Yh0, float *LoLo2, float *Yh1, int B,
               int inR, int inC, const double *h0, const double *h1, const double *la, const double *lb,

@@ -27,7 +27,20 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(handle, n), 'libdtcwt_hip.so does not export %s' % n
         assert n in _lib.SIGNATURES, 'binding lacks %s' % n
     assert sorted(_lib.SIGNATURES) == names
-    assert handle.dtcwt_hip_abi_version() == 1
+    # header, library and binding agree on the ABI version (a stale .so is refused by load_library)
+    hv = int(re.search(r'#define\s+DTCWT_HIP_ABI_VERSION\s+(\d+)', open(HEADER).read()).group(1))
+    assert handle.dtcwt_hip_abi_version() == hv == _lib.ABI_VERSION
+
+
+def test_stale_library_is_refused(tmp_path, monkeypatch):
+    """A library whose ABI version differs from the binding's is reported as 'rebuild', not as an AttributeError
+    on the first missing entry point."""
+    from dtcwt_amd.hip import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, '_lib_error', None)
+    monkeypatch.setattr(_lib, 'ABI_VERSION', _lib.ABI_VERSION + 1)
+    with pytest.raises(_lib.NoHIPPresentError, match='rebuild'):
+        _lib.load_library()
 
 
 def test_view_struct_layout():

@@ -78,20 +78,12 @@ def test_two_rank_gloo_tap_broadcast_and_sharding():
 
 
 def _emu_levels12(emu, X, b, q):
-    """Levels 1 + 2 of a batch through the host emulator of the fused tile program."""
-    import ctypes
-    B, r, c = X.shape
-    yh0 = np.full((B, r // 2, c // 2, 12), np.nan, np.float32)
-    lolo2 = np.full((B, r // 2, c // 2), np.nan, np.float32)
-    yh1 = np.full((B, r // 4, c // 4, 12), np.nan, np.float32)
-    d = lambda a: np.ascontiguousarray(np.asarray(a, np.float64).reshape(-1))
-    f = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-    h0a, h0b, g0a, g0b, h1a, h1b, g1a, g1b = q[:8]
-    taps = [d(b[0]), d(b[2]), d(h0b), d(h0a), d(h1b), d(h1a)]
-    rc = emu.emu_fwd12(len(taps[0]), len(taps[1]), len(taps[2]), f(X), None, f(yh0), f(lolo2), f(yh1), B, r, c,
-                       *[f(t) for t in taps])
-    assert rc == 0
-    return lolo2, yh0.view(np.complex64), yh1.view(np.complex64)
+    """Levels 1 + 2 of a batch through the host emulator of the fused per-level tile programs (k_fwd1, k_fwd2:
+    the kernels the plan launches)."""
+    from tests.test_emu_tiles import emu_fwd1, emu_fwd2
+    lolo1, yh0 = emu_fwd1(emu, X, b[0], b[2])
+    lolo2, yh1 = emu_fwd2(emu, lolo1, q)
+    return lolo2, yh0, yh1
 
 
 def _shard_worker(rank, world, port, q):
@@ -144,3 +136,55 @@ def test_two_rank_gloo_shard_transform_gather():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res[0] is True
+
+
+def _bench_shard_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    import bench
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        cfg = bench.CONFIGS['c5']
+        plan, global_batch = bench.shard_plan(cfg, world)
+        seed, images = plan[rank]
+        head = np.random.RandomState(seed).standard_normal(8).astype(np.float32)     # start of this rank's image 0
+        dt = torch.tensor([1e-3 * (1 + rank)], dtype=torch.float64)                  # rank r "took" (1 + r) ms
+        every = [torch.zeros_like(dt) for _ in range(world)]
+        dist.all_gather(every, dt)
+        mx = dt.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        got = [None] * world
+        dist.all_gather_object(got, (seed, images, head.tolist()))
+        px = float(images) * cfg['rows'] * cfg['cols']
+        q.put((rank, got, global_batch, [float(t) for t in every], bench.aggregate_value(world, px, 10, float(mx))))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_four_rank_gloo_bench_sharding_c5():
+    """bench.py's N-GPU arithmetic for BASELINE config[4] on four gloo ranks: rank r transforms 64 images of
+    seed 3 + 1000 r per step (weak scaling, 4 x 64 images in flight), the per-rank times are gathered for the
+    min / max of the JSON line, and `value` is all ranks' pixels over the SLOWEST rank's time."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    world = 4
+    procs = [ctx.Process(target=_bench_shard_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, got, global_batch, every, value in res:
+        assert [g[0] for g in got] == [3, 1003, 2003, 3003]
+        assert [g[1] for g in got] == [64] * 4 and global_batch == 256
+        heads = [tuple(g[2]) for g in got]
+        assert len(set(heads)) == 4                      # every rank's images differ
+        assert every == pytest.approx([1e-3, 2e-3, 3e-3, 4e-3])
+        # 4 ranks x 64 x 2048^2 px x 10 steps in 4 ms (the slowest rank)
+        assert value == pytest.approx(4 * 64 * 2048 * 2048 * 10 / 4e-3 / 1e6)

@@ -25,8 +25,9 @@ TOL = 2e-6
 
 
 def _build():
-    deps = [EMU_SRC] + [os.path.join(ROOT, 'dtcwt_amd', 'csrc', f) for f in
-                        ('fused2d_tiles.hpp', 'fused2d_tiles_v2.hpp', 'fused2d_l12.hpp', 'fused2d_table.hpp', 'fused3d_tiles.hpp', 'fused3d_inv_tiles.hpp')]
+    deps = [EMU_SRC, os.path.join(ROOT, 'tools', 'kbench', 'fused2d_l12.hpp')] + [
+        os.path.join(ROOT, 'dtcwt_amd', 'csrc', f) for f in
+        ('fused2d_tiles.hpp', 'fused2d_tiles_v2.hpp', 'fused2d_table.hpp', 'fused3d_tiles.hpp', 'fused3d_inv_tiles.hpp')]
     if os.path.exists(EMU_LIB) and all(os.path.getmtime(EMU_LIB) >= os.path.getmtime(d) for d in deps):
         return
     if not os.path.exists(HIPCC):

@@ -48,61 +48,6 @@ def test_c2_whole_pyramid_vs_oracle_4096():
     assert_close(z1, as_f64(X), INV_TOL, 'perfect reconstruction')
 
 
-def test_c2_fused_levels_whole_pyramid_4096(monkeypatch):
-    """The opt-in one-launch level-1+2 forward (DTCWT_HIP_FUSE12=1) at the headline size against the oracle."""
-    monkeypatch.setenv('DTCWT_HIP_FUSE12', '1')
-    rs = np.random.RandomState(4097)
-    X = rs.standard_normal((4096, 4096)).astype(np.float32)
-    t = Transform2d(B, Q)
-    assert t.plan(1, 4096, 4096, 4).fused12
-    p = t.forward(X, nlevels=4)
-    want = _oracle().forward(as_f64(X), nlevels=4)
-    assert_close(p.lowpass, want.lowpass, XFM_TOL, 'Yl')
-    for l in range(4):
-        assert_close(p.highpasses[l], want.highpasses[l], XFM_TOL, 'Yh[%d]' % l)
-
-
-def test_c2_fused_levels_equal_one_launch_per_level(monkeypatch):
-    """Levels 1+2 in one launch (DTCWT_HIP_FUSE12=1) give the same pyramid as one launch per level,
-    include_scale (LoLo1 written out as well) included, on a size whose edge tiles hang over the image."""
-    rs = np.random.RandomState(5)
-    X = rs.standard_normal((1160, 1416)).astype(np.float32)
-    monkeypatch.setenv('DTCWT_HIP_FUSE12', '1')
-    a = Transform2d(B, Q)
-    assert a.plan(1, 1160, 1416, 3).fused12
-    pa = a.forward(X, nlevels=3, include_scale=True)
-    monkeypatch.setenv('DTCWT_HIP_FUSE12', '0')
-    b = Transform2d(B, Q)
-    assert not b.plan(1, 1160, 1416, 3).fused12
-    pb = b.forward(X, nlevels=3, include_scale=True)
-    assert_close(pa.lowpass, pb.lowpass, 5e-7)
-    for l in range(3):
-        assert_close(pa.highpasses[l], pb.highpasses[l], 5e-7)
-        assert_close(pa.scales[l], pb.scales[l], 5e-7)
-    want = _oracle().forward(as_f64(X), nlevels=3, include_scale=True)
-    assert_close(pa.scales[0], want.scales[0], XFM_TOL)
-    assert_close(pa.highpasses[1], want.highpasses[1], XFM_TOL)
-
-
-@pytest.mark.parametrize('shape', [(64, 64), (68, 132), (127, 256), (200, 64), (1023, 516)])
-@pytest.mark.parametrize('bn', ['near_sym_a', 'antonini', 'legall'])
-def test_fused_levels_small_and_odd(shape, bn, monkeypatch):
-    """The one-launch level-1+2 path on small / odd (bottom row replicated) images whose tiles mostly
-    hang over the edge; sizes whose extension is not a multiple of 4 keep one launch per level."""
-    monkeypatch.setenv('DTCWT_HIP_FUSE12', '1')
-    B = bn
-    rs = np.random.RandomState(sum(shape))
-    X = rs.standard_normal(shape).astype(np.float32)
-    t = Transform2d(B, Q)
-    R, C = shape[0] + (shape[0] & 1), shape[1] + (shape[1] & 1)
-    assert t.plan(1, shape[0], shape[1], 2).fused12 == (R % 4 == 0 and C % 4 == 0)
-    p = t.forward(X, nlevels=2)
-    want = o.Transform2d(biort(B), qshift(Q)).forward(as_f64(X), nlevels=2)
-    assert_close(p.lowpass, want.lowpass, XFM_TOL)
-    for l in range(2):
-        assert_close(p.highpasses[l], want.highpasses[l], XFM_TOL)
-
-
 def test_c5_one_gpu_share_64x2048():
     """BASELINE config[4], one GPU's share: 64 images 2048 x 2048, nlevels=4, seed 3 + 1000*rank
     (SURVEY 8(d)).  Two images against the oracle; all 64 against the same image transformed alone."""
@@ -127,6 +72,51 @@ def test_c5_one_gpu_share_64x2048():
         assert np.array_equal(high[1][i], single.highpasses[3]), i
     z = t.inverse_channels(pb, 'nhw')
     assert np.abs(z - Xb).max() < 2e-5 * np.abs(Xb).max()
+
+
+def _image_of(a, i):
+    """Image *i* of a batched device array as a device view (no copy)."""
+    per = int(np.prod(a.shape[1:])) * a.dtype.itemsize
+    return DeviceArray(a.ctx, (1,) + tuple(a.shape[1:]), a.dtype, ptr=a.ptr + i * per, owner=a)
+
+
+def test_more_than_2_31_elements_on_one_gpu():
+    """172 x 2048^2 float32, nlevels=4 on ONE GPU: Yh[0] holds 172 x 1024^2 x 12 = 2.16e9 floats, beyond the 32-bit
+    record addressing of the fast paths -- the transform must take the 64-bit branches (fwd1s_rows_flush's general
+    index algebra, the 64-bit decode of the generic kernels) and still be right.  The reference has no size limit
+    (dtcwt/numpy/transform2d.py:40-188 takes any array).  First and last image against the oracle, a middle one
+    bit for bit against the same image transformed alone, then the inverse of the whole batch."""
+    nb, R, C, nl = 172, 2048, 2048, 4
+    ctx = default_context()
+    rs = np.random.RandomState(77)
+    base = rs.standard_normal((8, R, C)).astype(np.float32)
+    image = lambda i: (base[i % 8] * np.float32(1.0 + 0.01 * i)).astype(np.float32)     # every image different
+    X = DeviceArray(ctx, (nb, R, C), np.float32)
+    for i in range(nb):
+        _image_of(X, i).set(image(i)[None])
+    t, to = Transform2d(B, Q), _oracle()
+    pb = t.forward_channels(X, 'nhw', nlevels=nl)
+    yl, yh = pb.hip_lowpass, pb.hip_highpasses
+    assert 2 * yh[0].size > 2 ** 31 and yh[0].shape == (nb, R // 2, C // 2, 6)      # floats (complex64 pairs)
+    for i in (0, nb - 1):
+        want = to.forward(as_f64(image(i)), nlevels=nl)
+        assert_close(_image_of(yl, i).get()[0], want.lowpass, XFM_TOL, 'image %d Yl' % i)
+        for l in range(nl):
+            assert_close(_image_of(yh[l], i).get()[0], want.highpasses[l], XFM_TOL, 'image %d Yh[%d]' % (i, l))
+    mid = 97
+    single = t.forward(image(mid), nlevels=nl)
+    assert np.array_equal(_image_of(yl, mid).get()[0], single.lowpass)
+    for l in range(nl):
+        assert np.array_equal(_image_of(yh[l], mid).get()[0], single.highpasses[l]), l
+    Z = t.inverse_channels(pb, 'nhw', device_output=True)
+    assert Z.shape == (nb, R, C)
+    for i in (0, mid, nb - 1):
+        z = _image_of(Z, i).get()[0]
+        assert np.abs(z - image(i)).max() < 3e-6 * np.abs(image(i)).max(), i
+    # one image of the inverse bit for bit against the inverse of that image alone
+    assert np.array_equal(_image_of(Z, mid).get()[0], t.inverse(single))
+    del X, pb, Z
+    ctx.trim()
 
 
 @pytest.mark.parametrize('devices,bcast', [([0], False), ([0, 0], False), ([0, 0, 0], True)])
@@ -157,6 +147,25 @@ def test_mgpu_batch_split_matches_single_plan(devices, bcast):
     z = m.inverse(bufs, gm)
     zr = t.inverse_channels(ref, 'nhw', gain_mask=gm)
     assert np.array_equal(z, zr)
+    m.sync()
+
+
+def test_mgpu_include_scale():
+    """dtcwt_hip_mgpu_forward2d_scales: the per-level lowpass images (include_scale, transform2d.py:96-99, :160-163)
+    of a sharded batch equal those of the unsharded batch bit for bit and the oracle's within tolerance."""
+    from dtcwt_amd.hip.multigpu import MultiGPUTransform2d
+    X = np.random.RandomState(21).standard_normal((5, 200, 264)).astype(np.float32)
+    m = MultiGPUTransform2d(B, Q, devices=[0, 0], batch=5, rows=200, cols=264, nlevels=3)
+    bufs = m.forward(X, include_scale=True)
+    scales = m.gather_scales(bufs)
+    low, _ = m.gather_pyramid(bufs)
+    ref = Transform2d(B, Q).forward_channels(X, 'nhw', nlevels=3, include_scale=True)
+    assert np.array_equal(low, ref.lowpass)
+    for l in range(3):
+        assert np.array_equal(scales[l], ref.scales[l]), l
+    want = _oracle().forward(as_f64(X[4]), nlevels=3, include_scale=True)
+    for l in range(3):
+        assert_close(scales[l][4], want.scales[l], XFM_TOL)
     m.sync()
 
 

@@ -1,4 +1,4 @@
-// Micro-benchmark of the fused level-1+2 forward tile program (dtcwt_amd/csrc/fused2d_l12.hpp)
+// Micro-benchmark of the fused level-1+2 forward tile program (tools/kbench/fused2d_l12.hpp)
 // against the one-launch-per-level kernels it replaces, over several tile shapes.  Measurement
 // tool only (not part of libdtcwt_hip.so): it compiles the library's own fused2d.hip into this
 // translation unit so that other template configurations can be instantiated here.
@@ -8,6 +8,7 @@
 // Every variant is checked against the two-launch result before it is timed; timings rotate
 // over NSET buffer sets so that neither input nor outputs of a repetition are cache-resident.
 #include "../../dtcwt_amd/csrc/fused2d.hip"
+#include "fwd12_kernel.hpp"
 
 #include <cmath>
 #include <cstdio>
