@@ -300,6 +300,10 @@ class Context(object):
         """Return cached (freed) device buffers to the driver."""
         check(self._lib.dtcwt_hip_trim(self._h))
 
+    def copy_sync(self):
+        """Wait for the downloads enqueued with :meth:`DeviceArray.get_async`."""
+        check(self._lib.dtcwt_hip_copy_sync(self._h))
+
     def device_sync(self):
         """hipDeviceSynchronize(): every stream of this device."""
         check(self._lib.dtcwt_hip_device_sync(self._h))
@@ -387,7 +391,13 @@ class _HostPool(object):
     garbage collected AND nothing else (a slice, a reshaped view ...) still refers to the buffer,
     the buffer goes back to the pool for the next download of the same size.  Buffers under
     1 MiB are not pooled; ``DTCWT_HIP_HOST_POOL_MB`` bounds the idle memory (default 2048, 0
-    disables)."""
+    disables).
+
+    The buffers are PAGE-LOCKED (``dtcwt_hip_host_alloc`` = hipHostMalloc; ``DTCWT_HIP_PINNED_HOST=0``
+    or a failed allocation falls back to pageable ``np.empty``): a download into them is one DMA
+    transfer at the link rate with no staging copy, and it can be enqueued asynchronously
+    (:meth:`DeviceArray.get_async`, ``Pyramid.prefetch``) -- the lazy host copies of the reference's
+    OpenCL pyramid (dtcwt/opencl/transform2d.py:30-84), overlapped."""
 
     MIN_BYTES = 1 << 20
 
@@ -396,17 +406,41 @@ class _HostPool(object):
         self._idle = 0
         self._lock = threading.Lock()
         self.limit = int(os.environ.get('DTCWT_HIP_HOST_POOL_MB', '2048')) << 20
+        self.pinned = os.environ.get('DTCWT_HIP_PINNED_HOST', '1') != '0'
+        self.pinned_bytes = 0           # page-locked bytes currently allocated through this pool
         self._quiet_refs = None
         self._quiet_refs = self._calibrate()
 
     def _calibrate(self):
-        # references to a buffer seen inside give() when no user view exists
+        # references to a buffer seen inside give() when no user view exists; the buffer is built the way
+        # _new_base builds a page-locked one (np.frombuffer over a ctypes array), which is also an ndarray that
+        # does not own its data -- like every pooled base once it has been handed out as a view
         seen = []
-        base = np.empty(8, dtype=np.uint8)
+        raw = (ctypes.c_uint8 * 8)()
+        base = np.frombuffer(raw, dtype=np.uint8)
         arr = base.view(np.float32).reshape(2)
         weakref.finalize(arr, self.give, base, seen)
         del base, arr
         return seen[0] if seen else -1
+
+    def _unpin(self, ptr, nbytes):
+        try:
+            if _lib is not None:
+                _lib.dtcwt_hip_host_free(ptr)
+        finally:
+            self.pinned_bytes -= nbytes
+
+    def _new_base(self, nbytes):
+        """A byte buffer for downloads: page-locked when the library is there, pageable otherwise."""
+        if self.pinned and _lib is not None:
+            p = _vp()
+            if _lib.dtcwt_hip_host_alloc(nbytes, ctypes.byref(p)) == 0 and p.value:
+                raw = (ctypes.c_uint8 * nbytes).from_address(p.value)
+                base = np.frombuffer(raw, dtype=np.uint8)
+                self.pinned_bytes += nbytes
+                weakref.finalize(base, self._unpin, p.value, nbytes)      # when the last view of it is gone
+                return base
+        return np.frombuffer(bytearray(nbytes), dtype=np.uint8)
 
     def empty(self, shape, dtype):
         dtype = np.dtype(dtype)
@@ -420,7 +454,7 @@ class _HostPool(object):
                 base = lst.pop()
                 self._idle -= nbytes
         if base is None:
-            base = np.empty(nbytes, dtype=np.uint8)
+            base = self._new_base(nbytes)
         arr = base.view(dtype).reshape(shape)
         weakref.finalize(arr, self.give, base)
         return arr
@@ -509,6 +543,15 @@ class DeviceArray(object):
         out = host_pool.empty(self.shape, self.dtype)
         check(self.ctx._lib.dtcwt_hip_memcpy_d2h(self.ctx.handle, out.ctypes.data_as(_vp), self.ptr,
                                                  self.nbytes))
+        return out
+
+    def get_async(self):
+        """Enqueue the download on the context's copy stream (ordered after everything issued so far, not holding
+        up what is issued next) and return the destination array; its contents are valid after
+        ``ctx.copy_sync()``."""
+        out = host_pool.empty(self.shape, self.dtype)
+        check(self.ctx._lib.dtcwt_hip_memcpy_d2h_overlapped(self.ctx.handle, out.ctypes.data_as(_vp), self.ptr,
+                                                            self.nbytes))
         return out
 
     def set(self, X):

@@ -39,6 +39,7 @@ class Pyramid(object):
         self._high = tuple(x if (x is None or _is_dev(x)) else asfarray(x) for x in highpasses)
         self._scales = None if scales is None else tuple(x if _is_dev(x) else asfarray(x) for x in scales)
         self._host = {}
+        self._pending = {}      # key -> (destination array, context) of downloads started by prefetch()
 
     # ---- raw device handles (None where the entry was given as a host array) ----
     @property
@@ -61,9 +62,27 @@ class Pyramid(object):
         return len(self._high)
 
     # ---- NumPy-compatible attributes, memoised --------------------------------
+    def prefetch(self):
+        """Start downloading every device-resident entry now, without waiting: the copies run on the context's
+        copy stream into page-locked pooled buffers, behind the kernels that produce them and beside whatever is
+        enqueued next (the next image's upload and transform).  The first access to ``lowpass`` / ``highpasses``
+        / ``scales`` waits for them.  Transform2d.forward calls this for NumPy inputs -- the literal drop-in use,
+        where the caller is certain to read the result on the host."""
+        entries = [('l', self._low)] + [(('h', i), x) for i, x in enumerate(self._high)]
+        if self._scales is not None:
+            entries += [(('s', i), x) for i, x in enumerate(self._scales)]
+        for key, x in entries:
+            if x is not None and _is_dev(x) and key not in self._host and key not in self._pending:
+                self._pending[key] = (x.get_async(), x.ctx)
+        return self
+
     def _get(self, key, x):
         if x is None or not _is_dev(x):
             return x
+        if key in self._pending:
+            arr, ctx = self._pending.pop(key)
+            ctx.copy_sync()
+            self._host[key] = arr
         if key not in self._host:
             self._host[key] = x.get()
         return self._host[key]

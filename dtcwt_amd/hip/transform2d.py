@@ -15,6 +15,7 @@ There is no host fallback: without the library or a GPU the first use raises
 backend, dtcwt/tf/transform2d.py:179-336, :422-588).
 """
 import collections
+import os
 import ctypes
 import logging
 
@@ -215,6 +216,9 @@ class Transform2d(object):
             self.qshift = qshift
         self._ctx = ctx
         self._plans = collections.OrderedDict()
+        # NumPy image in -> the subbands start travelling to the host as soon as their kernels are enqueued
+        # (Pyramid.prefetch); DTCWT_HIP_PREFETCH_HOST=0 keeps the purely lazy copies of round 2
+        self.prefetch_host = os.environ.get('DTCWT_HIP_PREFETCH_HOST', '1') != '0'
 
     MAX_PLANS = 8       # fused plans kept per transform object (each owns per-level workspaces in HBM)
 
@@ -382,6 +386,7 @@ class Transform2d(object):
             if X.dtype not in (np.float32, np.float64):
                 raise TypeError('device inputs must be float32 or float64, not %s' % X.dtype)
             Xd = X
+            from_host = False
         else:
             X = np.atleast_2d(np.asanyarray(X))
             if np.issubdtype(X.dtype, np.complexfloating):
@@ -391,6 +396,7 @@ class Transform2d(object):
                     'x'.join(str(s) for s in X.shape)) + 'for the 2D transform in a hip backend. ' +
                     'Please enter each image slice separately.')
             Xd = self.ctx.to_device_float(X)         # asfarray semantics; integers are widened on the device
+            from_host = self.prefetch_host
         r, c = Xd.shape
         R, C = r + (r & 1), c + (c & 1)
         if nlevels == 0:
@@ -405,8 +411,12 @@ class Transform2d(object):
         self._log_extension((r, c), (R, C))
         drop = lambda a: a.reshape(a.shape[1:])
         if include_scale:
-            return Pyramid(drop(Yl), tuple(drop(y) for y in Yh), tuple(drop(s) for s in Ys))
-        return Pyramid(drop(Yl), tuple(drop(y) for y in Yh))
+            p = Pyramid(drop(Yl), tuple(drop(y) for y in Yh), tuple(drop(s) for s in Ys))
+        else:
+            p = Pyramid(drop(Yl), tuple(drop(y) for y in Yh))
+        # a NumPy image in means NumPy subbands out: start their downloads behind the kernels now (copy stream,
+        # page-locked buffers) instead of one blocking copy per subband at first access
+        return p.prefetch() if from_host else p
 
     # ------------------------------------------------------------------ inverse
     @staticmethod

@@ -113,8 +113,10 @@ def test_more_than_2_31_elements_on_one_gpu():
     for i in (0, mid, nb - 1):
         z = _image_of(Z, i).get()[0]
         assert np.abs(z - image(i)).max() < 3e-6 * np.abs(image(i)).max(), i
-    # one image of the inverse bit for bit against the inverse of that image alone
-    assert np.array_equal(_image_of(Z, mid).get()[0], t.inverse(single))
+    # ... and against the inverse of that image alone (a single image takes the small coarse-level tiles, the
+    # batch the large ones: the same sums formed by different kernel instantiations, equal to the last bit or two)
+    alone = t.inverse(single)
+    assert np.abs(_image_of(Z, mid).get()[0] - alone).max() <= 1e-6 * np.abs(alone).max()
     del X, pb, Z
     ctx.trim()
 

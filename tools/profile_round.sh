@@ -19,8 +19,8 @@ echo "fetch rc=$?" >> "$OUT/status.txt"
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_write" -o p --output-format csv -- $BENCH > "$OUT/pmc_write.log" 2>&1
 echo "write rc=$?" >> "$OUT/status.txt"
 cd $R
-cp "$(ls $OUT/trace/*/*kernel_stats.csv 2>/dev/null | head -1)" "$OUT/kernel_stats.csv" 2>/dev/null
-cp "$(ls $OUT/trace1/*/*kernel_stats.csv 2>/dev/null | head -1)" "$OUT/kernel_stats_streams1.csv" 2>/dev/null
+cp "$(find $OUT/trace -name "*kernel_stats.csv" | head -1)" "$OUT/kernel_stats.csv" 2>/dev/null
+cp "$(find $OUT/trace1 -name "*kernel_stats.csv" | head -1)" "$OUT/kernel_stats_streams1.csv" 2>/dev/null
 python tools/roofline_from_trace.py "$OUT" --write "$OUT/traffic.json" --source "profiles/${2:-r03}/roofline.json" > "$OUT/roofline.json" 2> "$OUT/roofline.err"
 python tools/pmc_summary.py "$OUT" > "$OUT/pmc_hbm_traffic.txt" 2>&1
 python $R/bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver_cmd.json" 2>/dev/null      # the driver's command, unprofiled
