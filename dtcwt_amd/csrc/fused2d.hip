@@ -36,7 +36,8 @@ __global__ void __launch_bounds__(DT_NT) k_fwd1(Fwd1Params p) {
     const int ntile = p.tilesR * p.tilesC * p.B;
     int t = tile_of(blockIdx.x, ntile, p.xcd_order);
     if (t >= ntile) return;
-    int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    int tc, tr, b;
+    dt_tile_decode(p, t, tc, tr, b);
     float *sLo = smem, *sHi = sLo + C::SL, *sBa = sHi + C::SL, *stage = smem + C::LDS_FLOATS;
     int r0 = tr * C::TR, c0 = tc * C::TC;
     fwd1d_cols<C>(p, sLo, sHi, threadIdx.x, b, r0, c0, sBa);
@@ -57,7 +58,8 @@ __global__ void __launch_bounds__(DT_NT) k_fwd2(Fwd2Params p) {
     const int ntile = p.tilesR * p.tilesC * p.B;
     int t = tile_of(blockIdx.x, ntile, p.xcd_order);
     if (t >= ntile) return;
-    int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    int tc, tr, b;
+    dt_tile_decode(p, t, tc, tr, b);
     float *sLo = smem, *sHi = sLo + C::SL, *sBa = sHi + C::SL, *stage = smem + C::LDS_FLOATS;
     int r0 = tr * C::TR, c0 = tc * C::TC;
     fwd2d_cols<C>(p, sLo, sHi, threadIdx.x, b, r0, c0, sBa);
@@ -81,6 +83,7 @@ inline unsigned grid_for(int ntile, int order = 1) {
 template <class C>
 int launch_fwd1(Fwd1Params &p, hipStream_t s) {
     p.tilesR = cdiv(p.LR, C::TR); p.tilesC = cdiv(p.LC, C::TC);
+    dt_set_tile_magic(p);
     dt_pack_c01<C::M0, C::M1>(p);
     k_fwd1<C><<<grid_for(p.tilesR * p.tilesC * p.B, p.xcd_order), DT_NT, 0, s>>>(p);
     return 0;
@@ -88,6 +91,7 @@ int launch_fwd1(Fwd1Params &p, hipStream_t s) {
 template <class C>
 int launch_fwd2(Fwd2Params &p, hipStream_t s) {
     p.tilesR = cdiv(p.LR / 2, C::TR); p.tilesC = cdiv(p.LC / 2, C::TC);
+    dt_set_tile_magic(p);
     dt_pack_lh(p);
     k_fwd2<C><<<grid_for(p.tilesR * p.tilesC * p.B, p.xcd_order), DT_NT, 0, s>>>(p);
     return 0;

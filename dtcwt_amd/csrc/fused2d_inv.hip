@@ -29,7 +29,8 @@ __global__ void __launch_bounds__(DT_NT) k_inv1(Inv1Params p) {
     const int ntile = p.tilesR * p.tilesC * p.B;
     int t = tile_of(blockIdx.x, ntile, p.xcd_order);
     if (t >= ntile) return;
-    int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    int tc, tr, b;
+    dt_tile_decode(p, t, tc, tr, b);
     float *srec = smem, *y1 = smem, *y2 = y1 + C::SY, *y3 = y2 + C::SY;     // y3: band-pass variant only
     int r0 = tr * C::TR, c0 = tc * C::TC;
     const float *Yhb = p.Yh + (int64_t)b * (p.R / 2) * (p.C / 2) * 12;
@@ -53,7 +54,8 @@ __global__ void __launch_bounds__(DT_NT) k_inv2(Inv2Params p) {
     const int ntile = p.tilesR * p.tilesC * p.B;
     int t = tile_of(blockIdx.x, ntile, p.xcd_order);
     if (t >= ntile) return;
-    int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    int tc, tr, b;
+    dt_tile_decode(p, t, tc, tr, b);
     float *srec = smem, *y1 = smem, *y2 = y1 + C::SY, *y3 = y2 + C::SY;     // y3: band-pass variant only
     int r0 = tr * C::TR, c0 = tc * C::TC;
     const float *Yhb = p.Yh + (int64_t)b * (p.zr / 2) * (p.zc / 2) * 12;
@@ -71,6 +73,7 @@ __global__ void __launch_bounds__(DT_NT) k_inv2(Inv2Params p) {
 template <class C>
 int launch_inv1(Inv1Params &p, hipStream_t s) {
     p.tilesR = cdiv(p.R, C::TR); p.tilesC = cdiv(p.C, C::TC);
+    dt_set_tile_magic(p);
     dt_pack_g01<C::M0, C::M1>(p);
     k_inv1<C><<<grid_for(p.tilesR * p.tilesC * p.B, p.xcd_order), DT_NT, 0, s>>>(p);
     return 0;
@@ -78,6 +81,7 @@ int launch_inv1(Inv1Params &p, hipStream_t s) {
 template <class C>
 int launch_inv2(Inv2Params &p, hipStream_t s) {
     p.tilesR = cdiv(p.zr, C::TR); p.tilesC = cdiv(p.zc, C::TC);
+    dt_set_tile_magic(p);
     // every shipped q-shift set: sum(g0a g0b) > 0 > sum(g1a g1b) (and the band-pass pair like g1) -- compile-time
     // filter phases; anything else takes the run-time flags
     const bool std_set = p.lo_pos && !p.hi_pos && (!C::BP || !p.bp_pos);

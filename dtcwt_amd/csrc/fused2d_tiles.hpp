@@ -79,6 +79,7 @@ struct Fwd1Params {
     int B, inR, inC;      // real input size (may be odd)
     int LR, LC;           // even-extended logical size (transform2d.py:86-94)
     int tilesR, tilesC;
+    unsigned mgC, mgRC;   // dt_tile_magic(): multipliers that replace the divisions by tilesC and tilesC * tilesR in the tile decode (0: divide)
     int xcd_order;        // 1: XCD-contiguous tile runs, 0: linear order
     float h0[DT_MAXT], h1[DT_MAXT];
     float h2[DT_MAXT];    // band-pass biort (6-vector sets): the diagonal subbands (transform2d.py:116-129)
@@ -130,6 +131,7 @@ struct Fwd2Params {
     int padR, padC;       // 0/1: one replicated row/col each side (transform2d.py:134-140)
     int LR, LC;           // inR + 2 padR, multiples of 4
     int tilesR, tilesC;
+    unsigned mgC, mgRC;   // dt_tile_magic(): multipliers that replace the divisions by tilesC and tilesC * tilesR in the tile decode (0: divide)
     int xcd_order;        // 1: XCD-contiguous tile runs, 0: linear order
     int stream_records;   // 1: records written with the non-temporal hint (arrays too big to stay cached)
     int lo_a_first, hi_a_first;   // sign of sum(ha*hb) of the lo / hi pair (lowlevel.py:143)
@@ -200,6 +202,7 @@ struct Inv1Params {
     float *X;             // [B][R][C]
     int B, R, C;
     int tilesR, tilesC;
+    unsigned mgC, mgRC;   // dt_tile_magic(): multipliers that replace the divisions by tilesC and tilesC * tilesR in the tile decode (0: divide)
     int xcd_order;        // 1: XCD-contiguous tile runs, 0: linear order
     float g[6];           // gain_mask column * sqrt(1/2)
     float g0[DT_MAXT], g1[DT_MAXT];
@@ -233,6 +236,7 @@ struct Inv2Params {
     int B, zr, zc;
     int cropR, cropC;     // 0/1
     int tilesR, tilesC;
+    unsigned mgC, mgRC;   // dt_tile_magic(): multipliers that replace the divisions by tilesC and tilesC * tilesR in the tile decode (0: divide)
     int xcd_order;        // 1: XCD-contiguous tile runs, 0: linear order
     int lo_pos, hi_pos;   // sum(ha*hb) > 0 of the g0 / g1 pair
     float g[6];
@@ -366,7 +370,34 @@ DT_HD int tile_of(int bid, int ntiles, int xcd_order) {
     if (xcd_order <= 0) return bid;
     if (xcd_order == 1) return xcd_tile(bid, ntiles);
     const int g = xcd_order, x = bid % 8, i = bid / 8;
+    if (g == 8) return (((i >> 3) * 8 + x) << 3) + (i & 7);      // the default group size: shifts, no division
     return ((i / g) * 8 + x) * g + i % g;       // may be >= ntiles: caller must skip
+}
+
+// Tile index -> (column tile, row tile, image).  Every wavefront of every workgroup used to open with two integer
+// divisions by run-time values (~150 scalar instructions and three v_rcp round trips before the first load is
+// issued: ~0.3 us of every workgroup's life, and most of what a coarse-level launch of one workgroup per CU costs
+// beyond its memory latency).  The host hands over ceil(2^32 / d) instead: q = (n * magic) >> 32 is exact for
+// n * d < 2^32 (dt_tile_magic checks that; otherwise, and for d = 1, magic = 0 and the kernel divides).
+inline unsigned dt_tile_magic(int d, int64_t nmax) {
+    if (d <= 1 || nmax * (int64_t)d >= ((int64_t)1 << 32)) return 0u;
+    return (unsigned)((((uint64_t)1 << 32) + (uint64_t)d - 1) / (uint64_t)d);
+}
+DT_HD int dt_fdiv(int n, int d, unsigned magic) {
+    return magic ? (int)(((unsigned long long)(unsigned)n * magic) >> 32) : n / d;
+}
+template <class P>
+inline void dt_set_tile_magic(P &p) {
+    const int64_t ntile = (int64_t)p.tilesR * p.tilesC * p.B + 64;      // + the surplus blocks of the rounded-up grid
+    p.mgC = dt_tile_magic(p.tilesC, ntile);
+    p.mgRC = dt_tile_magic(p.tilesC * p.tilesR, ntile);
+}
+template <class P>
+DT_HD void dt_tile_decode(const P &p, int t, int &tc, int &tr, int &b) {
+    const int row = dt_fdiv(t, p.tilesC, p.mgC);          // t / tilesC
+    tc = t - row * p.tilesC;
+    b = dt_fdiv(t, p.tilesC * p.tilesR, p.mgRC);
+    tr = row - b * p.tilesR;
 }
 
 }  // namespace dt2d

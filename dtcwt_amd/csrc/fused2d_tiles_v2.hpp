@@ -5,8 +5,9 @@
 // Column passes read their sliding window straight from global memory (coalesced rows, many
 // independent loads in flight per lane) instead of staging the input window in LDS first:
 // one LDS plane and one workgroup barrier less per tile.  Earlier generations and the
-// variants that were measured and dropped are kept out of the library, in
-// tools/kbench/tile_variants.hpp.
+// variants that were measured and dropped are not kept in the tree (their measurements are in
+// profiles/r01 and profiles/r02; the code is in the history up to round 2, tools/kbench/tile_variants.hpp);
+// tools/kbench/ko_bench.hip times the kernels below with their loads and stores knocked out.
 #pragma once
 #include "fused2d_tiles.hpp"
 

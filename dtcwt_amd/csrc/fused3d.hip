@@ -96,7 +96,8 @@ __global__ void __launch_bounds__(DT_NT) k_fwd3_l2_planes(dt2d::Fwd2Params p, fl
     __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS];
     const int t = xcd_tile3(ntile_xcd);
     if (t < 0) return;
-    const int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    int tc, tr, b;
+    dt2d::dt_tile_decode(p, t, tc, tr, b);
     float *sLo = smem, *sHi = sLo + C::SL;
     const int r0 = tr * C::TR, c0 = tc * C::TC;
     dt2d::fwd2d_cols<C>(p, sLo, sHi, threadIdx.x, b, r0, c0);
@@ -124,6 +125,7 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 template <class C>
 int launch_l2_planes(dt2d::Fwd2Params &p, float *planes, int64_t pstride, hipStream_t s) {
     p.tilesR = cdiv(p.LR / 2, C::TR); p.tilesC = cdiv(p.LC / 2, C::TC);
+    dt2d::dt_set_tile_magic(p);
     dt2d::dt_pack_lh(p);
     const int ntile = p.tilesR * p.tilesC * p.B;
     k_fwd3_l2_planes<C><<<xcd3_grid(ntile, XCD3_FWD_PLANES), DT_NT, 0, s>>>(p, planes, pstride, xcd3_arg(ntile, XCD3_FWD_PLANES));
@@ -317,7 +319,8 @@ __global__ void __launch_bounds__(DT_NT) k_inv3_l1_planes(dt2d::Inv1Params p, co
     __shared__ __attribute__((aligned(16))) float smem[2 * C::SY];
     const int t = xcd_tile3(ntile_xcd);
     if (t < 0) return;
-    const int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    int tc, tr, b;
+    dt2d::dt_tile_decode(p, t, tc, tr, b);
     float *y1 = smem, *y2 = y1 + C::SY;
     const int r0 = tr * C::TR, c0 = tc * C::TC;
     float wz[C::WN], w1[C::WN], w2[C::WN], w3[C::WN];
@@ -336,7 +339,8 @@ __global__ void __launch_bounds__(DT_NT) k_inv3_l2_planes(dt2d::Inv2Params p, co
     __shared__ __attribute__((aligned(16))) float smem[2 * C::SY];
     const int t = xcd_tile3(ntile_xcd);
     if (t < 0) return;
-    const int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);
+    int tc, tr, b;
+    dt2d::dt_tile_decode(p, t, tc, tr, b);
     float *y1 = smem, *y2 = y1 + C::SY;
     const int r0 = tr * C::TR, c0 = tc * C::TC;
     float wz[C::WS], w1[C::WS], w2[C::WS], w3[C::WS];
@@ -352,6 +356,7 @@ __global__ void __launch_bounds__(DT_NT) k_inv3_l2_planes(dt2d::Inv2Params p, co
 template <class C>
 void launch_inv3_l1_planes(dt2d::Inv1Params &b, const float *planes, int64_t ps, hipStream_t s) {
     b.tilesR = cdiv(b.R, C::TR); b.tilesC = cdiv(b.C, C::TC);
+    dt2d::dt_set_tile_magic(b);
     dt2d::dt_pack_g01<C::M0, C::M1>(b);
     const int ntile = b.tilesR * b.tilesC * b.B;
     k_inv3_l1_planes<C><<<xcd3_grid(ntile, XCD3_INV_L1_PLANES), DT_NT, 0, s>>>(b, planes, ps, xcd3_arg(ntile, XCD3_INV_L1_PLANES));
@@ -359,6 +364,7 @@ void launch_inv3_l1_planes(dt2d::Inv1Params &b, const float *planes, int64_t ps,
 template <class C>
 void launch_inv3_l2_planes(dt2d::Inv2Params &b, const float *planes, int64_t ps, hipStream_t s) {
     b.tilesR = cdiv(b.zr, C::TR); b.tilesC = cdiv(b.zc, C::TC);
+    dt2d::dt_set_tile_magic(b);
     const int ntile = b.tilesR * b.tilesC * b.B;
     k_inv3_l2_planes<C><<<xcd3_grid(ntile, XCD3_INV_L2_PLANES), DT_NT, 0, s>>>(b, planes, ps, xcd3_arg(ntile, XCD3_INV_L2_PLANES));
 }

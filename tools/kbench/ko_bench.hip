@@ -35,7 +35,8 @@ static inline unsigned grid_for(int ntile, int order = 1) {
     const int ntile = p.tilesR * p.tilesC * p.B;                                               \
     int t = tile_of(blockIdx.x, ntile, p.xcd_order);                                           \
     if (t >= ntile) return;                                                                    \
-    int tc = t % p.tilesC, tr = (t / p.tilesC) % p.tilesR, b = t / (p.tilesC * p.tilesR);      \
+    int tc, tr, b;                                                                             \
+    dt_tile_decode(p, t, tc, tr, b);                                                           \
     int trl = tr, tcl = tc;                                                                    \
     if (KO & 1) { trl = 2 + (tr & 3); tcl = 2 + (tc & 3); }                                    \
     if (KO & 2) { tr = 2 + (tr & 3); tc = 2 + (tc & 3); }
@@ -127,6 +128,7 @@ struct Set { float *X, *L1, *L2, *Y0, *Y1, *Z1, *Z0; };
 static Set sets[NSET];
 static int N = 4096, REPS = 40;
 static hipStream_t st;
+static int g_magic = 1;        // KO_MAGIC=0: divide in the tile decode (the round-2 prologue)
 static size_t g_xlds = 0;      // extra dynamic LDS per workgroup: lowers the occupancy without touching the code
 
 template <class F>
@@ -152,6 +154,7 @@ template <int KO> static double run_fwd1() {
         Fwd1Params p{}; p.X = sets[s].X; p.LoLo = sets[s].L1; p.Yh = sets[s].Y0; p.B = 1; p.inR = p.inC = p.LR = p.LC = N;
         p.xcd_order = 8; put(p.h0, H0O, 5); put(p.h1, H1O, 7); dt_pack_c01<5, 7>(p);
         p.tilesR = cdiv(N, F1::TR); p.tilesC = cdiv(N, F1::TC);
+        if (g_magic) dt_set_tile_magic(p);
         ko_fwd1<F1, KO><<<grid_for(p.tilesR * p.tilesC, 8), DT_NT, g_xlds, st>>>(p);
     });
 }
@@ -162,6 +165,7 @@ template <int KO> static double run_fwd2() {
         put(p.l_a, H0A, 10, true); put(p.l_b, H0A, 10); put(p.h_a, H1A, 10, true); put(p.h_b, H1A, 10);
         p.lo_a_first = 1; p.hi_a_first = 0; dt_pack_lh(p);
         p.tilesR = cdiv(N / 2, F2::TR); p.tilesC = cdiv(N / 2, F2::TC);
+        if (g_magic) dt_set_tile_magic(p);
         ko_fwd2<F2, KO><<<grid_for(p.tilesR * p.tilesC), DT_NT, g_xlds, st>>>(p);
     });
 }
@@ -171,6 +175,7 @@ template <int KO> static double run_inv1() {
         for (int d = 0; d < 6; ++d) p.g[d] = 0.70710678f;
         put(p.g0, G0O, 7); put(p.g1, G1O, 5); dt_pack_g01<7, 5>(p);
         p.tilesR = cdiv(N, I1::TR); p.tilesC = cdiv(N, I1::TC);
+        if (g_magic) dt_set_tile_magic(p);
         ko_inv1<I1, KO><<<grid_for(p.tilesR * p.tilesC), DT_NT, g_xlds, st>>>(p);
     });
 }
@@ -182,6 +187,7 @@ template <int KO> static double run_inv2() {
         put(p.l_a, H0A, 10); put(p.l_b, H0A, 10, true); put(p.h_a, H1A, 10); put(p.h_b, H1A, 10, true);
         p.lo_pos = 1; p.hi_pos = 0;
         p.tilesR = cdiv(N / 2, I2::TR); p.tilesC = cdiv(N / 2, I2::TC);
+        if (g_magic) dt_set_tile_magic(p);
         ko_inv2<I2, KO><<<grid_for(p.tilesR * p.tilesC), DT_NT, g_xlds, st>>>(p);
     });
 }
@@ -189,6 +195,8 @@ template <int KO> static double run_inv2() {
 int main(int argc, char **argv) {
     if (argc > 1) N = atoi(argv[1]);
     if (argc > 2) REPS = atoi(argv[2]);
+    if (const char *e = getenv("KO_MAGIC")) g_magic = atoi(e);
+    const bool sweep = getenv("KO_SWEEP") != nullptr;
     CK(hipStreamCreate(&st));
     const size_t px = (size_t)N * N;
     std::vector<float> h(px);
@@ -205,7 +213,7 @@ int main(int argc, char **argv) {
     }
     // settle the clocks
     for (int i = 0; i < 3; ++i) run_fwd1<0>();
-    printf("%dx%d, %d reps over %d buffer sets; us per launch\n", N, N, REPS, NSET);
+    printf("%dx%d, %d reps over %d buffer sets; us per launch; tile decode by %s\n", N, N, REPS, NSET, g_magic ? "magic multiply" : "division");
     printf("%-22s %9s %9s %9s %9s\n", "kernel", "full", "cached-ld", "no-store", "arith-only");
     for (int rep = 0; rep < 2; ++rep) {
         printf("%-22s %9.2f %9.2f %9.2f %9.2f\n", "k_fwd1 (level 1)", run_fwd1<0>(), run_fwd1<1>(), run_fwd1<2>(), run_fwd1<3>());
@@ -214,6 +222,7 @@ int main(int argc, char **argv) {
         printf("%-22s %9.2f %9.2f %9.2f %9.2f\n", "k_inv1 (level 1)", run_inv1<0>(), run_inv1<1>(), run_inv1<2>(), run_inv1<3>());
         fflush(stdout);
     }
+    if (!sweep) return 0;
     printf("\noccupancy sweep (extra dynamic LDS per workgroup), full / arith-only\n");
     const size_t xs[] = {0, 8 << 10, 16 << 10, 24 << 10, 40 << 10};
     for (size_t x : xs) {
