@@ -186,7 +186,19 @@ def main():
         os.dup2(2, 1)
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        # Two groups: RCCL (backend "nccl") carries the path's one collective, the broadcast of the filter taps over
+        # xGMI, and is torn down right after it; the barriers and the reduction of the ranks' times around the timed
+        # region run on a gloo group (host side) next to explicit device synchronisation.  With the RCCL communicator
+        # left alive the step itself ran slower -- its watchdog / proxy threads share the HIP runtime with the
+        # launching thread: 0.214-0.233 ms per step at one rank against 0.197 ms (profiles/r03/rccl_alive.txt).
+        # DTCWT_BENCH_BARRIER=nccl keeps the round-2 arrangement (everything on one RCCL group).
+        barrier_backend = os.environ.get('DTCWT_BENCH_BARRIER', 'gloo')
+        if barrier_backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            rccl_group = None
+        else:
+            dist.init_process_group('gloo')
+            rccl_group = dist.new_group(backend='nccl', device_id=torch.device('cuda', local_rank))
 
     import dtcwt_amd
     from dtcwt_amd.coeffs import biort, qshift
@@ -200,7 +212,12 @@ def main():
     bt, qt = biort(BIORT), qshift(QSHIFT)
     if use_dist:
         from dtcwt_amd.hip.sharding import broadcast_taps
-        bt, qt = broadcast_taps(bt, qt, dist, device=torch.device('cuda', local_rank), src=0)
+        bt, qt = broadcast_taps(bt, qt, dist, device=torch.device('cuda', local_rank), src=0, group=rccl_group)
+        rccl_ranks = dist.get_world_size(group=rccl_group)
+        if rccl_group is not None:
+            torch.cuda.synchronize()
+            dist.destroy_process_group(rccl_group)
+        red_dev = 'cuda' if barrier_backend == 'nccl' else 'cpu'      # where the timing reductions live
 
     B, R, C, NL = cfg['batch'], cfg['rows'], cfg['cols'], cfg['nlevels']
     nstreams = max(1, cfg.get('streams', args.streams))
@@ -241,14 +258,20 @@ def main():
         else:
             step_on(k)
 
-    def fence():
+    def drain():
+        """This rank's GPU work is done: every stream of the library, then the whole device."""
         for c in ctxs:
             c.sync()
-        if use_dist:
-            dist.barrier()
         if torch is not None and torch.cuda.is_available():
             torch.cuda.synchronize()
         ctx.device_sync()
+
+    def fence():
+        """Barrier over the ranks + device synchronisation (the bracket of the timed region)."""
+        drain()
+        if use_dist:
+            dist.barrier()
+            drain()             # the barrier is itself a collective kernel on this device
 
     # Device settle: measured on MI355X, the first ~20 ms of work after an idle period run ~20 % slower
     # (20 timed steps: 0.275 ms/step after 10 warmup steps, 0.225 after 200), so a short run would report
@@ -264,17 +287,22 @@ def main():
             step()
     for _ in range(args.warmup):
         step()
+    # The timed region: barrier + synchronise, K steps, synchronise -- the clock stops when THIS rank's work is
+    # done -- barrier + synchronise again; the job's time is the MAX over the ranks' times.  (With the clock stopped
+    # after the closing barrier instead, a RCCL barrier -- a collective launch plus its completion, ~1 ms -- would
+    # be charged to the K steps: +30 % on a 20-step run of 0.2 ms steps, measured at one rank.)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    fence()
+    drain()
     dt = time.perf_counter() - t0
+    fence()
     rank_ms = [dt / args.steps * 1e3]
     nccl_ranks = 1
     if use_dist:
-        nccl_ranks = dist.get_world_size()
-        mine = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        nccl_ranks = rccl_ranks
+        mine = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         every = [torch.zeros_like(mine) for _ in range(nccl_ranks)]
         dist.all_gather(every, mine)                    # every rank's own time: min / max in the JSON line
         rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
@@ -394,6 +422,8 @@ def main():
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
+        if saved_stdout is not None:
+            os.dup2(2, 1)           # what the collective library still has in its stdio buffer (its banner) goes to stderr
 
 
 def main_mgpu(args):

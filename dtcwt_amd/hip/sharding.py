@@ -35,8 +35,8 @@ def unpack_taps(flat, lengths, n_biort):
     return tuple(parts[:n_biort]), tuple(parts[n_biort:])
 
 
-def broadcast_taps(biort, qshift, dist, device=None, src=0):
-    """Broadcast rank *src*'s tap table to every rank of the default process group
+def broadcast_taps(biort, qshift, dist, device=None, src=0, group=None):
+    """Broadcast rank *src*'s tap table to every rank of the default process group, or of *group*
     (``dist`` = ``torch.distributed``).  With ``device`` set the buffer lives on that GPU
     (RCCL over xGMI); with ``None`` on the host (gloo, used by the CPU tests).  Every rank
     must pass tap tuples of the same lengths (the wavelet *names* are part of the job
@@ -48,5 +48,5 @@ def broadcast_taps(biort, qshift, dist, device=None, src=0):
     buf = torch.from_numpy(flat)
     if device is not None:
         buf = buf.to(device)
-    dist.broadcast(buf, src=src)
+    dist.broadcast(buf, src=src, group=group)
     return unpack_taps(buf.cpu().numpy(), lengths, len(biort))

@@ -48,7 +48,12 @@ def _worker(rank, world, port, q):
         if rank != 0:      # only rank 0 holds the real values
             b = tuple(np.full_like(h, np.nan) for h in b)
             qs = tuple(np.full_like(h, np.nan) for h in qs)
-        b2, q2 = broadcast_taps(b, qs, dist, device=None, src=0)
+        # bench.py's arrangement: the taps travel on a group of their own (RCCL there, gloo here) that is torn
+        # down right after the broadcast; barriers and reductions stay on the default group
+        g = dist.new_group(backend='gloo')
+        b2, q2 = broadcast_taps(b, qs, dist, device=None, src=0, group=g)
+        assert dist.get_world_size(group=g) == world
+        dist.destroy_process_group(g)
         ok = all(np.array_equal(x.reshape(-1), np.asarray(y).reshape(-1)) for x, y in
                  zip(b2 + q2, biort('near_sym_a') + qshift('qshift_a')))
         lo, hi = shard_range(9, rank, world)
