@@ -52,6 +52,57 @@ namespace dt2d {
 struct alignas(16) f4 { float x, y, z, w; };
 struct alignas(8) f2 { float x, y; };
 
+// ---- buffer addressing ------------------------------------------------------------------
+// A window row is (row base, uniform per wavefront) + (lane offset): with flat `global_load` every address is a
+// 64-bit VGPR pair, i.e. one v_lshl_add_u64 (or more) per load -- a third of all vector instructions of the level
+// kernels are such integer address arithmetic (profiles/r03/valu_mix.txt).  The buffer instructions of CDNA take the
+// base from a 128-bit resource descriptor in scalar registers, ONE 32-bit lane offset (VGPR, bytes) and a scalar
+// offset (SGPR, bytes) -- `buffer_load_dword v, v_off, s[rsrc], s_off offen` -- so stepping down the rows of a
+// window costs scalar multiplies only.  Offsets are unsigned 32-bit: a descriptor covers 4 GiB from its base, so the
+// base is the TILE's (or the image's) origin, re-made per workgroup with scalar arithmetic.  Out-of-range offsets
+// read 0 / drop the store, which nothing here relies on.  On the host (emulator) the same calls are pointer
+// arithmetic.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float dt_bv2 __attribute__((ext_vector_type(2)));
+typedef float dt_bv4 __attribute__((ext_vector_type(4)));
+struct DtBuf { __amdgpu_buffer_rsrc_t r; };
+// gfx9 family (gfx950 included) raw buffer: DATA_FORMAT = 32 in word 3, stride 0, num_records in bytes
+// The base must be the same in every lane; it is pinned into scalar registers here (readfirstlane), otherwise a
+// descriptor made inside divergent control flow lands in VGPRs and every load gets a waterfall loop around it.
+DT_HD DtBuf dt_buf(const void *base) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    void *ub = reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo);
+    DtBuf b; b.r = __builtin_amdgcn_make_buffer_rsrc(ub, 0, (int)0xffffffffu, 0x00020000); return b;
+}
+DT_HD float dt_buf_ld(const DtBuf &b, unsigned voff, unsigned soff) { return __builtin_amdgcn_raw_buffer_load_b32(b.r, voff, soff, 0); }
+DT_HD f2 dt_buf_ld2(const DtBuf &b, unsigned voff, unsigned soff) {
+    const dt_bv2 v = __builtin_amdgcn_raw_buffer_load_b64(b.r, voff, soff, 0); return f2{v.x, v.y};
+}
+DT_HD f4 dt_buf_ld4(const DtBuf &b, unsigned voff, unsigned soff) {
+    const dt_bv4 v = __builtin_amdgcn_raw_buffer_load_b128(b.r, voff, soff, 0); return f4{v.x, v.y, v.z, v.w};
+}
+// NT: the non-temporal hint (aux bit 1 on gfx94x / gfx950), as __builtin_nontemporal_store gives flat stores
+template <bool NT = false>
+DT_HD void dt_buf_st2(const DtBuf &b, unsigned voff, unsigned soff, const f2 &v) {
+    __builtin_amdgcn_raw_buffer_store_b64(dt_bv2{v.x, v.y}, b.r, voff, soff, NT ? 2 : 0);
+}
+template <bool NT = false>
+DT_HD void dt_buf_st4(const DtBuf &b, unsigned voff, unsigned soff, const f4 &v) {
+    __builtin_amdgcn_raw_buffer_store_b128(dt_bv4{v.x, v.y, v.z, v.w}, b.r, voff, soff, NT ? 2 : 0);
+}
+#else
+struct DtBuf { const char *p; };
+DT_HD DtBuf dt_buf(const void *base) { DtBuf b; b.p = static_cast<const char *>(base); return b; }
+DT_HD float dt_buf_ld(const DtBuf &b, unsigned voff, unsigned soff) { return *reinterpret_cast<const float *>(b.p + voff + (size_t)soff); }
+DT_HD f2 dt_buf_ld2(const DtBuf &b, unsigned voff, unsigned soff) { return *reinterpret_cast<const f2 *>(b.p + voff + (size_t)soff); }
+DT_HD f4 dt_buf_ld4(const DtBuf &b, unsigned voff, unsigned soff) { return *reinterpret_cast<const f4 *>(b.p + voff + (size_t)soff); }
+template <bool NT = false>
+DT_HD void dt_buf_st2(const DtBuf &b, unsigned voff, unsigned soff, const f2 &v) { *reinterpret_cast<f2 *>(const_cast<char *>(b.p) + voff + (size_t)soff) = v; }
+template <bool NT = false>
+DT_HD void dt_buf_st4(const DtBuf &b, unsigned voff, unsigned soff, const f4 &v) { *reinterpret_cast<f4 *>(const_cast<char *>(b.p) + voff + (size_t)soff) = v; }
+#endif
+
 // Half-sample symmetric reflection, ONE bounce: valid for -n <= u < 2n.  Branch-free on
 // purpose: a data-dependent branch per index splits the load sequences of the tile
 // programs into basic blocks and serialises their memory latencies (profiles/ round 1).

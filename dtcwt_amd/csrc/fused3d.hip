@@ -114,8 +114,8 @@ __global__ void __launch_bounds__(NT) k_fwd3_l2_axis0(Fwd3L2Params p) {
     float *ws = slab + wave * CPW * REC_LDS;
     const int cl = lane & (CPW - 1);                               // the lane's cell within the wavefront
     const int first = ((int)blockIdx.x * (NT / 64) + wave) * CPW;
-    if (CPW == 64) f3l2_axis0_stage<M>(p, first + cl, ws + cl * REC_LDS);
-    else f3l2_axis0_stage<M>(p, first + cl, ws + cl * REC_LDS, 2 * (lane >> 5), 2);
+    if (CPW == 64) f3l2_axis0_stage<M, 4>(p, first + cl, ws + cl * REC_LDS);
+    else f3l2_axis0_stage<M, 2>(p, first + cl, ws + cl * REC_LDS, 2 * (lane >> 5));
     DT_WAVE_LDS_SYNC();
     f3l2_axis0_flush<CPW>(p, first, lane, ws);
 }
@@ -139,6 +139,15 @@ inline bool narrow_wins(int n, int wide, int narrow) { return 10 * padded(n, nar
 template <int TR, int TC, int PS, int M>
 void launch_l2_planes_best(dt2d::Fwd2Params &p, float *planes, int64_t pstride, hipStream_t s) {
     if constexpr (M == 10) {
+        // tile shapes for the slices of a volume (DTCWT_HIP_L2P_TILE: 1 16x32, 2 32x32, 3 16x64, 4 32x64; 0 = by size)
+        static const int force = [] { const char *e = getenv("DTCWT_HIP_L2P_TILE"); return e ? atoi(e) : 0; }();
+        if (force == 1) { launch_l2_planes<dt2d::Fwd2DCfg<16, 32, 4, 10>>(p, planes, pstride, s); return; }
+        if (force == 2) { launch_l2_planes<dt2d::Fwd2DCfg<32, 32, 4, 10>>(p, planes, pstride, s); return; }
+        if (force == 3) { launch_l2_planes<dt2d::Fwd2DCfg<16, 64, 4, 10>>(p, planes, pstride, s); return; }
+        if (force == 4) { launch_l2_planes<dt2d::Fwd2DCfg<32, 64, 4, 10>>(p, planes, pstride, s); return; }
+        // slices whose lowpass is a multiple of 64 columns wide: 16 x 64 tiles (a full round of row-pass tasks and
+        // 256-byte plane rows per tile; 256^3 level 2: 29.4 us against 31.6 us with 16 x 32, profiles/r03/c4_l2_planes_tiles.txt)
+        if (force == 0 && (p.LC / 2) % 64 == 0) { launch_l2_planes<dt2d::Fwd2DCfg<16, 64, 4, 10>>(p, planes, pstride, s); return; }
         if (narrow_wins(p.LC / 2, TC, 32)) {
             launch_l2_planes<dt2d::Fwd2DCfg<16, 32, 4, 10>>(p, planes, pstride, s);
             return;

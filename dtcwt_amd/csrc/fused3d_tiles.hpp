@@ -499,14 +499,66 @@ DT_HD void f3l2_axis0_planes(const Fwd3L2Params &p, int c0, int base, int r0, fl
     }
 }
 
-template <int M>
-DT_HD void f3l2_axis0_stage(const Fwd3L2Params &p, int id, float *rec, int v0 = 0, int nv = 4) {
+// The INNER case with buffer addressing and the planes software-pipelined: the four plane volumes' base sits in a
+// scalar descriptor, a lane holds ONE byte offset per row of its cell, the slice offsets j * ss are scalar offsets
+// (no vector instruction per address: they were two thirds of this kernel's 1576 vector instructions per
+// wavefront), and the window of plane v + 1 is requested before plane v is filtered -- with two wavefronts per
+// SIMD (the record slabs fill the LDS) nothing else hides the latency of 40 dependent loads per plane, four times
+// per cell.  Needs the four plane volumes inside one 4 GiB descriptor.
+template <int M, int NV>
+DT_HD void f3l2_axis0_planes_buf(const Fwd3L2Params &p, int c0, int base, int r0, float *rec, int v0) {
+    const int ss = p.O1 * p.O2;
+    const dt2d::DtBuf pb = dt2d::dt_buf(p.P);
+    const unsigned ps4 = 4u * (unsigned)p.pstride, row = 4u * (unsigned)p.O2;
+    const unsigned vo = 4u * (unsigned)(base + r0 * ss) + (unsigned)v0 * ps4;
+    float w[2][4][2 * M];                                // two windows: [dj*2 + dk][slice]
+#pragma unroll
+    for (int j = 0; j < 2 * M; ++j) {
+        const f2 a = dt2d::dt_buf_ld2(pb, vo, 4u * (unsigned)(j * ss)), b = dt2d::dt_buf_ld2(pb, vo + row, 4u * (unsigned)(j * ss));
+        w[0][0][j] = a.x; w[0][1][j] = a.y; w[0][2][j] = b.x; w[0][3][j] = b.y;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if (i + 1 < NV) {
+            const unsigned vn = vo + (unsigned)(i + 1) * ps4;
+#pragma unroll
+            for (int j = 0; j < 2 * M; ++j) {
+                const f2 a = dt2d::dt_buf_ld2(pb, vn, 4u * (unsigned)(j * ss)), b = dt2d::dt_buf_ld2(pb, vn + row, 4u * (unsigned)(j * ss));
+                w[(i + 1) & 1][0][j] = a.x; w[(i + 1) & 1][1][j] = a.y; w[(i + 1) & 1][2][j] = b.x; w[(i + 1) & 1][3][j] = b.y;
+            }
+        }
+        const int v = v0 + i;
+        float lev[4], lod[4], hev[4], hod[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float A, Bv, Ah, Bh;
+            dt2d::dfilt_pair2<M>(w[i & 1][q], p.lh_a, p.lh_b, A, Bv, Ah, Bh);
+            lev[q] = p.lo_a_first ? A : Bv; lod[q] = p.lo_a_first ? Bv : A;
+            hev[q] = p.hi_a_first ? Ah : Bh; hod[q] = p.hi_a_first ? Bh : Ah;
+        }
+        if (v == 0) {
+            float *L = p.LLL + (int64_t)(2 * c0) * ss + base;
+            *reinterpret_cast<f2 *>(L) = f2{lev[0], lev[1]};
+            *reinterpret_cast<f2 *>(L + p.O2) = f2{lev[2], lev[3]};
+            *reinterpret_cast<f2 *>(L + ss) = f2{lod[0], lod[1]};
+            *reinterpret_cast<f2 *>(L + ss + p.O2) = f2{lod[2], lod[3]};
+        } else {
+            cube2c_record(rec + 8 * octant_slot(v), lev, lod);
+        }
+        cube2c_record(rec + 8 * octant_slot(4 + v), hev, hod);
+    }
+}
+
+template <int M, int NV = 4>
+DT_HD void f3l2_axis0_stage(const Fwd3L2Params &p, int id, float *rec, int v0 = 0, int nv = NV) {
     const int e2 = p.O2 / 2, e1 = p.O1 / 2, e0 = p.O0 / 2;
     if (id >= e0 * e1 * e2) return;
     const int c2 = id % e2, t = id / e2, c1 = t % e1, c0 = t / e1;
     const int base = (2 * c1) * p.O2 + 2 * c2;
     const int r0 = 4 * c0 - M + 2 - p.pad0;              // first slice of the window in the unpadded planes
-    if (r0 >= 0 && r0 + 2 * M <= p.n0) f3l2_axis0_planes<M, true>(p, c0, base, r0, rec, v0, nv);
+    const bool inner = r0 >= 0 && r0 + 2 * M <= p.n0;
+    if (inner && nv == NV && 16 * p.pstride < ((int64_t)1 << 32)) f3l2_axis0_planes_buf<M, NV>(p, c0, base, r0, rec, v0);
+    else if (inner) f3l2_axis0_planes<M, true>(p, c0, base, r0, rec, v0, nv);
     else f3l2_axis0_planes<M, false>(p, c0, base, r0, rec, v0, nv);
 }
 

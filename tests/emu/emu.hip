@@ -236,7 +236,7 @@ static int run_fwd3_l2(Fwd2Params a, dt3d::Fwd3L2Params b, float *planes) {
     while (((uintptr_t)ws) & 15) ++ws;
     for (int first = 0; first < cells; first += 32) {      // two lanes per cell, as the kernel runs coarse levels
         for (int l = 0; l < 64; ++l)
-            dt3d::f3l2_axis0_stage<C::M>(b, first + (l & 31), ws + (l & 31) * dt3d::REC_LDS, 2 * (l >> 5), 2);
+            dt3d::f3l2_axis0_stage<C::M, 2>(b, first + (l & 31), ws + (l & 31) * dt3d::REC_LDS, 2 * (l >> 5));
         for (int l = 0; l < 64; ++l) dt3d::f3l2_axis0_flush<32>(b, first, l, ws);
     }
     return 0;
