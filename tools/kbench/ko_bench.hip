@@ -23,12 +23,13 @@
 
 using namespace dt2d;
 
-#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline unsigned grid_for(int ntile, int order = 1) {
     const int q = 8 * (order > 1 ? order : 1);
     return (unsigned)(cdiv(ntile, q) * q);
 }
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 // KO bit 0: CACHED loads, bit 1: NOSTORE
 #define KO_TILE()                                                                              \
@@ -108,6 +109,66 @@ __global__ void __launch_bounds__(DT_NT) ko_inv2(Inv2Params p) {
     inv2r_fir<C, false, true>(p, wz, w1, w2, w3, y1, y2, threadIdx.x, nullptr);
     __syncthreads();
     inv2_rows<C, true>(p, y1, y2, threadIdx.x, b, r0, c0, nullptr);
+}
+
+// ---- phase stamps: where a workgroup's life goes -------------------------------------------------
+// s_memtime (shader clock) at every phase boundary, taken by lane 0 of wavefront 0 of each workgroup; the
+// differences go to ts[workgroup][phase] (plain stores; summed on the host).
+__device__ inline unsigned long long dt_now() { return __builtin_amdgcn_s_memtime(); }
+#define STAMP(k_)                                                                                          \
+    do {                                                                                                   \
+        if (threadIdx.x == 0) { const unsigned long long n_ = dt_now(); ts[(size_t)blockIdx.x * 8 + k_] = n_ - t_; t_ = n_; } \
+    } while (0)
+
+template <class C>
+__global__ void __launch_bounds__(DT_NT) st_inv2(Inv2Params p, unsigned long long *ts) {
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_ALIASED];
+    const int KO = 0;
+    KO_TILE()
+    (void)trl; (void)tcl;
+    unsigned long long t_ = dt_now();
+    float *srec = smem, *y1 = smem, *y2 = y1 + C::SY;
+    const int r0 = tr * C::TR, c0 = tc * C::TC;
+    const float *Yhb = p.Yh + (int64_t)b * (p.zr / 2) * (p.zc / 2) * 12;
+    float wz[C::WS], w1[C::WS], w2[C::WS], w3[C::WS];
+    inv2r_fetch<C>(p, wz, threadIdx.x, b, r0, c0);
+    inv_rec_stage<C::QR, C::QC>(Yhb, p.zr, p.zc, srec, r0 + C::ORG, c0 + C::ORG, threadIdx.x);
+    STAMP(0);                       // loads issued + waited for + records written to LDS (wave 0)
+    __syncthreads();
+    STAMP(1);                       // barrier 1
+    inv2r_gather<C>(p, srec, w1, w2, w3, threadIdx.x, r0, c0);
+    STAMP(2);                       // gather
+    __syncthreads();
+    STAMP(3);                       // barrier 2
+    inv2r_fir<C, false, true>(p, wz, w1, w2, w3, y1, y2, threadIdx.x, nullptr);
+    STAMP(4);                       // column FIR + y writes (includes waiting for the lowpass window loads)
+    __syncthreads();
+    STAMP(5);                       // barrier 3
+    inv2_rows<C, true>(p, y1, y2, threadIdx.x, b, r0, c0, nullptr);
+    STAMP(6);                       // row pass + stores issued
+}
+
+template <class C>
+__global__ void __launch_bounds__(DT_NT) st_fwd2(Fwd2Params p, unsigned long long *ts) {
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS + 4 * STAGE_FLOATS_PER_WAVE];
+    const int KO = 0;
+    KO_TILE()
+    (void)trl; (void)tcl;
+    unsigned long long t_ = dt_now();
+    float *sLo = smem, *sHi = sLo + C::SL, *stage = smem + C::LDS_FLOATS;
+    const int r0 = tr * C::TR, c0 = tc * C::TC;
+    fwd2d_cols<C>(p, sLo, sHi, threadIdx.x, b, r0, c0, nullptr);
+    STAMP(0);                       // column pass: loads, FIR, plane writes
+    __syncthreads();
+    STAMP(1);                       // barrier
+    for (int base = 0; base < C::TI * C::TJ; base += DT_NT) {
+        fwd2s_rows_compute<C>(p, sLo, sHi, stage, threadIdx.x, base, b, r0, c0, nullptr);
+        DT_WAVE_LDS_SYNC();
+        STAMP(2);                   // row pass + q2c + slab
+        fwd2s_rows_flush<C>(p, stage, threadIdx.x, base, b, r0, c0);
+        DT_WAVE_LDS_SYNC();
+        STAMP(3);                   // flush
+    }
 }
 
 static const double H0O[5] = {-0.05, 0.25, 0.6, 0.25, -0.05};
@@ -221,6 +282,47 @@ int main(int argc, char **argv) {
         printf("%-22s %9.2f %9.2f %9.2f %9.2f\n", "k_inv2 (level 2)", run_inv2<0>(), run_inv2<1>(), run_inv2<2>(), run_inv2<3>());
         printf("%-22s %9.2f %9.2f %9.2f %9.2f\n", "k_inv1 (level 1)", run_inv1<0>(), run_inv1<1>(), run_inv1<2>(), run_inv1<3>());
         fflush(stdout);
+    }
+    if (getenv("KO_STAMPS")) {
+        const size_t maxwg = 1 << 16;
+        unsigned long long *ts; CK(hipMalloc(&ts, maxwg * 8 * 8));
+        std::vector<unsigned long long> hts(maxwg * 8);
+        auto report = [&](const char *name, int nph, const char *const *lab, double us, size_t nwg) {
+            CK(hipMemcpy(hts.data(), ts, nwg * 8 * 8, hipMemcpyDeviceToHost));
+            double h[8] = {0}; size_t n = 0;
+            for (size_t w = 0; w < nwg; ++w) { if (!hts[w * 8]) continue; ++n; for (int k = 0; k < nph; ++k) h[k] += (double)hts[w * 8 + k]; }
+            double tot = 0; for (int k = 0; k < nph; ++k) tot += h[k];
+            printf("%s: %.2f us per launch, %zu workgroups stamped, mean life of wavefront 0: %.0f cycles (s_memtime)\n", name, us, n, tot / n);
+            for (int k = 0; k < nph; ++k) printf("    %-44s %8.0f cycles  %5.1f %%\n", lab[k], h[k] / n, 100.0 * h[k] / tot);
+        };
+        {
+            CK(hipMemset(ts, 0, maxwg * 8 * 8));
+            double us = time_it([&](int s) {
+                Inv2Params p{}; p.Z = sets[s].L2; p.Yh = sets[s].Y1; p.Out = sets[s].Z1; p.B = 1; p.zr = p.zc = N / 2; p.xcd_order = 1;
+                for (int d = 0; d < 6; ++d) p.g[d] = 0.70710678f;
+                put(p.l_a, H0A, 10); put(p.l_b, H0A, 10, true); put(p.h_a, H1A, 10); put(p.h_b, H1A, 10, true);
+                p.lo_pos = 1; p.hi_pos = 0;
+                p.tilesR = cdiv(N / 2, I2::TR); p.tilesC = cdiv(N / 2, I2::TC); dt_set_tile_magic(p);
+                st_inv2<I2><<<grid_for(p.tilesR * p.tilesC), DT_NT, 0, st>>>(p, ts);
+            });
+            const char *lab[] = {"fetch + stage records (incl. load latency)", "barrier 1", "gather (c2q from LDS records)", "barrier 2",
+                                 "column FIR + y writes", "barrier 3", "row pass + stores issued"};
+            report("k_inv2 (level 2)", 7, lab, us, grid_for(cdiv(N / 2, I2::TR) * cdiv(N / 2, I2::TC)));
+        }
+        {
+            CK(hipMemset(ts, 0, maxwg * 8 * 8));
+            double us = time_it([&](int s) {
+                Fwd2Params p{}; p.X = sets[s].L1; p.LoLo = sets[s].L2; p.Yh = sets[s].Y1; p.B = 1; p.inR = p.inC = p.LR = p.LC = N;
+                p.xcd_order = 1; p.stream_records = 1;
+                put(p.l_a, H0A, 10, true); put(p.l_b, H0A, 10); put(p.h_a, H1A, 10, true); put(p.h_b, H1A, 10);
+                p.lo_a_first = 1; p.hi_a_first = 0; dt_pack_lh(p);
+                p.tilesR = cdiv(N / 2, F2::TR); p.tilesC = cdiv(N / 2, F2::TC); dt_set_tile_magic(p);
+                st_fwd2<F2><<<grid_for(p.tilesR * p.tilesC), DT_NT, 0, st>>>(p, ts);
+            });
+            const char *lab[] = {"column pass (loads, FIR, plane writes)", "barrier", "row pass + q2c + slab", "flush (record stores issued)"};
+            report("k_fwd2 (level 2)", 4, lab, us, grid_for(cdiv(N / 2, F2::TR) * cdiv(N / 2, F2::TC)));
+        }
+        return 0;
     }
     if (!sweep) return 0;
     printf("\noccupancy sweep (extra dynamic LDS per workgroup), full / arith-only\n");
