@@ -70,6 +70,33 @@ __global__ void __launch_bounds__(DT_NT) k_inv2(Inv2Params p) {
     inv2_rows<C, STD>(p, y1, y2, threadIdx.x, b, r0, c0, y3);
 }
 
+// Level >= 2 inverse with the column phase in two halves (inv2r_gather_half / inv2r_fir_plane): fewer live registers,
+// records + one y plane in LDS -> six workgroups per CU.  Not for the band-pass sets (a third plane).
+template <class C, bool STD>
+__global__ void __launch_bounds__(DT_NT) k_inv2s(Inv2Params p) {
+    constexpr int SRECP = (C::LDS_ALIASED + 3) & ~3;
+    __shared__ __attribute__((aligned(16))) float smem[SRECP + C::SY];
+    const int ntile = p.tilesR * p.tilesC * p.B;
+    int t = tile_of(blockIdx.x, ntile, p.xcd_order);
+    if (t >= ntile) return;
+    int tc, tr, b;
+    dt_tile_decode(p, t, tc, tr, b);
+    float *srec = smem, *y2 = smem, *y1 = smem + SRECP;
+    const int r0 = tr * C::TR, c0 = tc * C::TC;
+    const float *Yhb = p.Yh + (int64_t)b * (p.zr / 2) * (p.zc / 2) * 12;
+    float wz[C::WS], wa[C::WS], wb[C::WS], wc[C::WS];
+    inv2r_fetch<C>(p, wz, threadIdx.x, b, r0, c0);
+    inv_rec_stage<C::QR, C::QC>(Yhb, p.zr, p.zc, srec, r0 + C::ORG, c0 + C::ORG, threadIdx.x);
+    __syncthreads();
+    inv2r_gather_half<C, 0>(p, srec, wa, wb, threadIdx.x, r0, c0);         // lh -> wa, hh -> wb
+    inv2r_fir_plane<C, STD>(p, wz, wa, y1, threadIdx.x);                    // y1 = Z (*) g0 + lh (*) g1: a plane of its own
+    inv2r_gather_half<C, 1>(p, srec, wc, wc, threadIdx.x, r0, c0);         // hl -> wc
+    __syncthreads();                                                        // every record is consumed: y2 goes over them
+    inv2r_fir_plane<C, STD>(p, wc, wb, y2, threadIdx.x);                    // y2 = hl (*) g0 + hh (*) g1
+    __syncthreads();
+    inv2_rows<C, STD>(p, y1, y2, threadIdx.x, b, r0, c0, nullptr);
+}
+
 template <class C>
 int launch_inv1(Inv1Params &p, hipStream_t s) {
     p.tilesR = cdiv(p.R, C::TR); p.tilesC = cdiv(p.C, C::TC);
@@ -85,6 +112,14 @@ int launch_inv2(Inv2Params &p, hipStream_t s) {
     // every shipped q-shift set: sum(g0a g0b) > 0 > sum(g1a g1b) (and the band-pass pair like g1) -- compile-time
     // filter phases; anything else takes the run-time flags
     const bool std_set = p.lo_pos && !p.hi_pos && (!C::BP || !p.bp_pos);
+    if constexpr (!C::BP) {         // DTCWT_HIP_INV2_SPLIT=0: the one-piece column phase of round 2 (k_inv2)
+        static const int split = [] { const char *e = getenv("DTCWT_HIP_INV2_SPLIT"); return e ? atoi(e) : 1; }();
+        if (split) {
+            if (std_set) k_inv2s<C, true><<<grid_for(p.tilesR * p.tilesC * p.B, p.xcd_order), DT_NT, 0, s>>>(p);
+            else k_inv2s<C, false><<<grid_for(p.tilesR * p.tilesC * p.B, p.xcd_order), DT_NT, 0, s>>>(p);
+            return 0;
+        }
+    }
     if (std_set) k_inv2<C, true><<<grid_for(p.tilesR * p.tilesC * p.B, p.xcd_order), DT_NT, 0, s>>>(p);
     else k_inv2<C, false><<<grid_for(p.tilesR * p.tilesC * p.B, p.xcd_order), DT_NT, 0, s>>>(p);
     return 0;

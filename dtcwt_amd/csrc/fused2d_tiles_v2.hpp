@@ -817,4 +817,93 @@ DT_HD void inv2r_fir(const Inv2Params &p, const float (&w0)[C::WS], const float 
     }
 }
 
+// ---- level >= 2 inverse, column phase in two halves (k_inv2s) -------------------------------------------------------
+// y1 = colifilt(Z) + colifilt(lh) and y2 = colifilt(hl) + colifilt(hh) need their four windows one pair at a time.
+// Gathering lh and hh first (both live in pieces 0 and 2 of a record), filtering y1 into a plane of its own, THEN
+// gathering hl (piece 1) and filtering y2 over the record buffer keeps 36 instead of 48 window registers alive and lets
+// the compiler stop hoarding LDS reads: 72 instead of 112 VGPRs at the packed-FMA instruction count, and with records +
+// one y plane = 26 KB of LDS, six workgroups per CU instead of four.  (39 % of a k_inv2 workgroup's life is the wait for
+// its window, and four workgroups do not cover it: profiles/r03/inv2_phase_stamps.txt.)  Same arithmetic in the same
+// order as inv2r_gather + inv2r_fir: bit-identical results.
+template <int E>
+DT_HD void rec_samples13_t(const float *rec, const float *g, float &t1, float &b1, float &t3, float &b3) {
+    const f4 r0 = reinterpret_cast<const f4 *>(rec)[0];
+    const f4 r2 = reinterpret_cast<const f4 *>(rec)[2];
+    if (E == 0) {
+        t1 = r0.x * g[0] + r2.z * g[5]; b1 = r0.y * g[0] - r2.w * g[5];
+        t3 = r0.z * g[1] + r2.x * g[4]; b3 = r0.w * g[1] - r2.y * g[4];
+    } else {
+        t1 = r0.y * g[0] + r2.w * g[5]; b1 = r2.z * g[5] - r0.x * g[0];
+        t3 = r0.w * g[1] + r2.y * g[4]; b3 = r2.x * g[4] - r0.z * g[1];
+    }
+}
+template <int E>
+DT_HD void rec_samples2_t(const float *rec, const float *g, float &t2, float &b2) {
+    const f4 r1 = reinterpret_cast<const f4 *>(rec)[1];
+    if (E == 0) { t2 = r1.x * g[2] + r1.z * g[3]; b2 = r1.y * g[2] - r1.w * g[3]; }
+    else { t2 = r1.y * g[2] + r1.w * g[3]; b2 = r1.z * g[3] - r1.x * g[2]; }
+}
+
+// WHICH 0: planes lh -> wa, hh -> wb;  WHICH 1: plane hl -> wa (wb untouched)
+template <class C, int E, int WHICH>
+DT_HD void inv2r_gather_half_e(const Inv2Params &p, const float *srec, float (&wa)[C::WS], float (&wb)[C::WS], int tid, int r0, int c0) {
+    const ColTask t = inv_col_task<C>(tid);
+    if (!t.valid) return;
+    const int ro = r0 + C::ORG, co = c0 + C::ORG;
+    const bool interior = ro >= 0 && ro + C::NR <= p.zr && co >= 0 && co + C::NC <= p.zc;
+    const int rs = C::RS * t.strip;
+    const float *rbase = srec + ((rs / 2) * C::QC + t.i) * 12;
+    if (interior) {
+#pragma unroll
+        for (int ru = 0; ru < C::WS / 2; ++ru) {
+            if (WHICH == 0) rec_samples13_t<E>(rbase + ru * C::QC * 12, p.g, wa[2 * ru], wa[2 * ru + 1], wb[2 * ru], wb[2 * ru + 1]);
+            else rec_samples2_t<E>(rbase + ru * C::QC * 12, p.g, wa[2 * ru], wa[2 * ru + 1]);
+        }
+    } else {
+        const int fc = reflect_i(co + 2 * t.i, p.zc) & 1;
+        const bool e1 = (E ^ fc) != 0;              // reflection may flip the column parity per lane
+#pragma unroll
+        for (int ru = 0; ru < C::WS / 2; ++ru) {
+            const int fr = reflect_i(ro + rs + 2 * ru, p.zr) & 1;
+            const float *rec = rbase + ru * C::QC * 12;
+            if (WHICH == 0) {
+                float ta0, ba0, tb0, bb0, ta1, ba1, tb1, bb1;
+                rec_samples13_t<0>(rec, p.g, ta0, ba0, tb0, bb0);
+                rec_samples13_t<1>(rec, p.g, ta1, ba1, tb1, bb1);
+                const float ta = e1 ? ta1 : ta0, ba = e1 ? ba1 : ba0, tb = e1 ? tb1 : tb0, bb = e1 ? bb1 : bb0;
+                wa[2 * ru] = fr ? ba : ta; wa[2 * ru + 1] = fr ? ta : ba;
+                wb[2 * ru] = fr ? bb : tb; wb[2 * ru + 1] = fr ? tb : bb;
+            } else {
+                float t0, b0, t1, b1;
+                rec_samples2_t<0>(rec, p.g, t0, b0);
+                rec_samples2_t<1>(rec, p.g, t1, b1);
+                const float tt = e1 ? t1 : t0, bb = e1 ? b1 : b0;
+                wa[2 * ru] = fr ? bb : tt; wa[2 * ru + 1] = fr ? tt : bb;
+            }
+        }
+    }
+}
+template <class C, int WHICH>
+DT_HD void inv2r_gather_half(const Inv2Params &p, const float *srec, float (&wa)[C::WS], float (&wb)[C::WS], int tid, int r0, int c0) {
+    if (DT_WAVE_UNIFORM((tid >> 6) & 1)) inv2r_gather_half_e<C, 1, WHICH>(p, srec, wa, wb, tid, r0, c0);
+    else inv2r_gather_half_e<C, 0, WHICH>(p, srec, wa, wb, tid, r0, c0);
+}
+
+// one y plane: colifilt(wa; lowpass pair) + colifilt(wb; highpass pair)
+template <class C, bool STD>
+DT_HD void inv2r_fir_plane(const Inv2Params &p, const float (&wa)[C::WS], const float (&wb)[C::WS], float *y, int tid) {
+    const ColTask t = inv_col_task<C>(tid);
+    if (!t.valid) return;
+    constexpr int LP = STD ? 1 : -1, HP = STD ? 0 : -1;
+    const int cc = 2 * t.i + t.e;
+#pragma unroll
+    for (int q = 0; q < C::JS; ++q) {
+        float *o = y + 4 * (t.strip * C::JS + q) * C::NC + cc;
+        dt_pk2 P = {0.f, 0.f}, Q = {0.f, 0.f};
+        ifilt4_acc<C, LP>(wa + 2 * q, p.l_a, p.l_b, p.lo_pos, P, Q);
+        ifilt4_acc<C, HP>(wb + 2 * q, p.h_a, p.h_b, p.hi_pos, P, Q);
+        o[0] = P.x; o[C::NC] = Q.x; o[2 * C::NC] = P.y; o[3 * C::NC] = Q.y;
+    }
+}
+
 }  // namespace dt2d

@@ -148,8 +148,27 @@ static int run_inv2(Inv2Params p) {
                 for (int t = 0; t < DT_NT; ++t) inv2r_fetch<C>(p, wz[t], t, b, r0, c0);
                 for (int t = 0; t < DT_NT; ++t)
                     inv_rec_stage<C::QR, C::QC>(Yhb, p.zr, p.zc, srec, r0 + C::ORG, c0 + C::ORG, t);
-                for (int t = 0; t < DT_NT; ++t) inv2r_gather<C>(p, srec, w1[t], w2[t], w3[t], t, r0, c0);
                 const bool std_set = p.lo_pos && !p.hi_pos && (!C::BP || !p.bp_pos);     // as launch_inv2 decides
+                if (!C::BP) {
+                    // k_inv2s: the column phase in two halves, y1 in a plane of its own, y2 over the records
+                    static float y1s[C::SY];
+                    for (int t = 0; t < DT_NT; ++t) inv2r_gather_half<C, 0>(p, srec, w1[t], w3[t], t, r0, c0);
+                    for (int t = 0; t < DT_NT; ++t) {
+                        if (std_set) inv2r_fir_plane<C, true>(p, wz[t], w1[t], y1s, t);
+                        else inv2r_fir_plane<C, false>(p, wz[t], w1[t], y1s, t);
+                    }
+                    for (int t = 0; t < DT_NT; ++t) inv2r_gather_half<C, 1>(p, srec, w2[t], w2[t], t, r0, c0);
+                    for (int t = 0; t < DT_NT; ++t) {
+                        if (std_set) inv2r_fir_plane<C, true>(p, w2[t], w3[t], y1, t);       // y2 = the record buffer
+                        else inv2r_fir_plane<C, false>(p, w2[t], w3[t], y1, t);
+                    }
+                    for (int t = 0; t < DT_NT; ++t) {
+                        if (std_set) inv2_rows<C, true>(p, y1s, y1, t, b, r0, c0, nullptr);
+                        else inv2_rows<C, false>(p, y1s, y1, t, b, r0, c0, nullptr);
+                    }
+                    continue;
+                }
+                for (int t = 0; t < DT_NT; ++t) inv2r_gather<C>(p, srec, w1[t], w2[t], w3[t], t, r0, c0);
                 for (int t = 0; t < DT_NT; ++t) {
                     if (std_set) inv2r_fir<C, false, true>(p, wz[t], w1[t], w2[t], w3[t], y1, y2, t, y3);
                     else inv2r_fir<C, false, false>(p, wz[t], w1[t], w2[t], w3[t], y1, y2, t, y3);
