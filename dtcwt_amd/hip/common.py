@@ -106,13 +106,23 @@ class Pyramid(object):
         """(lowpass, highpasses) as DeviceArrays on *ctx* (uploading host arrays);
         highpass entries may be None.  An entry whose host view has been handed out is uploaded from
         that view: the caller may have edited it."""
+        entries = [('l', self._low)] + [(('h', i), x) for i, x in enumerate(self._high)]
+        if real_dtype is not None:
+            # one precision for the whole pyramid, as NumPy's promotion gives the reference: float64 as soon as any
+            # entry is 64-bit (a float32 lowpass next to complex128 subbands must not reach a kernel as if they matched)
+            cur = [self._host.get(k, x) for k, x in entries if x is not None]
+            if any(np.dtype(x.dtype) in (np.dtype(np.float64), np.dtype(np.complex128)) for x in cur):
+                real_dtype = np.float64
+
         def up(x, cplx, key):
             if x is not None and key in self._host:
                 x = self._host[key]
-            if x is None or _is_dev(x):
+            if x is None:
                 return x
             if real_dtype is not None:
-                dt = (np.complex64 if real_dtype == np.float32 else np.complex128) if cplx else real_dtype
+                dt = np.dtype((np.complex64 if real_dtype == np.float32 else np.complex128) if cplx else real_dtype)
+                if _is_dev(x):
+                    return x if x.dtype == dt else ctx.to_device(x.get(), dtype=dt)     # rare: through the host
                 return ctx.to_device(x, dtype=dt)
-            return ctx.to_device(x)
+            return x if _is_dev(x) else ctx.to_device(x)
         return up(self._low, False, 'l'), tuple(up(x, True, ('h', i)) for i, x in enumerate(self._high))

@@ -171,6 +171,26 @@ def test_mgpu_include_scale():
     m.sync()
 
 
+def test_mgpu_create_validates_tap_lengths():
+    """dtcwt_hip_mgpu_create copies the tap tables before any plan sees them: lengths are checked first (a negative or
+    oversized length from a C caller was undefined behaviour)."""
+    import ctypes
+    from dtcwt_amd.hip import _lib
+    from dtcwt_amd.utils import flat_taps
+    L = _lib.lib()
+    pd = ctypes.POINTER(ctypes.c_double)
+    taps = [flat_taps(h) for h in biort(B)] + [flat_taps(h) for h in qshift(Q)]
+    bp = (pd * 4)(*[a.ctypes.data_as(pd) for a in taps[:4]])
+    qp = (pd * 8)(*[a.ctypes.data_as(pd) for a in taps[4:]])
+    dv = (ctypes.c_int * 1)(0)
+    for bad in (-1, 0, 41):
+        bl = (ctypes.c_int * 4)(bad, *[a.shape[0] for a in taps[1:4]])
+        ql = (ctypes.c_int * 8)(*[a.shape[0] for a in taps[4:]])
+        h = ctypes.c_void_p()
+        rc = L.dtcwt_hip_mgpu_create(1, dv, 2, 64, 64, 2, bp, bl, qp, ql, 0, ctypes.byref(h))
+        assert rc == -1 and b'out of range' in L.dtcwt_hip_last_error()
+
+
 def test_mgpu_more_shards_than_images():
     from dtcwt_amd.hip.multigpu import MultiGPUTransform2d
     X = np.random.RandomState(9).standard_normal((2, 128, 128)).astype(np.float32)

@@ -89,6 +89,28 @@ def test_1d_errors_and_zero_levels():
         t.inverse(bad)
 
 
+def test_1d_inverse_mixed_dtypes_and_long_gain_mask():
+    """A device pyramid whose lowpass and highpasses disagree in precision must not reach the native plan as if they
+    matched (it takes the level-by-level path, like a host pyramid with mixed dtypes does), and a gain mask longer
+    than nlevels is indexed per level as the reference does (dtcwt/numpy/transform1d.py:150-176), not reshaped."""
+    from dtcwt_amd.hip import default_context
+    rs = np.random.RandomState(12)
+    X = rs.standard_normal(256).astype(np.float32)
+    t = Transform1d()
+    to = o.Transform1d(biort('near_sym_a'), qshift('qshift_a'))
+    p = t.forward(X, nlevels=3)
+    want = to.forward(X.astype(np.float64), nlevels=3)
+    gm = np.array([1.0, 0.5, 2.0, 7.0, 9.0])             # two entries more than levels
+    z = t.inverse(p, gm)
+    assert_close(z, to.inverse(want, gm), INV_TOL)
+    # float32 lowpass with complex128 highpasses, both resident on the device
+    ctx = default_context()
+    mixed = Pyramid(ctx.to_device(np.asarray(p.lowpass, np.float32).reshape(-1, 1)),
+                    tuple(ctx.to_device(np.asarray(y, np.complex128).reshape(-1, 1)) for y in p.highpasses))
+    zm = np.ravel(t.inverse(mixed))
+    assert_close(zm, to.inverse(want), INV_TOL * 4)
+
+
 # ------------------------------------------------------------------------------ 3-D
 def _volume(s, xn):
     if xn == 'e32':
