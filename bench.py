@@ -193,12 +193,27 @@ def main():
         # launching thread: 0.214-0.233 ms per step at one rank against 0.197 ms (profiles/r03/rccl_alive.txt).
         # DTCWT_BENCH_BARRIER=nccl keeps the round-2 arrangement (everything on one RCCL group).
         barrier_backend = os.environ.get('DTCWT_BENCH_BARRIER', 'gloo')
+        if barrier_backend != 'nccl' and 'GLOO_SOCKET_IFNAME' not in os.environ:
+            # gloo picks its interface by resolving the host name, which containers often cannot: all ranks are on
+            # this node, the loopback interface will do
+            try:
+                socket.gethostbyname(socket.gethostname())
+            except OSError:
+                os.environ['GLOO_SOCKET_IFNAME'] = 'lo'
         if barrier_backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
             rccl_group = None
         else:
-            dist.init_process_group('gloo')
-            rccl_group = dist.new_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+            try:
+                dist.init_process_group('gloo')
+                rccl_group = dist.new_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+            except Exception as exc:       # no usable gloo transport here: everything on RCCL, as in round 2
+                print('bench.py: gloo group unavailable (%s); barriers on RCCL' % exc, file=sys.stderr)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                barrier_backend = 'nccl'
+                dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+                rccl_group = None
 
     import dtcwt_amd
     from dtcwt_amd.coeffs import biort, qshift
