@@ -114,7 +114,9 @@ int launch_inv2(Inv2Params &p, hipStream_t s) {
     const bool std_set = p.lo_pos && !p.hi_pos && (!C::BP || !p.bp_pos);
     if constexpr (!C::BP) {         // DTCWT_HIP_INV2_SPLIT=0: the one-piece column phase of round 2 (k_inv2)
         static const int split = [] { const char *e = getenv("DTCWT_HIP_INV2_SPLIT"); return e ? atoi(e) : 1; }();
-        if (split) {
+        // ... where there are workgroups to overlap: a launch of about one tile per CU is a latency chain, and the
+        // two-halves form is one LDS phase longer (a 512^2 lowpass: 8.2 -> 8.8 us; 1024^2: equal; 2048^2: 35.4 -> 33.4)
+        if (split && (split > 1 || p.tilesR * p.tilesC * p.B >= 2048)) {
             if (std_set) k_inv2s<C, true><<<grid_for(p.tilesR * p.tilesC * p.B, p.xcd_order), DT_NT, 0, s>>>(p);
             else k_inv2s<C, false><<<grid_for(p.tilesR * p.tilesC * p.B, p.xcd_order), DT_NT, 0, s>>>(p);
             return 0;
