@@ -113,11 +113,35 @@ __global__ void __launch_bounds__(NT) k_fwd3_l2_axis0(Fwd3L2Params p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *ws = slab + wave * CPW * REC_LDS;
     const int cl = lane & (CPW - 1);                               // the lane's cell within the wavefront
-    const int first = ((int)blockIdx.x * (NT / 64) + wave) * CPW;
+    const int first = p.id0 + ((int)blockIdx.x * (NT / 64) + wave) * CPW;
     if (CPW == 64) f3l2_axis0_stage<M, 4>(p, first + cl, ws + cl * REC_LDS);
     else f3l2_axis0_stage<M, 2>(p, first + cl, ws + cl * REC_LDS, 2 * (lane >> 5));
     DT_WAVE_LDS_SYNC();
     f3l2_axis0_flush<CPW>(p, first, lane, ws);
+}
+
+// Level >= 2, pass B, inner layers: two cells along axis 0 per lane pair (f3l2_axis0_pair_stage); one wavefront per
+// workgroup = 32 cell columns x layers (2 u, 2 u + 1).
+template <int M>
+__global__ void __launch_bounds__(64) k_fwd3_l2_axis0_pair(Fwd3L2Params p, int u0, int colblocks, int ninner, int lo_cells, int hi_first) {
+    __shared__ __attribute__((aligned(16))) float slab[64 * REC_LDS];
+    const int lane = threadIdx.x;
+    const int nbound = (int)gridDim.x - ninner;
+    const int w = (int)blockIdx.x - nbound;         // the (slow, reflecting) boundary blocks are dealt FIRST: they then run beside the inner ones
+    if (w >= 0) {
+        const int cb = w % colblocks, u = u0 + w / colblocks;
+        f3l2_axis0_pair_stage<M>(p, u, cb * 32 + (lane & 31), lane >> 5, slab, lane & 31);
+        DT_WAVE_LDS_SYNC();
+        f3l2_axis0_pair_flush(p, u, cb * 32, lane, slab);
+    } else {
+        // the boundary layers ride along in the same launch, 64 cells per wavefront with the one-cell program: cells
+        // [0, lo_cells) and [hi_first, end)
+        int first = (int)blockIdx.x * 64;
+        if (first >= lo_cells) first = hi_first + (first - lo_cells);
+        f3l2_axis0_stage<M, 4>(p, first + lane, slab + lane * REC_LDS);
+        DT_WAVE_LDS_SYNC();
+        f3l2_axis0_flush<64>(p, first, lane, slab);
+    }
 }
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -161,6 +185,24 @@ int launch_l2_axis0(Fwd3L2Params &p, int cus, hipStream_t s) {
     dt2d::dt_pack_lh(p);
 
     int cells = (p.O0 / 2) * (p.O1 / 2) * (p.O2 / 2);
+    // Large levels: the inner layers of cells two at a time along axis 0 (24 instead of 40 window slices per pair
+    // through L1), the boundary layers (windows that reach outside the volume) with the one-cell kernel.
+    // DTCWT_HIP_L2B_PAIR=0: the one-cell kernel everywhere.
+    if constexpr (C::M <= 18) {
+        static const int want = [] { const char *e = getenv("DTCWT_HIP_L2B_PAIR"); return e ? atoi(e) : 1; }();
+        const int e0 = p.O0 / 2, E = (p.O1 / 2) * (p.O2 / 2);
+        int lo = (C::M - 2 + p.pad0 + 3) / 4;                      // first layer whose window starts inside
+        int hi = (p.n0 - C::M - 2 + p.pad0) / 4;                   // last layer whose window ends inside
+        if (lo & 1) ++lo;                                          // pairs (2 u, 2 u + 1)
+        if (!(hi & 1)) --hi;
+        if (want && E % 64 == 0 && hi - lo + 1 >= 8 && cdiv(cells, DT_NT) >= 4 * cus && 16 * p.pstride < ((int64_t)1 << 32)) {
+            const int npair = (hi - lo + 1) / 2, colblocks = E / 32;
+            const int ninner = npair * colblocks, lo_cells = lo * E, hi_first = (hi + 1) * E;     // E % 64 == 0 below
+            const int nbound = (lo_cells + (e0 * E - hi_first)) / 64;
+            k_fwd3_l2_axis0_pair<C::M><<<(unsigned)(ninner + nbound), 64, 0, s>>>(p, lo / 2, colblocks, ninner, lo_cells, hi_first);
+            return 0;
+        }
+    }
     // coarse levels: single-wavefront workgroups so that every CU gets work
     // coarse levels: single-wavefront workgroups and two lanes per cell (half the dependent loads per thread: 64^3
     // cells 8.1 -> 7.4 us), so that every CU gets work; large levels are not latency-bound (no gain from the split:

@@ -441,6 +441,7 @@ struct Fwd3L2Params {
     int n0, pad0, L0;     // real slices, replicated planes per side, L0 = n0 + 2 pad0 (% 4 == 0)
     int O0, O1, O2;       // octant extents (L/2, all even)
     int lo_a_first, hi_a_first;
+    int id0, id1;         // pass B: the cells [id0, id1) of this launch (0, 0: all of them)
     float l_a[DT_MAXT], l_b[DT_MAXT], h_a[DT_MAXT], h_b[DT_MAXT];
     float lh_a[2 * DT_MAXT] __attribute__((aligned(8))), lh_b[2 * DT_MAXT] __attribute__((aligned(8)));   // dt_pack_lh()
 };
@@ -552,7 +553,7 @@ DT_HD void f3l2_axis0_planes_buf(const Fwd3L2Params &p, int c0, int base, int r0
 template <int M, int NV = 4>
 DT_HD void f3l2_axis0_stage(const Fwd3L2Params &p, int id, float *rec, int v0 = 0, int nv = NV) {
     const int e2 = p.O2 / 2, e1 = p.O1 / 2, e0 = p.O0 / 2;
-    if (id >= e0 * e1 * e2) return;
+    if (id >= (p.id1 ? p.id1 : e0 * e1 * e2)) return;
     const int c2 = id % e2, t = id / e2, c1 = t % e1, c0 = t / e1;
     const int base = (2 * c1) * p.O2 + 2 * c2;
     const int r0 = 4 * c0 - M + 2 - p.pad0;              // first slice of the window in the unpadded planes
@@ -562,10 +563,77 @@ DT_HD void f3l2_axis0_stage(const Fwd3L2Params &p, int id, float *rec, int v0 = 
     else f3l2_axis0_planes<M, false>(p, c0, base, r0, rec, v0, nv);
 }
 
+// ---- pass B, two cells along axis 0 per lane pair ---------------------------------------------------------------
+// What pass B waits for is the CU's vector-memory path: every plane slice is wanted by five cells along axis 0, so
+// 335 MB go through L1 for 67 MB of planes (profiles/r03/c4_passB.txt).  Cells (2u, 2u + 1) share 2M - 4 of their 2M
+// slices: a lane that filters BOTH from one window of 2M + 4 slices loads 24 instead of 40 slices per pair (M = 10).
+// A wavefront = 32 cell columns x 2 cells; lane l and lane l + 32 share a column and take planes (0, 1) / (2, 3).  Only
+// cells whose windows lie inside the volume (no reflection, no pad planes); the boundary layers go to the one-cell
+// kernel.  Buffer addressing as in f3l2_axis0_planes_buf.
+template <int M>
+DT_HD void f3l2_axis0_pair_stage(const Fwd3L2Params &p, int u, int col, int half, float *slab, int cl) {
+    constexpr int WP = 2 * M + 4;
+    const int ss = p.O1 * p.O2, e2 = p.O2 / 2;
+    const int c1 = col / e2, c2 = col - c1 * e2;
+    const int base = (2 * c1) * p.O2 + 2 * c2;
+    const int c0 = 2 * u, r0 = 4 * c0 - M + 2 - p.pad0;
+    const dt2d::DtBuf pb = dt2d::dt_buf(p.P);
+    const unsigned ps4 = 4u * (unsigned)p.pstride, row = 4u * (unsigned)p.O2;
+    const unsigned vo = 4u * (unsigned)(base + r0 * ss) + (unsigned)(2 * half) * ps4;
+#pragma unroll 1
+    for (int i = 0; i < 2; ++i) {
+        const int v = 2 * half + i;
+        const unsigned vv = vo + (unsigned)i * ps4;
+        float w[4][WP];
+#pragma unroll
+        for (int j = 0; j < WP; ++j) {
+            const f2 a = dt2d::dt_buf_ld2(pb, vv, 4u * (unsigned)(j * ss)), b = dt2d::dt_buf_ld2(pb, vv + row, 4u * (unsigned)(j * ss));
+            w[0][j] = a.x; w[1][j] = a.y; w[2][j] = b.x; w[3][j] = b.y;
+        }
+#pragma unroll
+        for (int cell = 0; cell < 2; ++cell) {
+            float lev[4], lod[4], hev[4], hod[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float A, Bv, Ah, Bh;
+                dt2d::dfilt_pair2<M>(w[q] + 4 * cell, p.lh_a, p.lh_b, A, Bv, Ah, Bh);
+                lev[q] = p.lo_a_first ? A : Bv; lod[q] = p.lo_a_first ? Bv : A;
+                hev[q] = p.hi_a_first ? Ah : Bh; hod[q] = p.hi_a_first ? Bh : Ah;
+            }
+            float *rec = slab + (cell * 32 + cl) * REC_LDS;
+            if (v == 0) {
+                float *L = p.LLL + (int64_t)(2 * (c0 + cell)) * ss + base;
+                *reinterpret_cast<f2 *>(L) = f2{lev[0], lev[1]};
+                *reinterpret_cast<f2 *>(L + p.O2) = f2{lev[2], lev[3]};
+                *reinterpret_cast<f2 *>(L + ss) = f2{lod[0], lod[1]};
+                *reinterpret_cast<f2 *>(L + ss + p.O2) = f2{lod[2], lod[3]};
+            } else {
+                cube2c_record(rec + 8 * octant_slot(v), lev, lod);
+            }
+            cube2c_record(rec + 8 * octant_slot(4 + v), hev, hod);
+        }
+    }
+}
+
+// the wavefront's 2 x 32 records: two runs of 32 consecutive records (cells col0 .. col0 + 31 of layers 2u and 2u + 1)
+DT_HD void f3l2_axis0_pair_flush(const Fwd3L2Params &p, int u, int col0, int lane, const float *slab) {
+    const int E = (p.O1 / 2) * (p.O2 / 2);
+    const f4 *src = reinterpret_cast<const f4 *>(slab);
+#pragma unroll
+    for (int cell = 0; cell < 2; ++cell) {
+        f4 *dst = reinterpret_cast<f4 *>(p.Yh + ((int64_t)(2 * u + cell) * E + col0) * 56);
+#pragma unroll
+        for (int it = 0; it < 7; ++it) {
+            const int piece = it * 64 + lane;                   // 32 records = 448 pieces
+            DT_STREAM_STORE_F4(dst + piece, src[slab_f4(cell * 32 * 14 + piece)]);
+        }
+    }
+}
+
 // first: id of the wavefront's first cell, CPW: cells per wavefront (64 or 32)
 template <int CPW = 64>
 DT_HD void f3l2_axis0_flush(const Fwd3L2Params &p, int first, int lane, const float *slab) {
-    const int ncell = (p.O0 / 2) * (p.O1 / 2) * (p.O2 / 2);
+    const int ncell = p.id1 ? p.id1 : (p.O0 / 2) * (p.O1 / 2) * (p.O2 / 2);
     const int n = ncell - first < CPW ? ncell - first : CPW;
     f4 *dst = reinterpret_cast<f4 *>(p.Yh + (int64_t)first * 56);
     const f4 *src = reinterpret_cast<const f4 *>(slab);
