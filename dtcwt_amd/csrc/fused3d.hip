@@ -27,12 +27,12 @@ __device__ __forceinline__ int xcd_tile3(int ntile_xcd) {
     return ((bid >> 3) < per && t < ntile_xcd) ? t : -1;
 }
 // bit mask of the kernels that take the XCD order (DTCWT_HIP_XCD3D): 1 k_fwd3_l1, 2 k_fwd3_l2_planes,
-// 4 k_inv3_axis0, 8 k_inv3_l1_planes, 16 k_inv3_l2_planes.  Measured at 256^3 (profiles/r02/xcd3d.txt): the
+// 4 k_inv3_axis0 / k_inv3_l1_axis02, 8 (was k_inv3_l1_planes: unused), 16 k_inv3_l2_planes.  Measured at 256^3 (profiles/r02/xcd3d.txt): the
 // forward kernels gain (pass A of level 2: 46 -> 34 us; the transform 252 -> 240 us); so do the plane passes of
 // the inverse once its level 1 runs in slabs (345 -> 322 us); the inverse march (4) does not.
-enum { XCD3_FWD_L1 = 1, XCD3_FWD_PLANES = 2, XCD3_INV_AXIS0 = 4, XCD3_INV_L1_PLANES = 8, XCD3_INV_L2_PLANES = 16 };
+enum { XCD3_FWD_L1 = 1, XCD3_FWD_PLANES = 2, XCD3_INV_AXIS0 = 4, XCD3_INV_L2_PLANES = 16 };
 inline bool xcd3_enabled(int bit) {
-    static const int mask = [] { const char *e = getenv("DTCWT_HIP_XCD3D"); return e ? atoi(e) : (XCD3_FWD_L1 | XCD3_FWD_PLANES | XCD3_INV_L1_PLANES | XCD3_INV_L2_PLANES); }();
+    static const int mask = [] { const char *e = getenv("DTCWT_HIP_XCD3D"); return e ? atoi(e) : (XCD3_FWD_L1 | XCD3_FWD_PLANES | XCD3_INV_L2_PLANES); }();
     return (mask & bit) != 0;
 }
 inline unsigned xcd3_grid(int ntile, int bit) { return xcd3_enabled(bit) ? (unsigned)(8 * ((ntile + 7) / 8)) : (unsigned)ntile; }
@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(DT_NT) k_inv3_axis0(Inv3AParams p, int ntile_x
     __shared__ __attribute__((aligned(16))) float slab[2][I3_SLAB];
     const int bid = xcd_tile3(ntile_xcd), tid = threadIdx.x;
     if (bid < 0) return;
-    const int tk = bid % p.tilesK, tj = (bid / p.tilesK) % p.tilesJ, ch = bid / (p.tilesK * p.tilesJ) + p.ch0;
+    const int tk = bid % p.tilesK, tj = (bid / p.tilesK) % p.tilesJ, ch = bid / (p.tilesK * p.tilesJ);
     const int cj0 = tj * I3_CJ, ck0 = tk * I3_CK, c0 = ch * p.chunk;
     const int c1 = min(c0 + p.chunk, p.n0 / 2);
     const int cs = c0 - (2 * F::HP + 1);            // warm-up steps fill the rings
@@ -363,25 +363,47 @@ __global__ void __launch_bounds__(DT_NT) k_inv3_axis0(Inv3AParams p, int ntile_x
     }
 }
 
-// pass B, level 1: column + row pass of the 2-D level-1 inverse tile program per slice, the
-// four planes in place of the lowpass and the c2q quad planes
-template <class C>
-__global__ void __launch_bounds__(DT_NT) k_inv3_l1_planes(dt2d::Inv1Params p, const float *planes, int64_t ps, int ntile_xcd) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * C::SY];
-    const int t = xcd_tile3(ntile_xcd);
-    if (t < 0) return;
-    int tc, tr, b;
-    dt2d::dt_tile_decode(p, t, tc, tr, b);
-    float *y1 = smem, *y2 = y1 + C::SY;
-    const int r0 = tr * C::TR, c0 = tc * C::TC;
-    float wz[C::WN], w1[C::WN], w2[C::WN], w3[C::WN];
-    dt2d::inv1r_fetch_from<C, true>(p, planes, wz, threadIdx.x, b, r0, c0);            // a1 = 0, a2 = 0
-    dt2d::inv1r_fetch_from<C, true>(p, planes + 2 * ps, w1, threadIdx.x, b, r0, c0);   // a1 = 1, a2 = 0
-    dt2d::inv1r_fetch_from<C, true>(p, planes + ps, w2, threadIdx.x, b, r0, c0);       // a1 = 0, a2 = 1
-    dt2d::inv1r_fetch_from<C, true>(p, planes + 3 * ps, w3, threadIdx.x, b, r0, c0);   // a1 = 1, a2 = 1
-    dt2d::inv1r_fir<C, true>(p, wz, w1, w2, w3, y1, y2, threadIdx.x);
+// level 1, first launch: unpack + axis-0 merge + axis-2 merge (fused3d_inv_tiles.hpp, I3Ex)
+template <class F, class G>
+__global__ void __launch_bounds__(G::NT, 4) k_inv3_l1_axis02(Inv3AParams p, int ntile_xcd) {
+    __shared__ __attribute__((aligned(16))) float slab[2][G::SLAB];
+    __shared__ __attribute__((aligned(16))) float E[I3Ex<G>::FLOATS];
+    const int bid = xcd_tile3(ntile_xcd), tid = threadIdx.x;
+    if (bid < 0) return;
+    const int tk = bid % p.tilesK, tj = (bid / p.tilesK) % p.tilesJ, ch = bid / (p.tilesK * p.tilesJ);
+    const int cj0 = tj * G::CJ, ck0 = tk * (G::CK - 2 * p.hal) - p.hal, c0 = ch * p.chunk;
+    const int c1 = min(c0 + p.chunk, p.n0 / 2);
+    const int q0 = c0 - F::HP, q1 = c1 - 1 + F::HP;       // virtual records added by this march
+    Inv3TState<F, G> st;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int t = 0; t < F::NA; ++t) st.acc[q][t] = 0.f;
+    i3a_issue_rec<F, G>(p, st, tid, cj0, ck0, q0);
+    i3a_issue_low<F, G>(p, st, tid, cj0, ck0, q0);
+    i3a_slab_write<F, G>(st, slab[0], tid);
+    i3a_issue_rec<F, G>(p, st, tid, cj0, ck0, q0 + 1);
     __syncthreads();
-    dt2d::inv1d_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0);
+    for (int q = q0; q <= q1; ++q) {
+        const int buf = (q - q0) & 1, c = q - F::HP;        // the output pair this step completes
+        float out[2][4];
+        i3a_accumulate<F, G>(p, st, slab[buf], tid, q, out);
+        i3a_slab_write<F, G>(st, slab[buf ^ 1], tid);
+        if (q < q1) {
+            i3a_issue_rec<F, G>(p, st, tid, cj0, ck0, q + 2);
+            i3a_issue_low<F, G>(p, st, tid, cj0, ck0, q + 1);
+        }
+        if (c >= c0) i3a_exchange<F, G>(p, out, E, tid, ck0);
+        __syncthreads();
+        if (c >= c0) i3a_merge_k<F, G>(p, E, tid, cj0, ck0, c);
+        __syncthreads();
+    }
+}
+
+// level 1, second launch: the axis-1 merge
+template <class F, int VEC, int RS>
+__global__ void __launch_bounds__(DT_NT) k_inv3_l1_axis1(Inv3BParams p) {
+    i3b_axis1<F, VEC, RS>(p, (int64_t)blockIdx.x * DT_NT + threadIdx.x);
 }
 
 // pass B, level >= 2
@@ -405,14 +427,6 @@ __global__ void __launch_bounds__(DT_NT) k_inv3_l2_planes(dt2d::Inv2Params p, co
 }
 
 template <class C>
-void launch_inv3_l1_planes(dt2d::Inv1Params &b, const float *planes, int64_t ps, hipStream_t s) {
-    b.tilesR = cdiv(b.R, C::TR); b.tilesC = cdiv(b.C, C::TC);
-    dt2d::dt_set_tile_magic(b);
-    dt2d::dt_pack_g01<C::M0, C::M1>(b);
-    const int ntile = b.tilesR * b.tilesC * b.B;
-    k_inv3_l1_planes<C><<<xcd3_grid(ntile, XCD3_INV_L1_PLANES), DT_NT, 0, s>>>(b, planes, ps, xcd3_arg(ntile, XCD3_INV_L1_PLANES));
-}
-template <class C>
 void launch_inv3_l2_planes(dt2d::Inv2Params &b, const float *planes, int64_t ps, hipStream_t s) {
     b.tilesR = cdiv(b.zr, C::TR); b.tilesC = cdiv(b.zc, C::TC);
     dt2d::dt_set_tile_magic(b);
@@ -420,9 +434,8 @@ void launch_inv3_l2_planes(dt2d::Inv2Params &b, const float *planes, int64_t ps,
     k_inv3_l2_planes<C><<<xcd3_grid(ntile, XCD3_INV_L2_PLANES), DT_NT, 0, s>>>(b, planes, ps, xcd3_arg(ntile, XCD3_INV_L2_PLANES));
 }
 
-// ch0, nch: the chunks of this launch (nch < 0: all of them); sets p.chunk / p.chunks either way
 template <class F>
-void launch_inv3_axis0(Inv3AParams &p, int cus, hipStream_t s, int ch0 = 0, int nch = -1) {
+void launch_inv3_axis0(Inv3AParams &p, int cus, hipStream_t s) {
     p.tilesJ = cdiv(p.n1 / 2, I3_CJ); p.tilesK = cdiv(p.n2 / 2, I3_CK);
     const int pairs = p.n0 / 2;
     int chunk = 64;             // long marches amortise the 2 HP + 1 warm-up steps
@@ -436,11 +449,44 @@ void launch_inv3_axis0(Inv3AParams &p, int cus, hipStream_t s, int ch0 = 0, int 
         if (v >= 1) chunk = v;
     }
     p.chunk = chunk; p.chunks = cdiv(pairs, chunk);
-    if (nch < 0) { ch0 = 0; nch = p.chunks; }
-    p.ch0 = ch0;
-    if (nch == 0) return;
-    const int ntile = p.tilesJ * p.tilesK * nch;
+    const int ntile = p.tilesJ * p.tilesK * p.chunks;
     k_inv3_axis0<F><<<xcd3_grid(ntile, XCD3_INV_AXIS0), DT_NT, 0, s>>>(p, xcd3_arg(ntile, XCD3_INV_AXIS0));
+}
+
+// level 1 with the axis-2 merge in the march: geometry by row length
+template <class F, class G>
+void launch_inv3_l1_axis02_g(Inv3AParams &p, int cus, hipStream_t s) {
+    const int e2 = p.n2 / 2;
+    p.hal = e2 > G::CK ? 2 : 0;
+    p.tilesJ = cdiv(p.n1 / 2, G::CJ); p.tilesK = p.hal ? cdiv(e2, G::CK - 4) : 1;
+    const int pairs = p.n0 / 2;
+    int chunk = 64;
+    while (chunk > 8 && (int64_t)p.tilesJ * p.tilesK * cdiv(pairs, chunk) < 2 * (int64_t)cus) chunk /= 2;
+    while (chunk > 2 && (int64_t)p.tilesJ * p.tilesK * cdiv(pairs, chunk) < (int64_t)cus / 2) chunk /= 2;
+    if (const char *e = getenv("DTCWT_HIP_CHUNK3D_INV")) {
+        int v = atoi(e);
+        if (v >= 1) chunk = v;
+    }
+    p.chunk = chunk; p.chunks = cdiv(pairs, chunk);
+    const int ntile = p.tilesJ * p.tilesK * p.chunks;
+    k_inv3_l1_axis02<F, G><<<xcd3_grid(ntile, XCD3_INV_AXIS0), G::NT, 0, s>>>(p, xcd3_arg(ntile, XCD3_INV_AXIS0));
+}
+template <class F>
+void launch_inv3_l1_axis02(Inv3AParams &p, int cus, hipStream_t s) {
+    const int e2 = p.n2 / 2;
+    if (e2 <= 32) launch_inv3_l1_axis02_g<F, I3Geo<512, 32>>(p, cus, s);
+    else if (e2 <= 64) launch_inv3_l1_axis02_g<F, I3Geo<512, 64>>(p, cus, s);
+    else launch_inv3_l1_axis02_g<F, I3Geo<512, 128>>(p, cus, s);
+}
+template <class F>
+void launch_inv3_l1_axis1(Inv3BParams &b, hipStream_t s) {
+    constexpr int RS = 8;
+    const int vec = (b.n2 & 3) == 0 ? 4 : 2;
+    b.kvecs = b.n2 / vec; b.strips = cdiv(b.n1, RS);
+    const int64_t tasks = (int64_t)b.kvecs * b.strips * b.S;
+    const unsigned grid = (unsigned)((tasks + DT_NT - 1) / DT_NT);
+    if (vec == 4) k_inv3_l1_axis1<F, 4, RS><<<grid, DT_NT, 0, s>>>(b);
+    else k_inv3_l1_axis1<F, 2, RS><<<grid, DT_NT, 0, s>>>(b);
 }
 
 // one-bounce reflection in the tile programs: the window reach (< 2 x taps) must not exceed
@@ -456,7 +502,7 @@ int check_inv3_dims(int64_t n0, int64_t n1, int64_t n2, int64_t S, int taps) {
 
 }  // namespace
 
-#define DT_INV3_L1_TABLE(X) X(16, 120, 8, 7, 5) X(16, 120, 8, 7, 9) X(16, 124, 8, 3, 5)
+#define DT_INV3_L1_TABLE(X) X(7, 5) X(7, 9) X(3, 5)
 #define DT_INV3_L2_TABLE(X) X(16, 56, 2, 10) X(16, 52, 2, 14)
 
 extern "C" int dtcwt_hip_inv3_level1(dtcwt_hip_ctx *ctx, const float *LLL, const float *Yh, int64_t n0, int64_t n1,
@@ -466,7 +512,7 @@ extern "C" int dtcwt_hip_inv3_level1(dtcwt_hip_ctx *ctx, const float *LLL, const
     DT_REQUIRE(m0 > 0 && m1 > 0 && m0 <= DT_MAXT && m1 <= DT_MAXT, "bad tap counts");
     if (int rc = check_inv3_dims(n0, n1, n2, n0, m0 > m1 ? m0 : m1)) return rc;
     bool have = false;
-#define X_(TR, TC, RS, A, B) if (m0 == A && m1 == B) have = true;
+#define X_(A, B) if (m0 == A && m1 == B) have = true;
     DT_INV3_L1_TABLE(X_)
 #undef X_
     if (!have) return dtcwt_set_error(-3, "no fused 3-D level-1 inverse for %d/%d-tap biort filters", m0, m1);
@@ -474,47 +520,26 @@ extern "C" int dtcwt_hip_inv3_level1(dtcwt_hip_ctx *ctx, const float *LLL, const
     a.LLL = LLL; a.Yh = Yh; a.n0 = (int)n0; a.n1 = (int)n1; a.n2 = (int)n2; a.S = (int)n0; a.crop0 = 0;
     a.pstride = n0 * n1 * n2;
     put_taps(a.l_a, g0o, m0); put_taps(a.h_a, g1o, m1);
-    dt2d::Inv1Params b{};
-    b.X = Z; b.B = (int)n0; b.R = (int)n1; b.C = (int)n2;
-    put_taps(b.g0, g0o, m0); put_taps(b.g1, g1o, m1);
     void *planes = nullptr;
-    if (int rc = dtcwt_hip_malloc(ctx, (size_t)(4 * a.pstride) * sizeof(float), &planes)) return rc;
+    if (int rc = dtcwt_hip_malloc(ctx, (size_t)(2 * a.pstride) * sizeof(float), &planes)) return rc;
     a.P = (float *)planes;
     DT_CHECK_HIP(hipSetDevice(ctx->device));
-    // Slabs along axis 0: pass A of a slab, then pass B of the same slab, the four planes of ONE slab in a buffer
-    // that the next slab reuses.  Measured at 256^3 (268 MB of planes): two slabs 345 us per inverse, one 355 us --
-    // pass A gains (2 x 75 instead of 162 us), pass B does not (the planes do not survive in the Infinity Cache
-    // next to the 537 MB pass A streams through).  DTCWT_HIP_INV3_SLABS: number of slabs (default: planes of at
-    // most 96 MB per slab, and never less than one march per slab).
-    int nslab = 1;
-    {
-        const char *e = getenv("DTCWT_HIP_INV3_SLABS");          // read per call: the tests switch it
-        const int forced = e ? atoi(e) : 0;
-        const int64_t plane_bytes = 4 * a.pstride * (int64_t)sizeof(float);
-        nslab = forced > 0 ? forced : (int)((plane_bytes + ((int64_t)96 << 20) - 1) / ((int64_t)96 << 20));
-    }
-#define X_(TR_, TC_, RS_, MA_, MB_)                                                         \
+    // (Running the level in slabs along axis 0 -- march and axis-1 merge per slab, Q of one slab in a reused buffer
+    // -- paid with the four plane-volumes of the previous scheme; with two it does not: 273 against 305 us at
+    // 256^3 with two slabs, 2.04 against 2.11 ms at 512^3 with seven.  profiles/r03/c4_inverse.txt)
+    Inv3BParams q{};
+    q.Q = (const float *)planes; q.pstride = a.pstride; q.Z = Z; q.S = (int)n0; q.n1 = (int)n1; q.n2 = (int)n2;
+    put_taps(q.g0, g0o, m0); put_taps(q.g1, g1o, m1);
+#define X_(MA_, MB_)                                                                        \
     if (m0 == MA_ && m1 == MB_) {                                                           \
-        launch_inv3_axis0<Inv3L1<MA_, MB_>>(a, ctx->cus, ctx->stream, 0, 0);   /* sets a.chunk / a.chunks only */ \
-        const int per = cdiv(a.chunks, nslab < a.chunks ? nslab : a.chunks);                \
-        for (int c0 = 0; c0 < a.chunks; c0 += per) {                                        \
-            const int nch = a.chunks - c0 < per ? a.chunks - c0 : per;                      \
-            a.so0 = 2 * c0 * a.chunk;                                                       \
-            a.slabS = 2 * nch * a.chunk < a.S - a.so0 ? 2 * nch * a.chunk : a.S - a.so0;    \
-            a.pstride = (int64_t)(2 * per * a.chunk < a.S ? 2 * per * a.chunk : a.S) * n1 * n2;   \
-            launch_inv3_axis0<Inv3L1<MA_, MB_>>(a, ctx->cus, ctx->stream, c0, nch);         \
-            b.B = a.slabS; b.X = Z + (int64_t)a.so0 * n1 * n2;                              \
-            if (narrow_wins(b.C, TC_, 56))                                                  \
-                launch_inv3_l1_planes<dt2d::Inv1RCfg<32, 56, 8, MA_, MB_>>(b, (const float *)planes, a.pstride, ctx->stream); \
-            else                                                                            \
-                launch_inv3_l1_planes<dt2d::Inv1RCfg<TR_, TC_, RS_, MA_, MB_>>(b, (const float *)planes, a.pstride, ctx->stream); \
-        }                                                                                   \
+        launch_inv3_l1_axis02<Inv3L1<MA_, MB_>>(a, ctx->cus, ctx->stream);                  \
+        launch_inv3_l1_axis1<Inv3L1<MA_, MB_>>(q, ctx->stream);                             \
     }
     DT_INV3_L1_TABLE(X_)
 #undef X_
-    hipError_t e = hipGetLastError();
+    hipError_t er = hipGetLastError();
     dtcwt_hip_free(ctx, planes);
-    if (e != hipSuccess) return dtcwt_set_error(-2, "3-D inverse launch failed: %s", hipGetErrorString(e));
+    if (er != hipSuccess) return dtcwt_set_error(-2, "3-D inverse launch failed: %s", hipGetErrorString(er));
     return 0;
 }
 
@@ -591,7 +616,7 @@ bool dtcwt_inv3_level1_ok(int64_t n0, int64_t n1, int64_t n2, int m0, int m1) {
     const int taps = m0 > m1 ? m0 : m1;
     const int minw = 2 * taps > 16 ? 2 * taps : 16;
     if (n0 < 12 || n1 < minw || n2 < minw || 4 * n0 * n1 * n2 >= ((int64_t)1 << 31)) return false;
-#define X_(TR, TC, RS, A, B) if (m0 == A && m1 == B) return true;
+#define X_(A, B) if (m0 == A && m1 == B) return true;
     DT_INV3_L1_TABLE(X_)
 #undef X_
     return false;

@@ -302,28 +302,64 @@ static void run_inv3_axis0(dt3d::Inv3AParams p, int chunk) {
             }
 }
 
-template <class C>
-static void run_inv3_l1_planes(Inv1Params p, const float *planes, int64_t ps) {
-    p.tilesR = cdiv(p.R, C::TR); p.tilesC = cdiv(p.C, C::TC);
-    dt_pack_g01<C::M0, C::M1>(p);
-    std::vector<float> smem(2 * C::SY + 4);
-    float *base = smem.data();
+// level 1: the march with the axis-2 merge (k_inv3_l1_axis02), then the axis-1 merge (k_inv3_l1_axis1)
+template <class F, class G>
+static void run_inv3_l1_axis02(dt3d::Inv3AParams p, int chunk) {
+    using namespace dt3d;
+    const int e2 = p.n2 / 2;
+    p.hal = e2 > G::CK ? 2 : 0;
+    p.tilesJ = cdiv(p.n1 / 2, G::CJ); p.tilesK = p.hal ? cdiv(e2, G::CK - 4) : 1;
+    p.chunk = chunk; p.chunks = cdiv(p.n0 / 2, chunk);
+    std::vector<float> mem(2 * G::SLAB + I3Ex<G>::FLOATS + 4);
+    float *base = mem.data();
     while (((uintptr_t)base) & 15) ++base;
-    float *y1 = base, *y2 = y1 + C::SY;
-    static float wz[DT_NT][C::WN], w1[DT_NT][C::WN], w2[DT_NT][C::WN], w3[DT_NT][C::WN];
-    for (int b = 0; b < p.B; ++b)
-        for (int tr = 0; tr < p.tilesR; ++tr)
-            for (int tc = 0; tc < p.tilesC; ++tc) {
-                int r0 = tr * C::TR, c0 = tc * C::TC;
-                for (int t = 0; t < DT_NT; ++t) {
-                    inv1r_fetch_from<C, true>(p, planes, wz[t], t, b, r0, c0);
-                    inv1r_fetch_from<C, true>(p, planes + 2 * ps, w1[t], t, b, r0, c0);
-                    inv1r_fetch_from<C, true>(p, planes + ps, w2[t], t, b, r0, c0);
-                    inv1r_fetch_from<C, true>(p, planes + 3 * ps, w3[t], t, b, r0, c0);
-                    inv1r_fir<C, true>(p, wz[t], w1[t], w2[t], w3[t], y1, y2, t);
+    float *slab[2] = {base, base + G::SLAB}, *E = base + 2 * G::SLAB;
+    static Inv3TState<F, G> st[G::NT];
+    static float out[G::NT][2][4];
+    for (int ch = 0; ch < p.chunks; ++ch)
+        for (int tj = 0; tj < p.tilesJ; ++tj)
+            for (int tk = 0; tk < p.tilesK; ++tk) {
+                const int cj0 = tj * G::CJ, ck0 = tk * (G::CK - 2 * p.hal) - p.hal, c0 = ch * p.chunk;
+                const int c1 = c0 + p.chunk < p.n0 / 2 ? c0 + p.chunk : p.n0 / 2;
+                const int q0 = c0 - F::HP, q1 = c1 - 1 + F::HP;
+                for (int t = 0; t < G::NT; ++t) {
+                    memset(&st[t], 0, sizeof(st[t]));
+                    i3a_issue_rec<F, G>(p, st[t], t, cj0, ck0, q0);
+                    i3a_issue_low<F, G>(p, st[t], t, cj0, ck0, q0);
+                    i3a_slab_write<F, G>(st[t], slab[0], t);
+                    i3a_issue_rec<F, G>(p, st[t], t, cj0, ck0, q0 + 1);
                 }
-                for (int t = 0; t < DT_NT; ++t) inv1d_rows<C>(p, y1, y2, t, b, r0, c0);
+                for (int q = q0; q <= q1; ++q) {
+                    const int buf = (q - q0) & 1, c = q - F::HP;
+                    for (int i = 0; i < I3Ex<G>::FLOATS; ++i) E[i] = NAN;       // nothing stale may be read
+                    for (int t = 0; t < G::NT; ++t) {
+                        i3a_accumulate<F, G>(p, st[t], slab[buf], t, q, out[t]);
+                        i3a_slab_write<F, G>(st[t], slab[buf ^ 1], t);
+                        if (q < q1) {
+                            i3a_issue_rec<F, G>(p, st[t], t, cj0, ck0, q + 2);
+                            i3a_issue_low<F, G>(p, st[t], t, cj0, ck0, q + 1);
+                        }
+                        if (c >= c0) i3a_exchange<F, G>(p, out[t], E, t, ck0);
+                    }
+                    if (c >= c0) for (int t = 0; t < G::NT; ++t) i3a_merge_k<F, G>(p, E, t, cj0, ck0, c);
+                }
             }
+}
+
+template <class F>
+static void run_inv3_l1(dt3d::Inv3AParams a, dt3d::Inv3BParams b, int chunk) {
+    using namespace dt3d;
+    const int e2 = a.n2 / 2;
+    if (e2 <= 32) run_inv3_l1_axis02<F, I3Geo<512, 32>>(a, chunk);
+    else if (e2 <= 64) run_inv3_l1_axis02<F, I3Geo<512, 64>>(a, chunk);
+    else run_inv3_l1_axis02<F, I3Geo<512, 128>>(a, chunk);
+    const int vec = (b.n2 & 3) == 0 ? 4 : 2;
+    b.kvecs = b.n2 / vec; b.strips = cdiv(b.n1, 8);
+    const int64_t tasks = (int64_t)b.kvecs * b.strips * b.S;
+    for (int64_t t = 0; t < tasks; ++t) {
+        if (vec == 4) i3b_axis1<F, 4, 8>(b, t);
+        else i3b_axis1<F, 2, 8>(b, t);
+    }
 }
 
 template <class C>
@@ -526,12 +562,12 @@ int emu_inv3_l1(int m0, int m1, const float *LLL, const float *Yh, float *planes
     a.LLL = LLL; a.Yh = Yh; a.P = planes; a.n0 = n0; a.n1 = n1; a.n2 = n2; a.S = n0; a.crop0 = 0;
     a.pstride = (int64_t)n0 * n1 * n2;
     put_taps(a.l_a, g0, m0); put_taps(a.h_a, g1, m1);
-    Inv1Params b{};
-    b.X = Z; b.B = n0; b.R = n1; b.C = n2;
+    dt3d::Inv3BParams b{};
+    b.Q = planes; b.pstride = a.pstride; b.Z = Z; b.S = n0; b.n1 = n1; b.n2 = n2;
     put_taps(b.g0, g0, m0); put_taps(b.g1, g1, m1);
-    if (m0 == 7 && m1 == 5) { run_inv3_axis0<dt3d::Inv3L1<7, 5>>(a, chunk); run_inv3_l1_planes<Inv1RCfg<16, 120, 8, 7, 5>>(b, planes, a.pstride); return 0; }
-    if (m0 == 7 && m1 == 9) { run_inv3_axis0<dt3d::Inv3L1<7, 9>>(a, chunk); run_inv3_l1_planes<Inv1RCfg<16, 120, 8, 7, 9>>(b, planes, a.pstride); return 0; }
-    if (m0 == 3 && m1 == 5) { run_inv3_axis0<dt3d::Inv3L1<3, 5>>(a, chunk); run_inv3_l1_planes<Inv1RCfg<16, 124, 8, 3, 5>>(b, planes, a.pstride); return 0; }
+    if (m0 == 7 && m1 == 5) { run_inv3_l1<dt3d::Inv3L1<7, 5>>(a, b, chunk); return 0; }
+    if (m0 == 7 && m1 == 9) { run_inv3_l1<dt3d::Inv3L1<7, 9>>(a, b, chunk); return 0; }
+    if (m0 == 3 && m1 == 5) { run_inv3_l1<dt3d::Inv3L1<3, 5>>(a, b, chunk); return 0; }
     return -3;
 }
 

@@ -317,14 +317,15 @@ def _rand_level(shape, seed):
     return Yl, Yh
 
 
-@pytest.mark.parametrize('shape,chunk', [((12, 40, 44), 4), ((12, 42, 70), 3), ((14, 40, 130), 64), ((12, 18, 20), 2)])
+@pytest.mark.parametrize('shape,chunk', [((12, 40, 44), 4), ((12, 42, 70), 3), ((14, 40, 130), 64), ((12, 18, 20), 2),
+                                         ((12, 18, 262), 3), ((12, 16, 512), 6)])   # rows of more than 128 cells: k tiles with halo cells
 @pytest.mark.parametrize('bname', ['near_sym_a', 'antonini', 'legall'])
 def test_inv3_level1_tiles(emu, shape, chunk, bname):
     Yl, Yh = _rand_level(shape, 21)
     b = biort(bname)
     g0, p0 = _d(b[1])
     g1, p1 = _d(b[3])
-    planes = np.full((4,) + shape, np.nan, np.float32)
+    planes = np.full((2,) + shape, np.nan, np.float32)       # Q[a1]: axes 0 and 2 merged
     Z = np.full(shape, np.nan, np.float32)
     rc = emu.emu_inv3_l1(len(g0), len(g1), _f(Yl), _f(Yh), _f(planes), _f(Z), shape[0], shape[1], shape[2], chunk,
                          p0, p1)
