@@ -575,11 +575,11 @@ extern "C" int dtcwt_hip_inv3_level2(dtcwt_hip_ctx *ctx, const float *LLL, const
 #define X_(TR_, TC_, JS_, M_)                                                               \
     if (m == M_) {                                                                          \
         launch_inv3_axis0<Inv3L2<M_>>(a, ctx->cus, ctx->stream);                            \
-        /* coarse levels (a latency chain: at most four workgroups per CU with the table's tile) take 8 x 64 tiles: \
-         * 64^2-sample planes 13.0 -> 9.6 us; at 128^2 the same tiles cost 53 instead of 45 us */ \
-        if (M_ == 10 && b.zc % 64 == 0 &&                                                   \
-            (int64_t)cdiv(b.zr, TR_) * cdiv(b.zc, TC_) * b.B <= 4 * (int64_t)ctx->cus)      \
-            launch_inv3_l2_planes<dt2d::Inv2RCfg<8, 64, JS_, 10>>(b, (const float *)planes, a.pstride, ctx->stream); \
+        /* planes a multiple of 64 columns wide take 12 x 64 tiles: the table's 16 x 56 leave a quarter of the lanes of \
+         * a 128-column plane idle (56 + 56 + 16) -- 128^2 planes 42.9 -> 34.5 us, 64^2 ones 10.2 -> 8.5 (8 x 64 tiles: \
+         * 37.0 / 9.8, 16 x 64 with strips of four: 36.2 / 10.2; profiles/r03/c4_inverse.txt) */ \
+        if (M_ == 10 && b.zc % 64 == 0)                                                     \
+            launch_inv3_l2_planes<dt2d::Inv2RCfg<12, 64, 2, 10>>(b, (const float *)planes, a.pstride, ctx->stream); \
         else                                                                                \
             launch_inv3_l2_planes<dt2d::Inv2RCfg<TR_, TC_, JS_, M_>>(b, (const float *)planes, a.pstride, ctx->stream); \
     }

@@ -586,7 +586,7 @@ int emu_inv3_l2(int m, const float *LLL, const float *Yh, float *planes, float *
     if (m == 10) {
         run_inv3_axis0<dt3d::Inv3L2<10>>(a, chunk);
         // planes whose width is a multiple of 64 go through the 8 x 64 tiles the library uses at coarse levels
-        if (n2 % 64 == 0) run_inv3_l2_planes<Inv2RCfg<8, 64, 2, 10>>(b, planes, a.pstride);
+        if (n2 % 64 == 0) run_inv3_l2_planes<Inv2RCfg<12, 64, 2, 10>>(b, planes, a.pstride);
         else run_inv3_l2_planes<Inv2RCfg<16, 56, 2, 10>>(b, planes, a.pstride);
         return 0;
     }
