@@ -2,7 +2,7 @@
 """Benchmark of the hot path: 2-D DT-CWT forward + inverse, 4096x4096 float32, nlevels=4,
 near_sym_a / qshift_a (BASELINE.json metric, configs[1]) on N MI355X GPUs of one node.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c5|c5full]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c5|c5full|c4]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one forward + one inverse of one batch per GPU, input and pyramid resident in
@@ -30,6 +30,11 @@ hipEvent-pair time around that kernel on the library's stream (an empty pair cos
 the same kernel under `rocprofv3 --kernel-trace` of this command (tools/profile_round.sh ->
 profiles/traffic.json), as is `traffic`.  cpu_baseline times the NumPy oracle (a port of the
 reference's algorithm) on the host, rank 0 only, after the process group is gone.
+
+`--config c4` (BASELINE configs[3], one volume: it does not shard, N = 1 only) times the 3-D transform the same way:
+a step = Transform3d forward + inverse of one 256^3 float32 volume, nlevels=3, rotating over `--sets` volumes on one
+stream; the roofline object is for k_fwd3_l1 (level 1 of the forward, 36 B/voxel), timed by a raw event pair around
+its own C entry.
 """
 import argparse
 import json
@@ -89,7 +94,7 @@ def parse_args(argv=None):
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=500)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--config', choices=sorted(CONFIGS), default='c2')
+    ap.add_argument('--config', choices=sorted(CONFIGS) + ['c4'], default='c2')
     ap.add_argument('--sets', type=int, default=4, help='distinct buffer sets the steps rotate over')
     ap.add_argument('--streams', type=int, default=2, help='HIP streams the steps alternate over (independent images: step k '
                     'runs on stream k %% S, each with its own plan and buffer sets): the small coarse-level kernels of one '
@@ -151,6 +156,8 @@ def cpu_baseline(cfg, Xh):
 
 def main():
     args = parse_args()
+    if args.config == 'c4':
+        return main_c4(args)
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and not args.mgpu:
         respawn_under_launcher(args)
     if args.mgpu:
@@ -439,6 +446,110 @@ def main():
         print(json.dumps(out), flush=True)
         if saved_stdout is not None:
             os.dup2(2, 1)           # what the collective library still has in its stdio buffer (its banner) goes to stderr
+
+
+def main_c4(args):
+    """BASELINE configs[3]: 3-D forward + inverse of ONE 256^3 float32 volume, nlevels=3 (near_sym_a / qshift_a).  A volume
+    is not sharded (replicas only), so this mode runs at N = 1."""
+    if args.gpus != 1 or int(os.environ.get('WORLD_SIZE', '1')) != 1:
+        raise SystemExit('bench.py --config c4: one volume does not shard; run it with --gpus 1')
+    import ctypes
+    from dtcwt_amd.coeffs import biort, qshift
+    from dtcwt_amd.hip import Context, DeviceArray, Transform3d, _lib
+    from dtcwt_amd.utils import flat_taps
+    n = args.rows or 256
+    nl = 3
+    ctx = Context(0)
+    t3 = Transform3d(BIORT, QSHIFT, ctx=ctx)
+    rs = np.random.RandomState(4)
+    vols = [ctx.to_device(rs.standard_normal((n, n, n)).astype(np.float32)) for _ in range(max(1, args.sets))]
+    state = {}
+
+    def step(k):
+        p = t3.forward(vols[k % len(vols)], nlevels=nl)
+        state['p'] = p
+        state['z'] = t3.inverse(p, device_output=True)
+
+    t_end = time.perf_counter() + args.settle_ms / 1e3
+    k = 0
+    while time.perf_counter() < t_end:
+        step(k); k += 1
+        if k % 8 == 0:
+            ctx.device_sync()
+    for w in range(args.warmup):
+        step(w)
+    ctx.device_sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    ctx.device_sync()
+    dt = time.perf_counter() - t0
+    last = vols[(args.steps - 1) % len(vols)]
+    err = float(np.abs(state['z'].get() - last.get()).max())
+    # forward-only and inverse-only times of the same protocol
+    ctx.device_sync(); t1 = time.perf_counter()
+    for k in range(args.steps):
+        state['p'] = t3.forward(vols[k % len(vols)], nlevels=nl)
+    ctx.device_sync(); dt_f = time.perf_counter() - t1
+    p = state['p']
+    ctx.device_sync(); t1 = time.perf_counter()
+    for k in range(args.steps):
+        state['z'] = t3.inverse(p, device_output=True)
+    ctx.device_sync(); dt_i = time.perf_counter() - t1
+
+    # the dominant kernel, k_fwd3_l1, alone: raw event pair around dtcwt_hip_fwd3_level1 (one launch), median
+    h0, h1 = flat_taps(biort(BIORT)[0]), flat_taps(biort(BIORT)[2])
+    pd = ctypes.POINTER(ctypes.c_double)
+    LLL = DeviceArray(ctx, (n, n, n), np.float32)
+    Yh0 = DeviceArray(ctx, (n // 2, n // 2, n // 2, 28), np.complex64)
+    e0, e1 = ctx.event(), ctx.event()
+    ks, empty = [], []
+    for r in range(24):
+        X = vols[r % len(vols)]
+        e0.record()
+        _lib.check(_lib.lib().dtcwt_hip_fwd3_level1(ctx.handle, X.ptr, n, n, n, h0.ctypes.data_as(pd), h0.shape[0],
+                                                    h1.ctypes.data_as(pd), h1.shape[0], LLL.ptr, Yh0.ptr))
+        e1.record()
+        ctx.device_sync()
+        ks.append(e0.elapsed_ms(e1))
+        e0.record(); e1.record(); ctx.device_sync()
+        empty.append(e0.elapsed_ms(e1))
+    kms = float(np.median(ks[4:]))
+    vox = float(n) ** 3
+    ms = dt / args.steps * 1e3
+    out = {
+        'metric': 'Mvoxels/s 3D DT-CWT fwd+inv, %d^3 f32, nlevels=%d, %s/%s, resident in HBM' % (n, nl, BIORT, QSHIFT),
+        'value': round(vox * args.steps / dt / 1e6, 1), 'unit': 'Mvoxels/s', 'n_gpus': 1, 'steps': args.steps,
+        'warmup': args.warmup, 'settle_ms': args.settle_ms, 'ms_per_step': round(ms, 5), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': '3D forward+inverse %dx%dx%d f32, nlevels=%d, %s/%s, one volume per step' % (n, n, n, nl, BIORT, QSHIFT),
+                   'sharding': 'replicas only: a volume is not sharded', 'buffer_sets': len(vols), 'streams': 1},
+        'fwd_ms_per_step': round(dt_f / args.steps * 1e3, 5), 'inv_ms_per_step': round(dt_i / args.steps * 1e3, 5),
+        'step_frac': round(72.0 * vox / (ms * 1e-3) / HBM_PEAK, 4),
+        'roofline': {'bound': 'hbm', 'kernel': 'k_fwd3_l1 (level-1 forward, one launch)',
+                     'achieved': round(36.0 * vox / (kms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                     'frac': round(36.0 * vox / (kms * 1e-3) / HBM_PEAK, 4), 'traffic': None,
+                     'kernel_ms': round(kms, 5), 'kernel_ms_is': 'median raw hipEvent pair around dtcwt_hip_fwd3_level1, 20 launches',
+                     'event_pair_overhead_ms': round(float(np.median(empty)), 5),
+                     'algorithmic_bytes_per_launch': 36.0 * vox},
+        'recon_max_abs_err': err,
+    }
+    if not args.no_cpu_baseline:
+        # the NumPy oracle (one core) on the first volume: ~15 s at 256^3
+        from oracle import dtcwt_oracle as o
+        m = n
+        Xh = vols[0].get()[:m, :m, :m].astype(np.float32)
+        to = o.Transform3d(biort(BIORT), qshift(QSHIFT))
+        c0 = time.perf_counter()
+        po = to.forward(Xh, nlevels=nl)
+        zo = to.inverse(po)
+        cdt = time.perf_counter() - c0
+        out['cpu_baseline'] = {'value': round(m ** 3 / cdt / 1e6, 3), 'unit': 'Mvoxels/s', 'cores': 1, 'kind': 'port',
+                               'host_cpus': os.cpu_count(), 'numpy': np.__version__,
+                               'sample': 'one %d^3 f32 volume fwd+inv nlevels=%d (%.1f s)' % (m, nl, cdt)}
+        zg = np.asarray(t3.inverse(t3.forward(Xh, nlevels=nl)))
+        out['gpu_vs_cpu_recon_max_abs_diff'] = float(np.abs(zg - zo).max())
+    print(json.dumps(out))
 
 
 def main_mgpu(args):

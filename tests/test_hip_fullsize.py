@@ -221,3 +221,29 @@ def test_bench_self_spawns_ranks(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line['n_gpus'] == 1 and line['config']['buffer_sets'] == 4 and line['recon_max_abs_err'] < 1e-4
+
+
+def test_bench_config_c4_line():
+    """`bench.py --config c4` (3-D forward + inverse of one volume, here 64^3) prints the one JSON line with the roofline
+    object of k_fwd3_l1 and a reconstruction that matches the oracle's."""
+    import subprocess
+    import sys
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    env.pop('RANK', None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--config', 'c4', '--rows', '64', '--steps', '3',
+                        '--warmup', '1', '--settle-ms', '0', '--sets', '2'],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line['unit'] == 'Mvoxels/s' and line['n_gpus'] == 1 and line['config']['buffer_sets'] == 2
+    assert line['roofline']['kernel'].startswith('k_fwd3_l1') and 0 < line['roofline']['frac'] < 1
+    assert line['recon_max_abs_err'] < 1e-4 and line['gpu_vs_cpu_recon_max_abs_diff'] < 1e-4
+    assert line['cpu_baseline']['kind'] == 'port'
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--config', 'c4', '--gpus', '2', '--steps', '1'],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and 'does not shard' in (r.stderr + r.stdout)
