@@ -52,19 +52,17 @@ __device__ __forceinline__ void fwd3_l1_march(const Fwd3L1Params &p, float *smem
     __builtin_amdgcn_s_waitcnt(0x0F70);
     int rot = 0;
     for (int i = i0; i < iend; i += 2) {             // chunks start and end on even slices
-        f3l1_axis0<C>(p, st, S0, XR, tid, rot);
+        f3l1_axis0<C, 0>(p, st, S0, XR, tid, rot);
         __syncthreads();
         f3l1_axis2<C>(p, S0, S1, tid);
         __syncthreads();
-        f3l1_rotate<C>(st, XR, tid, rot, false);
-        rot = rot + 1 == C::MR ? 0 : rot + 1;
         f3l1_axis1<C, FULL>(p, st.ev, S1, tid, i, j0, k0);
-        f3l1_axis0<C>(p, st, S0, XR, tid, rot);
+        f3l1_axis0<C, 1>(p, st, S0, XR, tid, rot);
         __syncthreads();
         f3l1_axis2<C>(p, S0, S1, tid);
         __syncthreads();
-        f3l1_rotate<C>(st, XR, tid, rot, true);
-        rot = rot + 1 == C::MR ? 0 : rot + 1;
+        f3l1_rotate2<C>(st, XR, tid, rot);
+        rot = rot + 2 >= C::MR ? rot + 2 - C::MR : rot + 2;
         f3l1_prefetch<C>(p, st, tid, i + 2);         // ahead of this pair's stores (reflected past the end: harmless)
         float od[8][4];
         f3l1_axis1<C, FULL>(p, od, S1, tid, i + 1, j0, k0);

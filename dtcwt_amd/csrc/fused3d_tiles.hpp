@@ -199,44 +199,65 @@ DT_HD void f3l1_prologue(const Fwd3L1Params &p, Fwd3L1State<C> &st, float *XR, i
 // both filters of axis 0 over a k-adjacent position pair: M0 + M1 packed FMAs, lo / hi pairs to S0
 template <class C>
 DT_HD void f3l1_axis0_pair(const Fwd3L1Params &p, const f3_v2f (&r)[C::MR], float *S0, int soff) {
+    // the two chains side by side: a packed FMA that feeds the next instruction costs a wait state (s_nop)
     f3_v2f lo = {0.f, 0.f}, hi = {0.f, 0.f};
 #pragma unroll
-    for (int d = C::H - C::H0; d <= C::H + C::H0; ++d) lo += p.c01[2 * d] * r[d];
-#pragma unroll
-    for (int k = 0; k < C::M1; ++k) hi += p.h1s[k] * r[C::H + C::H1 - k];      // the a0 = 1 half carries cube2c's 1/2 from here
+    for (int d = 0; d < C::MR; ++d) {
+        if (d >= C::H - C::H0 && d <= C::H + C::H0) lo += p.c01[2 * d] * r[d];
+        if (d >= C::H - C::H1 && d <= C::H + C::H1) hi += p.h1s[C::H + C::H1 - d] * r[d];    // the a0 = 1 half carries cube2c's 1/2 from here
+    }
     *reinterpret_cast<f3_v2f *>(S0 + soff) = lo;
     *reinterpret_cast<f3_v2f *>(S0 + C::PJ * C::S0S + soff) = hi;
 }
 
-// filter the ring (slices i-H .. i+H) along axis 0 into S0; rot = slices rotated so far (mod MR): the oldest
-// slice of the leftover ring sits in slot rot
-template <class C>
+// filter the ring along axis 0 into S0.  ODD = 0: slices i-H .. i+H = the ring; ODD = 1 (the second slice of a pair):
+// slices i-H+1 .. i+H+1 = ring[1 ..] and the first prefetched slice, so that the ring moves once per slice PAIR (by two
+// slots: 42 register moves per thread and pair instead of 84).  rot: the slot of the leftover ring (XR) that holds
+// the oldest slice.
+template <class C, int ODD>
 DT_HD void f3l1_axis0(const Fwd3L1Params &p, Fwd3L1State<C> &st, float *S0, const float *XR, int tid, int rot) {
 #pragma unroll
-    for (int s = 0; s < C::NPP; ++s) f3l1_axis0_pair<C>(p, st.ring[s], S0, st.soff[s]);
+    for (int s = 0; s < C::NPP; ++s) {
+        if (ODD) {
+            DT_PIN_HERE(st.nxa[s]);                       // the wait for the prefetched slice belongs here
+            f3_v2f r[C::MR];
+#pragma unroll
+            for (int t = 0; t < C::MR - 1; ++t) r[t] = st.ring[s][t + 1];
+            r[C::MR - 1] = st.nxa[s];
+            f3l1_axis0_pair<C>(p, r, S0, st.soff[s]);
+        } else {
+            f3l1_axis0_pair<C>(p, st.ring[s], S0, st.soff[s]);
+        }
+    }
     if (tid < C::NLEFT) {
         f3_v2f r[C::MR];
 #pragma unroll
-        for (int t = 0; t < C::MR; ++t) {
-            int slot = rot + t;
+        for (int t = 0; t < C::MR - ODD; ++t) {
+            int slot = rot + t + ODD;
             if (slot >= C::MR) slot -= C::MR;
             r[t] = *reinterpret_cast<const f3_v2f *>(XR + 2 * (slot * C::NLEFT + tid));
         }
+        if (ODD) r[C::MR - 1] = st.exa;
         f3l1_axis0_pair<C>(p, r, S0, st.esoff);
     }
 }
 
-// ring <- slices one further, the new one from nxa (second == false) or nxb
+// ring <- two slices further: the prefetched pair behind what is left
 template <class C>
-DT_HD void f3l1_rotate(Fwd3L1State<C> &st, float *XR, int tid, int rot, bool second) {
+DT_HD void f3l1_rotate2(Fwd3L1State<C> &st, float *XR, int tid, int rot) {
 #pragma unroll
     for (int s = 0; s < C::NPP; ++s) {
 #pragma unroll
-        for (int t = 0; t < C::MR - 1; ++t) st.ring[s][t] = st.ring[s][t + 1];
-        st.ring[s][C::MR - 1] = second ? st.nxb[s] : st.nxa[s];
+        for (int t = 0; t < C::MR - 2; ++t) st.ring[s][t] = st.ring[s][t + 2];
+        st.ring[s][C::MR - 2] = st.nxa[s];
+        st.ring[s][C::MR - 1] = st.nxb[s];
         DT_PIN_HERE(st.ring[s][C::MR - 1]);
     }
-    if (tid < C::NLEFT) *reinterpret_cast<f3_v2f *>(XR + 2 * (rot * C::NLEFT + tid)) = second ? st.exb : st.exa;
+    if (tid < C::NLEFT) {
+        const int r1 = rot + 1 >= C::MR ? rot + 1 - C::MR : rot + 1;
+        *reinterpret_cast<f3_v2f *>(XR + 2 * (rot * C::NLEFT + tid)) = st.exa;
+        *reinterpret_cast<f3_v2f *>(XR + 2 * (r1 * C::NLEFT + tid)) = st.exb;
+    }
 }
 
 // S1[2*a0 + a2][pj][k] = (axis-2 filter a2) of S0[a0][pj][.]
@@ -256,18 +277,24 @@ DT_HD void f3l1_axis2(const Fwd3L1Params &p, const float *S0, float *S1, int tid
             f4 v = src[q];
             w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
         }
-        f3_v2f a[4];                                      // (a2 = 0, a2 = 1) of outputs k = 4c .. 4c + 3
+        // (a2 = 0, a2 = 1) of outputs k = 4c .. 4c + 3, the even ones (0, 2) and the odd ones (1, 3) each in ONE
+        // four-register value: they leave as one 16-byte LDS write each, and register pairs that were accumulated
+        // apart had to be moved together first (4 v_mov per write).  The four chains side by side: a packed FMA
+        // that feeds its neighbour costs a wait state.
+        dt_v4f ev = {0.f, 0.f, 0.f, 0.f}, od = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            a[e] = f3_v2f{0.f, 0.f};
-#pragma unroll
-            for (int d = 0; d < C::MR; ++d) a[e] += f3l1_tap_pair<C>(p, d) * f3_v2f{w[e + d], w[e + d]};
+        for (int d = 0; d < C::MR; ++d) {
+            const f3_v2f tp = f3l1_tap_pair<C>(p, d);
+            ev.lo += tp * f3_v2f{w[d], w[d]};
+            od.lo += tp * f3_v2f{w[1 + d], w[1 + d]};
+            ev.hi += tp * f3_v2f{w[2 + d], w[2 + d]};
+            od.hi += tp * f3_v2f{w[3 + d], w[3 + d]};
         }
         // S1[a0][pj][k parity][k / 2] pairs: the even and the odd outputs of the task are 16 bytes each, at a 16-byte
         // lane stride (conflict-free), and stay packed for the axis-1 chains
         float *d = S1 + (((vol * C::PJ + pj) * 2) * (C::TK / 2) + 2 * c) * 2;
-        *reinterpret_cast<f4 *>(d) = f4{a[0].x, a[0].y, a[2].x, a[2].y};
-        *reinterpret_cast<f4 *>(d + C::TK) = f4{a[1].x, a[1].y, a[3].x, a[3].y};
+        *reinterpret_cast<dt_v4f *>(d) = ev;
+        *reinterpret_cast<dt_v4f *>(d + C::TK) = od;
     }
 }
 
@@ -313,20 +340,25 @@ DT_HD void f3l1_axis1(const Fwd3L1Params &p, float (&out)[8][4], const float *S1
             u[r][1] = *reinterpret_cast<const f3_v2f *>(q + C::TK);
         }
 #pragma unroll
-        for (int e = 0; e < 2; ++e)
+        for (int e = 0; e < 2; ++e) {
+            // the four chains of a row (lo / hi x two columns) side by side: no packed FMA feeds its neighbour
+            f3_v2f lo[2] = {{0.f, 0.f}, {0.f, 0.f}}, hi[2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+            for (int d = 0; d < 2 * C::H + 1; ++d)          // window offset: row e + d
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    if (d >= C::H - C::H0 && d <= C::H + C::H0) lo[c] += p.c01[2 * d] * u[e + d][c];
+                    if (d >= C::H - C::H1 && d <= C::H + C::H1) {
+                        if (a0 == 0) hi[c] += p.h1s[C::H + C::H1 - d] * u[e + d][c];
+                        else hi[c] += p.c01[2 * d + 1] * u[e + d][c];
+                    }
+                }
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                f3_v2f lo = {0.f, 0.f}, hi = {0.f, 0.f};
-#pragma unroll
-                for (int t = 0; t < C::M0; ++t) lo += p.c01[2 * (C::H + C::H0 - t)] * u[e + C::H + C::H0 - t][c];
-#pragma unroll
-                for (int t = 0; t < C::M1; ++t) {
-                    if (a0 == 0) hi += p.h1s[t] * u[e + C::H + C::H1 - t][c];
-                    else hi += p.c01[2 * (C::H + C::H1 - t) + 1] * u[e + C::H + C::H1 - t][c];
-                }
-                out[a0 * 4 + 0][e * 2 + c] = lo.x; out[a0 * 4 + 1][e * 2 + c] = lo.y;
-                out[a0 * 4 + 2][e * 2 + c] = hi.x; out[a0 * 4 + 3][e * 2 + c] = hi.y;
+                out[a0 * 4 + 0][e * 2 + c] = lo[c].x; out[a0 * 4 + 1][e * 2 + c] = lo[c].y;
+                out[a0 * 4 + 2][e * 2 + c] = hi[c].x; out[a0 * 4 + 3][e * 2 + c] = hi[c].y;
             }
+        }
     }
     if (FULL || (j < p.n1 && k < p.n2)) {
         float *L = p.LLL + ((int64_t)i * p.n1 + j) * p.n2 + k;

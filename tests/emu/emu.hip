@@ -204,23 +204,21 @@ static int run_fwd3_l1(dt3d::Fwd3L1Params p, int chunk) {
                 static float od[C::NT][8][4];
                 int rot = 0;
                 for (int i = i0; i < iend; i += 2) {
-                    for (int t = 0; t < C::NT; ++t) f3l1_axis0<C>(p, st[t], S0, XR, t, rot);
+                    for (int t = 0; t < C::NT; ++t) f3l1_axis0<C, 0>(p, st[t], S0, XR, t, rot);
                     for (int t = 0; t < C::NT; ++t) f3l1_axis2<C>(p, S0, S1, t);
                     for (int t = 0; t < C::NT; ++t) {
-                        f3l1_rotate<C>(st[t], XR, t, rot, false);
                         if (full) f3l1_axis1<C, true>(p, st[t].ev, S1, t, i, j0, k0);
                         else f3l1_axis1<C, false>(p, st[t].ev, S1, t, i, j0, k0);
                     }
-                    rot = rot + 1 == C::MR ? 0 : rot + 1;
-                    for (int t = 0; t < C::NT; ++t) f3l1_axis0<C>(p, st[t], S0, XR, t, rot);
+                    for (int t = 0; t < C::NT; ++t) f3l1_axis0<C, 1>(p, st[t], S0, XR, t, rot);
                     for (int t = 0; t < C::NT; ++t) f3l1_axis2<C>(p, S0, S1, t);
                     for (int t = 0; t < C::NT; ++t) {
-                        f3l1_rotate<C>(st[t], XR, t, rot, true);
+                        f3l1_rotate2<C>(st[t], XR, t, rot);
                         f3l1_prefetch<C>(p, st[t], t, i + 2);
                         if (full) f3l1_axis1<C, true>(p, od[t], S1, t, i + 1, j0, k0);
                         else f3l1_axis1<C, false>(p, od[t], S1, t, i + 1, j0, k0);
                     }
-                    rot = rot + 1 == C::MR ? 0 : rot + 1;
+                    rot = rot + 2 >= C::MR ? rot + 2 - C::MR : rot + 2;
                     for (int pass = 0; pass < C::SP; ++pass) {
                         for (int t = 0; t < C::NT; ++t) f3l1_pack_stage<C>(st[t].ev, od[t], stage, t, pass);
                         for (int t = 0; t < C::NT; ++t) {
