@@ -1,0 +1,89 @@
+// Launchers of the marching wavefront programs (march2d.hpp) behind the 2-D plan (fused2d.hip).
+//
+// Levels 1 + 2 of Transform2d.forward (dtcwt/numpy/transform2d.py:112-160) as ONE launch whose level-1 lowpass never
+// leaves the registers; used by dtcwt_hip_plan2d_forward when the geometry allows it, otherwise the plan keeps its
+// one tile-program launch per level.  Built without SLP vectorisation (Makefile): packed FMAs have no throughput
+// advantage on gfx950 and cost a v_mov per operand.
+#include <cmath>
+#include <cstdlib>
+
+#include "common.hpp"
+#include "march2d.hpp"
+
+namespace {
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+bool symmetric(const std::vector<double> &h) {
+    double mx = 0;
+    for (double v : h) mx = std::fmax(mx, std::fabs(v));
+    for (size_t k = 0; k < h.size() / 2; ++k)
+        if (std::fabs(h[k] - h[h.size() - 1 - k]) > 1e-12 * mx) return false;
+    return true;
+}
+
+// rows per band: one job = one wavefront = (strip, band, image) marches band_rows / 2 + M - 2 steps, of which M - 2 are
+// the (cheaper) warm-up steps above and below the band that its level-2 windows reach into.  The kernel needs ~190
+// registers, i.e. two wavefronts per SIMD: `slots` wavefronts are resident at a time, and a grid of slots + 1 jobs
+// takes as long as one of 2 x slots -- so the band height is the one that minimises rounds x steps.
+int pick_band_rows(int B, int R, int nstrip, int M, int cus) {
+    if (const char *e = getenv("DTCWT_HIP_MARCH_BAND")) { const int v = atoi(e) & ~3; if (v >= 8) return v; }
+    const int64_t slots = (int64_t)cus * 8;
+    int best = 64; double best_cost = 1e30;
+    for (int br = 24; br <= 512; br += 4) {
+        const int64_t jobs = (int64_t)B * nstrip * cdiv(R, br);
+        const int64_t rounds = (jobs + slots - 1) / slots;
+        const double cost = (double)rounds * (br / 2 + 0.45 * (M - 2));
+        if (cost < best_cost * 0.999) { best_cost = cost; best = br; }
+    }
+    return best;
+}
+
+}  // namespace
+
+// the geometry / filters the one-launch levels 1 + 2 handle; everything else stays with the tile programs
+bool dtcwt_march_fwd12_ok(int rows, int cols, const std::vector<double> &h0o, const std::vector<double> &h1o,
+                          const std::vector<double> &h0a) {
+    static const int off = [] { const char *e = getenv("DTCWT_HIP_MARCH"); return e && e[0] == '0'; }();
+    if (off) return false;
+    const int m0 = (int)h0o.size(), m1 = (int)h1o.size(), m = (int)h0a.size();
+    if (!((m0 == 5 && m1 == 7) || (m0 == 9 && m1 == 7) || (m0 == 5 && m1 == 3)) || m != 10) return false;
+    if (!symmetric(h0o) || !symmetric(h1o)) return false;     // mirrored halo lanes: see march2d.hpp
+    if (rows % 4 || cols % 4 || rows < 32 || cols < 32) return false;
+    if ((int64_t)rows * cols * 4 >= ((int64_t)1 << 31)) return false;     // 32-bit row offsets inside an image
+    return true;
+}
+
+template <int M0, int M1, int M>
+static int launch_fwd12(dtm::Fwd12mParams &p, int cus, hipStream_t s) {
+    using G = dtm::Fwd12m<M0, M1, M>;
+    p.nstrip = cdiv(p.C, 4 * G::VL);
+    p.band_rows = pick_band_rows(p.B, p.R, p.nstrip, M, cus);
+    p.nband = cdiv(p.R, p.band_rows);
+    const int64_t jobs = (int64_t)p.nstrip * p.nband * p.B;
+    if (jobs >= ((int64_t)1 << 31)) return -3;
+    dtm::k_fwd12m<M0, M1, M, 2, 0><<<(unsigned)jobs, 64, 0, s>>>(p);
+    return 0;
+}
+
+// X -> Yh0, Yh1, LoLo2; taps as the plan holds them (l_a .. h_b: coldfilt's first / second argument, Fwd2Params)
+int dtcwt_march_fwd12(const float *X, float *Yh0, float *Yh1, float *LoLo2, int B, int R, int C,
+                      const std::vector<double> &h0o, const std::vector<double> &h1o,
+                      const float *l_a, const float *l_b, const float *h_a, const float *h_b, int m,
+                      int lo_a_first, int hi_a_first, int cus, hipStream_t s) {
+    dtm::Fwd12mParams p{};
+    p.X = X; p.Yh0 = Yh0; p.Yh1 = Yh1; p.LoLo2 = LoLo2; p.B = B; p.R = R; p.C = C;
+    p.lo_a_first = lo_a_first; p.hi_a_first = hi_a_first;
+    for (int k = 0; k < dtm::MAXT1; ++k) {
+        p.h0[k] = k < (int)h0o.size() ? (float)h0o[k] : 0.f;
+        p.h1[k] = k < (int)h1o.size() ? (float)h1o[k] : 0.f;
+    }
+    dtm::dtm_pack_qshift(p, m, l_a, l_b, h_a, h_b);
+    const int m0 = (int)h0o.size(), m1 = (int)h1o.size();
+    if (m == 10) {
+        if (m0 == 5 && m1 == 7) return launch_fwd12<5, 7, 10>(p, cus, s);
+        if (m0 == 9 && m1 == 7) return launch_fwd12<9, 7, 10>(p, cus, s);
+        if (m0 == 5 && m1 == 3) return launch_fwd12<5, 3, 10>(p, cus, s);
+    }
+    return -3;
+}

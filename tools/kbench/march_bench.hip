@@ -1,0 +1,242 @@
+// Marching wavefront programs (dtcwt_amd/csrc/march2d.hpp) against the tile programs of the library:
+// same input, outputs compared, then timed over four rotating buffer sets with the knock-outs of ko_bench
+// (cached loads / stores to a few rows / both = arithmetic only).  Measurement tool, not product.
+//
+//   make -C tools/kbench march_bench && tools/kbench/march_bench [N=4096] [reps=40]
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <chrono>
+
+#include "fused2d_tiles.hpp"
+#include "fused2d_tiles_v2.hpp"
+#include "march2d.hpp"
+
+using namespace dt2d;
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline unsigned grid_for(int ntile, int order = 1) {
+    const int q = 8 * (order > 1 ? order : 1);
+    return (unsigned)(cdiv(ntile, q) * q);
+}
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+template <class C>
+__global__ void __launch_bounds__(DT_NT) ref_fwd1(Fwd1Params p) {
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS + 4 * STAGE_FLOATS_PER_WAVE];
+    const int ntile = p.tilesR * p.tilesC * p.B;
+    int t = tile_of(blockIdx.x, ntile, p.xcd_order);
+    if (t >= ntile) return;
+    int tc, tr, b;
+    dt_tile_decode(p, t, tc, tr, b);
+    float *sLo = smem, *sHi = sLo + C::SL, *stage = smem + C::LDS_FLOATS;
+    fwd1d_cols<C>(p, sLo, sHi, threadIdx.x, b, tr * C::TR, tc * C::TC, nullptr);
+    __syncthreads();
+    const int r0 = tr * C::TR, c0 = tc * C::TC;
+    constexpr int NQ = (C::TR / 2) * (C::TC / 2);
+    for (int base = 0; base < NQ; base += DT_NT) {
+        fwd1s_rows_compute<C>(p, sLo, sHi, stage, threadIdx.x, base, b, r0, c0, nullptr);
+        DT_WAVE_LDS_SYNC();
+        fwd1s_rows_flush<C>(p, stage, threadIdx.x, base, b, r0, c0);
+        DT_WAVE_LDS_SYNC();
+    }
+}
+
+template <class C>
+__global__ void __launch_bounds__(DT_NT) ref_fwd2(Fwd2Params p) {
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_FLOATS + 4 * STAGE_FLOATS_PER_WAVE];
+    const int ntile = p.tilesR * p.tilesC * p.B;
+    int t = tile_of(blockIdx.x, ntile, p.xcd_order);
+    if (t >= ntile) return;
+    int tc, tr, b;
+    dt_tile_decode(p, t, tc, tr, b);
+    float *sLo = smem, *sHi = sLo + C::SL, *stage = smem + C::LDS_FLOATS;
+    fwd2d_cols<C>(p, sLo, sHi, threadIdx.x, b, tr * C::TR, tc * C::TC, nullptr);
+    __syncthreads();
+    const int r0 = tr * C::TR, c0 = tc * C::TC;
+    for (int base = 0; base < C::TI * C::TJ; base += DT_NT) {
+        fwd2s_rows_compute<C>(p, sLo, sHi, stage, threadIdx.x, base, b, r0, c0, nullptr);
+        DT_WAVE_LDS_SYNC();
+        fwd2s_rows_flush<C>(p, stage, threadIdx.x, base, b, r0, c0);
+        DT_WAVE_LDS_SYNC();
+    }
+}
+
+static const double H0A[10] = {0.03516384, 0., -0.08832942, 0.23389032, 0.76027237, 0.5875183, 0., -0.11430184, 0., 0.};
+static const double H1A[10] = {0., 0., -0.11430184, 0., 0.5875183, -0.76027237, 0.23389032, 0.08832942, 0., -0.03516384};
+static void putr(float *dst, const double *src, int n, bool rev) { for (int k = 0; k < DT_MAXT; ++k) dst[k] = k < n ? (float)src[rev ? n - 1 - k : k] : 0.f; }
+
+static const double H0O[5] = {-0.05, 0.25, 0.6, 0.25, -0.05};
+static const double H1O[7] = {-0.0107142857142857, 0.0535714285714286, 0.260714285714286, -0.607142857142857,
+                              0.260714285714286, 0.0535714285714286, -0.0107142857142857};
+static void put(float *dst, const double *src, int n, int cap) { for (int k = 0; k < cap; ++k) dst[k] = k < n ? (float)src[k] : 0.f; }
+
+constexpr int NSET = 4;
+struct Set { float *X, *L1, *Y0, *L1r, *Y0r, *L2, *Y1, *L2r, *Y1r; };
+static Set sets[NSET];
+static int N = 4096, REPS = 40;
+static hipStream_t st, st_a, st_b;
+
+template <class F>
+static double time_it(F launch) {
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 8; ++i) launch(i % NSET);
+    CK(hipEventRecord(a, st));
+    for (int i = 0; i < REPS; ++i) launch(i % NSET);
+    CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
+    CK(hipGetLastError());
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    CK(hipEventDestroy(a)); CK(hipEventDestroy(b));
+    return ms * 1e3 / REPS;
+}
+
+// two independent images in flight: launches alternate over two streams (bench.py's default protocol)
+template <class F>
+static double time_two_streams(F launch) {
+    for (int i = 0; i < 8; ++i) { st = (i & 1) ? st_b : st_a; launch(i % NSET); }
+    CK(hipDeviceSynchronize());
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < REPS; ++i) { st = (i & 1) ? st_b : st_a; launch(i % NSET); }
+    CK(hipDeviceSynchronize());
+    const auto t1 = std::chrono::steady_clock::now();
+    st = st_a;
+    return std::chrono::duration<double, std::micro>(t1 - t0).count() / REPS;
+}
+
+using F1 = Fwd1DCfg<32, 64, 8, 5, 7>;
+using F2 = Fwd2DCfg<16, 56, 4, 10>;
+
+static void fill_fwd2(Fwd2Params &p) {
+    putr(p.l_a, H0A, 10, true); putr(p.l_b, H0A, 10, false); putr(p.h_a, H1A, 10, true); putr(p.h_b, H1A, 10, false);
+    p.lo_a_first = 1; p.hi_a_first = 0; dt_pack_lh(p);
+}
+static void launch_ref2(float *L1, float *L2, float *Y1) {
+    Fwd2Params p{}; p.X = L1; p.LoLo = L2; p.Yh = Y1; p.B = 1; p.inR = p.inC = p.LR = p.LC = N;
+    p.xcd_order = 1; p.stream_records = 1; fill_fwd2(p);
+    p.tilesR = cdiv(N / 2, F2::TR); p.tilesC = cdiv(N / 2, F2::TC);
+    dt_set_tile_magic(p);
+    ref_fwd2<F2><<<grid_for(p.tilesR * p.tilesC), DT_NT, 0, st>>>(p);
+}
+template <int P, int KO>
+static void launch_f12(int s, int band_rows) {
+    using G = dtm::Fwd12m<5, 7, 10>;
+    dtm::Fwd12mParams p{}; p.X = sets[s].X; p.Yh0 = sets[s].Y0; p.Yh1 = sets[s].Y1; p.LoLo2 = sets[s].L2; p.B = 1; p.R = p.C = N;
+    p.nstrip = cdiv(N, 4 * G::VL); p.band_rows = band_rows; p.nband = cdiv(N, band_rows);
+    put(p.h0, H0O, 5, dtm::MAXT1); put(p.h1, H1O, 7, dtm::MAXT1);
+    Fwd2Params q{}; fill_fwd2(q);
+    dtm::dtm_pack_qshift(p, 10, q.l_a, q.l_b, q.h_a, q.h_b); p.lo_a_first = q.lo_a_first; p.hi_a_first = q.hi_a_first;
+    dtm::k_fwd12m<5, 7, 10, P, KO><<<p.nstrip * p.nband, 64, 0, st>>>(p);
+}
+template <int P>
+static void run_f12(int band_rows) {
+    const double a = time_it([&](int s) { launch_f12<P, 0>(s, band_rows); });
+    const double b = time_it([&](int s) { launch_f12<P, 1>(s, band_rows); });
+    const double c = time_it([&](int s) { launch_f12<P, 2>(s, band_rows); });
+    const double d = time_it([&](int s) { launch_f12<P, 3>(s, band_rows); });
+    printf("k_fwd12m P=%d band_rows=%3d          %9.2f %9.2f %9.2f %9.2f\n", P, band_rows, a, b, c, d);
+    fflush(stdout);
+}
+
+static void launch_ref(int s, float *L, float *Y) {
+    Fwd1Params p{}; p.X = sets[s].X; p.LoLo = L; p.Yh = Y; p.B = 1; p.inR = p.inC = p.LR = p.LC = N;
+    p.xcd_order = 8; put(p.h0, H0O, 5, DT_MAXT); put(p.h1, H1O, 7, DT_MAXT); dt_pack_c01<5, 7>(p);
+    p.tilesR = cdiv(N, F1::TR); p.tilesC = cdiv(N, F1::TC);
+    dt_set_tile_magic(p);
+    ref_fwd1<F1><<<grid_for(p.tilesR * p.tilesC, 8), DT_NT, 0, st>>>(p);
+}
+
+template <int P, int WPB, int KO>
+static void launch_march(int s, int seg_rows) {
+    using G = dtm::Fwd1m<5, 7>;
+    dtm::Fwd1mParams p{}; p.X = sets[s].X; p.LoLo = sets[s].L1; p.Yh = sets[s].Y0; p.B = 1; p.R = p.C = N;
+    p.nstrip = cdiv(N, 4 * G::VL); p.seg_rows = seg_rows; p.nseg = cdiv(N, seg_rows);
+    put(p.h0, H0O, 5, dtm::MAXT1); put(p.h1, H1O, 7, dtm::MAXT1);
+    const int njob = p.nstrip * p.nseg;
+    dtm::k_fwd1m<5, 7, P, WPB, KO><<<cdiv(njob, WPB), 64 * WPB, 0, st>>>(p);
+}
+
+static double maxdiff(const float *a, const float *b, size_t n, double *mx) {
+    std::vector<float> ha(n), hb(n);
+    CK(hipMemcpy(ha.data(), a, n * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hb.data(), b, n * 4, hipMemcpyDeviceToHost));
+    double d = 0, m = 0;
+    int shown = 0; size_t nbad = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const double e = fabs((double)ha[i] - hb[i]);
+        d = fmax(d, e); m = fmax(m, fabs((double)hb[i]));
+        if (e > 1e-5) { ++nbad; if (shown < 12) { printf("   mismatch at %zu (row %zu, col %zu of %d): %g vs %g\n", i, i / N, i % N, N, ha[i], hb[i]); ++shown; } }
+    }
+    if (nbad) printf("   %zu mismatches\n", nbad);
+    *mx = m; return d;
+}
+
+template <int P, int WPB>
+static void run_all(int seg_rows) {
+    const double a = time_it([&](int s) { launch_march<P, WPB, 0>(s, seg_rows); });
+    const double b = time_it([&](int s) { launch_march<P, WPB, 1>(s, seg_rows); });
+    const double c = time_it([&](int s) { launch_march<P, WPB, 2>(s, seg_rows); });
+    const double d = time_it([&](int s) { launch_march<P, WPB, 3>(s, seg_rows); });
+    const double e = time_it([&](int s) { launch_march<P, WPB, 4>(s, seg_rows); });
+    const double f = time_it([&](int s) { launch_march<P, WPB, 5>(s, seg_rows); });
+    const double g = time_it([&](int s) { launch_march<P, WPB, 13>(s, seg_rows); });
+    printf("k_fwd1m P=%d WPB=%d seg_rows=%3d  %9.2f %9.2f %9.2f %9.2f | no store instr %6.2f, + cached ld %6.2f, + no DPP %6.2f\n", P, WPB, seg_rows, a, b, c, d, e, f, g);
+    fflush(stdout);
+}
+
+int main(int argc, char **argv) {
+    if (argc > 1) N = atoi(argv[1]);
+    if (argc > 2) REPS = atoi(argv[2]);
+    CK(hipStreamCreate(&st_a)); CK(hipStreamCreate(&st_b)); st = st_a;
+    const size_t px = (size_t)N * N;
+    std::vector<float> h(px);
+    for (size_t i = 0; i < px; ++i) h[i] = (float)((double)rand() / RAND_MAX - 0.5);
+    for (auto &s : sets) {
+        CK(hipMalloc(&s.X, px * 4)); CK(hipMalloc(&s.L1, px * 4)); CK(hipMalloc(&s.Y0, px * 12));
+        CK(hipMemcpy(s.X, h.data(), px * 4, hipMemcpyHostToDevice));
+        CK(hipMemset(s.L1, 0, px * 4)); CK(hipMemset(s.Y0, 0, px * 12));
+        CK(hipMalloc(&s.L2, px)); CK(hipMalloc(&s.Y1, px * 3)); CK(hipMemset(s.L2, 0, px)); CK(hipMemset(s.Y1, 0, px * 3));
+    }
+    CK(hipMalloc(&sets[0].L2r, px)); CK(hipMalloc(&sets[0].Y1r, px * 3));
+    CK(hipMalloc(&sets[0].L1r, px * 4)); CK(hipMalloc(&sets[0].Y0r, px * 12));
+    // correctness: march vs tile program on set 0
+    launch_ref(0, sets[0].L1r, sets[0].Y0r);
+    launch_march<2, 4, 0>(0, 32);
+    CK(hipStreamSynchronize(st));
+    double m1, m2;
+    const double d1 = maxdiff(sets[0].L1, sets[0].L1r, px, &m1), d2 = maxdiff(sets[0].Y0, sets[0].Y0r, px * 3, &m2);
+    printf("march vs tile program: LoLo max|diff| %.3g (max %.3g), Yh max|diff| %.3g (max %.3g)\n", d1, m1, d2, m2);
+    CK(hipMemset(sets[0].L1, 0, px * 4)); CK(hipMemset(sets[0].Y0, 0, px * 12));
+    launch_march<4, 1, 0>(0, 48);
+    CK(hipStreamSynchronize(st));
+    const double d3 = maxdiff(sets[0].L1, sets[0].L1r, px, &m1), d4 = maxdiff(sets[0].Y0, sets[0].Y0r, px * 3, &m2);
+    printf("march (P=4, 1 wave per block, 48-row segments): LoLo %.3g, Yh %.3g\n", d3, d4);
+
+    {   // levels 1 + 2 in one march against the two tile programs
+        launch_ref2(sets[0].L1r, sets[0].L2r, sets[0].Y1r);
+        for (int br : {64, 128, 32}) {
+            CK(hipMemset(sets[0].Y0, 0, px * 12)); CK(hipMemset(sets[0].Y1, 0, px * 3)); CK(hipMemset(sets[0].L2, 0, px));
+            launch_f12<2, 0>(0, br);
+            CK(hipStreamSynchronize(st));
+            double ma, mb, mc;
+            const double e0 = maxdiff(sets[0].Y0, sets[0].Y0r, px * 3, &ma), e1 = maxdiff(sets[0].Y1, sets[0].Y1r, px * 3 / 4, &mb),
+                         e2 = maxdiff(sets[0].L2, sets[0].L2r, px / 4, &mc);
+            printf("k_fwd12m (bands of %d rows) vs tile programs: Yh0 %.3g (max %.3g), Yh1 %.3g (max %.3g), LoLo2 %.3g (max %.3g)\n", br, e0, ma, e1, mb, e2, mc);
+        }
+    }
+    for (int i = 0; i < 30; ++i) launch_ref(i % NSET, sets[i % NSET].L1, sets[i % NSET].Y0);      // settle the clocks
+    printf("%dx%d, %d reps over %d buffer sets; us per launch\n", N, N, REPS, NSET);
+    printf("%-40s %9s %9s %9s %9s\n", "kernel", "full", "cached-ld", "no-store", "arith-only");
+    for (int rep = 0; rep < 2; ++rep) {
+        const double r = time_it([&](int s) { launch_ref(s, sets[s].L1, sets[s].Y0); });
+        printf("%-40s %9.2f\n", "k_fwd1 tile program (library)", r);
+        const double r2 = time_it([&](int s) { launch_ref2(sets[s].L1, sets[s].L2, sets[s].Y1); });
+        printf("%-40s %9.2f\n", "k_fwd2 tile program (library)", r2);
+        for (int br : {40, 64}) run_f12<2>(br);
+        printf("two streams, us per image: tile fwd1 + fwd2 %.2f", time_two_streams([&](int s) { launch_ref(s, sets[s].L1, sets[s].Y0); launch_ref2(sets[s].L1, sets[s].L2, sets[s].Y1); }));
+        for (int br : {40, 48, 64, 80, 96, 128}) printf(" | k_fwd12m bands of %d: %.2f", br, time_two_streams([&](int s) { launch_f12<2, 0>(s, br); }));
+        printf("\none stream, us per image: tile fwd1 + fwd2 %.2f\n", time_it([&](int s) { launch_ref(s, sets[s].L1, sets[s].Y0); launch_ref2(sets[s].L1, sets[s].L2, sets[s].Y1); }));
+    }
+    return 0;
+}
