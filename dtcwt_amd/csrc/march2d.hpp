@@ -127,6 +127,34 @@ __device__ __forceinline__ f4 col_fir(const f4 (&w)[WR], int q, const float *h) 
     return a;
 }
 
+// Both filters of a level-1 pass over the SAME samples, the filters symmetric (h[k] = h[M-1-k]: every biort set): the
+// mirror pairs are added once and shared, 2 + 3 adds + 3 + 4 multiply-adds for a 5- and a 7-tap filter instead of 12
+// (what separates the result from the tap-by-tap sum is the rounding of those adds: ~1 ulp either way).
+//   oa = sum_k a[k] x[c + HH + HA - k],  ob = sum_k b[k] x[c + HH + HB - k]
+template <int MA, int MB, int HH>
+__device__ __forceinline__ void sym_pair(const float *xc, const float *a, const float *b, float &oa, float &ob) {
+    constexpr int HA = MA / 2, HB = MB / 2, HM = HA > HB ? HA : HB;
+    float sm[HM + 1];
+    sm[0] = xc[0];
+#pragma unroll
+    for (int d = 1; d <= HM; ++d) sm[d] = xc[-d] + xc[d];
+    float ra = a[HA] * sm[0], rb = b[HB] * sm[0];
+#pragma unroll
+    for (int d = 1; d <= HA; ++d) ra += a[HA - d] * sm[d];
+#pragma unroll
+    for (int d = 1; d <= HB; ++d) rb += b[HB - d] * sm[d];
+    oa = ra; ob = rb;
+}
+// the lowpass one alone (warm-up rows)
+template <int MA, int HH>
+__device__ __forceinline__ float sym_one(const float *xc, const float *a) {
+    constexpr int HA = MA / 2;
+    float ra = a[HA] * xc[0];
+#pragma unroll
+    for (int d = 1; d <= HA; ++d) ra += a[HA - d] * (xc[-d] + xc[d]);
+    return ra;
+}
+
 // q2c of the lane's two quads of a plane (rows e0 / e1; the 1/sqrt2 is already in the row taps)
 //   z0 = (a - d) + j(b + c), z1 = (a + d) + j(b - c)  for  a b / c d
 struct Zq { float z0r, z0i, z1r, z1i; };
@@ -325,8 +353,8 @@ struct Fwd12m {
     static_assert(HH <= 4 && (M - 2) % 4 == 0 && M <= MAXT2, "halo lanes");
 };
 
-template <int M0, int M1, int M, int P, int KO>
-__global__ void __launch_bounds__(64) k_fwd12m(const Fwd12mParams p) {
+template <int M0, int M1, int M, int P, int KO, int WPS = 2>
+__global__ void __launch_bounds__(64, WPS) k_fwd12m(const Fwd12mParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using G = Fwd12m<M0, M1, M>;
     constexpr int HH = G::HH, WR = G::WR, HL = G::HL, HL2 = G::HL2, VL = G::VL, NP2 = G::NP2, PER = 4;
@@ -355,14 +383,19 @@ __global__ void __launch_bounds__(64) k_fwd12m(const Fwd12mParams p) {
     const int rb = band * p.band_rows;
     const int nrow = R - rb < p.band_rows ? R - rb : p.band_rows;
     const int rbase = rb - G::PRE;                     // first LoLo1 row the band's level-2 windows want
-    const int nst = nrow / 2 + G::PRE;                 // steps of two rows: rbase .. rb + nrow + PRE + 1
-    const int last_row = rbase + 2 * nst - 1 + HH;
+    // steps of two rows: rbase .. rb + nrow + PRE + 1, rounded up to whole periods of the register rings (the march
+    // loop has ONE exit: with a way out after every step the compiler copies the loop-carried rows -- loads still in
+    // flight among them -- into place on the way back, which waits for everything outstanding once per period); the
+    // surplus steps re-read the last row, own no output row and complete no pair of the band
+    const int nst = (nrow / 2 + G::PRE + PER - 1) / PER * PER;
+    const int last_row = rbase + 2 * (nrow / 2 + G::PRE) - 1 + HH;
 
     auto ldrow = [&](int u) -> f4 {
         u = u > last_row ? last_row : u;
         u = u < 0 ? -1 - u : u;
         u = u >= R ? 2 * R - 1 - u : u;
         if (KO & 1) u &= 15;
+        if (KO & 32) { const dt2d::dt_bv4 v = __builtin_amdgcn_raw_buffer_load_b128(bx.r, (unsigned)lc * 4u, (unsigned)u * pitch, 2); return f4{v.x, v.y, v.z, v.w}; }
         return dt2d::dt_buf_ld4(bx, (unsigned)lc * 4u, (unsigned)u * pitch);
     };
     auto fix = [&](f4 &v) { if (edge_strip) v = rev ? rev4(v) : v; };
@@ -404,7 +437,6 @@ __global__ void __launch_bounds__(64) k_fwd12m(const Fwd12mParams p) {
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int t = t0 + k;
-            if (t >= nst) break;
             const int r = rbase + 2 * t;               // rho0
             // rows leaving `pre` for the window of the next step; their slots take the loads of rows 2P further down
             const f4 in0 = pre[(2 * k) % (2 * P)], in1 = pre[(2 * k + 1) % (2 * P)];
@@ -415,21 +447,30 @@ __global__ void __launch_bounds__(64) k_fwd12m(const Fwd12mParams p) {
             for (int j = 0; j < WR; ++j) w[j] = ring[(2 * k + j) % WR];
 
             const bool in_band = r >= rb && r < rb + nrow;          // uniform
+            // the window by component: column filters run down wc[c][.]
+            float wc[4][WR];
+#pragma unroll
+            for (int j = 0; j < WR; ++j) { wc[0][j] = w[j].x; wc[1][j] = w[j].y; wc[2][j] = w[j].z; wc[3][j] = w[j].w; }
             f4 ll[2];
             if (in_band) {
                 f4 lh[2], hl[2], hh[2];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    const f4 lo = col_fir<M0, HH, WR>(w, q, h0), hi = col_fir<M1, HH, WR>(w, q, h1);
+                    float lo[4], hi[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) sym_pair<M0, M1, HH>(&wc[c][q + HH], h0, h1, lo[c], hi[c]);
                     float wl[4 + 2 * HH], wh[4 + 2 * HH];
-                    row_window<HH>(lo, wl);
-                    row_window<HH>(hi, wh);
-                    ll[q] = row_fir<M0, HH>(wl, h0);
-                    lh[q] = row_fir<M1, HH>(wl, h1);
-                    hl[q] = row_fir<M0, HH>(wh, h0);
-                    hh[q] = row_fir<M1, HH>(wh, h1);
+                    row_window<HH>(f4{lo[0], lo[1], lo[2], lo[3]}, wl);
+                    row_window<HH>(f4{hi[0], hi[1], hi[2], hi[3]}, wh);
+                    float a_[4], b_[4], c_[4], d_[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        sym_pair<M0, M1, HH>(&wl[c + HH], h0, h1, a_[c], b_[c]);
+                        sym_pair<M0, M1, HH>(&wh[c + HH], h0, h1, c_[c], d_[c]);
+                    }
+                    ll[q] = f4{a_[0], a_[1], a_[2], a_[3]}; lh[q] = f4{b_[0], b_[1], b_[2], b_[3]};
+                    hl[q] = f4{c_[0], c_[1], c_[2], c_[3]}; hh[q] = f4{d_[0], d_[1], d_[2], d_[3]};
                 }
-                const int ro = (KO & 2) ? (r & 15) : r;
                 {
                     const Zq a0 = q2c_s(hl[0].x, hl[0].y, hl[1].x, hl[1].y), a1 = q2c_s(hl[0].z, hl[0].w, hl[1].z, hl[1].w);
                     const Zq b0 = q2c_s(hh[0].x, hh[0].y, hh[1].x, hh[1].y), b1 = q2c_s(hh[0].z, hh[0].w, hh[1].z, hh[1].w);
@@ -442,22 +483,34 @@ __global__ void __launch_bounds__(64) k_fwd12m(const Fwd12mParams p) {
                     o[4] = f4{sq * c1q.z0r, sq * c1q.z0i, sq * c1q.z1r, sq * c1q.z1i};
                     o[5] = f4{sq * b1.z1r, sq * b1.z1i, sq * a1.z1r, sq * a1.z1i};
                 }
-                DT_WAVE_LDS_SYNC();
-                const DtBuf by = dt_buf_n(Y0b + (int64_t)(ro >> 1) * C * 6, 96u * nv);
-#pragma unroll
-                for (int m = 0; m < 6; ++m) {
-                    const f4 v = slab[6 * HL + lane + 64 * m];
-                    dt2d::dt_buf_st4<true>(by, yv + 1024u * m, 0u, v);
-                }
-                DT_WAVE_LDS_SYNC();
             } else {
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    const f4 lo = col_fir<M0, HH, WR>(w, q, h0);
-                    float wl[4 + 2 * HH];
-                    row_window<HH>(lo, wl);
-                    ll[q] = row_fir<M0, HH>(wl, h0);
+                    float lo[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) lo[c] = sym_one<M0, HH>(&wc[c][q + HH], h0);
+                    float wl[4 + 2 * HH], a_[4];
+                    row_window<HH>(f4{lo[0], lo[1], lo[2], lo[3]}, wl);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) a_[c] = sym_one<M0, HH>(&wl[c + HH], h0);
+                    ll[q] = f4{a_[0], a_[1], a_[2], a_[3]};
                 }
+            }
+            // The record stores are issued on EVERY step -- for rows outside the band against a descriptor of zero
+            // bytes, which drops them whole (and in order: tools/kbench/vmcnt_probe) -- so that every path through a
+            // step carries the same number of memory operations.  The compiler counts them per path and, where paths
+            // meet, assumes the fewest: with the stores inside the branch each use of a prefetched row waited for all
+            // but the youngest 4 operations, i.e. for the stores of the step before.
+            {
+                const int ro = (KO & 2) ? (r & 15) : r;
+                DT_WAVE_LDS_SYNC();
+                const DtBuf by = dt_buf_n(Y0b + (int64_t)(ro >> 1) * C * 6, in_band ? 96u * nv : 0u);
+#pragma unroll
+                for (int m = 0; m < 6; ++m) {
+                    const f4 v = slab[6 * HL + lane + 64 * m];
+                    if (KO & 16) dt2d::dt_buf_st4<false>(by, yv + 1024u * m, 0u, v); else dt2d::dt_buf_st4<true>(by, yv + 1024u * m, 0u, v);
+                }
+                DT_WAVE_LDS_SYNC();
             }
 
             // ---- level 2: the two LoLo1 rows of this step ----
@@ -501,7 +554,8 @@ __global__ void __launch_bounds__(64) k_fwd12m(const Fwd12mParams p) {
             if (k & 1) {
                 // rows 4n + 2, 4n + 3 are in: pair i = n - HL2 is complete
                 const int i2 = (r - 2) / 4 - HL2;
-                if (4 * i2 >= rb && 4 * i2 < rb + nrow) {           // uniform
+                const bool pair_ok = 4 * i2 >= rb && 4 * i2 < rb + nrow;        // uniform; otherwise the stores are dropped
+                {
                     const bool la = p.lo_a_first != 0, ha = p.hi_a_first != 0;
                     // column-lowpass plane rows (A lo / B lo), column-highpass plane rows (A hi / B hi)
                     float pl[2][4], ph[2][4];
@@ -518,9 +572,9 @@ __global__ void __launch_bounds__(64) k_fwd12m(const Fwd12mParams p) {
                         hl2[er][0] = la ? ph[er][0] : ph[er][1]; hl2[er][1] = la ? ph[er][1] : ph[er][0];
                         hh2[er][0] = ha ? ph[er][2] : ph[er][3]; hh2[er][1] = ha ? ph[er][3] : ph[er][2];
                     }
-                    const int io = (KO & 2) ? (i2 & 3) : i2;
-                    const DtBuf bl0 = dt_buf_n(L2b + (int64_t)(2 * io) * (C / 2), 8u * nv);
-                    const DtBuf bl1 = dt_buf_n(L2b + (int64_t)(2 * io + 1) * (C / 2), 8u * nv);
+                    const int io = pair_ok ? ((KO & 2) ? (i2 & 3) : i2) : 0;
+                    const DtBuf bl0 = dt_buf_n(L2b + (int64_t)(2 * io) * (C / 2), pair_ok ? 8u * nv : 0u);
+                    const DtBuf bl1 = dt_buf_n(L2b + (int64_t)(2 * io + 1) * (C / 2), pair_ok ? 8u * nv : 0u);
                     dt2d::dt_buf_st2<false>(bl0, l2v, 0u, dt2d::f2{llo[0][0], llo[0][1]});
                     dt2d::dt_buf_st2<false>(bl1, l2v, 0u, dt2d::f2{llo[1][0], llo[1][1]});
                     const Zq a = q2c_s(hl2[0][0], hl2[0][1], hl2[1][0], hl2[1][1]);
@@ -531,7 +585,7 @@ __global__ void __launch_bounds__(64) k_fwd12m(const Fwd12mParams p) {
                     o[1] = f4{sq * c.z0r, sq * c.z0i, sq * c.z1r, sq * c.z1i};
                     o[2] = f4{sq * bq.z1r, sq * bq.z1i, sq * a.z1r, sq * a.z1i};
                     DT_WAVE_LDS_SYNC();
-                    const DtBuf by1 = dt_buf_n(Y1b + (int64_t)io * (C / 4) * 12, 48u * nv);
+                    const DtBuf by1 = dt_buf_n(Y1b + (int64_t)io * (C / 4) * 12, pair_ok ? 48u * nv : 0u);
 #pragma unroll
                     for (int m = 0; m < 3; ++m) {
                         const f4 v = slab2[3 * HL + lane + 64 * m];
@@ -554,6 +608,261 @@ __global__ void __launch_bounds__(64) k_fwd12m(const Fwd12mParams p) {
             fix(e0); fix(e1);
             ring[(2 * k) % WR] = e0;
             ring[(2 * k + 1) % WR] = e1;
+        }
+    }
+#endif
+}
+
+
+// ======================================================================================================================
+// The same one-launch levels 1 + 2 as a PAIR of wavefronts per (strip, band): k_fwd12m needs ~190 registers -- two
+// wavefronts per SIMD -- and a 4096^2 image is only ~1900 of its jobs, so a SIMD holds one or two wavefronts that
+// cannot cover each other's memory and LDS waits (tools/kbench/march_bench: 53 us with every load and store knocked
+// out, 83 us with them, where its traffic needs ~65).  Here wavefront 0 of a workgroup runs level 1 and hands the two
+// LoLo1 rows of a step to wavefront 1 through a double-buffered 4 KiB LDS exchange (one s_barrier per step; the rows
+// are written BEFORE the level-1 highpass work of the step, which then overlaps wavefront 1's level-2 work);
+// wavefront 1 reads its 2M-sample row windows straight from the exchange (no DPP chain), scatters them into the
+// pending pairs and writes the level-2 outputs.  Each role fits 128 registers: four wavefronts per SIMD, every job of
+// a 4096^2 image resident at once, twice the wavefronts to hide latency with.
+// ======================================================================================================================
+#if defined(__HIP_DEVICE_COMPILE__)
+// LDS-only workgroup barrier: what precedes it are LDS writes of this wavefront (lgkmcnt), nothing in flight in the
+// vector-memory queues needs to land first -- __syncthreads() would wait for the prefetched rows and the stores too
+#define DTM_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+
+template <int M0, int M1, int M, int P, int KO>
+__global__ void __launch_bounds__(128, 4) k_fwd12w(const Fwd12mParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using G = Fwd12m<M0, M1, M>;
+    constexpr int HH = G::HH, WR = G::WR, HL = G::HL, HL2 = G::HL2, VL = G::VL, NP2 = G::NP2, PER = 4;
+    static_assert(PER % P == 0, "prefetch depth divides the ring period");
+    __shared__ __attribute__((aligned(16))) f4 slab[64 * 6 + 6 * G::HL + 8];
+    __shared__ __attribute__((aligned(16))) f4 slab2[64 * 3 + 3 * G::HL + 8];
+    __shared__ __attribute__((aligned(16))) f4 xbuf[2][2][64 + 2 * G::HL2];      // [step parity][row][HL2 + lane]
+    const int lane = threadIdx.x & 63;
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int job = blockIdx.x;
+    const int strip = job % p.nstrip, sb = job / p.nstrip, band = sb % p.nband, b = sb / p.nband;
+    const int R = p.R, C = p.C;
+    const int nv = (C - strip * (4 * VL)) / 4 < VL ? (C - strip * (4 * VL)) / 4 : VL;     // owning lanes
+    const int64_t img = (int64_t)b * R * C;
+    const int rb = band * p.band_rows;
+    const int nrow = R - rb < p.band_rows ? R - rb : p.band_rows;
+    const int rbase = rb - G::PRE;
+    const int nst = (nrow / 2 + G::PRE + PER - 1) / PER * PER;
+    const float sq = 0.70710678118654752440f;
+    const unsigned yv = 16u * (unsigned)lane;
+
+    if (role == 0) {
+        // ------------------------------------------------------------------ level 1
+        const int c0 = strip * (4 * VL) - 4 * HL + 4 * lane;
+        const bool rev = c0 < 0 || c0 >= C;
+        int lc = c0 < 0 ? -c0 - 4 : (c0 >= C ? 2 * C - 4 - c0 : c0);
+        lc = lc < 0 ? 0 : (lc > C - 4 ? C - 4 : lc);
+        const bool edge_strip = strip == 0 || (strip + 1) * (4 * VL) + 4 * HL >= C;
+        const DtBuf bx = dt_buf2g(p.X + img);
+        float *const Y0b = p.Yh0 + img * 3 + (int64_t)strip * (VL * 24);
+        const unsigned pitch = (unsigned)C * 4u;
+        const int last_row = rbase + 2 * (nrow / 2 + G::PRE) - 1 + HH;
+        auto ldrow = [&](int u) -> f4 {
+            u = u > last_row ? last_row : u;
+            u = u < 0 ? -1 - u : u;
+            u = u >= R ? 2 * R - 1 - u : u;
+            if (KO & 1) u &= 15;
+            return dt2d::dt_buf_ld4(bx, (unsigned)lc * 4u, (unsigned)u * pitch);
+        };
+        auto fix = [&](f4 &v) { if (edge_strip) v = rev ? rev4(v) : v; };
+        float h0[M0], h1[M1];
+#pragma unroll
+        for (int k = 0; k < M0; ++k) h0[k] = p.h0[k];
+#pragma unroll
+        for (int k = 0; k < M1; ++k) h1[k] = p.h1[k];
+
+        f4 ring[WR], pre[2 * P];
+#pragma unroll
+        for (int i = 0; i < WR; ++i) ring[i] = ldrow(rbase - HH + i);
+#pragma unroll
+        for (int i = 0; i < 2 * P; ++i) pre[i] = ldrow(rbase - HH + WR + i);
+#pragma unroll
+        for (int i = 0; i < WR; ++i) asm volatile("" : "+v"(ring[i].x), "+v"(ring[i].y), "+v"(ring[i].z), "+v"(ring[i].w) : : "memory");
+#pragma unroll
+        for (int i = 0; i < 2 * P; ++i) asm volatile("" : "+v"(pre[i].x), "+v"(pre[i].y), "+v"(pre[i].z), "+v"(pre[i].w) : : "memory");
+#pragma unroll
+        for (int i = 0; i < WR; ++i) fix(ring[i]);
+
+        for (int t0 = 0; t0 < nst; t0 += PER) {
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int t = t0 + k;
+                const int r = rbase + 2 * t;
+                const f4 in0 = pre[(2 * k) % (2 * P)], in1 = pre[(2 * k + 1) % (2 * P)];
+                pre[(2 * k) % (2 * P)] = ldrow(r - HH + WR + 2 * P);
+                pre[(2 * k + 1) % (2 * P)] = ldrow(r - HH + WR + 2 * P + 1);
+                float wc[4][WR];
+#pragma unroll
+                for (int j = 0; j < WR; ++j) {
+                    const f4 &x = ring[(2 * k + j) % WR];
+                    wc[0][j] = x.x; wc[1][j] = x.y; wc[2][j] = x.z; wc[3][j] = x.w;
+                }
+                const bool in_band = r >= rb && r < rb + nrow;          // uniform
+                float hi[2][4];
+                f4 lh[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    float lo[4], wl[4 + 2 * HH], a_[4], b_[4];
+                    if (in_band) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) sym_pair<M0, M1, HH>(&wc[c][q + HH], h0, h1, lo[c], hi[q][c]);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) lo[c] = sym_one<M0, HH>(&wc[c][q + HH], h0);
+                    }
+                    row_window<HH>(f4{lo[0], lo[1], lo[2], lo[3]}, wl);
+                    if (in_band) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) sym_pair<M0, M1, HH>(&wl[c + HH], h0, h1, a_[c], b_[c]);
+                        lh[q] = f4{b_[0], b_[1], b_[2], b_[3]};
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) a_[c] = sym_one<M0, HH>(&wl[c + HH], h0);
+                    }
+                    xbuf[t & 1][q][HL2 + lane] = f4{a_[0], a_[1], a_[2], a_[3]};
+                }
+                DTM_LDS_BARRIER();                      // the step's LoLo1 rows are wavefront 1's now
+                if (in_band) {
+                    f4 hl[2], hh[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        float wh[4 + 2 * HH], c_[4], d_[4];
+                        row_window<HH>(f4{hi[q][0], hi[q][1], hi[q][2], hi[q][3]}, wh);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) sym_pair<M0, M1, HH>(&wh[c + HH], h0, h1, c_[c], d_[c]);
+                        hl[q] = f4{c_[0], c_[1], c_[2], c_[3]}; hh[q] = f4{d_[0], d_[1], d_[2], d_[3]};
+                    }
+                    const Zq a0 = q2c_s(hl[0].x, hl[0].y, hl[1].x, hl[1].y), a1 = q2c_s(hl[0].z, hl[0].w, hl[1].z, hl[1].w);
+                    const Zq b0 = q2c_s(hh[0].x, hh[0].y, hh[1].x, hh[1].y), b1 = q2c_s(hh[0].z, hh[0].w, hh[1].z, hh[1].w);
+                    const Zq c0q = q2c_s(lh[0].x, lh[0].y, lh[1].x, lh[1].y), c1q = q2c_s(lh[0].z, lh[0].w, lh[1].z, lh[1].w);
+                    f4 *o = slab + lane * 6;
+                    o[0] = f4{sq * a0.z0r, sq * a0.z0i, sq * b0.z0r, sq * b0.z0i};
+                    o[1] = f4{sq * c0q.z0r, sq * c0q.z0i, sq * c0q.z1r, sq * c0q.z1i};
+                    o[2] = f4{sq * b0.z1r, sq * b0.z1i, sq * a0.z1r, sq * a0.z1i};
+                    o[3] = f4{sq * a1.z0r, sq * a1.z0i, sq * b1.z0r, sq * b1.z0i};
+                    o[4] = f4{sq * c1q.z0r, sq * c1q.z0i, sq * c1q.z1r, sq * c1q.z1i};
+                    o[5] = f4{sq * b1.z1r, sq * b1.z1i, sq * a1.z1r, sq * a1.z1i};
+                }
+                {   // stores on every step, dropped whole outside the band: see k_fwd12m
+                    const int ro = (KO & 2) ? (r & 15) : r;
+                    DT_WAVE_LDS_SYNC();
+                    const DtBuf by = dt_buf_n(Y0b + (int64_t)(ro >> 1) * C * 6, in_band ? 96u * nv : 0u);
+#pragma unroll
+                    for (int m = 0; m < 6; ++m) {
+                        const f4 v = slab[6 * HL + lane + 64 * m];
+                        dt2d::dt_buf_st4<true>(by, yv + 1024u * m, 0u, v);
+                    }
+                    DT_WAVE_LDS_SYNC();
+                }
+                f4 e0 = in0, e1 = in1;
+                fix(e0); fix(e1);
+                ring[(2 * k) % WR] = e0;
+                ring[(2 * k + 1) % WR] = e1;
+            }
+        }
+    } else {
+        // ------------------------------------------------------------------ level 2
+        float *const Y1b = p.Yh1 + (img / 4) * 3 + (int64_t)strip * (VL * 12);
+        float *const L2b = p.LoLo2 + img / 4 + strip * (VL * 2);
+        const unsigned l2v = 8u * (unsigned)(lane - HL);
+        float S[NP2][4][4];
+#pragma unroll
+        for (int a = 0; a < NP2; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) S[a][c][v] = 0.f;
+        for (int t0 = 0; t0 < nst; t0 += 2) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int t = t0 + k;
+                const int r = rbase + 2 * t;
+                DTM_LDS_BARRIER();                      // the rows of step t are in xbuf[t & 1]
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    float rv[4] = {0.f, 0.f, 0.f, 0.f};
+                    const f4 *src = &xbuf[t & 1][q][lane];          // lanes l - HL2 .. l + HL2 (the pad either end is never used by an owning lane)
+#pragma unroll
+                    for (int d = 0; d < 2 * HL2 + 1; ++d) {
+                        const f4 x = src[d];
+                        const float e[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const int j = 4 * d + c, tt = j >> 1;
+                            if (j & 1) { rv[1] += p.tb_lo[tt] * e[c]; rv[3] += p.tb_hi[tt] * e[c]; }
+                            else       { rv[0] += p.ta_lo[tt] * e[c]; rv[2] += p.ta_hi[tt] * e[c]; }
+                        }
+                    }
+                    const int phi = 2 * k + q;
+#pragma unroll
+                    for (int a = 0; a < NP2; ++a) {
+                        const int tt = (phi + 8 * HL2 - 4 * a) >> 1;
+                        const float cl_ = (phi & 1) ? p.tb_lo[tt] : p.ta_lo[tt], ch_ = (phi & 1) ? p.tb_hi[tt] : p.ta_hi[tt];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            S[a][(phi & 1) ? 2 : 0][v] += cl_ * rv[v];
+                            S[a][(phi & 1) ? 3 : 1][v] += ch_ * rv[v];
+                        }
+                    }
+                }
+                if (k & 1) {
+                    const int i2 = (r - 2) / 4 - HL2;
+                    const bool pair_ok = 4 * i2 >= rb && 4 * i2 < rb + nrow;
+                    const bool la = p.lo_a_first != 0, ha = p.hi_a_first != 0;
+                    float pl[2][4], ph[2][4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        pl[0][v] = la ? S[0][0][v] : S[0][2][v]; pl[1][v] = la ? S[0][2][v] : S[0][0][v];
+                        ph[0][v] = ha ? S[0][1][v] : S[0][3][v]; ph[1][v] = ha ? S[0][3][v] : S[0][1][v];
+                    }
+                    float llo[2][2], lh2[2][2], hl2[2][2], hh2[2][2];
+#pragma unroll
+                    for (int er = 0; er < 2; ++er) {
+                        llo[er][0] = la ? pl[er][0] : pl[er][1]; llo[er][1] = la ? pl[er][1] : pl[er][0];
+                        lh2[er][0] = ha ? pl[er][2] : pl[er][3]; lh2[er][1] = ha ? pl[er][3] : pl[er][2];
+                        hl2[er][0] = la ? ph[er][0] : ph[er][1]; hl2[er][1] = la ? ph[er][1] : ph[er][0];
+                        hh2[er][0] = ha ? ph[er][2] : ph[er][3]; hh2[er][1] = ha ? ph[er][3] : ph[er][2];
+                    }
+                    const int io = pair_ok ? ((KO & 2) ? (i2 & 3) : i2) : 0;
+                    const DtBuf bl0 = dt_buf_n(L2b + (int64_t)(2 * io) * (C / 2), pair_ok ? 8u * nv : 0u);
+                    const DtBuf bl1 = dt_buf_n(L2b + (int64_t)(2 * io + 1) * (C / 2), pair_ok ? 8u * nv : 0u);
+                    dt2d::dt_buf_st2<false>(bl0, l2v, 0u, dt2d::f2{llo[0][0], llo[0][1]});
+                    dt2d::dt_buf_st2<false>(bl1, l2v, 0u, dt2d::f2{llo[1][0], llo[1][1]});
+                    const Zq a = q2c_s(hl2[0][0], hl2[0][1], hl2[1][0], hl2[1][1]);
+                    const Zq bq = q2c_s(hh2[0][0], hh2[0][1], hh2[1][0], hh2[1][1]);
+                    const Zq c = q2c_s(lh2[0][0], lh2[0][1], lh2[1][0], lh2[1][1]);
+                    f4 *o = slab2 + lane * 3;
+                    o[0] = f4{sq * a.z0r, sq * a.z0i, sq * bq.z0r, sq * bq.z0i};
+                    o[1] = f4{sq * c.z0r, sq * c.z0i, sq * c.z1r, sq * c.z1i};
+                    o[2] = f4{sq * bq.z1r, sq * bq.z1i, sq * a.z1r, sq * a.z1i};
+                    DT_WAVE_LDS_SYNC();
+                    const DtBuf by1 = dt_buf_n(Y1b + (int64_t)io * (C / 4) * 12, pair_ok ? 48u * nv : 0u);
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+                        const f4 v = slab2[3 * HL + lane + 64 * m];
+                        dt2d::dt_buf_st4<false>(by1, yv + 1024u * m, 0u, v);
+                    }
+                    DT_WAVE_LDS_SYNC();
+#pragma unroll
+                    for (int a2 = 0; a2 + 1 < NP2; ++a2)
+#pragma unroll
+                        for (int c2 = 0; c2 < 4; ++c2)
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) S[a2][c2][v] = S[a2 + 1][c2][v];
+#pragma unroll
+                    for (int c2 = 0; c2 < 4; ++c2)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) S[NP2 - 1][c2][v] = 0.f;
+                }
+            }
         }
     }
 #endif

@@ -120,7 +120,7 @@ static void launch_ref2(float *L1, float *L2, float *Y1) {
     dt_set_tile_magic(p);
     ref_fwd2<F2><<<grid_for(p.tilesR * p.tilesC), DT_NT, 0, st>>>(p);
 }
-template <int P, int KO>
+template <int P, int KO, int WPS = 2>
 static void launch_f12(int s, int band_rows) {
     using G = dtm::Fwd12m<5, 7, 10>;
     dtm::Fwd12mParams p{}; p.X = sets[s].X; p.Yh0 = sets[s].Y0; p.Yh1 = sets[s].Y1; p.LoLo2 = sets[s].L2; p.B = 1; p.R = p.C = N;
@@ -128,15 +128,34 @@ static void launch_f12(int s, int band_rows) {
     put(p.h0, H0O, 5, dtm::MAXT1); put(p.h1, H1O, 7, dtm::MAXT1);
     Fwd2Params q{}; fill_fwd2(q);
     dtm::dtm_pack_qshift(p, 10, q.l_a, q.l_b, q.h_a, q.h_b); p.lo_a_first = q.lo_a_first; p.hi_a_first = q.hi_a_first;
-    dtm::k_fwd12m<5, 7, 10, P, KO><<<p.nstrip * p.nband, 64, 0, st>>>(p);
+    dtm::k_fwd12m<5, 7, 10, P, KO, WPS><<<p.nstrip * p.nband, 64, 0, st>>>(p);
+}
+template <int P, int KO>
+static void launch_f12w(int s, int band_rows) {
+    using G = dtm::Fwd12m<5, 7, 10>;
+    dtm::Fwd12mParams p{}; p.X = sets[s].X; p.Yh0 = sets[s].Y0; p.Yh1 = sets[s].Y1; p.LoLo2 = sets[s].L2; p.B = 1; p.R = p.C = N;
+    p.nstrip = cdiv(N, 4 * G::VL); p.band_rows = band_rows; p.nband = cdiv(N, band_rows);
+    put(p.h0, H0O, 5, dtm::MAXT1); put(p.h1, H1O, 7, dtm::MAXT1);
+    Fwd2Params q{}; fill_fwd2(q);
+    dtm::dtm_pack_qshift(p, 10, q.l_a, q.l_b, q.h_a, q.h_b); p.lo_a_first = q.lo_a_first; p.hi_a_first = q.hi_a_first;
+    dtm::k_fwd12w<5, 7, 10, P, KO><<<p.nstrip * p.nband, 128, 0, st>>>(p);
 }
 template <int P>
+static void run_f12w(int band_rows) {
+    const double a = time_it([&](int s) { launch_f12w<P, 0>(s, band_rows); });
+    const double b = time_it([&](int s) { launch_f12w<P, 1>(s, band_rows); });
+    const double c = time_it([&](int s) { launch_f12w<P, 2>(s, band_rows); });
+    const double d = time_it([&](int s) { launch_f12w<P, 3>(s, band_rows); });
+    printf("k_fwd12w P=%d band_rows=%3d (2 roles)    %9.2f %9.2f %9.2f %9.2f\n", P, band_rows, a, b, c, d);
+    fflush(stdout);
+}
+template <int P, int WPS = 2>
 static void run_f12(int band_rows) {
-    const double a = time_it([&](int s) { launch_f12<P, 0>(s, band_rows); });
-    const double b = time_it([&](int s) { launch_f12<P, 1>(s, band_rows); });
-    const double c = time_it([&](int s) { launch_f12<P, 2>(s, band_rows); });
-    const double d = time_it([&](int s) { launch_f12<P, 3>(s, band_rows); });
-    printf("k_fwd12m P=%d band_rows=%3d          %9.2f %9.2f %9.2f %9.2f\n", P, band_rows, a, b, c, d);
+    const double a = time_it([&](int s) { launch_f12<P, 0, WPS>(s, band_rows); });
+    const double b = time_it([&](int s) { launch_f12<P, 1, WPS>(s, band_rows); });
+    const double c = time_it([&](int s) { launch_f12<P, 2, WPS>(s, band_rows); });
+    const double d = time_it([&](int s) { launch_f12<P, 3, WPS>(s, band_rows); });
+    printf("k_fwd12m P=%d band_rows=%3d waves/SIMD %d %9.2f %9.2f %9.2f %9.2f\n", P, band_rows, WPS, a, b, c, d);
     fflush(stdout);
 }
 
@@ -215,9 +234,9 @@ int main(int argc, char **argv) {
 
     {   // levels 1 + 2 in one march against the two tile programs
         launch_ref2(sets[0].L1r, sets[0].L2r, sets[0].Y1r);
-        for (int br : {64, 128, 32}) {
+        for (int br : {64, 128, 32, -40, -24}) {
             CK(hipMemset(sets[0].Y0, 0, px * 12)); CK(hipMemset(sets[0].Y1, 0, px * 3)); CK(hipMemset(sets[0].L2, 0, px));
-            launch_f12<2, 0>(0, br);
+            if (br > 0) launch_f12<2, 0>(0, br); else launch_f12w<2, 0>(0, -br);
             CK(hipStreamSynchronize(st));
             double ma, mb, mc;
             const double e0 = maxdiff(sets[0].Y0, sets[0].Y0r, px * 3, &ma), e1 = maxdiff(sets[0].Y1, sets[0].Y1r, px * 3 / 4, &mb),
@@ -233,9 +252,12 @@ int main(int argc, char **argv) {
         printf("%-40s %9.2f\n", "k_fwd1 tile program (library)", r);
         const double r2 = time_it([&](int s) { launch_ref2(sets[s].L1, sets[s].L2, sets[s].Y1); });
         printf("%-40s %9.2f\n", "k_fwd2 tile program (library)", r2);
-        for (int br : {40, 64}) run_f12<2>(br);
+        run_f12<2>(40);
+        printf("k_fwd12m bands of 40: plain record stores %.2f, nt loads %.2f, both %.2f\n", time_it([&](int s) { launch_f12<2, 16>(s, 40); }), time_it([&](int s) { launch_f12<2, 32>(s, 40); }), time_it([&](int s) { launch_f12<2, 48>(s, 40); }));
+        run_f12w<2>(40);
         printf("two streams, us per image: tile fwd1 + fwd2 %.2f", time_two_streams([&](int s) { launch_ref(s, sets[s].L1, sets[s].Y0); launch_ref2(sets[s].L1, sets[s].L2, sets[s].Y1); }));
-        for (int br : {40, 48, 64, 80, 96, 128}) printf(" | k_fwd12m bands of %d: %.2f", br, time_two_streams([&](int s) { launch_f12<2, 0>(s, br); }));
+        for (int br : {40, 80}) printf(" | k_fwd12m bands of %d: %.2f", br, time_two_streams([&](int s) { launch_f12<2, 0>(s, br); }));
+        for (int br : {40}) printf(" | k_fwd12w bands of %d: %.2f", br, time_two_streams([&](int s) { launch_f12w<2, 0>(s, br); }));
         printf("\none stream, us per image: tile fwd1 + fwd2 %.2f\n", time_it([&](int s) { launch_ref(s, sets[s].L1, sets[s].Y0); launch_ref2(sets[s].L1, sets[s].L2, sets[s].Y1); }));
     }
     return 0;
