@@ -25,6 +25,11 @@ int dtcwt_march_fwd12(const float *X, float *Yh0, float *Yh1, float *LoLo2, int 
                       const std::vector<double> &h0o, const std::vector<double> &h1o,
                       const float *l_a, const float *l_b, const float *h_a, const float *h_b, int m,
                       int lo_a_first, int hi_a_first, int cus, hipStream_t s);
+bool dtcwt_march_inv21_ok(int rows, int cols, const std::vector<double> &g0o, const std::vector<double> &g1o,
+                          const std::vector<double> &g0a, bool lo_pos, bool hi_pos);
+int dtcwt_march_inv21(const float *Z2, const float *Yh1, const float *Yh0, float *X, int B, int R, int C,
+                      const std::vector<double> &g0o, const std::vector<double> &g1o, const float *l_a, const float *l_b,
+                      const float *h_a, const float *h_b, const float *gain1, const float *gain2, int cus, hipStream_t s);
 
 namespace {
 
@@ -386,6 +391,11 @@ int dtcwt_hip_plan2d_inverse(dtcwt_hip_plan2d *p, const float *Yl, const void *c
     const int nl = p->nlevels;
     const double rs = 0.70710678118654752440;
     const float *in = Yl;
+    // levels 2 + 1 in one launch (march2d.hpp) under the same conditions as the forward's levels 1 + 2
+    const bool march21 = nl >= 2 && p->bp1[1].empty() && p->bp2[2].empty() && p->lv[0].inR == p->lv[0].LR &&
+                         p->lv[0].inC == p->lv[0].LC && p->lv[1].padR == 0 && p->lv[1].padC == 0 &&
+                         dtcwt_march_inv21_ok(p->lv[0].LR, p->lv[0].LC, p->biort[1], p->biort[3], p->qshift[2],
+                                              dotd(p->qshift[3], p->qshift[2]) > 0, dotd(p->qshift[7], p->qshift[6]) > 0);
     for (int l = nl - 1; l >= 0; --l) {
         const Level &L = p->lv[l];
         DT_REQUIRE(Yh[l], "NULL Yh at level %d", l);
@@ -393,6 +403,24 @@ int dtcwt_hip_plan2d_inverse(dtcwt_hip_plan2d *p, const float *Yl, const void *c
         for (int d = 0; d < 6; ++d) g[d] = (float)(rs * (gain ? gain[d * nl + l] : 1.0));
         int rc;
         if (p->profiling) DT_CHECK_HIP(hipEventRecord(p->ev[2 * (nl + l)], s));
+        if (l == 1 && march21) {
+            DT_REQUIRE(Yh[0], "NULL Yh at level 0");
+            float g1[6];
+            for (int d = 0; d < 6; ++d) g1[d] = (float)(rs * (gain ? gain[d * nl + 0] : 1.0));
+            Inv2Params q{};
+            put_taps(q.l_a, p->qshift[3]); put_taps(q.l_b, p->qshift[2]);
+            put_taps(q.h_a, p->qshift[7]); put_taps(q.h_b, p->qshift[6]);
+            rc = dtcwt_march_inv21(in, (const float *)Yh[1], (const float *)Yh[0], Z, p->batch, p->lv[0].LR, p->lv[0].LC,
+                                   p->biort[1], p->biort[3], q.l_a, q.l_b, q.h_a, q.h_b, g1, g, p->ctx->cus, s);
+            if (rc) return dtcwt_set_error(rc, "no marching inverse kernel for levels 2 + 1");
+            DT_CHECK_HIP(hipGetLastError());
+            if (p->profiling) {     // level 1 has no launch of its own: an empty event pair
+                DT_CHECK_HIP(hipEventRecord(p->ev[2 * (nl + 1) + 1], s));
+                DT_CHECK_HIP(hipEventRecord(p->ev[2 * nl], s));
+                DT_CHECK_HIP(hipEventRecord(p->ev[2 * nl + 1], s));
+            }
+            break;
+        }
         if (l == 0) {
             Inv1Params q{};
             q.Z = in; q.Yh = (const float *)Yh[0]; q.X = Z;

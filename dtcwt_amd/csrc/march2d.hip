@@ -54,6 +54,41 @@ bool dtcwt_march_fwd12_ok(int rows, int cols, const std::vector<double> &h0o, co
     return true;
 }
 
+// levels 2 + 1 of the inverse in one launch: the same geometry rules as the forward, the synthesis filters of near_sym_a
+// (7, 5 taps), 10-tap q-shift filters with the standard phases
+bool dtcwt_march_inv21_ok(int rows, int cols, const std::vector<double> &g0o, const std::vector<double> &g1o,
+                          const std::vector<double> &g0a, bool lo_pos, bool hi_pos) {
+    static const int off = [] { const char *e = getenv("DTCWT_HIP_MARCH_INV"); return e && e[0] == '0'; }();
+    static const int off_all = [] { const char *e = getenv("DTCWT_HIP_MARCH"); return e && e[0] == '0'; }();
+    if (off || off_all) return false;
+    if (g0o.size() != 7 || g1o.size() != 5 || g0a.size() != 10 || !lo_pos || hi_pos) return false;
+    if (rows % 4 || cols % 4 || rows < 32 || cols < 32) return false;
+    if ((int64_t)rows * cols * 4 >= ((int64_t)1 << 31)) return false;
+    return true;
+}
+
+int dtcwt_march_inv21(const float *Z2, const float *Yh1, const float *Yh0, float *X, int B, int R, int C,
+                      const std::vector<double> &g0o, const std::vector<double> &g1o, const float *l_a, const float *l_b,
+                      const float *h_a, const float *h_b, const float *gain1, const float *gain2, int cus, hipStream_t s) {
+    using G = dtm::Inv21m<7, 5, 10>;
+    dtm::Inv21mParams p{};
+    p.Z2 = Z2; p.Yh1 = Yh1; p.Yh0 = Yh0; p.X = X; p.B = B; p.R = R; p.C = C;
+    for (int k = 0; k < dtm::MAXT1; ++k) {
+        p.g0o[k] = k < (int)g0o.size() ? (float)g0o[k] : 0.f;
+        p.g1o[k] = k < (int)g1o.size() ? (float)g1o[k] : 0.f;
+    }
+    for (int k = 0; k < dtm::MAXT2; ++k) { p.l_a[k] = l_a[k]; p.l_b[k] = l_b[k]; p.h_a[k] = h_a[k]; p.h_b[k] = h_b[k]; }
+    for (int d = 0; d < 6; ++d) { p.g1[d] = gain1[d]; p.g2[d] = gain2[d]; }
+    dtm::dtm_pack_inv_biort(p, 7, 5);
+    p.nstrip = cdiv(C, 4 * G::VL);
+    p.band_rows = pick_band_rows(B, R, p.nstrip, 10, cus);
+    p.nband = cdiv(R, p.band_rows);
+    const int64_t jobs = (int64_t)p.nstrip * p.nband * B;
+    if (jobs >= ((int64_t)1 << 31)) return -3;
+    dtm::k_inv21m<7, 5, 10, 0><<<(unsigned)jobs, 64, 0, s>>>(p);
+    return 0;
+}
+
 template <int M0, int M1, int M>
 static int launch_fwd12(dtm::Fwd12mParams &p, int cus, hipStream_t s) {
     using G = dtm::Fwd12m<M0, M1, M>;
@@ -83,6 +118,7 @@ int dtcwt_march_fwd12(const float *X, float *Yh0, float *Yh1, float *LoLo2, int 
         p.h1[k] = k < (int)h1o.size() ? (float)h1o[k] : 0.f;
     }
     dtm::dtm_pack_qshift(p, m, l_a, l_b, h_a, h_b);
+    dtm::dtm_pack_biort(p, (int)h0o.size(), (int)h1o.size());
     const int m0 = (int)h0o.size(), m1 = (int)h1o.size();
     if (m == 10) {
         if (m0 == 5 && m1 == 7) return launch_fwd12<5, 7, 10>(p, cus, s);

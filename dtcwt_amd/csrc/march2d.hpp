@@ -155,6 +155,40 @@ __device__ __forceinline__ float sym_one(const float *xc, const float *a) {
     return ra;
 }
 
+// ---- hand-packed forms ------------------------------------------------------------------------------------------------
+// A wavefront issues at most one vector instruction every four cycles, and these kernels run one or two wavefronts to
+// a SIMD (their register needs; a 4096^2 image is only ~1900 jobs): they are bound by the number of instructions a
+// wavefront issues (profiles/r04/pmc_march.txt: VALU active = instructions x 4 cycles = 60 % of the kernel), so two
+// multiply-adds per v_pk_fma_f32 halve what matters.  The pairs are chosen so that no operand has to be moved into
+// place: (lowpass, highpass) of the column pass on the same sample, (Lo plane, Hi plane) of the row pass with the same tap.
+typedef float pk2 __attribute__((ext_vector_type(2)));
+// Operands of a packed instruction are 64-bit register pairs.  A scalar broadcast to both halves occupies a whole pair
+// if it lives in a register of its own, and a broadcast of one half of a SCALAR-register pair is materialised as a new
+// pair (s_mov) -- both were tried and spilled.  What costs nothing is broadcasting one half of a VECTOR-register pair
+// (op_sel).  So: taps come as true (lowpass, highpass) pairs in scalar registers, samples live as true pairs of
+// neighbours in vector registers (two columns of a row / (Lo, Hi) of a column / two samples of a window) and are
+// broadcast by half.
+#define DTM_BX(v_) pk2{(v_).x, (v_).x}
+#define DTM_BY(v_) pk2{(v_).y, (v_).y}
+// Column pass, two neighbouring columns: x[j] = their samples in window row j (xc = centre); hp[d] = (h0, h1) at
+// distance d.  (lo, hi) of the first and of the second column.
+template <int HH>
+__device__ __forceinline__ void col_lohi2(const pk2 *xc, const pk2 *hp, pk2 &c0, pk2 &c1) {
+    pk2 a = hp[0] * DTM_BX(xc[0]), b = hp[0] * DTM_BY(xc[0]);
+#pragma unroll
+    for (int d = 1; d <= HH; ++d) { const pk2 sm = xc[-d] + xc[d]; a += hp[d] * DTM_BX(sm); b += hp[d] * DTM_BY(sm); }
+    c0 = a; c1 = b;
+}
+// Row pass at one column over the interleaved window W[i] = (Lo, Hi) of column i (wc_ = centre):
+// (ll, lh) = (h0, h1) * Lo row, (hl, hh) = (h0, h1) * Hi row
+template <int HH>
+__device__ __forceinline__ void row_lohi(const pk2 *wc_, const pk2 *hp, pk2 &ol, pk2 &oh) {
+    pk2 a = hp[0] * DTM_BX(wc_[0]), b = hp[0] * DTM_BY(wc_[0]);
+#pragma unroll
+    for (int d = 1; d <= HH; ++d) { const pk2 sm = wc_[-d] + wc_[d]; a += hp[d] * DTM_BX(sm); b += hp[d] * DTM_BY(sm); }
+    ol = a; oh = b;
+}
+
 // q2c of the lane's two quads of a plane (rows e0 / e1; the 1/sqrt2 is already in the row taps)
 //   z0 = (a - d) + j(b + c), z1 = (a + d) + j(b - c)  for  a b / c d
 struct Zq { float z0r, z0i, z1r, z1i; };
@@ -327,6 +361,10 @@ struct Fwd12mParams {
     // level-2 taps by window offset: A = sum_t ta[t] w[2t], B = sum_t tb[t] w[2t + 1] over the 2M-sample window whose
     // element j is logical sample 4i - M + 2 + j (fused2d_tiles.hpp: dfilt_pair); dtm_pack_qshift() fills them
     float ta_lo[MAXT2], tb_lo[MAXT2], ta_hi[MAXT2], tb_hi[MAXT2];
+    // the same as (lowpass, highpass) pairs: one v_pk_fma_f32 with the sample broadcast does both filters of a window
+    // position -- and the level-1 taps by distance d from the centre as (h0, h1) pairs (h0 zero beyond its half length)
+    float ta2[2 * MAXT2] __attribute__((aligned(8))), tb2[2 * MAXT2] __attribute__((aligned(8)));
+    float hp[2 * (MAXT1 / 2 + 1)] __attribute__((aligned(8)));
 };
 
 // ha / hb: the FIRST / SECOND filter argument of coldfilt (Fwd2Params::l_a, l_b and h_a, h_b)
@@ -339,6 +377,18 @@ inline void dtm_pack_qshift(Pm &p, int M, const float *l_a, const float *l_b, co
         p.tb_lo[(2 * M - 2 - 4 * k) / 2] = l_b[2 * k]; p.tb_lo[(2 * M - 4 - 4 * k) / 2] = l_b[2 * k + 1];
         p.ta_hi[(2 * M - 2 - 4 * k) / 2] = h_a[2 * k]; p.ta_hi[(2 * M - 4 - 4 * k) / 2] = h_a[2 * k + 1];
         p.tb_hi[(2 * M - 2 - 4 * k) / 2] = h_b[2 * k]; p.tb_hi[(2 * M - 4 - 4 * k) / 2] = h_b[2 * k + 1];
+    }
+    for (int t = 0; t < MAXT2; ++t) {
+        p.ta2[2 * t] = p.ta_lo[t]; p.ta2[2 * t + 1] = p.ta_hi[t];
+        p.tb2[2 * t] = p.tb_lo[t]; p.tb2[2 * t + 1] = p.tb_hi[t];
+    }
+}
+// (h0, h1) by distance from the centre tap; m0, m1: the (odd) lengths
+template <class Pm>
+inline void dtm_pack_biort(Pm &p, int m0, int m1) {
+    for (int d = 0; d <= MAXT1 / 2; ++d) {
+        p.hp[2 * d] = d <= m0 / 2 ? p.h0[m0 / 2 - d] : 0.f;
+        p.hp[2 * d + 1] = d <= m1 / 2 ? p.h1[m1 / 2 - d] : 0.f;
     }
 }
 
@@ -357,7 +407,7 @@ template <int M0, int M1, int M, int P, int KO, int WPS = 2>
 __global__ void __launch_bounds__(64, WPS) k_fwd12m(const Fwd12mParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using G = Fwd12m<M0, M1, M>;
-    constexpr int HH = G::HH, WR = G::WR, HL = G::HL, HL2 = G::HL2, VL = G::VL, NP2 = G::NP2, PER = 4;
+    constexpr int HH = G::HH, WR = G::WR, HL = G::HL, HL2 = G::HL2, VL = G::VL, NP2 = G::NP2, PER = 4, H0_ = G::H0;
     static_assert(PER % P == 0, "prefetch depth divides the ring period");
     __shared__ __attribute__((aligned(16))) f4 slab[64 * 6 + 6 * G::HL + 8];
     __shared__ __attribute__((aligned(16))) f4 slab2[64 * 3 + 3 * G::HL + 8];
@@ -422,13 +472,13 @@ __global__ void __launch_bounds__(64, WPS) k_fwd12m(const Fwd12mParams p) {
 
     // pending level-2 pairs, oldest first: S[slot][which][v], which = A lo, A hi, B lo, B hi (column filter),
     // v = row-pass value L_A, L_B, H_A, H_B
-    float S[NP2][4][4];
+    pk2 S2[NP2][2][4];
 #pragma unroll
     for (int a = 0; a < NP2; ++a)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int v = 0; v < 4; ++v) S[a][c][v] = 0.f;
+            for (int v = 0; v < 4; ++v) S2[a][c][v] = pk2{0.f, 0.f};
 
     const unsigned yv = 16u * (unsigned)lane;
     const unsigned l2v = 8u * (unsigned)(lane - HL);
@@ -447,29 +497,30 @@ __global__ void __launch_bounds__(64, WPS) k_fwd12m(const Fwd12mParams p) {
             for (int j = 0; j < WR; ++j) w[j] = ring[(2 * k + j) % WR];
 
             const bool in_band = r >= rb && r < rb + nrow;          // uniform
-            // the window by component: column filters run down wc[c][.]
-            float wc[4][WR];
+            // the window as column pairs: wp[0][j] = columns (0, 1) of window row j, wp[1][j] = columns (2, 3)
+            pk2 wp[2][WR];
 #pragma unroll
-            for (int j = 0; j < WR; ++j) { wc[0][j] = w[j].x; wc[1][j] = w[j].y; wc[2][j] = w[j].z; wc[3][j] = w[j].w; }
+            for (int j = 0; j < WR; ++j) { wp[0][j] = pk2{w[j].x, w[j].y}; wp[1][j] = pk2{w[j].z, w[j].w}; }
+            const pk2 *hpp = reinterpret_cast<const pk2 *>(p.hp);
             f4 ll[2];
             if (in_band) {
                 f4 lh[2], hl[2], hh[2];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    float lo[4], hi[4];
+                    // W[i] = (Lo, Hi) of column i - HH: own columns from the column pass, the rest from the neighbours
+                    pk2 W[4 + 2 * HH];
+                    col_lohi2<HH>(&wp[0][q + HH], hpp, W[HH], W[HH + 1]);
+                    col_lohi2<HH>(&wp[1][q + HH], hpp, W[HH + 2], W[HH + 3]);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) sym_pair<M0, M1, HH>(&wc[c][q + HH], h0, h1, lo[c], hi[c]);
-                    float wl[4 + 2 * HH], wh[4 + 2 * HH];
-                    row_window<HH>(f4{lo[0], lo[1], lo[2], lo[3]}, wl);
-                    row_window<HH>(f4{hi[0], hi[1], hi[2], hi[3]}, wh);
-                    float a_[4], b_[4], c_[4], d_[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        sym_pair<M0, M1, HH>(&wl[c + HH], h0, h1, a_[c], b_[c]);
-                        sym_pair<M0, M1, HH>(&wh[c + HH], h0, h1, c_[c], d_[c]);
+                    for (int j = 0; j < HH; ++j) {
+                        W[j] = pk2{dpp_from_left(W[4 + j].x), dpp_from_left(W[4 + j].y)};
+                        W[HH + 4 + j] = pk2{dpp_from_right(W[HH + j].x), dpp_from_right(W[HH + j].y)};
                     }
-                    ll[q] = f4{a_[0], a_[1], a_[2], a_[3]}; lh[q] = f4{b_[0], b_[1], b_[2], b_[3]};
-                    hl[q] = f4{c_[0], c_[1], c_[2], c_[3]}; hh[q] = f4{d_[0], d_[1], d_[2], d_[3]};
+                    pk2 ol[4], oh[4];           // (ll, lh) and (hl, hh) of the four columns
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) row_lohi<HH>(&W[c + HH], hpp, ol[c], oh[c]);
+                    ll[q] = f4{ol[0].x, ol[1].x, ol[2].x, ol[3].x}; lh[q] = f4{ol[0].y, ol[1].y, ol[2].y, ol[3].y};
+                    hl[q] = f4{oh[0].x, oh[1].x, oh[2].x, oh[3].x}; hh[q] = f4{oh[0].y, oh[1].y, oh[2].y, oh[3].y};
                 }
                 {
                     const Zq a0 = q2c_s(hl[0].x, hl[0].y, hl[1].x, hl[1].y), a1 = q2c_s(hl[0].z, hl[0].w, hl[1].z, hl[1].w);
@@ -488,7 +539,15 @@ __global__ void __launch_bounds__(64, WPS) k_fwd12m(const Fwd12mParams p) {
                 for (int q = 0; q < 2; ++q) {
                     float lo[4];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) lo[c] = sym_one<M0, HH>(&wc[c][q + HH], h0);
+                    for (int c = 0; c < 4; ++c) {
+                        float xs[2 * H0_ + 1];
+#pragma unroll
+                        for (int j = 0; j < 2 * H0_ + 1; ++j) {
+                            const f4 &x = w[q + HH - H0_ + j];
+                            xs[j] = c == 0 ? x.x : (c == 1 ? x.y : (c == 2 ? x.z : x.w));
+                        }
+                        lo[c] = sym_one<M0, HH>(&xs[H0_], h0);
+                    }
                     float wl[4 + 2 * HH], a_[4];
                     row_window<HH>(f4{lo[0], lo[1], lo[2], lo[3]}, wl);
 #pragma unroll
@@ -516,39 +575,32 @@ __global__ void __launch_bounds__(64, WPS) k_fwd12m(const Fwd12mParams p) {
             // ---- level 2: the two LoLo1 rows of this step ----
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                constexpr int NW = 2 * M;
-                float w2[NW];
+                // the 2M-sample window as M pairs of neighbouring samples: (A sample, B sample) of window position t
+                pk2 w2[M];
                 {
                     float cl[4] = {ll[q].x, ll[q].y, ll[q].z, ll[q].w}, cr[4] = {ll[q].x, ll[q].y, ll[q].z, ll[q].w};
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) w2[4 * HL2 + c] = cl[c];
+                    w2[2 * HL2] = pk2{cl[0], cl[1]}; w2[2 * HL2 + 1] = pk2{cl[2], cl[3]};
 #pragma unroll
                     for (int d = 1; d <= HL2; ++d) {
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            cl[c] = dpp_from_left(cl[c]);   w2[4 * (HL2 - d) + c] = cl[c];
-                            cr[c] = dpp_from_right(cr[c]);  w2[4 * (HL2 + d) + c] = cr[c];
-                        }
+                        for (int c = 0; c < 4; ++c) { cl[c] = dpp_from_left(cl[c]); cr[c] = dpp_from_right(cr[c]); }
+                        w2[2 * (HL2 - d)] = pk2{cl[0], cl[1]}; w2[2 * (HL2 - d) + 1] = pk2{cl[2], cl[3]};
+                        w2[2 * (HL2 + d)] = pk2{cr[0], cr[1]}; w2[2 * (HL2 + d) + 1] = pk2{cr[2], cr[3]};
                     }
                 }
-                float rv[4] = {0.f, 0.f, 0.f, 0.f};
+                const pk2 *ta2 = reinterpret_cast<const pk2 *>(p.ta2), *tb2 = reinterpret_cast<const pk2 *>(p.tb2);
+                pk2 rA = {0.f, 0.f}, rB = {0.f, 0.f};          // (L_A, H_A), (L_B, H_B)
 #pragma unroll
-                for (int tt = 0; tt < M; ++tt) {
-                    rv[0] += p.ta_lo[tt] * w2[2 * tt];
-                    rv[1] += p.tb_lo[tt] * w2[2 * tt + 1];
-                    rv[2] += p.ta_hi[tt] * w2[2 * tt];
-                    rv[3] += p.tb_hi[tt] * w2[2 * tt + 1];
-                }
+                for (int tt = 0; tt < M; ++tt) { rA += ta2[tt] * DTM_BX(w2[tt]); rB += tb2[tt] * DTM_BY(w2[tt]); }
+                // down the columns: a row of phase phi is an A row (phi even) or a B row of the pairs it reaches;
+                // S2[slot][A / B][v] = (column lowpass, column highpass) of row value v = L_A, L_B, H_A, H_B
                 const int phi = 2 * (k & 1) + q;           // row 4n + phi of its group (rbase % 4 == 0)
 #pragma unroll
                 for (int a = 0; a < NP2; ++a) {
                     const int tt = (phi + 8 * HL2 - 4 * a) >> 1;
-                    const float cl_ = (phi & 1) ? p.tb_lo[tt] : p.ta_lo[tt], ch_ = (phi & 1) ? p.tb_hi[tt] : p.ta_hi[tt];
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        S[a][(phi & 1) ? 2 : 0][v] += cl_ * rv[v];
-                        S[a][(phi & 1) ? 3 : 1][v] += ch_ * rv[v];
-                    }
+                    const pk2 cc = (phi & 1) ? tb2[tt] : ta2[tt];
+                    S2[a][phi & 1][0] += cc * DTM_BX(rA); S2[a][phi & 1][1] += cc * DTM_BX(rB);
+                    S2[a][phi & 1][2] += cc * DTM_BY(rA); S2[a][phi & 1][3] += cc * DTM_BY(rB);
                 }
             }
             if (k & 1) {
@@ -561,8 +613,8 @@ __global__ void __launch_bounds__(64, WPS) k_fwd12m(const Fwd12mParams p) {
                     float pl[2][4], ph[2][4];
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
-                        pl[0][v] = la ? S[0][0][v] : S[0][2][v]; pl[1][v] = la ? S[0][2][v] : S[0][0][v];
-                        ph[0][v] = ha ? S[0][1][v] : S[0][3][v]; ph[1][v] = ha ? S[0][3][v] : S[0][1][v];
+                        pl[0][v] = la ? S2[0][0][v].x : S2[0][1][v].x; pl[1][v] = la ? S2[0][1][v].x : S2[0][0][v].x;
+                        ph[0][v] = ha ? S2[0][0][v].y : S2[0][1][v].y; ph[1][v] = ha ? S2[0][1][v].y : S2[0][0][v].y;
                     }
                     float llo[2][2], lh2[2][2], hl2[2][2], hh2[2][2];
 #pragma unroll
@@ -596,13 +648,13 @@ __global__ void __launch_bounds__(64, WPS) k_fwd12m(const Fwd12mParams p) {
 #pragma unroll
                 for (int a = 0; a + 1 < NP2; ++a)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
+                    for (int c = 0; c < 2; ++c)
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) S[a][c][v] = S[a + 1][c][v];
+                        for (int v = 0; v < 4; ++v) S2[a][c][v] = S2[a + 1][c][v];
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
+                for (int c = 0; c < 2; ++c)
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) S[NP2 - 1][c][v] = 0.f;
+                    for (int v = 0; v < 4; ++v) S2[NP2 - 1][c][v] = pk2{0.f, 0.f};
             }
             f4 e0 = in0, e1 = in1;
             fix(e0); fix(e1);
@@ -864,6 +916,379 @@ __global__ void __launch_bounds__(128, 4) k_fwd12w(const Fwd12mParams p) {
                 }
             }
         }
+    }
+#endif
+}
+
+
+// ======================================================================================================================
+// Levels 2 + 1 of the inverse transform in one march (transform2d.py:242-293): the level-2 output Z1 never leaves the
+// registers.
+//
+// A macro-step takes ONE pair of level-2 input rows (two rows of Z2, one row of Yh1 records: one record per lane) and
+// produces FOUR rows of X:
+//   level 2  c2q of the lane's record; the row interpolation first (u0 = R0 z + R1 p23, u1 = R0 p05 + R1 p14: ten
+//            samples = the lane's two columns + two lanes either side by DPP), then the column interpolation in
+//            transposed form: the pair adds into the pending sums of the five groups of four Z1 rows whose windows
+//            contain it (colifilt, lowlevel.py:156-260).  Rows-then-columns keeps ONE pending plane
+//            (5 groups x 4 rows x 4 columns = 80 registers); it is the reference's sum in another order.
+//   level 1  twice per macro-step: two rows of Z1 + one row of Yh0 records (two per lane, through the slab) -> c2q ->
+//            row filters (v0 = g0o * Z1 + g1o * q23, v1 = g0o * q05 + g1o * q14, DPP halo of one lane) -> transposed
+//            column filters into 8 pending rows of X; the two oldest leave as 16-byte stores.
+// The rows of a macro-step are requested one macro-step ahead (64 registers in flight); loads and stores are issued on
+// every macro-step, for rows outside the band against descriptors that drop them (see k_fwd12m).
+// Symmetric extension: rows by reflected indices (a reflected record row also swaps the two rows of its quads),
+// columns by mirrored lanes (their records come from the mirror lane, quads flipped); colifilt of a symmetrically
+// extended plane is the symmetric extension of colifilt's output, so Z1 needs no special case at the image edge.
+// Only the standard phases (sum(g0a g0b) > 0, sum(g1a g1b) < 0: every shipped q-shift set) and M = 10.
+// ======================================================================================================================
+struct Inv21mParams {
+    const float *Z2;      // [B][R/2][C/2]
+    const float *Yh1;     // [B][R/4][C/4][12]
+    const float *Yh0;     // [B][R/2][C/2][12]
+    float *X;             // [B][R][C]
+    int B, R, C;          // R % 4 == 0, C % 4 == 0
+    int nstrip, nband, band_rows;
+    float g1[6], g2[6];   // gain x sqrt(1/2) per subband of level 1 / level 2
+    float g0o[MAXT1], g1o[MAXT1];
+    // colifilt(., g0b, g0a), colifilt(., g1b, g1a): first / second argument.  Read as pairs (h[2k], h[2k + 1]): the two
+    // output phases a window sample feeds are one packed multiply-add
+    float l_a[MAXT2] __attribute__((aligned(8))), l_b[MAXT2] __attribute__((aligned(8)));
+    float h_a[MAXT2] __attribute__((aligned(8))), h_b[MAXT2] __attribute__((aligned(8)));
+    // level-1 taps by distance d from the centre, each twice (g, g): the row filters run on (plane, plane) pairs with
+    // the tap common to both halves, and a broadcast from half a scalar pair is not free (see the forward kernel)
+    float gd0[2 * (MAXT1 / 2 + 1)] __attribute__((aligned(8))), gd1[2 * (MAXT1 / 2 + 1)] __attribute__((aligned(8)));
+};
+template <class Pm>
+inline void dtm_pack_inv_biort(Pm &p, int m0, int m1) {
+    for (int d = 0; d <= MAXT1 / 2; ++d) {
+        p.gd0[2 * d] = p.gd0[2 * d + 1] = d <= m0 / 2 ? p.g0o[m0 / 2 - d] : 0.f;
+        p.gd1[2 * d] = p.gd1[2 * d + 1] = d <= m1 / 2 ? p.g1o[m1 / 2 - d] : 0.f;
+    }
+}
+
+template <int M0, int M1, int M>
+struct Inv21m {
+    static constexpr int H0 = M0 / 2, H1 = M1 / 2;
+    static constexpr int HL1 = 1, HL2 = 2, HL = HL1 + HL2;
+    static constexpr int VL = 64 - 2 * HL;
+    static constexpr int NG = M / 2;              // pending groups of four Z1 rows
+    static constexpr int NPX = M0 > M1 + 2 ? M0 + 1 : M1 + 3;     // pending rows of X
+    static_assert(M == 10 && H0 <= 4 && H1 <= 4 && M0 % 2 == 1 && M1 % 2 == 1, "filters the marching inverse is built for");
+    static_assert(M0 == M1 + 2, "pending-row bookkeeping assumes len(g0o) = len(g1o) + 2");
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// c2q of one subband pair (A.4): quad a b / c d from w0, w1 (complex) and their gains (x sqrt(1/2))
+__device__ __forceinline__ void c2q_quad(float w0r, float w0i, float w1r, float w1i, float ga, float gb, float (&q)[2][2]) {
+    const float pr = ga * w0r, pi = ga * w0i, qr = gb * w1r, qi = gb * w1i;
+    q[0][0] = pr + qr; q[0][1] = pi + qi; q[1][0] = pi - qi; q[1][1] = qr - pr;
+}
+// interpolating row filter (colifilt along a row), standard phases: four outputs from the 10-sample window w
+// (element j = sample 2 jx - 4 + j); POS: sum(ha hb) > 0
+template <bool POS>
+__device__ __forceinline__ void ifilt_row(const float (&w)[10], const float *ha, const float *hb, float (&y)[4]) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const float lo = w[8 - 2 * k], hi = w[9 - 2 * k];
+        const float xa = POS ? hi : lo, xb = POS ? lo : hi;
+        y[0] += ha[2 * k] * xb; y[1] += hb[2 * k] * xa; y[2] += ha[2 * k + 1] * xb; y[3] += hb[2 * k + 1] * xa;
+    }
+}
+// the same on pairs: W[i] = samples (2 jx - 4 + 2i, + 1), i.e. the (even, odd) = ("lo", "hi") samples of lane jx - 2 + i;
+// ha2[k] = (ha[2k], ha[2k + 1]).  E = (y0, y2) and O = (y1, y3) are accumulated.
+template <bool POS>
+__device__ __forceinline__ void ifilt_row2(const pk2 (&W)[5], const pk2 *ha2, const pk2 *hb2, pk2 &E, pk2 &O) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        if (POS) { E += ha2[k] * DTM_BX(W[4 - k]); O += hb2[k] * DTM_BY(W[4 - k]); }
+        else     { E += ha2[k] * DTM_BY(W[4 - k]); O += hb2[k] * DTM_BX(W[4 - k]); }
+    }
+}
+__device__ __forceinline__ void win5(float v0, float v1, pk2 (&W)[5]) {
+    W[2] = pk2{v0, v1};
+    const float l0 = dpp_from_left(v0), l1 = dpp_from_left(v1), r0 = dpp_from_right(v0), r1 = dpp_from_right(v1);
+    W[1] = pk2{l0, l1}; W[3] = pk2{r0, r1};
+    W[0] = pk2{dpp_from_left(l0), dpp_from_left(l1)}; W[4] = pk2{dpp_from_right(r0), dpp_from_right(r1)};
+}
+// the window of a half-resolution plane row: the lane's two samples + two lanes either side
+__device__ __forceinline__ void win10(float v0, float v1, float (&w)[10]) {
+    w[4] = v0; w[5] = v1;
+    const float l0 = dpp_from_left(v0), l1 = dpp_from_left(v1), r0 = dpp_from_right(v0), r1 = dpp_from_right(v1);
+    w[2] = l0; w[3] = l1; w[6] = r0; w[7] = r1;
+    w[0] = dpp_from_left(l0); w[1] = dpp_from_left(l1); w[8] = dpp_from_right(r0); w[9] = dpp_from_right(r1);
+}
+#endif
+
+template <int M0, int M1, int M, int KO>
+__global__ void __launch_bounds__(64) k_inv21m(const Inv21mParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using G = Inv21m<M0, M1, M>;
+    constexpr int H0 = G::H0, H1 = G::H1, HL = G::HL, VL = G::VL, NG = G::NG, NPX = G::NPX;
+    __shared__ __attribute__((aligned(16))) f4 slab[2][64 * 6 + 6 * G::HL + 8];
+    const int lane = threadIdx.x;
+    const int job = blockIdx.x;
+    const int strip = job % p.nstrip, sb = job / p.nstrip, band = sb % p.nband, b = sb / p.nband;
+    const int R = p.R, C = p.C;
+    const int cb = strip * (4 * VL) - 4 * HL;             // column of lane 0
+    const int c0 = cb + 4 * lane;
+    const bool mir = c0 < 0 || c0 >= C;
+    const bool edge_strip = cb < 0 || cb + 256 > C;      // uniform: some lane is mirrored
+    const int nv = (C - strip * (4 * VL)) / 4 < VL ? (C - strip * (4 * VL)) / 4 : VL;
+    // where the lane's half-resolution samples / its level-2 record / its level-1 records come from
+    int zl = c0 < 0 ? -2 - c0 / 2 : (c0 >= C ? C - 2 - c0 / 2 : c0 / 2);
+    zl = zl < 0 ? 0 : (zl > C / 2 - 2 ? C / 2 - 2 : zl);
+    int ql = c0 < 0 ? -1 - c0 / 4 : (c0 >= C ? C / 2 - 1 - c0 / 4 : c0 / 4);
+    ql = ql < 0 ? 0 : (ql > C / 4 - 1 ? C / 4 - 1 : ql);
+    int sl = c0 < 0 ? (-c0 - 4 - cb) / 4 : (c0 >= C ? (2 * C - 4 - c0 - cb) / 4 : lane);
+    sl = sl < 0 ? 0 : (sl > 63 ? 63 : sl);
+    // the level-1 record pieces of a row this wavefront fetches: lanes lmin .. lmax are inside the image
+    const int lmin = cb < 0 ? -cb / 4 : 0, lmax = (C - cb) / 4 - 1 < 63 ? (C - cb) / 4 - 1 : 63;
+
+    const int64_t img = (int64_t)b * R * C;
+    const DtBuf bz = dt_buf2g(p.Z2 + img / 4);
+    const DtBuf b2 = dt_buf2g(p.Yh1 + (img / 4) * 3);
+    const float *const Y0b = p.Yh0 + img * 3 + (int64_t)(cb + 4 * lmin) * 6;       // record of lane lmin in row 0
+    float *const Xb = p.X + img + strip * (4 * VL);
+    const unsigned zpitch = (unsigned)C * 2u, r2pitch = (unsigned)C * 12u;          // bytes per Z2 row, per Yh1 record row
+    const unsigned r1bytes = (unsigned)(lmax - lmin + 1) * 96u;
+
+    const int rb = band * p.band_rows;
+    const int nrow = R - rb < p.band_rows ? R - rb : p.band_rows;
+    const int j0 = rb / 4 - 1, j1 = (rb + nrow) / 4;      // groups of Z1 rows level 1 reads
+    const int nfirst = j0 - 2, nms = j1 - j0 + 5;         // level-2 pairs j0 - 2 .. j1 + 2
+
+    float g0o[M0], g1o[M1];
+#pragma unroll
+    for (int k = 0; k < M0; ++k) g0o[k] = p.g0o[k];
+#pragma unroll
+    for (int k = 0; k < M1; ++k) g1o[k] = p.g1o[k];
+
+    // ---- requests -----------------------------------------------------------------------------------------------
+    auto zrow = [&](int u) { u = u < 0 ? -1 - u : u; u = u >= R / 2 ? R - 1 - u : u; u = u < 0 ? 0 : (u > R / 2 - 1 ? R / 2 - 1 : u); return (KO & 1) ? (u & 7) : u; };
+    auto ld_z2 = [&](int u) -> dt2d::f2 { return dt2d::dt_buf_ld2(bz, (unsigned)zl * 4u, (unsigned)zrow(u) * zpitch); };
+    auto pair_row = [&](int n, bool &sw) { sw = n < 0 || n >= R / 4; n = n < 0 ? -1 - n : n; n = n >= R / 4 ? R / 2 - 1 - n : n; n = n < 0 ? 0 : (n > R / 4 - 1 ? R / 4 - 1 : n); return (KO & 1) ? (n & 3) : n; };
+    auto rec_row = [&](int rr, bool &sw) { sw = rr < 0 || rr >= R / 2; rr = rr < 0 ? -1 - rr : rr; rr = rr >= R / 2 ? R - 1 - rr : rr; rr = rr < 0 ? 0 : (rr > R / 2 - 1 ? R / 2 - 1 : rr); return (KO & 1) ? (rr & 7) : rr; };
+
+    dt2d::f2 z2p[2];
+    f4 r2p[3], r1p[2][6];
+    auto request = [&](int n) {        // level-2 inputs of pair n, level-1 record rows of group n - 2
+        bool sw;
+        z2p[0] = ld_z2(2 * n); z2p[1] = ld_z2(2 * n + 1);
+        const unsigned ro2 = (unsigned)pair_row(n, sw) * r2pitch;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) r2p[m] = dt2d::dt_buf_ld4(b2, (unsigned)ql * 48u + 16u * m, ro2);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int rr = rec_row(2 * (n - 2) + e, sw);
+            const DtBuf br = dt_buf_n(Y0b + (int64_t)rr * C * 6, r1bytes);
+#pragma unroll
+            for (int m = 0; m < 6; ++m) r1p[e][m] = dt2d::dt_buf_ld4(br, 16u * (unsigned)lane + 1024u * m, 0u);
+        }
+    };
+    request(nfirst);
+    asm volatile("" : "+v"(z2p[0].x), "+v"(z2p[0].y), "+v"(z2p[1].x), "+v"(z2p[1].y) : : "memory");
+#pragma unroll
+    for (int m = 0; m < 3; ++m) asm volatile("" : "+v"(r2p[m].x), "+v"(r2p[m].y), "+v"(r2p[m].z), "+v"(r2p[m].w) : : "memory");
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int m = 0; m < 6; ++m) asm volatile("" : "+v"(r1p[e][m].x), "+v"(r1p[e][m].y), "+v"(r1p[e][m].z), "+v"(r1p[e][m].w) : : "memory");
+
+    // pending Z1 groups: PzE[a][c] = rows (0, 2), PzO[a][c] = rows (1, 3) of group slot a, column c
+    pk2 PzE[NG][4], PzO[NG][4];
+    float PX[NPX][4];
+#pragma unroll
+    for (int a = 0; a < NG; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { PzE[a][c] = pk2{0.f, 0.f}; PzO[a][c] = pk2{0.f, 0.f}; }
+#pragma unroll
+    for (int i = 0; i < NPX; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) PX[i][c] = 0.f;
+
+    const unsigned xv = 16u * (unsigned)(lane - HL);
+
+    for (int ms = 0; ms < nms; ++ms) {
+        const int n = nfirst + ms, j = n - 2;
+        bool sw2, sw1[2];
+        (void)pair_row(n, sw2);
+        (void)rec_row(2 * j, sw1[0]); (void)rec_row(2 * j + 1, sw1[1]);
+        // ---- what was requested a macro-step ago: the level-1 records to the slab, the level-2 inputs through c2q
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int m = 0; m < 6; ++m) slab[e][6 * lmin + lane + 64 * m] = r1p[e][m];
+        float z[2][2], p05[2][2], p23[2][2], p14[2][2];
+        {
+            const f4 ra = r2p[0], rc = r2p[1], re = r2p[2];
+            c2q_quad(ra.x, ra.y, re.z, re.w, p.g2[0], p.g2[5], p05);
+            c2q_quad(rc.x, rc.y, rc.z, rc.w, p.g2[2], p.g2[3], p23);
+            c2q_quad(ra.z, ra.w, re.x, re.y, p.g2[1], p.g2[4], p14);
+            z[0][0] = z2p[0].x; z[0][1] = z2p[0].y; z[1][0] = z2p[1].x; z[1][1] = z2p[1].y;
+            if (sw2) {
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    float t_;
+                    t_ = p05[0][f]; p05[0][f] = p05[1][f]; p05[1][f] = t_;
+                    t_ = p23[0][f]; p23[0][f] = p23[1][f]; p23[1][f] = t_;
+                    t_ = p14[0][f]; p14[0][f] = p14[1][f]; p14[1][f] = t_;
+                }
+            }
+            if (edge_strip) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    float t_;
+                    t_ = z[e][0]; z[e][0] = mir ? z[e][1] : t_; z[e][1] = mir ? t_ : z[e][1];
+                    t_ = p05[e][0]; p05[e][0] = mir ? p05[e][1] : t_; p05[e][1] = mir ? t_ : p05[e][1];
+                    t_ = p23[e][0]; p23[e][0] = mir ? p23[e][1] : t_; p23[e][1] = mir ? t_ : p23[e][1];
+                    t_ = p14[e][0]; p14[e][0] = mir ? p14[e][1] : t_; p14[e][1] = mir ? t_ : p14[e][1];
+                }
+            }
+        }
+        request(n + 1);
+
+        // ---- level 2: rows, then columns into the pending groups
+        const pk2 *la2 = reinterpret_cast<const pk2 *>(p.l_a), *lb2 = reinterpret_cast<const pk2 *>(p.l_b);
+        const pk2 *ha2 = reinterpret_cast<const pk2 *>(p.h_a), *hb2 = reinterpret_cast<const pk2 *>(p.h_b);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            // u0 = R0 z + R1 p23, u1 = R0 p05 + R1 p14 as (u[0], u[2]) and (u[1], u[3])
+            pk2 U0E = {0.f, 0.f}, U0O = {0.f, 0.f}, U1E = {0.f, 0.f}, U1O = {0.f, 0.f}, W[5];
+            win5(z[e][0], z[e][1], W);     ifilt_row2<true>(W, la2, lb2, U0E, U0O);
+            win5(p23[e][0], p23[e][1], W); ifilt_row2<false>(W, ha2, hb2, U0E, U0O);
+            win5(p05[e][0], p05[e][1], W); ifilt_row2<true>(W, la2, lb2, U1E, U1O);
+            win5(p14[e][0], p14[e][1], W); ifilt_row2<false>(W, ha2, hb2, U1E, U1O);
+#pragma unroll
+            for (int a = 0; a < NG; ++a) {          // slot a = group n - 2 + a, tap pair k = a
+                if (e == 0) {       // the even ("lo") row of the pair: rows (0, 2) through g0, rows (1, 3) through g1
+                    PzE[a][0] += la2[a] * DTM_BX(U0E); PzE[a][2] += la2[a] * DTM_BY(U0E);
+                    PzE[a][1] += la2[a] * DTM_BX(U0O); PzE[a][3] += la2[a] * DTM_BY(U0O);
+                    PzO[a][0] += hb2[a] * DTM_BX(U1E); PzO[a][2] += hb2[a] * DTM_BY(U1E);
+                    PzO[a][1] += hb2[a] * DTM_BX(U1O); PzO[a][3] += hb2[a] * DTM_BY(U1O);
+                } else {
+                    PzO[a][0] += lb2[a] * DTM_BX(U0E); PzO[a][2] += lb2[a] * DTM_BY(U0E);
+                    PzO[a][1] += lb2[a] * DTM_BX(U0O); PzO[a][3] += lb2[a] * DTM_BY(U0O);
+                    PzE[a][0] += ha2[a] * DTM_BX(U1E); PzE[a][2] += ha2[a] * DTM_BY(U1E);
+                    PzE[a][1] += ha2[a] * DTM_BX(U1O); PzE[a][3] += ha2[a] * DTM_BY(U1O);
+                }
+            }
+        }
+        // ---- level 1 on the completed group j = n - 2 (Z1 rows 4j .. 4j + 3 = Pz[0])
+        DT_WAVE_LDS_SYNC();
+        const bool grp = j >= j0 && j <= j1;           // uniform
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int rho = 4 * j + 2 * h;
+            if (grp) {
+                float q05[2][4], q23[2][4], q14[2][4];
+                {
+                    const f4 *sp = slab[h] + 6 * sl;
+                    f4 s_[6];
+#pragma unroll
+                    for (int m = 0; m < 6; ++m) s_[m] = sp[m];
+                    float A05[2][2], A23[2][2], A14[2][2], B05[2][2], B23[2][2], B14[2][2];
+                    c2q_quad(s_[0].x, s_[0].y, s_[2].z, s_[2].w, p.g1[0], p.g1[5], A05);
+                    c2q_quad(s_[1].x, s_[1].y, s_[1].z, s_[1].w, p.g1[2], p.g1[3], A23);
+                    c2q_quad(s_[0].z, s_[0].w, s_[2].x, s_[2].y, p.g1[1], p.g1[4], A14);
+                    c2q_quad(s_[3].x, s_[3].y, s_[5].z, s_[5].w, p.g1[0], p.g1[5], B05);
+                    c2q_quad(s_[4].x, s_[4].y, s_[4].z, s_[4].w, p.g1[2], p.g1[3], B23);
+                    c2q_quad(s_[3].z, s_[3].w, s_[5].x, s_[5].y, p.g1[1], p.g1[4], B14);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+#pragma unroll
+                        for (int f = 0; f < 2; ++f) {
+                            q05[e][f] = A05[e][f]; q05[e][2 + f] = B05[e][f];
+                            q23[e][f] = A23[e][f]; q23[e][2 + f] = B23[e][f];
+                            q14[e][f] = A14[e][f]; q14[e][2 + f] = B14[e][f];
+                        }
+                    }
+                    if (sw1[h]) {               // a reflected record row (image top / bottom): its quads upside down
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            float t_;
+                            t_ = q05[0][c]; q05[0][c] = q05[1][c]; q05[1][c] = t_;
+                            t_ = q23[0][c]; q23[0][c] = q23[1][c]; q23[1][c] = t_;
+                            t_ = q14[0][c]; q14[0][c] = q14[1][c]; q14[1][c] = t_;
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        if (edge_strip) {       // mirrored lanes: the mirror lane's four columns in reverse
+                            float t_;
+#define DTM_REV4(x_) t_ = x_[e][0]; x_[e][0] = mir ? x_[e][3] : t_; x_[e][3] = mir ? t_ : x_[e][3]; \
+                     t_ = x_[e][1]; x_[e][1] = mir ? x_[e][2] : t_; x_[e][2] = mir ? t_ : x_[e][2];
+                            DTM_REV4(q05) DTM_REV4(q23) DTM_REV4(q14)
+#undef DTM_REV4
+                        }
+                    }
+                }
+                const pk2 *gd0 = reinterpret_cast<const pk2 *>(p.gd0), *gd1 = reinterpret_cast<const pk2 *>(p.gd1);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    // (Z1, q05) through g0o and (q23, q14) through g1o, the filters symmetric: V[c] = (v0[c], v1[c])
+                    const int zr = 2 * h + e;       // row of the group: rows 0, 2 in PzE (x, y), rows 1, 3 in PzO
+                    pk2 Wa[4 + 2 * H0], Wb[4 + 2 * H1], V[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float zv = (zr & 1) ? ((zr & 2) ? PzO[0][c].y : PzO[0][c].x) : ((zr & 2) ? PzE[0][c].y : PzE[0][c].x);
+                        Wa[H0 + c] = pk2{zv, q05[e][c]};
+                        Wb[H1 + c] = pk2{q23[e][c], q14[e][c]};
+                    }
+#pragma unroll
+                    for (int i = 0; i < H0; ++i) {
+                        Wa[i] = pk2{dpp_from_left(Wa[4 + i].x), dpp_from_left(Wa[4 + i].y)};
+                        Wa[H0 + 4 + i] = pk2{dpp_from_right(Wa[H0 + i].x), dpp_from_right(Wa[H0 + i].y)};
+                    }
+#pragma unroll
+                    for (int i = 0; i < H1; ++i) {
+                        Wb[i] = pk2{dpp_from_left(Wb[4 + i].x), dpp_from_left(Wb[4 + i].y)};
+                        Wb[H1 + 4 + i] = pk2{dpp_from_right(Wb[H1 + i].x), dpp_from_right(Wb[H1 + i].y)};
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        pk2 a_ = gd0[0] * Wa[H0 + c];
+#pragma unroll
+                        for (int d = 1; d <= H0; ++d) a_ += gd0[d] * (Wa[H0 + c - d] + Wa[H0 + c + d]);
+                        a_ += gd1[0] * Wb[H1 + c];
+#pragma unroll
+                        for (int d = 1; d <= H1; ++d) a_ += gd1[d] * (Wb[H1 + c - d] + Wb[H1 + c + d]);
+                        V[c] = a_;
+                    }
+                    const float v0[4] = {V[0].x, V[1].x, V[2].x, V[3].x}, v1[4] = {V[0].y, V[1].y, V[2].y, V[3].y};
+                    // columns, transposed: PX[i] is row rho - H0 + i
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                        for (int k = 0; k < M0; ++k) PX[e + k][c] += g0o[k] * v0[c];
+#pragma unroll
+                        for (int k = 0; k < M1; ++k) PX[e + (H0 - H1) + k][c] += g1o[k] * v1[c];
+                    }
+                }
+            }
+            // rows rho - H0, rho - H0 + 1 are complete
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int x = rho - H0 + e;
+                const bool ok = x >= rb && x < rb + nrow;
+                const int xo = ok ? ((KO & 2) ? (x & 15) : x) : 0;
+                const DtBuf bo = dt_buf_n(Xb + (int64_t)xo * C, ok ? 16u * nv : 0u);
+                dt2d::dt_buf_st4<true>(bo, xv, 0u, f4{PX[e][0], PX[e][1], PX[e][2], PX[e][3]});
+            }
+#pragma unroll
+            for (int i = 0; i + 2 < NPX; ++i)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) PX[i][c] = PX[i + 2][c];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { PX[NPX - 2][c] = 0.f; PX[NPX - 1][c] = 0.f; }
+        }
+        DT_WAVE_LDS_SYNC();
+#pragma unroll
+        for (int a = 0; a + 1 < NG; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { PzE[a][c] = PzE[a + 1][c]; PzO[a][c] = PzO[a + 1][c]; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { PzE[NG - 1][c] = pk2{0.f, 0.f}; PzO[NG - 1][c] = pk2{0.f, 0.f}; }
     }
 #endif
 }

@@ -65,6 +65,52 @@ __global__ void __launch_bounds__(DT_NT) ref_fwd2(Fwd2Params p) {
     }
 }
 
+template <class C>
+__global__ void __launch_bounds__(DT_NT) ref_inv1(Inv1Params p) {
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_ALIASED];
+    const int ntile = p.tilesR * p.tilesC * p.B;
+    int t = tile_of(blockIdx.x, ntile, p.xcd_order);
+    if (t >= ntile) return;
+    int tc, tr, b;
+    dt_tile_decode(p, t, tc, tr, b);
+    float *srec = smem, *y1 = smem, *y2 = y1 + C::SY;
+    const int r0 = tr * C::TR, c0 = tc * C::TC;
+    const float *Yhb = p.Yh + (int64_t)b * (p.R / 2) * (p.C / 2) * 12;
+    float wz[C::WN], w1[C::WN], w2[C::WN], w3[C::WN];
+    inv1r_fetch<C>(p, wz, threadIdx.x, b, r0, c0);
+    inv_rec_stage<C::QR, C::QC>(Yhb, p.R, p.C, srec, r0 - C::HE, c0 - C::HE, threadIdx.x);
+    __syncthreads();
+    inv1r_gather<C>(p, srec, w1, w2, w3, threadIdx.x, r0, c0);
+    __syncthreads();
+    inv1r_fir<C>(p, wz, w1, w2, w3, y1, y2, threadIdx.x, nullptr);
+    __syncthreads();
+    inv1d_rows<C>(p, y1, y2, threadIdx.x, b, r0, c0, nullptr);
+}
+template <class C>
+__global__ void __launch_bounds__(DT_NT) ref_inv2(Inv2Params p) {
+    __shared__ __attribute__((aligned(16))) float smem[C::LDS_ALIASED];
+    const int ntile = p.tilesR * p.tilesC * p.B;
+    int t = tile_of(blockIdx.x, ntile, p.xcd_order);
+    if (t >= ntile) return;
+    int tc, tr, b;
+    dt_tile_decode(p, t, tc, tr, b);
+    float *srec = smem, *y1 = smem, *y2 = y1 + C::SY;
+    const int r0 = tr * C::TR, c0 = tc * C::TC;
+    const float *Yhb = p.Yh + (int64_t)b * (p.zr / 2) * (p.zc / 2) * 12;
+    float wz[C::WS], w1[C::WS], w2[C::WS], w3[C::WS];
+    inv2r_fetch<C>(p, wz, threadIdx.x, b, r0, c0);
+    inv_rec_stage<C::QR, C::QC>(Yhb, p.zr, p.zc, srec, r0 + C::ORG, c0 + C::ORG, threadIdx.x);
+    __syncthreads();
+    inv2r_gather<C>(p, srec, w1, w2, w3, threadIdx.x, r0, c0);
+    __syncthreads();
+    inv2r_fir<C, false, true>(p, wz, w1, w2, w3, y1, y2, threadIdx.x, nullptr);
+    __syncthreads();
+    inv2_rows<C, true>(p, y1, y2, threadIdx.x, b, r0, c0, nullptr);
+}
+static const double G0O[7] = {-0.0107142857142857, -0.0535714285714286, 0.260714285714286, 0.607142857142857,
+                              0.260714285714286, -0.0535714285714286, -0.0107142857142857};
+static const double G1O[5] = {-0.05, -0.25, 0.6, -0.25, -0.05};
+
 static const double H0A[10] = {0.03516384, 0., -0.08832942, 0.23389032, 0.76027237, 0.5875183, 0., -0.11430184, 0., 0.};
 static const double H1A[10] = {0., 0., -0.11430184, 0., 0.5875183, -0.76027237, 0.23389032, 0.08832942, 0., -0.03516384};
 static void putr(float *dst, const double *src, int n, bool rev) { for (int k = 0; k < DT_MAXT; ++k) dst[k] = k < n ? (float)src[rev ? n - 1 - k : k] : 0.f; }
@@ -75,7 +121,7 @@ static const double H1O[7] = {-0.0107142857142857, 0.0535714285714286, 0.2607142
 static void put(float *dst, const double *src, int n, int cap) { for (int k = 0; k < cap; ++k) dst[k] = k < n ? (float)src[k] : 0.f; }
 
 constexpr int NSET = 4;
-struct Set { float *X, *L1, *Y0, *L1r, *Y0r, *L2, *Y1, *L2r, *Y1r; };
+struct Set { float *X, *L1, *Y0, *L1r, *Y0r, *L2, *Y1, *L2r, *Y1r, *Xo, *Xor; };
 static Set sets[NSET];
 static int N = 4096, REPS = 40;
 static hipStream_t st, st_a, st_b;
@@ -127,8 +173,46 @@ static void launch_f12(int s, int band_rows) {
     p.nstrip = cdiv(N, 4 * G::VL); p.band_rows = band_rows; p.nband = cdiv(N, band_rows);
     put(p.h0, H0O, 5, dtm::MAXT1); put(p.h1, H1O, 7, dtm::MAXT1);
     Fwd2Params q{}; fill_fwd2(q);
-    dtm::dtm_pack_qshift(p, 10, q.l_a, q.l_b, q.h_a, q.h_b); p.lo_a_first = q.lo_a_first; p.hi_a_first = q.hi_a_first;
+    dtm::dtm_pack_qshift(p, 10, q.l_a, q.l_b, q.h_a, q.h_b); dtm::dtm_pack_biort(p, 5, 7); p.lo_a_first = q.lo_a_first; p.hi_a_first = q.hi_a_first;
     dtm::k_fwd12m<5, 7, 10, P, KO, WPS><<<p.nstrip * p.nband, 64, 0, st>>>(p);
+}
+using I1 = Inv1RCfg<16, 120, 8, 7, 5>;
+using I2 = Inv2RCfg<16, 56, 2, 10>;
+static const float GAINS[6] = {0.70710678f, 0.6f, 0.8f, 0.70710678f, 0.5f, 0.9f};
+static void fill_inv2(Inv2Params &p) {     // any 10-tap values with the standard phases (as tools/kbench/ko_bench)
+    putr(p.l_a, H0A, 10, false); putr(p.l_b, H0A, 10, true); putr(p.h_a, H1A, 10, false); putr(p.h_b, H1A, 10, true);
+    p.lo_pos = 1; p.hi_pos = 0;
+    for (int d = 0; d < 6; ++d) p.g[d] = GAINS[d];
+}
+// the library's two tile programs: Z2 = sets[s].L2, Yh1 = Y1, Yh0 = Y0 -> Z1 (L1) -> X
+static void launch_ref_inv(int s, float *Z1, float *Xout) {
+    Inv2Params q{}; q.Z = sets[s].L2; q.Yh = sets[s].Y1; q.Out = Z1; q.B = 1; q.zr = q.zc = N / 2; q.xcd_order = 1; fill_inv2(q);
+    q.tilesR = cdiv(N / 2, I2::TR); q.tilesC = cdiv(N / 2, I2::TC); dt_set_tile_magic(q);
+    ref_inv2<I2><<<grid_for(q.tilesR * q.tilesC), DT_NT, 0, st>>>(q);
+    Inv1Params p{}; p.Z = Z1; p.Yh = sets[s].Y0; p.X = Xout; p.B = 1; p.R = p.C = N; p.xcd_order = 1;
+    for (int d = 0; d < 6; ++d) p.g[d] = GAINS[5 - d];
+    put(p.g0, G0O, 7, DT_MAXT); put(p.g1, G1O, 5, DT_MAXT); dt_pack_g01<7, 5>(p);
+    p.tilesR = cdiv(N, I1::TR); p.tilesC = cdiv(N, I1::TC); dt_set_tile_magic(p);
+    ref_inv1<I1><<<grid_for(p.tilesR * p.tilesC), DT_NT, 0, st>>>(p);
+}
+template <int KO>
+static void launch_i21(int s, int band_rows, float *Xout) {
+    using G = dtm::Inv21m<7, 5, 10>;
+    dtm::Inv21mParams p{}; p.Z2 = sets[s].L2; p.Yh1 = sets[s].Y1; p.Yh0 = sets[s].Y0; p.X = Xout; p.B = 1; p.R = p.C = N;
+    p.nstrip = cdiv(N, 4 * G::VL); p.band_rows = band_rows; p.nband = cdiv(N, band_rows);
+    Inv2Params q{}; fill_inv2(q);
+    for (int k = 0; k < dtm::MAXT2; ++k) { p.l_a[k] = q.l_a[k]; p.l_b[k] = q.l_b[k]; p.h_a[k] = q.h_a[k]; p.h_b[k] = q.h_b[k]; }
+    for (int d = 0; d < 6; ++d) { p.g2[d] = GAINS[d]; p.g1[d] = GAINS[5 - d]; }
+    put(p.g0o, G0O, 7, dtm::MAXT1); put(p.g1o, G1O, 5, dtm::MAXT1); dtm::dtm_pack_inv_biort(p, 7, 5);
+    dtm::k_inv21m<7, 5, 10, KO><<<p.nstrip * p.nband, 64, 0, st>>>(p);
+}
+static void run_i21(int band_rows) {
+    const double a = time_it([&](int s) { launch_i21<0>(s, band_rows, sets[s].Xo); });
+    const double b = time_it([&](int s) { launch_i21<1>(s, band_rows, sets[s].Xo); });
+    const double c = time_it([&](int s) { launch_i21<2>(s, band_rows, sets[s].Xo); });
+    const double d = time_it([&](int s) { launch_i21<3>(s, band_rows, sets[s].Xo); });
+    printf("k_inv21m band_rows=%3d                    %9.2f %9.2f %9.2f %9.2f\n", band_rows, a, b, c, d);
+    fflush(stdout);
 }
 template <int P, int KO>
 static void launch_f12w(int s, int band_rows) {
@@ -137,7 +221,7 @@ static void launch_f12w(int s, int band_rows) {
     p.nstrip = cdiv(N, 4 * G::VL); p.band_rows = band_rows; p.nband = cdiv(N, band_rows);
     put(p.h0, H0O, 5, dtm::MAXT1); put(p.h1, H1O, 7, dtm::MAXT1);
     Fwd2Params q{}; fill_fwd2(q);
-    dtm::dtm_pack_qshift(p, 10, q.l_a, q.l_b, q.h_a, q.h_b); p.lo_a_first = q.lo_a_first; p.hi_a_first = q.hi_a_first;
+    dtm::dtm_pack_qshift(p, 10, q.l_a, q.l_b, q.h_a, q.h_b); dtm::dtm_pack_biort(p, 5, 7); p.lo_a_first = q.lo_a_first; p.hi_a_first = q.hi_a_first;
     dtm::k_fwd12w<5, 7, 10, P, KO><<<p.nstrip * p.nband, 128, 0, st>>>(p);
 }
 template <int P>
@@ -218,6 +302,8 @@ int main(int argc, char **argv) {
         CK(hipMalloc(&s.L2, px)); CK(hipMalloc(&s.Y1, px * 3)); CK(hipMemset(s.L2, 0, px)); CK(hipMemset(s.Y1, 0, px * 3));
     }
     CK(hipMalloc(&sets[0].L2r, px)); CK(hipMalloc(&sets[0].Y1r, px * 3));
+    for (auto &s : sets) { CK(hipMalloc(&s.Xo, px * 4)); CK(hipMemset(s.Xo, 0, px * 4)); }
+    CK(hipMalloc(&sets[0].Xor, px * 4));
     CK(hipMalloc(&sets[0].L1r, px * 4)); CK(hipMalloc(&sets[0].Y0r, px * 12));
     // correctness: march vs tile program on set 0
     launch_ref(0, sets[0].L1r, sets[0].Y0r);
@@ -244,6 +330,29 @@ int main(int argc, char **argv) {
             printf("k_fwd12m (bands of %d rows) vs tile programs: Yh0 %.3g (max %.3g), Yh1 %.3g (max %.3g), LoLo2 %.3g (max %.3g)\n", br, e0, ma, e1, mb, e2, mc);
         }
     }
+    {   // levels 2 + 1 of the inverse in one march against the two tile programs (inputs: the pyramid the forward just made)
+        launch_ref(0, sets[0].L1r, sets[0].Y0); launch_ref2(sets[0].L1r, sets[0].L2, sets[0].Y1);
+        launch_ref_inv(0, sets[0].L1, sets[0].Xor);
+        for (int br : {40, 64, 24}) {
+            CK(hipMemset(sets[0].Xo, 0, px * 4));
+            launch_i21<0>(0, br, sets[0].Xo);
+            CK(hipStreamSynchronize(st));
+            double ma;
+            const double e0 = maxdiff(sets[0].Xo, sets[0].Xor, px, &ma);
+            printf("k_inv21m (bands of %d rows) vs tile programs: X %.3g (max %.3g)\n", br, e0, ma);
+        }
+        for (int s2 = 1; s2 < NSET; ++s2) { launch_ref(s2, sets[s2].L1, sets[s2].Y0); launch_ref2(sets[s2].L1, sets[s2].L2, sets[s2].Y1); }
+    }
+    if (argc > 3) {     // profile mode: a few launches of the marching kernels, whole and with loads / stores knocked out
+        for (int s2 = 1; s2 < NSET; ++s2) { launch_ref(s2, sets[s2].L1, sets[s2].Y0); launch_ref2(sets[s2].L1, sets[s2].L2, sets[s2].Y1); }
+        for (int i = 0; i < 12; ++i) {
+            launch_f12<2, 0>(i % NSET, 40); launch_f12<2, 3>(i % NSET, 40);
+            launch_i21<0>(i % NSET, 40, sets[i % NSET].Xo); launch_i21<3>(i % NSET, 40, sets[i % NSET].Xo);
+            launch_ref(i % NSET, sets[i % NSET].L1, sets[i % NSET].Y0);
+        }
+        CK(hipDeviceSynchronize());
+        return 0;
+    }
     for (int i = 0; i < 30; ++i) launch_ref(i % NSET, sets[i % NSET].L1, sets[i % NSET].Y0);      // settle the clocks
     printf("%dx%d, %d reps over %d buffer sets; us per launch\n", N, N, REPS, NSET);
     printf("%-40s %9s %9s %9s %9s\n", "kernel", "full", "cached-ld", "no-store", "arith-only");
@@ -253,6 +362,8 @@ int main(int argc, char **argv) {
         const double r2 = time_it([&](int s) { launch_ref2(sets[s].L1, sets[s].L2, sets[s].Y1); });
         printf("%-40s %9.2f\n", "k_fwd2 tile program (library)", r2);
         run_f12<2>(40);
+        printf("%-40s %9.2f\n", "k_inv2 + k_inv1 tile programs", time_it([&](int s) { launch_ref_inv(s, sets[s].L1, sets[s].Xo); }));
+        for (int br : {40, 48, 64}) run_i21(br);
         printf("k_fwd12m bands of 40: plain record stores %.2f, nt loads %.2f, both %.2f\n", time_it([&](int s) { launch_f12<2, 16>(s, 40); }), time_it([&](int s) { launch_f12<2, 32>(s, 40); }), time_it([&](int s) { launch_f12<2, 48>(s, 40); }));
         run_f12w<2>(40);
         printf("two streams, us per image: tile fwd1 + fwd2 %.2f", time_two_streams([&](int s) { launch_ref(s, sets[s].L1, sets[s].Y0); launch_ref2(sets[s].L1, sets[s].L2, sets[s].Y1); }));
