@@ -23,13 +23,18 @@ images (the coarse-level kernels of one image overlap the level-1 kernels of the
 the latency of one forward + inverse: `one_stream_ms_per_step` in the same line is the same
 rotating-buffer protocol on ONE stream.
 
-The roofline object is for the dominant kernel (the level kernel with the longest median
-duration, k_inv1 or k_fwd1): `kernel_ms` is the MEDIAN over the profiled steps of the raw
+The roofline object is for the dominant kernel (the launch with the longest median duration: the
+forward's levels 1 + 2, which run as ONE marching launch k_fwd12m when the geometry allows, or the
+level-1 kernels k_fwd1 / k_inv1, or the inverse's one-launch levels 2 + 1, k_inv21m): `kernel_ms` is the MEDIAN over the profiled steps of the raw
 hipEvent-pair time around that kernel on the library's stream (an empty pair costs
 `event_pair_overhead_ms`, reported, not subtracted); `rocprof_kernel_ms` next to it is the median of
 the same kernel under `rocprofv3 --kernel-trace` of this command (tools/profile_round.sh ->
 profiles/traffic.json), as is `traffic`.  cpu_baseline times the NumPy oracle (a port of the
 reference's algorithm) on the host, rank 0 only, after the process group is gone.
+
+At N = 1 the default (c2) run also times short versions of the other single-GPU BASELINE configs -- c3, one GPU's
+share of c5, c4 -- as sub-runs of this script after its own measurement and before the CPU baseline, and reports
+them under `other_configs` (`--no-other-configs` skips them).
 
 `--config c4` (BASELINE configs[3], one volume: it does not shard, N = 1 only) times the 3-D transform the same way:
 a step = Transform3d forward + inverse of one 256^3 float32 volume, nlevels=3, rotating over `--sets` volumes on one
@@ -102,6 +107,8 @@ def parse_args(argv=None):
     ap.add_argument('--mgpu', action='store_true', help='N > 1 from ONE process: dtcwt_hip_mgpu_* with a host '
                     'thread per device instead of one process per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true', help='c2 at N = 1 only: do not append short runs of '
+                    'c3, c5 (the share of one GPU) and c4 as "other_configs"')
     ap.add_argument('--graph', action='store_true', help='replay the level kernels of a step as one hipGraph '
                     '(measured: not faster than plain stream launches, so not the default)')
     ap.add_argument('--settle-ms', type=float, default=300.0,
@@ -378,9 +385,12 @@ def main():
     plan.set_profiling(False)
     kf = np.median(kf, axis=0); ki = np.median(ki, axis=0)
     px = float(B) * R * C
-    # algorithmic bytes per launch of the level-1 kernels (SURVEY 8(d) per-unit figures x pixels):
-    #   X 4 + LoLo1 4 + Yh[0] 12 = 20 B/px (inverse mirrored)
-    cand = [('k_fwd1 (level-1 forward)', kf[0], 20.0), ('k_inv1 (level-1 inverse)', ki[0], 20.0)]
+    # algorithmic bytes per launch (SURVEY 8(d) per-unit figures x pixels), inverse mirrored:
+    #   level-1 kernels              X 4 + LoLo1 4 + Yh[0] 12            = 20 B/px
+    #   levels 1 + 2 in one launch   X 4 + Yh[0] 12 + Yh[1] 3 + LoLo2 1  = 20 B/px (LoLo1 stays in registers)
+    fwd12, inv21 = plan.launches() if NL >= 2 else (False, False)
+    cand = [('k_fwd12m (levels 1+2 forward, one launch)', kf[0], 20.0) if fwd12 else ('k_fwd1 (level-1 forward)', kf[0], 20.0),
+            ('k_inv21m (levels 2+1 inverse, one launch)', ki[1], 20.0) if inv21 else ('k_inv1 (level-1 inverse)', ki[0], 20.0)]
     name, ms, bpp = max(cand, key=lambda c: c[1])
     achieved = bpp * px / (ms * 1e-3) / 1e9       # GB/s
     roofline = {'bound': 'hbm', 'kernel': name, 'achieved': round(achieved, 1), 'peak': HBM_PEAK / 1e9,
@@ -389,6 +399,8 @@ def main():
                 'rocprof_kernel_ms': None, 'algorithmic_bytes_per_launch': bpp * px,
                 'fwd_kernel_ms': [round(float(x), 5) for x in kf],
                 'inv_kernel_ms': [round(float(x), 5) for x in ki],
+                'launches': {'fwd_levels_1_2_one_launch': bool(fwd12), 'inv_levels_2_1_one_launch': bool(inv21),
+                             'note': 'a shared launch is timed under the level it starts with; the other level shows an empty event pair'},
                 'sum_kernel_ms': round(float(kf.sum() + ki.sum()), 5), 'event_pair_overhead_ms': round(null_ms, 5),
                 'step_frac': round(STEP_BYTES_PER_PX * px / (dt / args.steps) / HBM_PEAK, 4)}
     tr = os.path.join(ROOT, 'profiles', 'traffic.json')
@@ -432,6 +444,11 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
 
+    # ---- the other single-GPU BASELINE configs, short, as sub-runs of this script (c2 at N = 1 only) ----
+    if rank == 0 and world == 1 and args.config == 'c2' and not args.no_other_configs and not args.mgpu:
+        sets.clear()            # hand this run's 1.6 GB of buffers back before the sub-runs allocate theirs
+        out['other_configs'] = other_configs()
+
     # ---- CPU baseline: the oracle (a NumPy port of the reference's algorithm), rank 0 ----
     if rank == 0 and not args.no_cpu_baseline:
         out['cpu_baseline'], zc = cpu_baseline(cfg, Xh0)
@@ -446,6 +463,37 @@ def main():
         print(json.dumps(out), flush=True)
         if saved_stdout is not None:
             os.dup2(2, 1)           # what the collective library still has in its stdio buffer (its banner) goes to stderr
+
+
+def other_configs():
+    """Short runs of the other single-GPU BASELINE configs under the same protocol (rotating buffer sets, settle phase,
+    device-synchronised timed region), each as `python bench.py --config X --no-cpu-baseline`: c3 (64 x 1024^2 nl=5), c5
+    (one GPU's share of the 512-image batch: 64 x 2048^2 nl=4) and c4 (3-D 256^3 nl=3).  The reference's own benchmark
+    script times every case it names in one run (scripts/benchmark_opencl.py:57-100)."""
+    res = {}
+    for name, extra in (('c3', ['--steps', '40']), ('c5_share', ['--config', 'c5', '--steps', '20']), ('c4', ['--steps', '40'])):
+        cfgname = 'c5' if name == 'c5_share' else name
+        cmd = [sys.executable, os.path.abspath(__file__), '--config', cfgname, '--no-cpu-baseline', '--no-other-configs',
+               '--warmup', '5', '--settle-ms', '150'] + [e for e in extra if e not in ('--config', 'c5')]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
+            d = json.loads(line)
+            keep = {'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'], 'steps': d['steps'],
+                    'workload': d['config']['workload'], 'step_frac': d['roofline'].get('step_frac'),
+                    'wall_s': round(time.perf_counter() - t0, 1)}
+            if name == 'c4':
+                keep.update({k: d.get(k) for k in ('fwd_ms_per_step', 'inv_ms_per_step')})
+                keep['k_fwd3_l1_frac'] = d['roofline'].get('frac')
+                keep['step_frac'] = d.get('step_frac')
+            else:
+                keep['one_stream_ms_per_step'] = d.get('one_stream_ms_per_step')
+                keep['launches'] = d['roofline'].get('launches')
+            res[name] = keep
+        except Exception as exc:            # a failed sub-run must not cost the headline line
+            res[name] = {'error': '%s: %s' % (type(exc).__name__, exc)}
+    return res
 
 
 def main_c4(args):

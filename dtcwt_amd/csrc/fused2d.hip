@@ -25,8 +25,8 @@ int dtcwt_march_fwd12(const float *X, float *Yh0, float *Yh1, float *LoLo2, int 
                       const std::vector<double> &h0o, const std::vector<double> &h1o,
                       const float *l_a, const float *l_b, const float *h_a, const float *h_b, int m,
                       int lo_a_first, int hi_a_first, int cus, hipStream_t s);
-bool dtcwt_march_inv21_ok(int rows, int cols, const std::vector<double> &g0o, const std::vector<double> &g1o,
-                          const std::vector<double> &g0a, bool lo_pos, bool hi_pos);
+bool dtcwt_march_inv21_ok(int batch, int rows, int cols, const std::vector<double> &g0o, const std::vector<double> &g1o,
+                          const std::vector<double> &g0a, bool lo_pos, bool hi_pos, int cus);
 int dtcwt_march_inv21(const float *Z2, const float *Yh1, const float *Yh0, float *X, int B, int R, int C,
                       const std::vector<double> &g0o, const std::vector<double> &g1o, const float *l_a, const float *l_b,
                       const float *h_a, const float *h_b, const float *gain1, const float *gain2, int cus, hipStream_t s);
@@ -177,7 +177,29 @@ struct dtcwt_hip_plan2d {
     int fwd1_order = 8;
 };
 
+// levels 1 + 2 of the forward / 2 + 1 of the inverse in one marching launch (march2d.hpp): not for the band-pass sets,
+// odd-size extension or level-2 padding
+static bool plan_march_geometry(const dtcwt_hip_plan2d *p) {
+    return p->nlevels >= 2 && p->lv[0].inR == p->lv[0].LR && p->lv[0].inC == p->lv[0].LC && p->lv[1].padR == 0 && p->lv[1].padC == 0;
+}
+static bool plan_march_fwd12(const dtcwt_hip_plan2d *p) {
+    return plan_march_geometry(p) && p->bp1[0].empty() && p->bp2[0].empty() &&
+           dtcwt_march_fwd12_ok(p->lv[0].LR, p->lv[0].LC, p->biort[0], p->biort[2], p->qshift[0]);
+}
+static bool plan_march_inv21(const dtcwt_hip_plan2d *p) {
+    return plan_march_geometry(p) && p->bp1[1].empty() && p->bp2[2].empty() &&
+           dtcwt_march_inv21_ok(p->batch, p->lv[0].LR, p->lv[0].LC, p->biort[1], p->biort[3], p->qshift[2],
+                                dotd(p->qshift[3], p->qshift[2]) > 0, dotd(p->qshift[7], p->qshift[6]) > 0, p->ctx->cus);
+}
+
 extern "C" {
+
+int dtcwt_hip_plan2d_launches(const dtcwt_hip_plan2d *p, int *fwd12, int *inv21) {
+    DT_REQUIRE(p, "NULL plan");
+    if (fwd12) *fwd12 = plan_march_fwd12(p) ? 1 : 0;
+    if (inv21) *inv21 = plan_march_inv21(p) ? 1 : 0;
+    return 0;
+}
 
 int dtcwt_hip_plan2d_create(dtcwt_hip_ctx *ctx, int batch, int rows, int cols, int nlevels,
                             const double *const *biort_host, const int *biort_len,
@@ -311,9 +333,7 @@ int dtcwt_hip_plan2d_forward(dtcwt_hip_plan2d *p, const float *X, float *Yl, voi
     const float *in = X;
     // Levels 1 + 2 in one launch (march2d.hpp) when the level-1 lowpass is not an output (`scales`), the image needs
     // no odd-size extension or level-2 padding, and the filters are ones the marching program is built for
-    const bool march12 = nl >= 2 && !Ys && p->bp1[0].empty() && p->bp2[0].empty() && p->lv[0].inR == p->lv[0].LR &&
-                         p->lv[0].inC == p->lv[0].LC && p->lv[1].padR == 0 && p->lv[1].padC == 0 &&
-                         dtcwt_march_fwd12_ok(p->lv[0].LR, p->lv[0].LC, p->biort[0], p->biort[2], p->qshift[0]);
+    const bool march12 = !Ys && plan_march_fwd12(p);
     for (int l = 0; l < nl; ++l) {
         const Level &L = p->lv[l];
         float *lo = (l == nl - 1 && !Ys) ? Yl : (Ys ? Ys[l] : p->work[l]);
@@ -392,10 +412,7 @@ int dtcwt_hip_plan2d_inverse(dtcwt_hip_plan2d *p, const float *Yl, const void *c
     const double rs = 0.70710678118654752440;
     const float *in = Yl;
     // levels 2 + 1 in one launch (march2d.hpp) under the same conditions as the forward's levels 1 + 2
-    const bool march21 = nl >= 2 && p->bp1[1].empty() && p->bp2[2].empty() && p->lv[0].inR == p->lv[0].LR &&
-                         p->lv[0].inC == p->lv[0].LC && p->lv[1].padR == 0 && p->lv[1].padC == 0 &&
-                         dtcwt_march_inv21_ok(p->lv[0].LR, p->lv[0].LC, p->biort[1], p->biort[3], p->qshift[2],
-                                              dotd(p->qshift[3], p->qshift[2]) > 0, dotd(p->qshift[7], p->qshift[6]) > 0);
+    const bool march21 = plan_march_inv21(p);
     for (int l = nl - 1; l >= 0; --l) {
         const Level &L = p->lv[l];
         DT_REQUIRE(Yh[l], "NULL Yh at level %d", l);

@@ -54,7 +54,7 @@ _dbl = ctypes.c_double
 _pd = ctypes.POINTER(ctypes.c_double)
 
 # name -> (restype, argtypes); every symbol include/dtcwt_hip.h declares
-ABI_VERSION = 2          # == DTCWT_HIP_ABI_VERSION of include/dtcwt_hip.h (checked in load_library)
+ABI_VERSION = 3          # == DTCWT_HIP_ABI_VERSION of include/dtcwt_hip.h (checked in load_library)
 
 SIGNATURES = {
     'dtcwt_hip_abi_version': (_i, []),
@@ -137,6 +137,7 @@ SIGNATURES = {
     'dtcwt_hip_graph_launch': (_i, [_vp]),
     'dtcwt_hip_graph_destroy': (_i, [_vp]),
     'dtcwt_hip_plan2d_kernel_ms': (_i, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
+    'dtcwt_hip_plan2d_launches': (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     'dtcwt_hip_plan3d_create': (_i, [_vp, _i64, _i64, _i64, _i, _i, ctypes.POINTER(_pd), ctypes.POINTER(_i),
                                      ctypes.POINTER(_pd), ctypes.POINTER(_i), ctypes.POINTER(_vp)]),
     'dtcwt_hip_plan3d_destroy': (_i, [_vp]),

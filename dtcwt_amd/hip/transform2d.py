@@ -137,6 +137,12 @@ class _Plan2d(object):
         check(self._lib.dtcwt_hip_plan2d_kernel_ms(self._h, f, i))
         return list(f), list(i)
 
+    def launches(self):
+        """(levels 1 + 2 of the forward in one launch?, levels 2 + 1 of the inverse in one launch?)"""
+        a, b = ctypes.c_int(0), ctypes.c_int(0)
+        check(self._lib.dtcwt_hip_plan2d_launches(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return bool(a.value), bool(b.value)
+
     def __del__(self):
         # The plan dereferences its context when it is destroyed.  When both die in one garbage
         # cycle (typically at interpreter exit) the finalisers run in arbitrary order: if the

@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 /* 2: plan1d_*, plan3d_*, mgpu_* (round 2), mgpu_forward2d_scales, host_alloc / host_free / memcpy_*_async (round 3) */
-#define DTCWT_HIP_ABI_VERSION 2
+#define DTCWT_HIP_ABI_VERSION 3
 
 #define DTCWT_HIP_F32 0
 #define DTCWT_HIP_F64 1
@@ -336,6 +336,11 @@ int dtcwt_hip_plan2d_set_bandpass(dtcwt_hip_plan2d *plan, const double *h2o, con
  * inverse (inv_ms[l]) call, l = 0 .. nlevels-1.  Either pointer may be NULL. */
 int dtcwt_hip_plan2d_set_profiling(dtcwt_hip_plan2d *plan, int enable);
 int dtcwt_hip_plan2d_kernel_ms(dtcwt_hip_plan2d *plan, float *fwd_ms, float *inv_ms);
+/* Which levels share a launch: *fwd12 = 1 when levels 1 + 2 of the forward transform (without `scales`) run as ONE
+ * marching launch whose level-1 lowpass never leaves the registers (dtcwt/numpy/transform2d.py:112-160 in one pass),
+ * *inv21 = 1 likewise for levels 2 + 1 of the inverse (:242-293).  kernel_ms() then reports the shared launch under
+ * the level it starts with (fwd_ms[0], inv_ms[1]) and an empty event pair under the other.  Either pointer may be NULL. */
+int dtcwt_hip_plan2d_launches(const dtcwt_hip_plan2d *plan, int *fwd12, int *inv21);
 
 /* A plan's level loop as a hipGraph on fixed buffers: the forward transform of X into (Yl, Yh[, Ys])
  * and, when Z is not NULL, the inverse of that pyramid into Z (gain_mask_host as for
