@@ -614,6 +614,11 @@ def main_mgpu(args):
         raise SystemExit('bench.py --mgpu --gpus %d: only %d HIP device(s) visible' % (args.gpus, ndev))
     N = args.gpus
     B, R, C, NL = cfg['batch'], cfg['rows'], cfg['cols'], cfg['nlevels']
+    # RCCL (loaded by the library for the tap broadcast) prints its banner on stdout, some of it at exit: stdout is
+    # kept for the one JSON line of the contract, everything else goes to stderr
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     m = MultiGPUTransform2d(biort(BIORT), qshift(QSHIFT), devices=list(range(N)), batch=N * B, rows=R, cols=C,
                             nlevels=NL, broadcast_taps=True)
     nsets = max(1, args.sets)
@@ -669,7 +674,10 @@ def main_mgpu(args):
         out['cpu_baseline'], _ = cpu_baseline(cfg, Xh[0])
     else:
         out['cpu_baseline'] = None
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
     print(json.dumps(out), flush=True)
+    os.dup2(2, 1)
 
 
 if __name__ == '__main__':

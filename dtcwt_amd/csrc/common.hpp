@@ -12,6 +12,12 @@
 
 #include "dtcwt_hip.h"
 
+// The kernels are written for gfx950 (MI355X) only: 160 KiB of LDS per CU (the 3-D level-1 inverse declares 78 KiB
+// for one workgroup), wave64, the gfx950 forms of the buffer / LDS instructions.  Other targets are not supported.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libdtcwt_hip is a gfx950 (MI355X) library: build with --offload-arch=gfx950"
+#endif
+
 struct dtcwt_hip_ctx {
     int device;
     hipStream_t stream;

@@ -394,13 +394,16 @@ inline void dtm_pack_biort(Pm &p, int m0, int m1) {
 
 template <int M0, int M1, int M>
 struct Fwd12m {
-    static constexpr int H0 = M0 / 2, H1 = M1 / 2, HH = H0 > H1 ? H0 : H1;
+    static constexpr int H0 = M0 / 2, H1 = M1 / 2;
+    // the window is always 2 x 3 + 2 rows: the register ring of the march has a period of WR / 2 = 4 steps, which is
+    // what the loop is unrolled by (shorter filters meet zero taps, longer ones stay with the tile programs)
+    static constexpr int HH = 3;
     static constexpr int HL1 = 1, HL2 = (M - 2) / 4, HL = HL1 + HL2;
     static constexpr int VL = 64 - 2 * HL;
     static constexpr int WR = 2 * HH + 2;
     static constexpr int NP2 = M / 2;             // pending level-2 row pairs
     static constexpr int PRE = M - 2;             // LoLo1 rows a band needs above its first row (and PRE + 1... below)
-    static_assert(HH <= 4 && (M - 2) % 4 == 0 && M <= MAXT2, "halo lanes");
+    static_assert(H0 <= HH && H1 <= HH && (M - 2) % 4 == 0 && M <= MAXT2, "filters the marching forward is built for");
 };
 
 template <int M0, int M1, int M, int P, int KO, int WPS = 2>

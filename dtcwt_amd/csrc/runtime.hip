@@ -140,6 +140,8 @@ int dtcwt_hip_ctx_destroy(dtcwt_hip_ctx *c) {
 int dtcwt_hip_sync(dtcwt_hip_ctx *c) {
     DT_REQUIRE(c, "ctx is NULL");
     DT_CHECK_HIP(hipStreamSynchronize(c->stream));
+    // "the context is idle" includes the downloads that overlap its kernels (dtcwt_hip_memcpy_d2h_overlapped)
+    if (c->copy_stream) DT_CHECK_HIP(hipStreamSynchronize(c->copy_stream));
     return 0;
 }
 
@@ -218,6 +220,9 @@ int dtcwt_hip_memcpy_d2h(dtcwt_hip_ctx *c, void *dst, const void *src, size_t by
     DT_REQUIRE(c, "ctx is NULL");
     if (!bytes) return 0;
     DT_CHECK_HIP(hipSetDevice(c->device));
+    // a blocking download is ordered after the overlapped ones as well: its destination may be a pooled host buffer
+    // that one of them was still writing when its owner let go of it
+    if (c->copy_stream) DT_CHECK_HIP(hipStreamSynchronize(c->copy_stream));
     DT_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     DT_CHECK_HIP(hipStreamSynchronize(c->stream));
     return 0;
@@ -262,9 +267,14 @@ int dtcwt_hip_memcpy_d2h_overlapped(dtcwt_hip_ctx *c, void *dst, const void *src
     DT_REQUIRE(c, "ctx is NULL");
     if (!bytes) return 0;
     DT_CHECK_HIP(hipSetDevice(c->device));
-    if (!c->copy_stream) {
-        DT_CHECK_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-        DT_CHECK_HIP(hipEventCreateWithFlags(&c->copy_event, hipEventDisableTiming));
+    {
+        std::lock_guard<std::mutex> lk(c->pool_mu);         // two threads of one context: one stream, not two
+        if (!c->copy_stream) {
+            hipStream_t st = nullptr;
+            DT_CHECK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            DT_CHECK_HIP(hipEventCreateWithFlags(&c->copy_event, hipEventDisableTiming));
+            c->copy_stream = st;
+        }
     }
     DT_CHECK_HIP(hipEventRecord(c->copy_event, c->stream));
     DT_CHECK_HIP(hipStreamWaitEvent(c->copy_stream, c->copy_event, 0));

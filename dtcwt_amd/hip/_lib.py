@@ -405,7 +405,9 @@ class _HostPool(object):
     def __init__(self):
         self._free = {}
         self._idle = 0
-        self._lock = threading.Lock()
+        # re-entrant: dropping the last reference to a page-locked buffer runs its finaliser (_unpin, which takes the
+        # lock for the byte count) wherever that happens -- also inside trim() / give() while they hold it
+        self._lock = threading.RLock()
         self.limit = int(os.environ.get('DTCWT_HIP_HOST_POOL_MB', '2048')) << 20
         self.pinned = os.environ.get('DTCWT_HIP_PINNED_HOST', '1') != '0'
         self.pinned_bytes = 0           # page-locked bytes currently allocated through this pool
@@ -429,7 +431,8 @@ class _HostPool(object):
             if _lib is not None:
                 _lib.dtcwt_hip_host_free(ptr)
         finally:
-            self.pinned_bytes -= nbytes
+            with self._lock:            # finalisers run on whichever thread drops the last view
+                self.pinned_bytes -= nbytes
 
     def _new_base(self, nbytes):
         """A byte buffer for downloads: page-locked when the library is there, pageable otherwise."""
@@ -438,10 +441,14 @@ class _HostPool(object):
             if _lib.dtcwt_hip_host_alloc(nbytes, ctypes.byref(p)) == 0 and p.value:
                 raw = (ctypes.c_uint8 * nbytes).from_address(p.value)
                 base = np.frombuffer(raw, dtype=np.uint8)
-                self.pinned_bytes += nbytes
+                with self._lock:
+                    self.pinned_bytes += nbytes
                 weakref.finalize(base, self._unpin, p.value, nbytes)      # when the last view of it is gone
                 return base
-        return np.frombuffer(bytearray(nbytes), dtype=np.uint8)
+        # pageable: over the memory of an uninitialised array (a bytearray would be zero-filled first: one more pass
+        # over hundreds of MB); like the page-locked base it is an ndarray that does not own its data and is the
+        # .base of every view handed out, which is what give() counts on
+        return np.frombuffer(np.empty(nbytes, dtype=np.uint8).data, dtype=np.uint8)
 
     def empty(self, shape, dtype):
         dtype = np.dtype(dtype)
@@ -474,8 +481,9 @@ class _HostPool(object):
 
     def trim(self):
         with self._lock:
-            self._free.clear()
+            old, self._free = self._free, {}
             self._idle = 0
+        old.clear()             # the buffers' finalisers run here, outside the lock
 
 
 host_pool = _HostPool()

@@ -14,6 +14,8 @@ the authoritative copy of that entry -- the reference's idiom
 transforms upload it again instead of using the device buffer it came from.  Code that wants
 to stay on the device uses the ``hip_*`` handles and never touches the NumPy attributes.
 """
+import weakref
+
 import numpy as np
 
 from dtcwt_amd.utils import asfarray
@@ -24,6 +26,22 @@ __all__ = ['Pyramid', 'nlevels_of']
 
 def _is_dev(x):
     return isinstance(x, DeviceArray)
+
+
+def _drain(pending):
+    """Finaliser of a Pyramid dropped with downloads still in flight: wait for them.  The copies read the pyramid's
+    device buffers and write pooled page-locked host buffers; both go back to their pools when the pyramid dies, and
+    neither pool knows about the copy stream -- the next blocking download of the same size would be handed a buffer
+    a stale DMA is still writing.  Runs before the pyramid's attributes are released."""
+    ctxs = {}
+    for _arr, ctx in pending.values():
+        ctxs[id(ctx)] = ctx
+    pending.clear()
+    for ctx in ctxs.values():
+        try:
+            ctx.copy_sync()
+        except Exception:
+            pass
 
 
 def nlevels_of(pyramid):
@@ -40,6 +58,7 @@ class Pyramid(object):
         self._scales = None if scales is None else tuple(x if _is_dev(x) else asfarray(x) for x in scales)
         self._host = {}
         self._pending = {}      # key -> (destination array, context) of downloads started by prefetch()
+        weakref.finalize(self, _drain, self._pending)
 
     # ---- raw device handles (None where the entry was given as a host array) ----
     @property
@@ -67,7 +86,9 @@ class Pyramid(object):
         copy stream into page-locked pooled buffers, behind the kernels that produce them and beside whatever is
         enqueued next (the next image's upload and transform).  The first access to ``lowpass`` / ``highpasses``
         / ``scales`` waits for them.  Transform2d.forward calls this for NumPy inputs -- the literal drop-in use,
-        where the caller is certain to read the result on the host."""
+        where the caller is certain to read the result on the host.  A prefetched entry is a snapshot: kernels that
+        edit the device buffers afterwards are not reflected by the NumPy attributes (use the ``hip_*`` handles).
+        A pyramid dropped unread waits for its downloads before its buffers are recycled."""
         entries = [('l', self._low)] + [(('h', i), x) for i, x in enumerate(self._high)]
         if self._scales is not None:
             entries += [(('s', i), x) for i, x in enumerate(self._scales)]

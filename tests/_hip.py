@@ -5,12 +5,22 @@ from tests._golden import rel_err
 
 LOW_TOL = 1e-6      # low-level filters, float32 (the reference's tests/util.py:11 uses 1e-6 max-abs)
 XFM_TOL = 1e-6      # transforms, float32: max|a-b| / max|b| per subband (north star: 1e-6 relative)
-INV_TOL = 3e-6      # float32 reconstructions accumulate two more filter stages per level
+INV_TOL = 1e-6      # float32 reconstructions: the north-star bound as well (worst seen over the suite: 4.3e-7, gpurun_out/parity_worst.json)
 F64_TOL = 1e-12
+
+
+# worst relative error seen per tolerance class in this session; tests/conftest.py writes it to
+# gpurun_out/parity_worst.json so that a drift from 2e-7 to 2.9e-6 under a 3e-6 bound does not pass unseen
+WORST = {}
 
 
 def assert_close(a, b, tol, what=''):
     e = rel_err(a, b)
+    key = '%g' % tol
+    w = WORST.setdefault(key, {'worst': 0.0, 'what': '', 'n': 0})
+    w['n'] += 1
+    if e > w['worst']:
+        w['worst'], w['what'] = float(e), what
     assert e <= tol, '%s rel err %.3e > %g' % (what, e, tol)
 
 

@@ -71,7 +71,7 @@ def test_c5_one_gpu_share_64x2048():
         assert np.array_equal(high[0][i], single.highpasses[0]), i
         assert np.array_equal(high[1][i], single.highpasses[3]), i
     z = t.inverse_channels(pb, 'nhw')
-    assert np.abs(z - Xb).max() < 2e-5 * np.abs(Xb).max()
+    assert np.abs(z - Xb).max() < 1e-6 * np.abs(Xb).max()
 
 
 def _image_of(a, i):
@@ -80,13 +80,27 @@ def _image_of(a, i):
     return DeviceArray(a.ctx, (1,) + tuple(a.shape[1:]), a.dtype, ptr=a.ptr + i * per, owner=a)
 
 
-def test_more_than_2_31_elements_on_one_gpu():
-    """172 x 2048^2 float32, nlevels=4 on ONE GPU: Yh[0] holds 172 x 1024^2 x 12 = 2.16e9 floats, beyond the 32-bit
+def _device_memory_gb():
+    import ctypes
+    from dtcwt_amd.hip import _lib
+    cus, mem = ctypes.c_int(0), ctypes.c_size_t(0)
+    name = ctypes.create_string_buffer(256)
+    _lib.load_library().dtcwt_hip_device_info(0, name, ctypes.byref(cus), ctypes.byref(mem))
+    return mem.value / 2 ** 30
+
+
+@pytest.mark.parametrize('nb', [172, 512])
+def test_more_than_2_31_elements_on_one_gpu(nb):
+    """nb = 512: the WHOLE C5 batch (BASELINE configs[4], 512 x 2048^2, what `bench.py --config c5full` times) on one
+    GPU, ~65 GB of buffers; skipped on a device with less than 128 GB.
+    172 x 2048^2 float32, nlevels=4 on ONE GPU: Yh[0] holds 172 x 1024^2 x 12 = 2.16e9 floats, beyond the 32-bit
     record addressing of the fast paths -- the transform must take the 64-bit branches (fwd1s_rows_flush's general
     index algebra, the 64-bit decode of the generic kernels) and still be right.  The reference has no size limit
     (dtcwt/numpy/transform2d.py:40-188 takes any array).  First and last image against the oracle, a middle one
     bit for bit against the same image transformed alone, then the inverse of the whole batch."""
-    nb, R, C, nl = 172, 2048, 2048, 4
+    R, C, nl = 2048, 2048, 4
+    if nb > 172 and _device_memory_gb() < 128:
+        pytest.skip('needs ~65 GB of device memory')
     ctx = default_context()
     rs = np.random.RandomState(77)
     base = rs.standard_normal((8, R, C)).astype(np.float32)
@@ -103,7 +117,7 @@ def test_more_than_2_31_elements_on_one_gpu():
         assert_close(_image_of(yl, i).get()[0], want.lowpass, XFM_TOL, 'image %d Yl' % i)
         for l in range(nl):
             assert_close(_image_of(yh[l], i).get()[0], want.highpasses[l], XFM_TOL, 'image %d Yh[%d]' % (i, l))
-    mid = 97
+    mid = nb // 2 + 11
     single = t.forward(image(mid), nlevels=nl)
     assert np.array_equal(_image_of(yl, mid).get()[0], single.lowpass)
     for l in range(nl):
@@ -112,7 +126,7 @@ def test_more_than_2_31_elements_on_one_gpu():
     assert Z.shape == (nb, R, C)
     for i in (0, mid, nb - 1):
         z = _image_of(Z, i).get()[0]
-        assert np.abs(z - image(i)).max() < 3e-6 * np.abs(image(i)).max(), i
+        assert np.abs(z - image(i)).max() < 1e-6 * np.abs(image(i)).max(), i
     # ... and against the inverse of that image alone (a single image takes the small coarse-level tiles, the
     # batch the large ones: the same sums formed by different kernel instantiations, equal to the last bit or two)
     alone = t.inverse(single)
@@ -197,7 +211,7 @@ def test_mgpu_more_shards_than_images():
     m = MultiGPUTransform2d(B, Q, devices=[0, 0, 0], batch=2, rows=128, cols=128, nlevels=2)
     assert [s[2] for s in m.shards] == [1, 1, 0]
     z = m.inverse(m.forward(X))
-    assert np.abs(z - X).max() < 1e-5
+    assert np.abs(z - X).max() < 2e-6
 
 
 def test_bench_self_spawns_ranks(tmp_path):
@@ -247,3 +261,30 @@ def test_bench_config_c4_line():
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--config', 'c4', '--gpus', '2', '--steps', '1'],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and 'does not shard' in (r.stderr + r.stdout)
+
+
+def test_scale_run_script_produces_one_line_per_mode(tmp_path):
+    """tools/scale_run.sh is what the first run on an 8-GPU node will be started with: here with the devices this box
+    has (normally one), a few steps per line -- every (config, N, mode) it runs must leave one well-formed bench line
+    and the efficiency table at the end must print."""
+    import json
+    import os
+    import subprocess
+    from dtcwt_amd.hip import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / 'scale')
+    env = dict(os.environ, SCALE_RUN_FAST='1')
+    r = subprocess.run(['bash', os.path.join(root, 'tools', 'scale_run.sh'), out, '10'], capture_output=True, text=True,
+                       timeout=800, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [json.loads(l) for l in open(os.path.join(out, 'scale.jsonl')) if l.strip().startswith('{')]
+    ndev = _lib.device_count()
+    want = [(c, n, m) for c in ('c2', 'c5') for n in (1, 2, 4, 8) if n <= ndev for m in ('ranks', 'mgpu')]
+    assert len(rows) == len(want), (len(rows), want, r.stderr[-2000:])
+    for row, (c, n, m) in zip(rows, want):
+        assert row['n_gpus'] == n and row['value'] > 0 and row['ms_per_step'] > 0 and row['unit'] == 'Mpixels/s'
+        if m == 'ranks':
+            assert row['rank_ms_per_step']['max'] >= row['rank_ms_per_step']['min'] > 0
+        assert ('mgpu' in row['launch']) == (m == 'mgpu')
+        assert ('4096' in row['metric']) == (c == 'c2')
+    assert r.stdout.count('efficiency') == len(want)

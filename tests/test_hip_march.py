@@ -1,0 +1,152 @@
+"""The one-launch levels 1 + 2 (forward) / 2 + 1 (inverse) of the float32 2-D plan -- the marching wavefront programs
+of dtcwt_amd/csrc/march2d.hpp -- against the oracle and against the per-level tile programs they replace, at sizes that
+put the band and strip boundaries, the mirrored halo lanes and the reflected rows everywhere they can be.
+
+Reference behaviour: dtcwt/numpy/transform2d.py:112-160 (forward levels 1, 2), :242-293 (inverse levels 2, 1).
+Also: the page-locked / overlapped host path of the Pyramid (prefetch, dropped pyramids, views outliving them)."""
+import gc
+
+import numpy as np
+import pytest
+
+from oracle import dtcwt_oracle as o
+from dtcwt_amd.coeffs import biort, qshift
+from dtcwt_amd.hip import Transform2d, Pyramid, DeviceArray, default_context
+from tests._hip import assert_close, assert_pyramids_close, as_f64, XFM_TOL, INV_TOL
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(64, 64), (256, 320), (96, 1036), (520, 236), (1024, 232), (200, 464), (44, 940)]
+
+
+def _fwd_inv(X, nl, gm=None):
+    t = Transform2d()
+    assert t.plan(X.shape[0] if X.ndim == 3 else 1, X.shape[-2], X.shape[-1], nl) is not None
+    p = t.forward(X, nlevels=nl)
+    ys = [np.array(y) for y in p.highpasses]
+    yl = np.array(p.lowpass)
+    z = np.array(t.inverse(Pyramid(yl, tuple(ys)), gm))
+    return yl, ys, z
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+@pytest.mark.parametrize('band', [None, 8, 24])
+def test_march_matches_tile_programs_and_oracle(shape, band, monkeypatch):
+    rs = np.random.RandomState(5)
+    X = rs.standard_normal(shape).astype(np.float32)
+    nl = 2 if min(shape) < 160 else 3
+    gm = rs.uniform(0.3, 1.4, size=(6, nl)) * (rs.uniform(size=(6, nl)) > 0.2)
+    monkeypatch.setenv('DTCWT_HIP_MARCH', '0')
+    yl0, ys0, z0 = _fwd_inv(X, nl, gm)
+    monkeypatch.setenv('DTCWT_HIP_MARCH', '1')
+    monkeypatch.setenv('DTCWT_HIP_MARCH_INV', '1')          # also where the bands would be short
+    if band:
+        monkeypatch.setenv('DTCWT_HIP_MARCH_BAND', str(band))
+    t = Transform2d()
+    f12, i21 = t.plan(1, shape[0], shape[1], nl).launches()
+    assert f12 and i21
+    yl1, ys1, z1 = _fwd_inv(X, nl, gm)
+    # the two paths sum in different orders (mirror pairs first, rows before columns): not bit-identical, both right
+    assert_close(yl1, yl0, 2e-6, 'Yl march vs tiles')
+    for a, b in zip(ys1, ys0):
+        assert_close(a, b, 2e-6, 'Yh march vs tiles')
+    assert_close(z1, z0, 2e-6, 'inverse march vs tiles')
+    to = o.Transform2d(biort('near_sym_a'), qshift('qshift_a'))
+    want = to.forward(as_f64(X), nlevels=nl)
+    assert_close(yl1, want.lowpass, XFM_TOL, 'Yl')
+    for l, (a, b) in enumerate(zip(ys1, want.highpasses)):
+        assert_close(a, b, XFM_TOL, 'Yh[%d]' % l)
+    assert_close(z1, to.inverse(want, gm), INV_TOL, 'inverse')
+
+
+def test_march_on_a_batch_and_other_level1_filters(monkeypatch):
+    monkeypatch.setenv('DTCWT_HIP_MARCH_INV', '1')
+    rs = np.random.RandomState(6)
+    X = rs.standard_normal((3, 128, 248)).astype(np.float32)
+    for bn in ('near_sym_a', 'legall', 'antonini'):       # forward: up to 7 taps; inverse: near_sym_a only
+        t, to = Transform2d(bn, 'qshift_a'), o.Transform2d(biort(bn), qshift('qshift_a'))
+        f12, i21 = t.plan(3, 128, 248, 3).launches()
+        assert f12 == (bn != 'antonini') and i21 == (bn == 'near_sym_a')
+        p = t.forward_channels(X, 'nhw', nlevels=3)
+        for b in range(3):
+            want = to.forward(as_f64(X[b]), nlevels=3)
+            assert_close(p.lowpass[b], want.lowpass, XFM_TOL, '%s Yl' % bn)
+            for l in range(3):
+                assert_close(p.highpasses[l][b], want.highpasses[l], XFM_TOL, '%s Yh[%d]' % (bn, l))
+        assert_close(t.inverse_channels(p, 'nhw'), X, INV_TOL, '%s reconstruction' % bn)
+
+
+def test_march_is_not_used_where_it_does_not_apply():
+    t = Transform2d()
+    assert t.plan(1, 254, 256, 3).launches() == (False, False)           # level-2 padding (254 % 4)
+    assert t.plan(1, 255, 256, 3).launches() == (False, False)           # odd-size extension
+    assert Transform2d('near_sym_b', 'qshift_b').plan(1, 256, 256, 3).launches() == (False, False)
+    f12, i21 = t.plan(1, 4096, 4096, 4).launches()
+    assert f12 and not i21          # one image: the inverse's bands would be short (DTCWT_HIP_MARCH_INV=1 forces it)
+    assert t.plan(64, 1024, 1024, 3).launches() == (True, True)
+    # `scales` needs the level-1 lowpass: the forward then keeps its one launch per level, and says so by being right
+    rs = np.random.RandomState(7)
+    X = rs.standard_normal((256, 256)).astype(np.float32)
+    p = t.forward(X, nlevels=3, include_scale=True)
+    want = o.Transform2d(biort('near_sym_a'), qshift('qshift_a')).forward(as_f64(X), nlevels=3, include_scale=True)
+    assert_pyramids_close(p, want, XFM_TOL, same_dtype=False)
+
+
+# ---- the host path: page-locked pool, overlapped downloads, Pyramid.prefetch ------------------------------------------
+def test_prefetched_and_lazy_downloads_agree():
+    rs = np.random.RandomState(8)
+    X = rs.standard_normal((512, 512)).astype(np.float32)
+    t = Transform2d()
+    p1 = t.forward(X, nlevels=3)                    # NumPy input: prefetch starts behind the kernels
+    p2 = t.forward(default_context().to_device(X), nlevels=3)      # device input: lazy
+    assert np.array_equal(p1.lowpass, p2.lowpass)
+    for a, b in zip(p1.highpasses, p2.highpasses):
+        assert np.array_equal(a, b)
+    assert np.array_equal(t.inverse(p1), t.inverse(p2))            # p1 with its downloads read, p2 from the device
+
+
+def test_dropping_an_unread_prefetched_pyramid_is_safe():
+    """The pinned host buffers and the device buffers of a pyramid dropped unread go back to their pools only after
+    its downloads have finished: a blocking download of the same size right afterwards must not see them."""
+    rs = np.random.RandomState(9)
+    t = Transform2d()
+    X = rs.standard_normal((1024, 1024)).astype(np.float32)
+    Y = rs.standard_normal((1024, 1024)).astype(np.float32)
+    want = [np.array(h) for h in t.forward(Y, nlevels=2).highpasses]
+    for _ in range(5):
+        p = t.forward(X, nlevels=2)                 # prefetch in flight ...
+        del p                                       # ... dropped unread
+        gc.collect()
+        q = t.forward(default_context().to_device(Y), nlevels=2)
+        got = [q.hip_highpasses[l].get() for l in range(2)]        # blocking downloads into recycled buffers
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
+
+
+def test_a_view_may_outlive_its_pyramid_and_inverse_with_pending_downloads():
+    rs = np.random.RandomState(10)
+    X = rs.standard_normal((768, 512)).astype(np.float32)
+    t = Transform2d()
+    p = t.forward(X, nlevels=3)
+    z = t.inverse(p)                                # downloads still pending: the inverse uses the device buffers
+    assert_close(z, X, INV_TOL, 'reconstruction')
+    row = p.highpasses[0][5]                        # a view of a pooled page-locked buffer
+    keep = row.copy()
+    del p
+    gc.collect()
+    for _ in range(3):
+        t.forward(X[::-1].copy(), nlevels=3).highpasses            # would reuse the buffer if the view did not pin it
+    assert np.array_equal(row, keep)
+
+
+def test_pageable_host_buffers(monkeypatch):
+    from dtcwt_amd.hip import _lib
+    monkeypatch.setattr(_lib.host_pool, 'pinned', False)
+    _lib.host_pool.trim()
+    rs = np.random.RandomState(11)
+    X = rs.standard_normal((512, 640)).astype(np.float32)
+    t = Transform2d()
+    p = t.forward(X, nlevels=2)
+    want = o.Transform2d(biort('near_sym_a'), qshift('qshift_a')).forward(as_f64(X), nlevels=2)
+    assert_pyramids_close(p, want, XFM_TOL, same_dtype=False)
+    _lib.host_pool.trim()

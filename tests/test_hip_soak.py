@@ -63,7 +63,7 @@ def test_soak_3d_1d_fixed_seed():
         e = max([rel(p.lowpass, want.lowpass)] + [rel(a, b) for a, b in zip(p.highpasses, want.highpasses)])
         assert e < 2e-6, ('3d fwd', shape, bn, qn, nl, ext, e)
         e = rel(t.inverse(p), to.inverse(want))
-        assert e < 2e-5, ('3d inv', shape, bn, qn, nl, ext, e)
+        assert e < 1.5e-6, ('3d inv', shape, bn, qn, nl, ext, e)
         done += 1
     assert done >= 40
     for _ in range(40):

@@ -6,7 +6,7 @@
 #   mgpu   one process, dtcwt_hip_mgpu_* with a host thread per device
 # Every line of <outdir>/scale.jsonl is one bench.py JSON line (n_gpus, value, ms_per_step, nccl_ranks,
 # rank_ms_per_step min / max ...).  Linear weak scaling reads N x the N = 1 value: 8 x ~82,000 Mpix/s for C5.
-# Usage: tools/scale_run.sh [outdir] [steps]
+# Usage: tools/scale_run.sh [outdir] [steps]      (SCALE_RUN_FAST=1: no CPU baseline at N = 1 either)
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=${1:-$R/gpurun_out/scale}
@@ -18,13 +18,13 @@ NDEV=$(python -c "import sys; sys.path.insert(0, '$R'); from dtcwt_amd.hip impor
 for cfg in c2 c5; do
   for n in 1 2 4 8; do
     if [ "$n" -gt "$NDEV" ]; then echo "skip $cfg N=$n: $NDEV device(s) visible" | tee -a "$OUT/skipped.txt"; continue; fi
-    base=""; [ "$n" -gt 1 ] && base="--no-cpu-baseline"
+    base="--no-other-configs"; { [ "$n" -gt 1 ] || [ "${SCALE_RUN_FAST:-0}" = 1 ]; } && base="$base --no-cpu-baseline"
     for mode in ranks mgpu; do
       extra=""; [ "$mode" = mgpu ] && extra="--mgpu"
       [ "$cfg" = c5 ] && steps=$((STEPS / 5 + 2)) || steps=$STEPS
       echo "== $cfg N=$n $mode" >&2
       timeout 900 python "$R/bench.py" --gpus $n --config $cfg --steps $steps --warmup 5 $base $extra \
-          2> "$OUT/${cfg}_n${n}_${mode}.err" | tail -1 | tee -a "$OUT/scale.jsonl"
+          2> "$OUT/${cfg}_n${n}_${mode}.err" | grep '^{' | tail -1 | tee -a "$OUT/scale.jsonl"
     done
   done
 done
