@@ -220,7 +220,6 @@ int dtcwt_hip_plan2d_create(dtcwt_hip_ctx *ctx, int batch, int rows, int cols, i
     for (int i = 0; i < 4; ++i) p->biort[i].assign(biort_host[i], biort_host[i] + biort_len[i]);
     for (int i = 0; i < 8; ++i) p->qshift[i].assign(qshift_host[i], qshift_host[i] + qshift_len[i]);
     { const char *e = getenv("DTCWT_HIP_XCD_ORDER"); p->xcd_order = e ? atoi(e) : -1; }
-    { const char *e = getenv("DTCWT_HIP_FWD1_ORDER"); p->fwd1_order = e ? atoi(e) : 8; }
     { const char *e = getenv("DTCWT_HIP_SMALL_TILES"); p->small_tiles = e ? (e[0] == '1' ? 1 : 0) : -1; }
     p->extR = rows + (rows & 1);
     p->extC = cols + (cols & 1);

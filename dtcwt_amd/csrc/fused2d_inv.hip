@@ -112,13 +112,14 @@ int launch_inv2(Inv2Params &p, hipStream_t s) {
     // every shipped q-shift set: sum(g0a g0b) > 0 > sum(g1a g1b) (and the band-pass pair like g1) -- compile-time
     // filter phases; anything else takes the run-time flags
     const bool std_set = p.lo_pos && !p.hi_pos && (!C::BP || !p.bp_pos);
-    if constexpr (!C::BP) {         // DTCWT_HIP_INV2_SPLIT=0: the one-piece column phase of round 2 (k_inv2)
-        static const int split = [] { const char *e = getenv("DTCWT_HIP_INV2_SPLIT"); return e ? atoi(e) : 1; }();
-        // ... where there are workgroups to overlap: a launch of about one tile per CU is a latency chain, and the
-        // two-halves form is one LDS phase longer (a 512^2 lowpass: 8.2 -> 8.8 us; 1024^2: equal; 2048^2: 35.4 -> 33.4)
-        if (split && (split > 1 || p.tilesR * p.tilesC * p.B >= 2048)) {
-            if (std_set) k_inv2s<C, true><<<grid_for(p.tilesR * p.tilesC * p.B, p.xcd_order), DT_NT, 0, s>>>(p);
-            else k_inv2s<C, false><<<grid_for(p.tilesR * p.tilesC * p.B, p.xcd_order), DT_NT, 0, s>>>(p);
+    // The column phase in two halves (k_inv2s: six workgroups per CU) where there are workgroups to overlap -- 2048 tiles
+    // and more: a 2048^2 lowpass 35.4 -> 33.4 us -- the one-piece k_inv2 for the small launches, which are latency
+    // chains (a 512^2 lowpass: 8.2 us against 8.8), for the band-pass sets (a third plane) and for filters with
+    // other phases than the shipped sets.  One sweep decided it (profiles/r03/inv2_phase_stamps.txt, README of
+    // profiles/r04); the environment switch of round 3 is gone, and with it the k_inv2s instantiations nothing used.
+    if constexpr (!C::BP && C::TR >= 16) {
+        if (std_set && p.tilesR * p.tilesC * p.B >= 2048) {
+            k_inv2s<C, true><<<grid_for(p.tilesR * p.tilesC * p.B, p.xcd_order), DT_NT, 0, s>>>(p);
             return 0;
         }
     }

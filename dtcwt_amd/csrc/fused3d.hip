@@ -161,15 +161,9 @@ inline bool narrow_wins(int n, int wide, int narrow) { return 10 * padded(n, nar
 template <int TR, int TC, int PS, int M>
 void launch_l2_planes_best(dt2d::Fwd2Params &p, float *planes, int64_t pstride, hipStream_t s) {
     if constexpr (M == 10) {
-        // tile shapes for the slices of a volume (DTCWT_HIP_L2P_TILE: 1 16x32, 2 32x32, 3 16x64, 4 32x64; 0 = by size)
-        static const int force = [] { const char *e = getenv("DTCWT_HIP_L2P_TILE"); return e ? atoi(e) : 0; }();
-        if (force == 1) { launch_l2_planes<dt2d::Fwd2DCfg<16, 32, 4, 10>>(p, planes, pstride, s); return; }
-        if (force == 2) { launch_l2_planes<dt2d::Fwd2DCfg<32, 32, 4, 10>>(p, planes, pstride, s); return; }
-        if (force == 3) { launch_l2_planes<dt2d::Fwd2DCfg<16, 64, 4, 10>>(p, planes, pstride, s); return; }
-        if (force == 4) { launch_l2_planes<dt2d::Fwd2DCfg<32, 64, 4, 10>>(p, planes, pstride, s); return; }
         // slices whose lowpass is a multiple of 64 columns wide: 16 x 64 tiles (a full round of row-pass tasks and
         // 256-byte plane rows per tile; 256^3 level 2: 29.4 us against 31.6 us with 16 x 32, profiles/r03/c4_l2_planes_tiles.txt)
-        if (force == 0 && (p.LC / 2) % 64 == 0) { launch_l2_planes<dt2d::Fwd2DCfg<16, 64, 4, 10>>(p, planes, pstride, s); return; }
+        if ((p.LC / 2) % 64 == 0) { launch_l2_planes<dt2d::Fwd2DCfg<16, 64, 4, 10>>(p, planes, pstride, s); return; }
         if (narrow_wins(p.LC / 2, TC, 32)) {
             launch_l2_planes<dt2d::Fwd2DCfg<16, 32, 4, 10>>(p, planes, pstride, s);
             return;
@@ -185,15 +179,13 @@ int launch_l2_axis0(Fwd3L2Params &p, int cus, hipStream_t s) {
     int cells = (p.O0 / 2) * (p.O1 / 2) * (p.O2 / 2);
     // Large levels: the inner layers of cells two at a time along axis 0 (24 instead of 40 window slices per pair
     // through L1), the boundary layers (windows that reach outside the volume) with the one-cell kernel.
-    // DTCWT_HIP_L2B_PAIR=0: the one-cell kernel everywhere.
     if constexpr (C::M <= 18) {
-        static const int want = [] { const char *e = getenv("DTCWT_HIP_L2B_PAIR"); return e ? atoi(e) : 1; }();
         const int e0 = p.O0 / 2, E = (p.O1 / 2) * (p.O2 / 2);
         int lo = (C::M - 2 + p.pad0 + 3) / 4;                      // first layer whose window starts inside
         int hi = (p.n0 - C::M - 2 + p.pad0) / 4;                   // last layer whose window ends inside
         if (lo & 1) ++lo;                                          // pairs (2 u, 2 u + 1)
         if (!(hi & 1)) --hi;
-        if (want && E % 64 == 0 && hi - lo + 1 >= 8 && cdiv(cells, DT_NT) >= 4 * cus && 16 * p.pstride < ((int64_t)1 << 32)) {
+        if (E % 64 == 0 && hi - lo + 1 >= 8 && cdiv(cells, DT_NT) >= 4 * cus && 16 * p.pstride < ((int64_t)1 << 32)) {
             const int npair = (hi - lo + 1) / 2, colblocks = E / 32;
             const int ninner = npair * colblocks, lo_cells = lo * E, hi_first = (hi + 1) * E;     // E % 64 == 0 below
             const int nbound = (lo_cells + (e0 * E - hi_first)) / 64;
@@ -219,10 +211,6 @@ int launch_fwd3_l1(Fwd3L1Params &p, int cus, hipStream_t s) {
     // still has to put several workgroups on every CU
     int chunk = 64;
     while (chunk > 8 && (int64_t)p.tilesJ * p.tilesK * cdiv(p.n0, chunk) < 4 * (int64_t)cus) chunk /= 2;
-    if (const char *e = getenv("DTCWT_HIP_CHUNK3D")) {
-        int v = atoi(e);
-        if (v >= 2 && v % 2 == 0) chunk = v;
-    }
     p.chunk = chunk;
     p.chunks = cdiv(p.n0, chunk);
     f3l1_pack_taps<C>(p);
@@ -442,10 +430,6 @@ void launch_inv3_axis0(Inv3AParams &p, int cus, hipStream_t s) {
     // all, but the level is a latency chain: 32^3 cells 22.6 -> 14.2 us); with a workgroup per CU or more, 8 stays
     // (64^3 cells: 35 us at 8, 45 us at 4)
     while (chunk > 2 && (int64_t)p.tilesJ * p.tilesK * cdiv(pairs, chunk) < (int64_t)cus) chunk /= 2;
-    if (const char *e = getenv("DTCWT_HIP_CHUNK3D_INV")) {
-        int v = atoi(e);
-        if (v >= 1) chunk = v;
-    }
     p.chunk = chunk; p.chunks = cdiv(pairs, chunk);
     const int ntile = p.tilesJ * p.tilesK * p.chunks;
     k_inv3_axis0<F><<<xcd3_grid(ntile, XCD3_INV_AXIS0), DT_NT, 0, s>>>(p, xcd3_arg(ntile, XCD3_INV_AXIS0));
@@ -461,10 +445,6 @@ void launch_inv3_l1_axis02_g(Inv3AParams &p, int cus, hipStream_t s) {
     int chunk = 64;
     while (chunk > 8 && (int64_t)p.tilesJ * p.tilesK * cdiv(pairs, chunk) < 2 * (int64_t)cus) chunk /= 2;
     while (chunk > 2 && (int64_t)p.tilesJ * p.tilesK * cdiv(pairs, chunk) < (int64_t)cus / 2) chunk /= 2;
-    if (const char *e = getenv("DTCWT_HIP_CHUNK3D_INV")) {
-        int v = atoi(e);
-        if (v >= 1) chunk = v;
-    }
     p.chunk = chunk; p.chunks = cdiv(pairs, chunk);
     const int ntile = p.tilesJ * p.tilesK * p.chunks;
     k_inv3_l1_axis02<F, G><<<xcd3_grid(ntile, XCD3_INV_AXIS0), G::NT, 0, s>>>(p, xcd3_arg(ntile, XCD3_INV_AXIS0));

@@ -104,11 +104,8 @@ static int launch_fwd12(dtm::Fwd12mParams &p, int cus, hipStream_t s) {
     p.nband = cdiv(p.R, p.band_rows);
     const int64_t jobs = (int64_t)p.nstrip * p.nband * p.B;
     if (jobs >= ((int64_t)1 << 31)) return -3;
-    // KO bit 5 = X rows loaded with the non-temporal hint: 81.4 against 85.4 us at 4096^2 alone (tools/kbench/march_bench),
-    // no difference inside the transform (bench.py: 0.1826 ms per step either way) -- off unless asked for
-    const bool nt = [] { const char *e = getenv("DTCWT_HIP_MARCH_NT_LOADS"); return e && e[0] == '1'; }();
-    if (nt) dtm::k_fwd12m<M0, M1, M, 2, 32><<<(unsigned)jobs, 64, 0, s>>>(p);
-    else dtm::k_fwd12m<M0, M1, M, 2, 0><<<(unsigned)jobs, 64, 0, s>>>(p);
+    // (X rows loaded with the non-temporal hint: 81.4 against 85.4 us alone, no difference inside the transform -- not used)
+    dtm::k_fwd12m<M0, M1, M, 2, 0><<<(unsigned)jobs, 64, 0, s>>>(p);
     return 0;
 }
 

@@ -357,4 +357,26 @@ int dtcwt_hip_mgpu_gather(dtcwt_hip_mgpu *m, const void *const *dev, size_t byte
     });
 }
 
+// page-locked host memory, enqueue only: completion at dtcwt_hip_mgpu_sync() (dtcwt_hip_sync waits for a context's
+// stream and for its copy stream)
+int dtcwt_hip_mgpu_scatter_async(dtcwt_hip_mgpu *m, const void *host, size_t bytes_per_image, void *const *dev) {
+    DT_REQUIRE(m && host && dev, "NULL argument");
+    return on_all(m, [&](int d) -> int {
+        Shard &s = m->sh[d];
+        if (!s.count) return 0;
+        return dtcwt_hip_memcpy_h2d_async(s.ctx, dev[d], (const char *)host + (size_t)s.start * bytes_per_image,
+                                          (size_t)s.count * bytes_per_image);
+    });
+}
+
+int dtcwt_hip_mgpu_gather_async(dtcwt_hip_mgpu *m, const void *const *dev, size_t bytes_per_image, void *host) {
+    DT_REQUIRE(m && host && dev, "NULL argument");
+    return on_all(m, [&](int d) -> int {
+        Shard &s = m->sh[d];
+        if (!s.count) return 0;
+        return dtcwt_hip_memcpy_d2h_overlapped(s.ctx, (char *)host + (size_t)s.start * bytes_per_image, dev[d],
+                                               (size_t)s.count * bytes_per_image);
+    });
+}
+
 }  // extern "C"

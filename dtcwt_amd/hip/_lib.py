@@ -164,6 +164,8 @@ SIGNATURES = {
     'dtcwt_hip_mgpu_sync': (_i, [_vp]),
     'dtcwt_hip_mgpu_scatter': (_i, [_vp, _vp, _sz, ctypes.POINTER(_vp)]),
     'dtcwt_hip_mgpu_gather': (_i, [_vp, ctypes.POINTER(_vp), _sz, _vp]),
+    'dtcwt_hip_mgpu_scatter_async': (_i, [_vp, _vp, _sz, ctypes.POINTER(_vp)]),
+    'dtcwt_hip_mgpu_gather_async': (_i, [_vp, ctypes.POINTER(_vp), _sz, _vp]),
 }
 
 

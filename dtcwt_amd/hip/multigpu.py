@@ -146,6 +146,26 @@ class MultiGPUTransform2d(object):
         check(self._lib.dtcwt_hip_mgpu_gather(self._h, self._ptrs(dev), per, out.ctypes.data_as(_vp)))
         return out
 
+    def pinned_empty(self, shape_tail, dtype):
+        """A page-locked host array [batch, ...] for scatter_async / gather_async (from the pool of pinned buffers)."""
+        from dtcwt_amd.hip._lib import host_pool
+        return host_pool.empty((self.batch,) + tuple(shape_tail), dtype)
+
+    def scatter_async(self, host, dev):
+        """As :meth:`scatter`, enqueue only: *host* must be page-locked (:meth:`pinned_empty`) and stay untouched
+        until :meth:`sync`; every shard's upload runs on its own stream ahead of the transforms issued after it."""
+        assert host.flags.c_contiguous and host.shape[0] == self.batch
+        per = host.nbytes // self.batch
+        check(self._lib.dtcwt_hip_mgpu_scatter_async(self._h, host.ctypes.data_as(_vp), per, self._ptrs(dev)))
+
+    def gather_async(self, dev, out):
+        """As :meth:`gather` into the page-locked array *out*, enqueue only: the downloads run on the shards' copy
+        streams behind the kernels issued so far; *out* is valid after :meth:`sync`."""
+        assert out.flags.c_contiguous and out.shape[0] == self.batch
+        per = out.nbytes // self.batch
+        check(self._lib.dtcwt_hip_mgpu_gather_async(self._h, self._ptrs(dev), per, out.ctypes.data_as(_vp)))
+        return out
+
     # ---- transforms ------------------------------------------------------------------
     def forward_into(self, bufs):
         flat = [bufs.Yh[d][l] for d in range(self.ndev) for l in range(self.nlevels)]

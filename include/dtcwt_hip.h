@@ -430,6 +430,14 @@ int dtcwt_hip_mgpu_sync(dtcwt_hip_mgpu *mgpu);
 /* host batch [batch][bytes_per_image] <-> the shards' device buffers (each shard copies its own slice from its thread) */
 int dtcwt_hip_mgpu_scatter(dtcwt_hip_mgpu *mgpu, const void *host, size_t bytes_per_image, void *const *dev);
 int dtcwt_hip_mgpu_gather(dtcwt_hip_mgpu *mgpu, const void *const *dev, size_t bytes_per_image, void *host);
+/* The same without waiting: `host` must be page-locked (dtcwt_hip_host_alloc) and stay untouched until
+ * dtcwt_hip_mgpu_sync().  Every shard's upload is enqueued on its own stream (ordered before the transforms issued
+ * after it), every shard's download on its context's copy stream behind what its stream holds so far -- a host-fed
+ * batch (C5: 8.6 GB in, 43 GB out over eight host links) then overlaps its copies with the other shards' kernels
+ * instead of eight blocking, staged, pageable copies (the reference's examples/register_video.py:125-156 scatters
+ * frames with blocking MPI sends). */
+int dtcwt_hip_mgpu_scatter_async(dtcwt_hip_mgpu *mgpu, const void *host, size_t bytes_per_image, void *const *dev);
+int dtcwt_hip_mgpu_gather_async(dtcwt_hip_mgpu *mgpu, const void *const *dev, size_t bytes_per_image, void *host);
 
 /* ---------------------------------------------------------------- re-sampling ------ */
 /* Replaces dtcwt/sampling.py.  An image is [H][W][ncomp] of the real

@@ -10,4 +10,4 @@ t3 = Transform3d(ctx=ctx)
 ts = []
 for _ in range(int(os.environ.get('REPS', '20'))):
     t0 = time.perf_counter(); p = t3.forward(V, nlevels=3); ctx.device_sync(); ts.append(time.perf_counter() - t0)
-print('chunk=%s fwd min %.1f us' % (os.environ.get('DTCWT_HIP_CHUNK3D', 'auto'), min(ts) * 1e6))
+print('chunk=%s fwd min %.1f us' % ('auto', min(ts) * 1e6))
