@@ -81,8 +81,7 @@ def test_march_is_not_used_where_it_does_not_apply():
     assert t.plan(1, 254, 256, 3).launches() == (False, False)           # level-2 padding (254 % 4)
     assert t.plan(1, 255, 256, 3).launches() == (False, False)           # odd-size extension
     assert Transform2d('near_sym_b', 'qshift_b').plan(1, 256, 256, 3).launches() == (False, False)
-    f12, i21 = t.plan(1, 4096, 4096, 4).launches()
-    assert f12 and not i21          # one image: the inverse's bands would be short (DTCWT_HIP_MARCH_INV=1 forces it)
+    assert t.plan(1, 4096, 4096, 4).launches() == (True, True)
     assert t.plan(64, 1024, 1024, 3).launches() == (True, True)
     # `scales` needs the level-1 lowpass: the forward then keeps its one launch per level, and says so by being right
     rs = np.random.RandomState(7)

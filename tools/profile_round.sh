@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/${1:-gpurun_out/prof}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline"
+BENCH="python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs"
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o bench --output-format csv -- $BENCH > "$OUT/bench_under_trace.json" 2> "$OUT/trace.err"
 echo "trace rc=$?" > "$OUT/status.txt"
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace1" -o bench --output-format csv -- $BENCH --streams 1 > "$OUT/bench_under_trace_streams1.json" 2> "$OUT/trace1.err"
@@ -21,8 +21,9 @@ echo "write rc=$?" >> "$OUT/status.txt"
 cd $R
 cp "$(find $OUT/trace -name "*kernel_stats.csv" | head -1)" "$OUT/kernel_stats.csv" 2>/dev/null
 cp "$(find $OUT/trace1 -name "*kernel_stats.csv" | head -1)" "$OUT/kernel_stats_streams1.csv" 2>/dev/null
-python tools/roofline_from_trace.py "$OUT" --write "$OUT/traffic.json" --source "profiles/${2:-r03}/roofline.json" > "$OUT/roofline.json" 2> "$OUT/roofline.err"
+python tools/roofline_from_trace.py "$OUT" --write "$OUT/traffic.json" --source "profiles/${2:-r04}/roofline.json" > "$OUT/roofline.json" 2> "$OUT/roofline.err"
 python tools/pmc_summary.py "$OUT" > "$OUT/pmc_hbm_traffic.txt" 2>&1
 python $R/bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_driver_cmd.json" 2>/dev/null      # the driver's command, unprofiled
-python $R/bench.py --streams 1 --no-cpu-baseline --steps 20 --warmup 5 > "$OUT/bench_streams1.json" 2>/dev/null
+python $R/bench.py --streams 1 --no-cpu-baseline --no-other-configs --steps 20 --warmup 5 > "$OUT/bench_streams1.json" 2>/dev/null
+for st in 3 4; do python $R/bench.py --streams $st --no-cpu-baseline --no-other-configs --steps 20 --warmup 5 > "$OUT/bench_streams$st.json" 2>/dev/null; done
 cat "$OUT/status.txt"

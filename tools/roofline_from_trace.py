@@ -94,7 +94,7 @@ def main():
                            'Counts fabric requests, Infinity-Cache hits included.' % a.last,
                 '_algorithmic_bytes_per_launch': 20 * px, 'source': a.source or a.outdir, 'rocprof_median_us': {},
                 'rocprof_median_us_one_stream': {}}
-        for fam_name, short in (('k_fwd1#0', 'k_fwd1'), ('k_inv1#0', 'k_inv1')):
+        for fam_name, short in (('k_fwd1#0', 'k_fwd1'), ('k_inv1#0', 'k_inv1'), ('k_fwd12m#0', 'k_fwd12m'), ('k_inv21m#0', 'k_inv21m')):
             if fam_name in table:
                 side['rocprof_median_us'][short] = round(table[fam_name]['median_us'], 2)
                 if 'one_stream_median_us' in table[fam_name]:
