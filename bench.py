@@ -13,12 +13,14 @@ environment) the script re-executes itself under `torch.distributed.run` with N 
 `--mgpu` instead drives the N devices from ONE process through dtcwt_hip_mgpu_* (one host
 thread per device).  Rank 0 prints ONE JSON line.
 
-Steps rotate over `--sets` (default 4) distinct sets of input / pyramid / output buffers, about
+Steps rotate over `--sets` (default 8) distinct sets of input / pyramid / output buffers, about
 0.4 GB each for the headline config, so that no step finds its input or the previous step's
 pyramid in the 256 MiB Infinity Cache; `resident_ms_per_step` in the JSON line is the same
 step on ONE buffer set (what round 1 reported), for comparison.
 
-`ms_per_step` / `value` are throughput over `--streams` (default 2) HIP streams of independent
+`ms_per_step` / `value` are throughput over `--streams` (default 4; two until round 4: with the
+marching kernels, which run one or two wavefronts to a SIMD, four images in flight measured 0.178
+against 0.187 ms per step, profiles/r04/ab_streams.txt) HIP streams of independent
 images (the coarse-level kernels of one image overlap the level-1 kernels of the next); it is not
 the latency of one forward + inverse: `one_stream_ms_per_step` in the same line is the same
 rotating-buffer protocol on ONE stream.
@@ -100,8 +102,8 @@ def parse_args(argv=None):
     ap.add_argument('--steps', type=int, default=500)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--config', choices=sorted(CONFIGS) + ['c4'], default='c2')
-    ap.add_argument('--sets', type=int, default=4, help='distinct buffer sets the steps rotate over')
-    ap.add_argument('--streams', type=int, default=2, help='HIP streams the steps alternate over (independent images: step k '
+    ap.add_argument('--sets', type=int, default=8, help='distinct buffer sets the steps rotate over')
+    ap.add_argument('--streams', type=int, default=4, help='HIP streams the steps alternate over (independent images: step k '
                     'runs on stream k %% S, each with its own plan and buffer sets): the small coarse-level kernels of one '
                     'image overlap the large level-1 kernels of the next')
     ap.add_argument('--mgpu', action='store_true', help='N > 1 from ONE process: dtcwt_hip_mgpu_* with a host '
