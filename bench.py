@@ -259,6 +259,8 @@ def main():
     t2s = [dtcwt_amd.hip.Transform2d(tuple(bt), tuple(qt), ctx=c) for c in ctxs]
     plans = [t.plan(B, R, C, NL) for t in t2s]
     t2, plan = t2s[0], plans[0]
+    for pl in plans:
+        pl.set_concurrency(nstreams)        # the images in flight on the device: the marching launches size their bands by it
     rs = np.random.RandomState(shard_plan(cfg, world)[0][rank][0])   # random, not zero: DVFS; per-shard seed
     sets = []
     for k in range(nsets):
@@ -346,8 +348,10 @@ def main():
         return DeviceArray(a.ctx, (1,) + tuple(shape), np.float32, ptr=a.ptr, owner=a).get()[0]
     err = max(float(np.abs(first_image(s[3], plan.ext)[:64, :64] - first_image(s[0], (R, C))[:64, :64]).max()) for s in sets)
 
-    # the same step on one buffer set and one stream only (input and pyramid may stay in the Infinity Cache)
+    # the same step on one buffer set and one stream only (input and pyramid may stay in the Infinity Cache): ONE
+    # transform in flight, and the plan is told so
     fence()
+    plan.set_concurrency(1)
     px_step = B * R * C
     nres = 100 if px_step <= 2 ** 25 else max(5, min(args.steps, 100))      # short timed regions carry ~0.5 ms of start / drain cost
     for _ in range(5):

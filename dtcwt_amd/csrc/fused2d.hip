@@ -24,12 +24,12 @@ bool dtcwt_march_fwd12_ok(int rows, int cols, const std::vector<double> &h0o, co
 int dtcwt_march_fwd12(const float *X, float *Yh0, float *Yh1, float *LoLo2, int B, int R, int C,
                       const std::vector<double> &h0o, const std::vector<double> &h1o,
                       const float *l_a, const float *l_b, const float *h_a, const float *h_b, int m,
-                      int lo_a_first, int hi_a_first, int cus, hipStream_t s);
+                      int lo_a_first, int hi_a_first, int cus, int in_flight, hipStream_t s);
 bool dtcwt_march_inv21_ok(int batch, int rows, int cols, const std::vector<double> &g0o, const std::vector<double> &g1o,
                           const std::vector<double> &g0a, bool lo_pos, bool hi_pos, int cus);
 int dtcwt_march_inv21(const float *Z2, const float *Yh1, const float *Yh0, float *X, int B, int R, int C,
                       const std::vector<double> &g0o, const std::vector<double> &g1o, const float *l_a, const float *l_b,
-                      const float *h_a, const float *h_b, const float *gain1, const float *gain2, int cus, hipStream_t s);
+                      const float *h_a, const float *h_b, const float *gain1, const float *gain2, int cus, int in_flight, hipStream_t s);
 
 namespace {
 
@@ -175,6 +175,7 @@ struct dtcwt_hip_plan2d {
     // (1.11 x; linear order: 133 MB, 1.99 x, every XCD's L2 fetching its own copy of the shared halo lines) in
     // 60-62 us instead of 64-66; one run per XCD (order 1) is slower (79 us: the write streams thin out).
     int fwd1_order = 8;
+    int concurrency = 1;              // independent transforms in flight on the device (dtcwt_hip_plan2d_set_concurrency)
 };
 
 // levels 1 + 2 of the forward / 2 + 1 of the inverse in one marching launch (march2d.hpp): not for the band-pass sets,
@@ -193,6 +194,12 @@ static bool plan_march_inv21(const dtcwt_hip_plan2d *p) {
 }
 
 extern "C" {
+
+int dtcwt_hip_plan2d_set_concurrency(dtcwt_hip_plan2d *p, int n) {
+    DT_REQUIRE(p && n >= 1 && n <= 1024, "transforms in flight: 1 .. 1024");
+    p->concurrency = n;
+    return 0;
+}
 
 int dtcwt_hip_plan2d_launches(const dtcwt_hip_plan2d *p, int *fwd12, int *inv21) {
     DT_REQUIRE(p, "NULL plan");
@@ -347,7 +354,7 @@ int dtcwt_hip_plan2d_forward(dtcwt_hip_plan2d *p, const float *X, float *Yl, voi
             put_taps(q.h_a, p->qshift[5]); put_taps(q.h_b, p->qshift[4]);
             rc = dtcwt_march_fwd12(in, (float *)Yh[0], (float *)Yh[1], lo2, p->batch, L.LR, L.LC, p->biort[0], p->biort[2],
                                    q.l_a, q.l_b, q.h_a, q.h_b, (int)p->qshift[0].size(),
-                                   dotd(p->qshift[1], p->qshift[0]) > 0, dotd(p->qshift[5], p->qshift[4]) > 0, p->ctx->cus, s);
+                                   dotd(p->qshift[1], p->qshift[0]) > 0, dotd(p->qshift[5], p->qshift[4]) > 0, p->ctx->cus, p->concurrency, s);
             if (rc) return dtcwt_set_error(rc, "no marching forward kernel for levels 1 + 2");
             DT_CHECK_HIP(hipGetLastError());
             if (p->profiling) {     // level 2 has no launch of its own: an empty event pair
@@ -427,7 +434,7 @@ int dtcwt_hip_plan2d_inverse(dtcwt_hip_plan2d *p, const float *Yl, const void *c
             put_taps(q.l_a, p->qshift[3]); put_taps(q.l_b, p->qshift[2]);
             put_taps(q.h_a, p->qshift[7]); put_taps(q.h_b, p->qshift[6]);
             rc = dtcwt_march_inv21(in, (const float *)Yh[1], (const float *)Yh[0], Z, p->batch, p->lv[0].LR, p->lv[0].LC,
-                                   p->biort[1], p->biort[3], q.l_a, q.l_b, q.h_a, q.h_b, g1, g, p->ctx->cus, s);
+                                   p->biort[1], p->biort[3], q.l_a, q.l_b, q.h_a, q.h_b, g1, g, p->ctx->cus, p->concurrency, s);
             if (rc) return dtcwt_set_error(rc, "no marching inverse kernel for levels 2 + 1");
             DT_CHECK_HIP(hipGetLastError());
             if (p->profiling) {     // level 1 has no launch of its own: an empty event pair

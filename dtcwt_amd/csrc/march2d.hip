@@ -22,6 +22,8 @@ bool symmetric(const std::vector<double> &h) {
     return true;
 }
 
+// (`B` counts the images in flight on the device: the batch of the launch x the caller's hint of how many independent
+// transforms run beside it -- their jobs fill the same slots.)
 // rows per band: one job = one wavefront = (strip, band, image) marches band_rows / 2 + M - 2 steps, of which M - 2 are
 // the (cheaper) warm-up steps above and below the band that its level-2 windows reach into.  The kernel needs ~190
 // registers, i.e. two wavefronts per SIMD: `slots` wavefronts are resident at a time, and a grid of slots + 1 jobs
@@ -77,7 +79,7 @@ bool dtcwt_march_inv21_ok(int batch, int rows, int cols, const std::vector<doubl
 
 int dtcwt_march_inv21(const float *Z2, const float *Yh1, const float *Yh0, float *X, int B, int R, int C,
                       const std::vector<double> &g0o, const std::vector<double> &g1o, const float *l_a, const float *l_b,
-                      const float *h_a, const float *h_b, const float *gain1, const float *gain2, int cus, hipStream_t s) {
+                      const float *h_a, const float *h_b, const float *gain1, const float *gain2, int cus, int in_flight, hipStream_t s) {
     using G = dtm::Inv21m<7, 5, 10>;
     dtm::Inv21mParams p{};
     p.Z2 = Z2; p.Yh1 = Yh1; p.Yh0 = Yh0; p.X = X; p.B = B; p.R = R; p.C = C;
@@ -89,7 +91,7 @@ int dtcwt_march_inv21(const float *Z2, const float *Yh1, const float *Yh0, float
     for (int d = 0; d < 6; ++d) { p.g1[d] = gain1[d]; p.g2[d] = gain2[d]; }
     dtm::dtm_pack_inv_biort(p, 7, 5);
     p.nstrip = cdiv(C, 4 * G::VL);
-    p.band_rows = pick_band_rows(B, R, p.nstrip, 10, cus);
+    p.band_rows = pick_band_rows(B * in_flight, R, p.nstrip, 10, cus);
     p.nband = cdiv(R, p.band_rows);
     const int64_t jobs = (int64_t)p.nstrip * p.nband * B;
     if (jobs >= ((int64_t)1 << 31)) return -3;
@@ -98,10 +100,10 @@ int dtcwt_march_inv21(const float *Z2, const float *Yh1, const float *Yh0, float
 }
 
 template <int M0, int M1, int M>
-static int launch_fwd12(dtm::Fwd12mParams &p, int cus, hipStream_t s) {
+static int launch_fwd12(dtm::Fwd12mParams &p, int cus, int in_flight, hipStream_t s) {
     using G = dtm::Fwd12m<M0, M1, M>;
     p.nstrip = cdiv(p.C, 4 * G::VL);
-    p.band_rows = pick_band_rows(p.B, p.R, p.nstrip, M, cus);
+    p.band_rows = pick_band_rows(p.B * in_flight, p.R, p.nstrip, M, cus);
     p.nband = cdiv(p.R, p.band_rows);
     const int64_t jobs = (int64_t)p.nstrip * p.nband * p.B;
     if (jobs >= ((int64_t)1 << 31)) return -3;
@@ -114,7 +116,7 @@ static int launch_fwd12(dtm::Fwd12mParams &p, int cus, hipStream_t s) {
 int dtcwt_march_fwd12(const float *X, float *Yh0, float *Yh1, float *LoLo2, int B, int R, int C,
                       const std::vector<double> &h0o, const std::vector<double> &h1o,
                       const float *l_a, const float *l_b, const float *h_a, const float *h_b, int m,
-                      int lo_a_first, int hi_a_first, int cus, hipStream_t s) {
+                      int lo_a_first, int hi_a_first, int cus, int in_flight, hipStream_t s) {
     dtm::Fwd12mParams p{};
     p.X = X; p.Yh0 = Yh0; p.Yh1 = Yh1; p.LoLo2 = LoLo2; p.B = B; p.R = R; p.C = C;
     p.lo_a_first = lo_a_first; p.hi_a_first = hi_a_first;
@@ -126,8 +128,8 @@ int dtcwt_march_fwd12(const float *X, float *Yh0, float *Yh1, float *LoLo2, int 
     dtm::dtm_pack_biort(p, (int)h0o.size(), (int)h1o.size());
     const int m0 = (int)h0o.size(), m1 = (int)h1o.size();
     if (m == 10) {
-        if (m0 == 5 && m1 == 7) return launch_fwd12<5, 7, 10>(p, cus, s);
-        if (m0 == 5 && m1 == 3) return launch_fwd12<5, 3, 10>(p, cus, s);
+        if (m0 == 5 && m1 == 7) return launch_fwd12<5, 7, 10>(p, cus, in_flight, s);
+        if (m0 == 5 && m1 == 3) return launch_fwd12<5, 3, 10>(p, cus, in_flight, s);
     }
     return -3;
 }

@@ -137,6 +137,11 @@ class _Plan2d(object):
         check(self._lib.dtcwt_hip_plan2d_kernel_ms(self._h, f, i))
         return list(f), list(i)
 
+    def set_concurrency(self, transforms_in_flight):
+        """Hint: how many independent transforms are kept in flight on this device at a time (other plans on other
+        streams included); the marching launches choose their band height by it.  Results do not depend on it."""
+        check(self._lib.dtcwt_hip_plan2d_set_concurrency(self._h, int(transforms_in_flight)))
+
     def launches(self):
         """(levels 1 + 2 of the forward in one launch?, levels 2 + 1 of the inverse in one launch?)"""
         a, b = ctypes.c_int(0), ctypes.c_int(0)

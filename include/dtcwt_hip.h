@@ -341,6 +341,12 @@ int dtcwt_hip_plan2d_kernel_ms(dtcwt_hip_plan2d *plan, float *fwd_ms, float *inv
  * *inv21 = 1 likewise for levels 2 + 1 of the inverse (:242-293).  kernel_ms() then reports the shared launch under
  * the level it starts with (fwd_ms[0], inv_ms[1]) and an empty event pair under the other.  Either pointer may be NULL. */
 int dtcwt_hip_plan2d_launches(const dtcwt_hip_plan2d *plan, int *fwd12, int *inv21);
+/* How many independent transforms the caller keeps in flight on this device at a time (this plan's included; other
+ * plans on other streams -- the images of a video, the members of a batch handed over one by one; default 1).  The
+ * marching launches cut an image into bands of rows, each of which re-reads the rows its filters reach into above
+ * and below: one image alone needs ~40-row bands to fill the GPU, four in flight are served better by ~150-row bands
+ * (4096^2 fwd + inv: 0.152 against 0.167 ms per image).  A hint only: results do not depend on it. */
+int dtcwt_hip_plan2d_set_concurrency(dtcwt_hip_plan2d *plan, int transforms_in_flight);
 
 /* A plan's level loop as a hipGraph on fixed buffers: the forward transform of X into (Yl, Yh[, Ys])
  * and, when Z is not NULL, the inverse of that pyramid into Z (gain_mask_host as for
