@@ -14,6 +14,7 @@
 #include "fused2d_tiles.hpp"
 #include "fused2d_tiles_v2.hpp"
 #include "march2d.hpp"
+#include "march_experiments.hpp"
 
 using namespace dt2d;
 
@@ -170,11 +171,11 @@ template <int P, int KO, int WPS = 2>
 static void launch_f12(int s, int band_rows) {
     using G = dtm::Fwd12m<5, 7, 10>;
     dtm::Fwd12mParams p{}; p.X = sets[s].X; p.Yh0 = sets[s].Y0; p.Yh1 = sets[s].Y1; p.LoLo2 = sets[s].L2; p.B = 1; p.R = p.C = N;
-    p.nstrip = cdiv(N, 4 * G::VL); p.band_rows = band_rows; p.nband = cdiv(N, band_rows);
+    const unsigned jobs = dtm::dtm_set_jobs(p.jb, 1, N, cdiv(N, 4 * G::VL), band_rows);
     put(p.h0, H0O, 5, dtm::MAXT1); put(p.h1, H1O, 7, dtm::MAXT1);
     Fwd2Params q{}; fill_fwd2(q);
     dtm::dtm_pack_qshift(p, 10, q.l_a, q.l_b, q.h_a, q.h_b); dtm::dtm_pack_biort(p, 5, 7); p.lo_a_first = q.lo_a_first; p.hi_a_first = q.hi_a_first;
-    dtm::k_fwd12m<5, 7, 10, P, KO, WPS><<<p.nstrip * p.nband, 64, 0, st>>>(p);
+    dtm::k_fwd12m<5, 7, 10, P, KO, WPS><<<jobs, 64, 0, st>>>(p);
 }
 using I1 = Inv1RCfg<16, 120, 8, 7, 5>;
 using I2 = Inv2RCfg<16, 56, 2, 10>;
@@ -199,12 +200,12 @@ template <int KO>
 static void launch_i21(int s, int band_rows, float *Xout) {
     using G = dtm::Inv21m<7, 5, 10>;
     dtm::Inv21mParams p{}; p.Z2 = sets[s].L2; p.Yh1 = sets[s].Y1; p.Yh0 = sets[s].Y0; p.X = Xout; p.B = 1; p.R = p.C = N;
-    p.nstrip = cdiv(N, 4 * G::VL); p.band_rows = band_rows; p.nband = cdiv(N, band_rows);
+    const unsigned jobs = dtm::dtm_set_jobs(p.jb, 1, N, cdiv(N, 4 * G::VL), band_rows);
     Inv2Params q{}; fill_inv2(q);
     for (int k = 0; k < dtm::MAXT2; ++k) { p.l_a[k] = q.l_a[k]; p.l_b[k] = q.l_b[k]; p.h_a[k] = q.h_a[k]; p.h_b[k] = q.h_b[k]; }
     for (int d = 0; d < 6; ++d) { p.g2[d] = GAINS[d]; p.g1[d] = GAINS[5 - d]; }
     put(p.g0o, G0O, 7, dtm::MAXT1); put(p.g1o, G1O, 5, dtm::MAXT1); dtm::dtm_pack_inv_biort(p, 7, 5);
-    dtm::k_inv21m<7, 5, 10, KO><<<p.nstrip * p.nband, 64, 0, st>>>(p);
+    dtm::k_inv21m<7, 5, 10, KO><<<jobs, 64, 0, st>>>(p);
 }
 static void run_i21(int band_rows) {
     const double a = time_it([&](int s) { launch_i21<0>(s, band_rows, sets[s].Xo); });
@@ -218,11 +219,11 @@ template <int P, int KO>
 static void launch_f12w(int s, int band_rows) {
     using G = dtm::Fwd12m<5, 7, 10>;
     dtm::Fwd12mParams p{}; p.X = sets[s].X; p.Yh0 = sets[s].Y0; p.Yh1 = sets[s].Y1; p.LoLo2 = sets[s].L2; p.B = 1; p.R = p.C = N;
-    p.nstrip = cdiv(N, 4 * G::VL); p.band_rows = band_rows; p.nband = cdiv(N, band_rows);
+    const unsigned jobs = dtm::dtm_set_jobs(p.jb, 1, N, cdiv(N, 4 * G::VL), band_rows);
     put(p.h0, H0O, 5, dtm::MAXT1); put(p.h1, H1O, 7, dtm::MAXT1);
     Fwd2Params q{}; fill_fwd2(q);
     dtm::dtm_pack_qshift(p, 10, q.l_a, q.l_b, q.h_a, q.h_b); dtm::dtm_pack_biort(p, 5, 7); p.lo_a_first = q.lo_a_first; p.hi_a_first = q.hi_a_first;
-    dtm::k_fwd12w<5, 7, 10, P, KO><<<p.nstrip * p.nband, 128, 0, st>>>(p);
+    dtm::k_fwd12w<5, 7, 10, P, KO><<<jobs, 128, 0, st>>>(p);
 }
 template <int P>
 static void run_f12w(int band_rows) {
