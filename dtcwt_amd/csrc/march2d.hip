@@ -93,6 +93,7 @@ int dtcwt_march_inv21(const float *Z2, const float *Yh1, const float *Yh0, float
     const int nstrip = cdiv(C, 4 * G::VL);
     if ((int64_t)nstrip * cdiv(R, 8) * B >= ((int64_t)1 << 30)) return -3;
     const unsigned jobs = dtm::dtm_set_jobs(p.jb, B, R, nstrip, pick_band_rows(B * in_flight, R, nstrip, 10, cus));
+    // (record rows loaded with the non-temporal hint: no difference, 0.1581 against 0.1586 ms per step)
     dtm::k_inv21m<7, 5, 10, 0><<<jobs, 64, 0, s>>>(p);
     return 0;
 }
