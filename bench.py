@@ -116,6 +116,7 @@ def parse_args(argv=None):
     ap.add_argument('--settle-ms', type=float, default=300.0,
                     help='untimed steps for this long before the W warmup steps: after an idle period the '
                          'device needs ~20 ms of load to reach its sustained clock (0 disables)')
+    ap.add_argument('--nlevels', type=int, default=None, help='experiments only: another level count than the config names')
     ap.add_argument('--rows', type=int, default=None)
     ap.add_argument('--cols', type=int, default=None)
     ap.add_argument('--batch', type=int, default=None, help='images per GPU per step')
@@ -179,7 +180,7 @@ def main():
         print('bench.py: --gpus %d but the launcher started %d rank(s); reporting n_gpus=%d'
               % (args.gpus, world, world), file=sys.stderr)
     cfg = dict(CONFIGS[args.config])
-    for k in ('rows', 'cols', 'batch'):
+    for k in ('rows', 'cols', 'batch', 'nlevels'):
         if getattr(args, k) is not None:
             cfg[k] = getattr(args, k)
     dist = None
