@@ -697,10 +697,14 @@ __global__ void __launch_bounds__(64) k_inv21m(const Inv21mParams p) {
         const unsigned ro2 = (unsigned)pair_row(n, sw) * r2pitch;
 #pragma unroll
         for (int m = 0; m < 3; ++m) r2p[m] = dt2d::dt_buf_ld4(b2, (unsigned)ql * 48u + 16u * m, ro2);
+        // the record rows of a group level 1 does not run on (the first two and last two macro-steps of a band) are
+        // requested against zero bytes: the loads are issued -- every macro-step carries the same memory operations --
+        // and move nothing (they were a quarter of the kernel's record traffic at 40-row bands: 32 rows fetched, 24 used)
+        const bool gok = n - 2 >= j0 && n - 2 <= j1;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int rr = rec_row(2 * (n - 2) + e, sw);
-            const DtBuf br = dt_buf_n(Y0b + (int64_t)rr * C * 6, r1bytes);
+            const DtBuf br = dt_buf_n(Y0b + (int64_t)rr * C * 6, gok ? r1bytes : 0u);
 #pragma unroll
             for (int m = 0; m < 6; ++m) r1p[e][m] = dt2d::dt_buf_ld4(br, 16u * (unsigned)lane + 1024u * m, 0u);
         }
