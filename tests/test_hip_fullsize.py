@@ -254,11 +254,12 @@ def test_bench_self_spawns_ranks(tmp_path):
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode != 0 and 'visible' in (r.stderr + r.stdout)
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1',
-                        '--settle-ms', '0', '--no-cpu-baseline', '--rows', '512', '--cols', '512'],
+                        '--settle-ms', '0', '--no-cpu-baseline', '--no-other-configs', '--rows', '512', '--cols', '512'],
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert line['n_gpus'] == 1 and line['config']['buffer_sets'] == 4 and line['recon_max_abs_err'] < 1e-4
+    assert line['n_gpus'] == 1 and line['config']['buffer_sets'] == 8 and line['config']['streams'] == 4
+    assert line['recon_max_abs_err'] < 1e-4 and line['roofline']['launches']['fwd_levels_1_2_one_launch']
 
 
 def test_bench_config_c4_line():
