@@ -79,15 +79,13 @@ inline unsigned dtm_set_jobs(MarchJobs &j, int B, int R, int nstrip, int band_ro
     j.nunit = B * j.nband * j.ngrp;
     return (unsigned)(((j.nunit + 7) / 8) * 8 * j.gstrips);         // workgroups
 }
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ bool dtm_job(const MarchJobs &j, int w, int &strip, int &band, int &b) {
+DT_HD bool dtm_job(const MarchJobs &j, int w, int &strip, int &band, int &b) {
     const int x = w & 7, i = w >> 3;
     const int u = (i / j.gstrips) * 8 + x, sidx = i % j.gstrips;
     const int g = u % j.ngrp, ub = u / j.ngrp;
     strip = g * j.gstrips + sidx; band = ub % j.nband; b = ub / j.nband;
     return u < j.nunit && strip < j.nstrip;
 }
-#endif
 
 constexpr int MAXT1 = 9;        // longest level-1 filter a one-lane halo serves (halo <= 4 columns)
 

@@ -11,6 +11,7 @@
 
 #include "fused2d_tiles.hpp"
 #include "fused2d_tiles_v2.hpp"
+#include "march2d.hpp"
 #include "../../tools/kbench/fused2d_l12.hpp"      /* measurement-only tile program (not in the library) */
 #include "fused2d_table.hpp"
 #include "fused3d_tiles.hpp"
@@ -389,6 +390,31 @@ static void run_inv3_l2_planes(Inv2Params p, const float *planes, int64_t ps) {
 #define EMU_INV2(TR, TC, JS, M) if (m == M) return run_inv2<Inv2RCfg<TR, TC, JS, M>>(p);
 
 extern "C" {
+
+// the level-2 taps of the marching forward kernel as dtm_pack_qshift() lays them out: ta / tb by window offset
+// (A = sum_t ta[t] w[2t], B = sum_t tb[t] w[2t + 1] over the 2M-sample window starting at sample 4i - M + 2)
+int emu_march_pack_qshift(int M, const float *l_a, const float *l_b, const float *h_a, const float *h_b, float *out) {
+    dtm::Fwd12mParams p{};
+    dtm::dtm_pack_qshift(p, M, l_a, l_b, h_a, h_b);
+    for (int t = 0; t < dtm::MAXT2; ++t) {
+        out[t] = p.ta_lo[t]; out[dtm::MAXT2 + t] = p.tb_lo[t]; out[2 * dtm::MAXT2 + t] = p.ta_hi[t]; out[3 * dtm::MAXT2 + t] = p.tb_hi[t];
+        if (p.ta2[2 * t] != p.ta_lo[t] || p.ta2[2 * t + 1] != p.ta_hi[t] || p.tb2[2 * t] != p.tb_lo[t] || p.tb2[2 * t + 1] != p.tb_hi[t]) return -1;
+    }
+    return dtm::MAXT2;
+}
+
+// the job order of the marching launches (march2d.hpp): for workgroup w of the grid dtm_set_jobs() asks for, which
+// (strip, band, image) it marches, or -1 x 3 when it leaves at once; returns the grid size
+int emu_march_jobs(int B, int R, int nstrip, int band_rows, int *out, int cap) {
+    dtm::MarchJobs j{};
+    const int grid = (int)dtm::dtm_set_jobs(j, B, R, nstrip, band_rows);
+    for (int w = 0; w < grid && w < cap; ++w) {
+        int s, bd, b;
+        if (dtm::dtm_job(j, w, s, bd, b)) { out[3 * w] = s; out[3 * w + 1] = bd; out[3 * w + 2] = b; }
+        else out[3 * w] = out[3 * w + 1] = out[3 * w + 2] = -1;
+    }
+    return grid;
+}
 
 // all pointers are HOST pointers
 int emu_fwd1(int m0, int m1, const float *X, float *LoLo, float *Yh, int B, int inR, int inC,

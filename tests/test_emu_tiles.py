@@ -27,7 +27,8 @@ TOL = 2e-6
 def _build():
     deps = [EMU_SRC, os.path.join(ROOT, 'tools', 'kbench', 'fused2d_l12.hpp')] + [
         os.path.join(ROOT, 'dtcwt_amd', 'csrc', f) for f in
-        ('fused2d_tiles.hpp', 'fused2d_tiles_v2.hpp', 'fused2d_table.hpp', 'fused3d_tiles.hpp', 'fused3d_inv_tiles.hpp')]
+        ('fused2d_tiles.hpp', 'fused2d_tiles_v2.hpp', 'fused2d_table.hpp', 'fused3d_tiles.hpp', 'fused3d_inv_tiles.hpp',
+         'march2d.hpp')]
     if os.path.exists(EMU_LIB) and all(os.path.getmtime(EMU_LIB) >= os.path.getmtime(d) for d in deps):
         return
     if not os.path.exists(HIPCC):
@@ -355,3 +356,57 @@ def test_inv3_level2_tiles(emu, shape, crops, chunk, qname):
     sl = tuple(slice(c, full.shape[a] - c) for a, c in enumerate(crops))
     want = full[sl]
     assert Z.shape == want.shape and rel(Z, want) < TOL
+
+
+@pytest.mark.parametrize('B,R,nstrip,band', [(1, 4096, 18, 40), (1, 4096, 18, 148), (4, 4096, 18, 148), (64, 2048, 9, 256),
+                                             (64, 1024, 5, 176), (3, 128, 2, 8), (1, 64, 1, 24), (2, 520, 14, 36), (5, 44, 13, 12)])
+def test_march_job_order_is_a_bijection(emu, B, R, nstrip, band):
+    """The workgroup -> (strip, band, image) map of the marching launches (dtm_job, march2d.hpp): every job exactly once,
+    surplus workgroups leave, and the strips of one (image, band) sit on at most `ngrp` XCDs (workgroup w runs on XCD
+    w % 8) in contiguous runs -- what lets neighbouring strips share their halo columns through one L2."""
+    nband = -(-R // band)
+    cap = 8 * (B * nband * 2 + 8) * (nstrip + 2)
+    out = (ctypes.c_int * (3 * cap))()
+    emu.emu_march_jobs.restype = ctypes.c_int
+    grid = emu.emu_march_jobs(B, R, nstrip, band, out, cap)
+    assert 0 < grid <= cap
+    jobs = np.frombuffer(out, dtype=np.int32)[:3 * grid].reshape(grid, 3)
+    live = jobs[jobs[:, 0] >= 0]
+    assert len(live) == B * nband * nstrip
+    keys = live[:, 2].astype(np.int64) * nband * nstrip + live[:, 1] * nstrip + live[:, 0]
+    assert len(np.unique(keys)) == len(keys) and keys.min() == 0 and keys.max() == B * nband * nstrip - 1
+    assert grid < 2 * len(live) + 8 * (nstrip + 1)          # the padding is bounded
+    w = np.nonzero(jobs[:, 0] >= 0)[0]
+    xcd = w % 8
+    ngrp = 2 if nstrip >= 14 else 1
+    for b in range(min(B, 2)):
+        for bd in (0, nband - 1):
+            sel = (live[:, 2] == b) & (live[:, 1] == bd)
+            assert len(np.unique(xcd[sel])) <= ngrp
+
+
+def test_march_level2_taps_reproduce_coldfilt(emu):
+    """dtm_pack_qshift (march2d.hpp): with the taps laid out by window offset, A = sum_t ta[t] w[2t] and
+    B = sum_t tb[t] w[2t + 1] over the window of 2M samples starting at 4i - M + 2 are rows 2i and 2i + 1 of
+    coldfilt(X, ha, hb) (dtcwt/numpy/lowlevel.py:82-154; the order of the pair by the sign of sum(ha hb))."""
+    h0a, h0b, g0a, g0b, h1a, h1b, g1a, g1b = [np.asarray(v, dtype=np.float64).ravel() for v in qshift('qshift_a')]
+    M = len(h0a)
+    f = lambda v: np.ascontiguousarray(np.concatenate([v, np.zeros(40 - M)]), dtype=np.float32)
+    la, lb, ha, hb = f(h0b), f(h0a), f(h1b), f(h1a)          # coldfilt(X, h0b, h0a), coldfilt(X, h1b, h1a)
+    out = np.zeros(80, dtype=np.float32)
+    fp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    emu.emu_march_pack_qshift.restype = ctypes.c_int
+    assert emu.emu_march_pack_qshift(M, fp(la), fp(lb), fp(ha), fp(hb), fp(out)) == 20
+    ta_lo, tb_lo, ta_hi, tb_hi = (out[20 * k:20 * k + M].astype(np.float64) for k in range(4))
+    rs = np.random.RandomState(3)
+    X = rs.standard_normal((48, 3))
+    r = X.shape[0]
+    ext = lambda u: X[np.where(u < 0, -1 - u, np.where(u >= r, 2 * r - 1 - u, u))]          # half-sample symmetric
+    for (ta, tb, fa, fb) in ((ta_lo, tb_lo, h0b, h0a), (ta_hi, tb_hi, h1b, h1a)):
+        want = o.coldfilt(X, fa, fb)
+        a_first = np.dot(fa, fb) > 0
+        for i in range(r // 4):
+            w = ext(np.arange(4 * i - M + 2, 4 * i + M + 2))
+            A = (ta[:, None] * w[0::2]).sum(0); Bv = (tb[:, None] * w[1::2]).sum(0)
+            first, second = (A, Bv) if a_first else (Bv, A)
+            assert np.abs(first - want[2 * i]).max() < 1e-6 and np.abs(second - want[2 * i + 1]).max() < 1e-6
