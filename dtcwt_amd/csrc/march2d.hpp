@@ -1,22 +1,25 @@
-// Marching wavefront programs of the float32 2-D DT-CWT (gfx950).
+// Marching wavefront programs of the float32 2-D DT-CWT (gfx950): levels 1 + 2 of the forward transform (k_fwd12m) and
+// levels 2 + 1 of the inverse (k_inv21m) as ONE launch each, the level-1 lowpass never leaving the registers.
 //
-// The tile programs of fused2d_tiles_v2.hpp hand the column pass to the row pass through LDS planes and
-// workgroup barriers; profiles/r03/ko_bench.txt shows them spending 160 us of CU time per 4096^2 step on 24 us
-// of FMAs.  Here ONE WAVEFRONT is the unit of work and nothing is shared between wavefronts:
+// The tile programs of fused2d_tiles_v2.hpp hand the column pass to the row pass through LDS planes and workgroup
+// barriers, one launch per level.  Here ONE WAVEFRONT is the unit of work and nothing is shared between wavefronts:
 //
 //   * a wavefront owns a strip of 64 x 4 = 256 adjacent columns (lane l holds columns 4l .. 4l+3 of the strip
-//     as one float4: a row of the strip is ONE 1 KiB global_load_dwordx4) and marches down a segment of rows;
+//     as one float4: a row of the strip is ONE 1 KiB load) and marches down a band of rows;
 //   * the column filters run over a register ring of the last rows (static indices: the march loop is unrolled
-//     over one period of the ring), so their window costs no LDS and no halo re-computation;
+//     over one period of the ring) or, transposed, into pending sums -- no LDS, no halo re-computation across rows;
 //   * the row filters take the neighbouring columns from the neighbouring LANES with DPP wave shifts
 //     (v_mov_b32_dpp wave_shr:1 / wave_shl:1): the first and the last HL lanes of a strip are halo lanes;
 //   * q2c / c2q are lane-local (a lane owns whole 2 x 2 quads), the 48-byte subband records travel through a
 //     wave-private LDS slab so that every global access is a run of consecutive 16-byte pieces;
-//   * rows are requested P steps ahead of their use; there is no barrier anywhere, so the load, FMA and store
-//     streams of the wavefronts of a CU overlap freely.
+//   * rows are requested ahead of their use; there is no barrier anywhere, so the load, FMA and store streams of
+//     the wavefronts of a CU overlap freely.
+// What the hardware taught on the way (data hazard of 16-byte buffer stores, vmcnt per path, one instruction per four
+// cycles per wavefront, true-pair packing) is written where it matters below and in DESIGN.md section 4 "Round 4".
+// The first prototypes (level 1 alone, a pair of wavefronts per job) are in tools/kbench/march_experiments.hpp.
 //
-// Reference: dtcwt/numpy/transform2d.py:112-130 (level 1 forward), :275-293 (level 1 inverse), q2c :301-322,
-// c2q :324-350; colfilter dtcwt/numpy/lowlevel.py:47-80.
+// Reference: dtcwt/numpy/transform2d.py:112-160 (forward levels 1, 2), :242-293 (inverse levels 2, 1), q2c :301-322,
+// c2q :324-350; colfilter / coldfilt / colifilt dtcwt/numpy/lowlevel.py:47-80, :82-154, :156-260.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -31,10 +34,8 @@ using dt2d::dt_buf;
 using dt2d::f4;
 
 #if defined(__HIP_DEVICE_COMPILE__)
-// A raw buffer over [base, base + 2 GiB): a lane offset with bit 31 set is out of range, i.e. the hardware drops the
-// store (and returns 0 for a load).  Lanes that own nothing keep such an offset, so no store of the march loop sits in
-// a divergent branch -- with exec-masked store blocks the compiler cannot count the outstanding memory operations of a
-// path and waits for (nearly) all of them at every use of a prefetched row.
+// A raw buffer over [base, base + 2 GiB) for the row loads: the row offset rides in the scalar offset field, the
+// lane's column in the vector offset (loads have no hazard with a register there; an image is < 2 GiB: march2d.hip).
 constexpr unsigned OOB = 0x80000000u;
 __device__ __forceinline__ DtBuf dt_buf2g(const void *base) {
     const unsigned long long v = reinterpret_cast<unsigned long long>(base);
@@ -105,52 +106,8 @@ __device__ __forceinline__ void row_window(const f4 &v, float (&w)[4 + 2 * HH]) 
     for (int j = 0; j < HH; ++j) w[HH + 4 + j] = NODPP ? e[j] : dpp_from_right(e[j]);
 }
 
-// out[c] = sum_k h[k] w[c + HH + H - k]   (convolution, lowlevel.py:26-44), c = 0..3
-template <int M, int HH>
-__device__ __forceinline__ f4 row_fir(const float (&w)[4 + 2 * HH], const float *h) {
-    constexpr int H = M / 2;
-    float o[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        float a = 0.f;
-#pragma unroll
-        for (int k = 0; k < M; ++k) a += h[k] * w[c + HH + H - k];
-        o[c] = a;
-    }
-    return f4{o[0], o[1], o[2], o[3]};
-}
-
-template <int M, int HH, int WR>
-__device__ __forceinline__ f4 col_fir(const f4 (&w)[WR], int q, const float *h) {
-    constexpr int H = M / 2;
-    f4 a{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < M; ++k) {
-        const f4 &x = w[q + HH + H - k];
-        a.x += h[k] * x.x; a.y += h[k] * x.y; a.z += h[k] * x.z; a.w += h[k] * x.w;
-    }
-    return a;
-}
-
-// Both filters of a level-1 pass over the SAME samples, the filters symmetric (h[k] = h[M-1-k]: every biort set): the
-// mirror pairs are added once and shared, 2 + 3 adds + 3 + 4 multiply-adds for a 5- and a 7-tap filter instead of 12
-// (what separates the result from the tap-by-tap sum is the rounding of those adds: ~1 ulp either way).
-//   oa = sum_k a[k] x[c + HH + HA - k],  ob = sum_k b[k] x[c + HH + HB - k]
-template <int MA, int MB, int HH>
-__device__ __forceinline__ void sym_pair(const float *xc, const float *a, const float *b, float &oa, float &ob) {
-    constexpr int HA = MA / 2, HB = MB / 2, HM = HA > HB ? HA : HB;
-    float sm[HM + 1];
-    sm[0] = xc[0];
-#pragma unroll
-    for (int d = 1; d <= HM; ++d) sm[d] = xc[-d] + xc[d];
-    float ra = a[HA] * sm[0], rb = b[HB] * sm[0];
-#pragma unroll
-    for (int d = 1; d <= HA; ++d) ra += a[HA - d] * sm[d];
-#pragma unroll
-    for (int d = 1; d <= HB; ++d) rb += b[HB - d] * sm[d];
-    oa = ra; ob = rb;
-}
-// the lowpass one alone (warm-up rows)
+// A symmetric filter (h[k] = h[M-1-k]: every biort set) at one column, the mirror pairs added first: the lowpass on
+// the warm-up rows, where level 1 only has to feed level 2 (xc = centre of the window)
 template <int MA, int HH>
 __device__ __forceinline__ float sym_one(const float *xc, const float *a) {
     constexpr int HA = MA / 2;

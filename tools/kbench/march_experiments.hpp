@@ -10,6 +10,54 @@
 
 namespace dtm {
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// out[c] = sum_k h[k] w[c + HH + H - k]   (convolution, lowlevel.py:26-44), c = 0..3
+template <int M, int HH>
+__device__ __forceinline__ f4 row_fir(const float (&w)[4 + 2 * HH], const float *h) {
+    constexpr int H = M / 2;
+    float o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < M; ++k) a += h[k] * w[c + HH + H - k];
+        o[c] = a;
+    }
+    return f4{o[0], o[1], o[2], o[3]};
+}
+
+template <int M, int HH, int WR>
+__device__ __forceinline__ f4 col_fir(const f4 (&w)[WR], int q, const float *h) {
+    constexpr int H = M / 2;
+    f4 a{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+        const f4 &x = w[q + HH + H - k];
+        a.x += h[k] * x.x; a.y += h[k] * x.y; a.z += h[k] * x.z; a.w += h[k] * x.w;
+    }
+    return a;
+}
+
+// Both filters of a level-1 pass over the SAME samples, the filters symmetric (h[k] = h[M-1-k]: every biort set): the
+// mirror pairs are added once and shared, 2 + 3 adds + 3 + 4 multiply-adds for a 5- and a 7-tap filter instead of 12
+// (what separates the result from the tap-by-tap sum is the rounding of those adds: ~1 ulp either way).
+//   oa = sum_k a[k] x[c + HH + HA - k],  ob = sum_k b[k] x[c + HH + HB - k]
+template <int MA, int MB, int HH>
+__device__ __forceinline__ void sym_pair(const float *xc, const float *a, const float *b, float &oa, float &ob) {
+    constexpr int HA = MA / 2, HB = MB / 2, HM = HA > HB ? HA : HB;
+    float sm[HM + 1];
+    sm[0] = xc[0];
+#pragma unroll
+    for (int d = 1; d <= HM; ++d) sm[d] = xc[-d] + xc[d];
+    float ra = a[HA] * sm[0], rb = b[HB] * sm[0];
+#pragma unroll
+    for (int d = 1; d <= HA; ++d) ra += a[HA - d] * sm[d];
+#pragma unroll
+    for (int d = 1; d <= HB; ++d) rb += b[HB - d] * sm[d];
+    oa = ra; ob = rb;
+}
+#endif
+
 struct Fwd1mParams {
     const float *X;       // [B][R][C]
     float *LoLo;          // [B][R][C]
