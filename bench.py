@@ -492,7 +492,8 @@ def other_configs():
                     'workload': d['config']['workload'], 'step_frac': d['roofline'].get('step_frac'),
                     'wall_s': round(time.perf_counter() - t0, 1)}
             if name == 'c4':
-                keep.update({k: d.get(k) for k in ('fwd_ms_per_step', 'inv_ms_per_step')})
+                keep.update({k: d.get(k) for k in ('fwd_ms_per_step', 'inv_ms_per_step', 'ms_per_step_one_stream')})
+                keep['streams'] = d['config'].get('streams')
                 keep['k_fwd3_l1_frac'] = d['roofline'].get('frac')
                 keep['step_frac'] = d.get('step_frac')
             else:
@@ -516,15 +517,25 @@ def main_c4(args):
     n = args.rows or 256
     nl = 3
     ctx = Context(0)
-    t3 = Transform3d(BIORT, QSHIFT, ctx=ctx)
+    # independent volumes in flight on separate streams, as the default configuration does with images: the coarse levels
+    # (a few hundred workgroups) of one volume run beside the level-1 launches of another
+    nstreams = max(1, args.streams)
+    nsets = max(nstreams, args.sets)
+    if nsets % nstreams:
+        nsets = (nsets // nstreams + 1) * nstreams
+    ctxs = [ctx] + [Context(0) for _ in range(nstreams - 1)]
+    t3s = [Transform3d(BIORT, QSHIFT, ctx=c) for c in ctxs]
     rs = np.random.RandomState(4)
-    vols = [ctx.to_device(rs.standard_normal((n, n, n)).astype(np.float32)) for _ in range(max(1, args.sets))]
+    vols = [ctxs[k % nstreams].to_device(rs.standard_normal((n, n, n)).astype(np.float32)) for k in range(nsets)]
+    t3 = t3s[0]
     state = {}
 
     def step(k):
-        p = t3.forward(vols[k % len(vols)], nlevels=nl)
-        state['p'] = p
-        state['z'] = t3.inverse(p, device_output=True)
+        s = k % nsets
+        t = t3s[s % nstreams]
+        p = t.forward(vols[s], nlevels=nl)
+        state['p', s % nstreams] = p
+        state['z', s % nstreams] = t.inverse(p, device_output=True)
 
     t_end = time.perf_counter() + args.settle_ms / 1e3
     k = 0
@@ -540,18 +551,30 @@ def main_c4(args):
         step(k)
     ctx.device_sync()
     dt = time.perf_counter() - t0
-    last = vols[(args.steps - 1) % len(vols)]
-    err = float(np.abs(state['z'].get() - last.get()).max())
+    ls = (args.steps - 1) % nsets
+    err = float(np.abs(state['z', ls % nstreams].get() - vols[ls].get()).max())
     # forward-only and inverse-only times of the same protocol
     ctx.device_sync(); t1 = time.perf_counter()
     for k in range(args.steps):
-        state['p'] = t3.forward(vols[k % len(vols)], nlevels=nl)
+        s = k % nsets
+        state['p', s % nstreams] = t3s[s % nstreams].forward(vols[s], nlevels=nl)
     ctx.device_sync(); dt_f = time.perf_counter() - t1
-    p = state['p']
+    for q in range(nstreams):
+        if ('p', q) not in state:
+            state['p', q] = t3s[q].forward(vols[q], nlevels=nl)
     ctx.device_sync(); t1 = time.perf_counter()
     for k in range(args.steps):
-        state['z'] = t3.inverse(p, device_output=True)
+        q = k % nstreams
+        state['z', q] = t3s[q].inverse(state['p', q], device_output=True)
     ctx.device_sync(); dt_i = time.perf_counter() - t1
+    # one volume at a time on one stream: the latency of a single forward + inverse
+    ctx.device_sync(); t1 = time.perf_counter()
+    own = [s for s in range(nsets) if s % nstreams == 0]
+    for k in range(args.steps):
+        p1 = t3.forward(vols[own[k % len(own)]], nlevels=nl)
+        z1 = t3.inverse(p1, device_output=True)
+    ctx.device_sync(); dt_1 = time.perf_counter() - t1
+    del p1, z1
 
     # the dominant kernel, k_fwd3_l1, alone: raw event pair around dtcwt_hip_fwd3_level1 (one launch), median
     h0, h1 = flat_taps(biort(BIORT)[0]), flat_taps(biort(BIORT)[2])
@@ -579,7 +602,9 @@ def main_c4(args):
         'warmup': args.warmup, 'settle_ms': args.settle_ms, 'ms_per_step': round(ms, 5), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': '3D forward+inverse %dx%dx%d f32, nlevels=%d, %s/%s, one volume per step' % (n, n, n, nl, BIORT, QSHIFT),
-                   'sharding': 'replicas only: a volume is not sharded', 'buffer_sets': len(vols), 'streams': 1},
+                   'sharding': 'replicas only: a volume is not sharded', 'buffer_sets': len(vols), 'streams': nstreams,
+                   'ms_per_step_is': 'throughput over %d overlapped stream(s) of independent volumes' % nstreams},
+        'ms_per_step_one_stream': round(dt_1 / args.steps * 1e3, 5),
         'fwd_ms_per_step': round(dt_f / args.steps * 1e3, 5), 'inv_ms_per_step': round(dt_i / args.steps * 1e3, 5),
         'step_frac': round(72.0 * vox / (ms * 1e-3) / HBM_PEAK, 4),
         'roofline': {'bound': 'hbm', 'kernel': 'k_fwd3_l1 (level-1 forward, one launch)',

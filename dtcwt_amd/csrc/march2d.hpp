@@ -332,6 +332,7 @@ __global__ void __launch_bounds__(64, WPS) k_fwd12m(const Fwd12mParams p) {
             for (int j = 0; j < WR; ++j) { wp[0][j] = pk2{w[j].x, w[j].y}; wp[1][j] = pk2{w[j].z, w[j].w}; }
             const pk2 *hpp = reinterpret_cast<const pk2 *>(p.hp);
             f4 ll[2];
+            f4 pv[6];                                   // (KO & 64) planar pyramid: a lane's two coefficients of each subband
             if (in_band) {
                 f4 lh[2], hl[2], hh[2];
 #pragma unroll
@@ -355,15 +356,26 @@ __global__ void __launch_bounds__(64, WPS) k_fwd12m(const Fwd12mParams p) {
                     const Zq a0 = q2c_s(hl[0].x, hl[0].y, hl[1].x, hl[1].y), a1 = q2c_s(hl[0].z, hl[0].w, hl[1].z, hl[1].w);
                     const Zq b0 = q2c_s(hh[0].x, hh[0].y, hh[1].x, hh[1].y), b1 = q2c_s(hh[0].z, hh[0].w, hh[1].z, hh[1].w);
                     const Zq c0q = q2c_s(lh[0].x, lh[0].y, lh[1].x, lh[1].y), c1q = q2c_s(lh[0].z, lh[0].w, lh[1].z, lh[1].w);
+                    if constexpr ((KO & 64) != 0) {
+                        pv[0] = f4{sq * a0.z0r, sq * a0.z0i, sq * a1.z0r, sq * a1.z0i}; pv[1] = f4{sq * b0.z0r, sq * b0.z0i, sq * b1.z0r, sq * b1.z0i};
+                        pv[2] = f4{sq * c0q.z0r, sq * c0q.z0i, sq * c1q.z0r, sq * c1q.z0i}; pv[3] = f4{sq * c0q.z1r, sq * c0q.z1i, sq * c1q.z1r, sq * c1q.z1i};
+                        pv[4] = f4{sq * b0.z1r, sq * b0.z1i, sq * b1.z1r, sq * b1.z1i}; pv[5] = f4{sq * a0.z1r, sq * a0.z1i, sq * a1.z1r, sq * a1.z1i};
+                    }
                     f4 *o = slab + lane * 6;
+                    if constexpr ((KO & 64) == 0) {
                     o[0] = f4{sq * a0.z0r, sq * a0.z0i, sq * b0.z0r, sq * b0.z0i};
                     o[1] = f4{sq * c0q.z0r, sq * c0q.z0i, sq * c0q.z1r, sq * c0q.z1i};
                     o[2] = f4{sq * b0.z1r, sq * b0.z1i, sq * a0.z1r, sq * a0.z1i};
                     o[3] = f4{sq * a1.z0r, sq * a1.z0i, sq * b1.z0r, sq * b1.z0i};
                     o[4] = f4{sq * c1q.z0r, sq * c1q.z0i, sq * c1q.z1r, sq * c1q.z1i};
                     o[5] = f4{sq * b1.z1r, sq * b1.z1i, sq * a1.z1r, sq * a1.z1i};
+                    }
                 }
             } else {
+                if constexpr ((KO & 64) != 0) {
+#pragma unroll
+                    for (int m = 0; m < 6; ++m) pv[m] = f4{0.f, 0.f, 0.f, 0.f};
+                }
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     float lo[4];
@@ -389,7 +401,17 @@ __global__ void __launch_bounds__(64, WPS) k_fwd12m(const Fwd12mParams p) {
             // step carries the same number of memory operations.  The compiler counts them per path and, where paths
             // meet, assumes the fewest: with the stores inside the branch each use of a prefetched row waited for all
             // but the youngest 4 operations, i.e. for the stores of the step before.
-            {
+            if constexpr ((KO & 64) != 0) {
+                // experiment (tools/kbench/march_bench): the pyramid as six planes [6][R/2][C/2] of complex64 -- a lane
+                // stores its own two coefficients of each subband, nothing goes through the slab
+                const int ro = (KO & 2) ? (r & 15) : r;
+                float *const Y0p = p.Yh0 + img * 3 + strip * (VL * 4) + (int64_t)(ro >> 1) * C;
+#pragma unroll
+                for (int m = 0; m < 6; ++m) {
+                    const DtBuf by = dt_buf_n(Y0p + (int64_t)m * (R / 2) * C, in_band ? 16u * nv : 0u);
+                    dt2d::dt_buf_st4<true>(by, 16u * (unsigned)(lane - HL), 0u, pv[m]);
+                }
+            } else {
                 const int ro = (KO & 2) ? (r & 15) : r;
                 DT_WAVE_LDS_SYNC();
                 const DtBuf by = dt_buf_n(Y0b + (int64_t)(ro >> 1) * C * 6, in_band ? 96u * nv : 0u);
@@ -461,6 +483,16 @@ __global__ void __launch_bounds__(64, WPS) k_fwd12m(const Fwd12mParams p) {
                     const Zq a = q2c_s(hl2[0][0], hl2[0][1], hl2[1][0], hl2[1][1]);
                     const Zq bq = q2c_s(hh2[0][0], hh2[0][1], hh2[1][0], hh2[1][1]);
                     const Zq c = q2c_s(lh2[0][0], lh2[0][1], lh2[1][0], lh2[1][1]);
+                    if constexpr ((KO & 64) != 0) {
+                        float *const Y1p = p.Yh1 + (img / 4) * 3 + strip * (VL * 2) + (int64_t)io * (C / 2);
+                        const dt2d::f2 q6[6] = {{sq * a.z0r, sq * a.z0i}, {sq * bq.z0r, sq * bq.z0i}, {sq * c.z0r, sq * c.z0i},
+                                                {sq * c.z1r, sq * c.z1i}, {sq * bq.z1r, sq * bq.z1i}, {sq * a.z1r, sq * a.z1i}};
+#pragma unroll
+                        for (int m = 0; m < 6; ++m) {
+                            const DtBuf by1 = dt_buf_n(Y1p + (int64_t)m * (R / 4) * (C / 2), pair_ok ? 8u * nv : 0u);
+                            dt2d::dt_buf_st2<false>(by1, l2v, 0u, q6[m]);
+                        }
+                    } else {
                     f4 *o = slab2 + lane * 3;
                     o[0] = f4{sq * a.z0r, sq * a.z0i, sq * bq.z0r, sq * bq.z0i};
                     o[1] = f4{sq * c.z0r, sq * c.z0i, sq * c.z1r, sq * c.z1i};
@@ -473,6 +505,7 @@ __global__ void __launch_bounds__(64, WPS) k_fwd12m(const Fwd12mParams p) {
                         dt2d::dt_buf_st4<false>(by1, yv + 1024u * m, 0u, v);
                     }
                     DT_WAVE_LDS_SYNC();
+                    }
                 }
 #pragma unroll
                 for (int a = 0; a + 1 < NP2; ++a)
@@ -650,8 +683,17 @@ __global__ void __launch_bounds__(64) k_inv21m(const Inv21mParams p) {
         bool sw;
         z2p[0] = ld_z2(2 * n); z2p[1] = ld_z2(2 * n + 1);
         const unsigned ro2 = (unsigned)pair_row(n, sw) * r2pitch;
+        if constexpr ((KO & 64) != 0) {        // experiment: planar pyramid, a lane fetches its own coefficient of each subband
+            const unsigned ro2p = ro2 / 6u, pl2 = (unsigned)R * (unsigned)C / 2u;      // bytes per row / per plane of Yh1
+            dt2d::f2 q6[6];
+#pragma unroll
+            for (int m = 0; m < 6; ++m) q6[m] = dt2d::dt_buf_ld2(b2, (unsigned)ql * 8u + pl2 * m, ro2p);
+            r2p[0] = f4{q6[0].x, q6[0].y, q6[1].x, q6[1].y}; r2p[1] = f4{q6[2].x, q6[2].y, q6[3].x, q6[3].y};
+            r2p[2] = f4{q6[4].x, q6[4].y, q6[5].x, q6[5].y};
+        } else {
 #pragma unroll
         for (int m = 0; m < 3; ++m) r2p[m] = dt2d::dt_buf_ld4(b2, (unsigned)ql * 48u + 16u * m, ro2);
+        }
         // the record rows of a group level 1 does not run on (the first two and last two macro-steps of a band) are
         // requested against zero bytes: the loads are issued -- every macro-step carries the same memory operations --
         // and move nothing (they were a quarter of the kernel's record traffic at 40-row bands: 32 rows fetched, 24 used)
@@ -659,6 +701,15 @@ __global__ void __launch_bounds__(64) k_inv21m(const Inv21mParams p) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int rr = rec_row(2 * (n - 2) + e, sw);
+            if constexpr ((KO & 64) != 0) {
+                const float *const Y0p = p.Yh0 + img * 3 + (cb + 4 * lmin) + (int64_t)rr * C;
+#pragma unroll
+                for (int m = 0; m < 6; ++m) {
+                    const DtBuf br = dt_buf_n(Y0p + (int64_t)m * (R / 2) * C, gok ? r1bytes / 6u : 0u);
+                    r1p[e][m] = dt2d::dt_buf_ld4(br, 16u * (unsigned)(sl - lmin), 0u);
+                }
+                continue;
+            }
             const DtBuf br = dt_buf_n(Y0b + (int64_t)rr * C * 6, gok ? r1bytes : 0u);
 #pragma unroll
             for (int m = 0; m < 6; ++m) r1p[e][m] = dt2d::dt_buf_ld4(br, 16u * (unsigned)lane + 1024u * m, 0u);
@@ -693,10 +744,13 @@ __global__ void __launch_bounds__(64) k_inv21m(const Inv21mParams p) {
         (void)pair_row(n, sw2);
         (void)rec_row(2 * j, sw1[0]); (void)rec_row(2 * j + 1, sw1[1]);
         // ---- what was requested a macro-step ago: the level-1 records to the slab, the level-2 inputs through c2q
+        f4 s1[2][6];                    // (KO & 64): the lane's own coefficients, no slab
 #pragma unroll
         for (int e = 0; e < 2; ++e)
 #pragma unroll
-            for (int m = 0; m < 6; ++m) slab[e][6 * lmin + lane + 64 * m] = r1p[e][m];
+            for (int m = 0; m < 6; ++m) {
+                if constexpr ((KO & 64) != 0) s1[e][m] = r1p[e][m]; else slab[e][6 * lmin + lane + 64 * m] = r1p[e][m];
+            }
         float z[2][2], p05[2][2], p23[2][2], p14[2][2];
         {
             const f4 ra = r2p[0], rc = r2p[1], re = r2p[2];
@@ -765,6 +819,11 @@ __global__ void __launch_bounds__(64) k_inv21m(const Inv21mParams p) {
                     f4 s_[6];
 #pragma unroll
                     for (int m = 0; m < 6; ++m) s_[m] = sp[m];
+                    if constexpr ((KO & 64) != 0) {
+                        s_[0] = f4{s1[h][0].x, s1[h][0].y, s1[h][1].x, s1[h][1].y}; s_[1] = f4{s1[h][2].x, s1[h][2].y, s1[h][3].x, s1[h][3].y};
+                        s_[2] = f4{s1[h][4].x, s1[h][4].y, s1[h][5].x, s1[h][5].y}; s_[3] = f4{s1[h][0].z, s1[h][0].w, s1[h][1].z, s1[h][1].w};
+                        s_[4] = f4{s1[h][2].z, s1[h][2].w, s1[h][3].z, s1[h][3].w}; s_[5] = f4{s1[h][4].z, s1[h][4].w, s1[h][5].z, s1[h][5].w};
+                    }
                     float A05[2][2], A23[2][2], A14[2][2], B05[2][2], B23[2][2], B14[2][2];
                     c2q_quad(s_[0].x, s_[0].y, s_[2].z, s_[2].w, p.g1[0], p.g1[5], A05);
                     c2q_quad(s_[1].x, s_[1].y, s_[1].z, s_[1].w, p.g1[2], p.g1[3], A23);

@@ -234,6 +234,20 @@ static void run_f12w(int band_rows) {
     printf("k_fwd12w P=%d band_rows=%3d (2 roles)    %9.2f %9.2f %9.2f %9.2f\n", P, band_rows, a, b, c, d);
     fflush(stdout);
 }
+// the pyramid as six planes per level instead of 48-byte records (KO bit 64): no slab on either side
+static void run_planar(int band_rows) {
+    const double a = time_it([&](int s) { launch_f12<2, 64>(s, band_rows); });
+    const double b = time_it([&](int s) { launch_f12<2, 65>(s, band_rows); });
+    const double c = time_it([&](int s) { launch_f12<2, 66>(s, band_rows); });
+    const double d = time_it([&](int s) { launch_f12<2, 67>(s, band_rows); });
+    printf("k_fwd12m PLANAR pyramid, band_rows=%3d    %9.2f %9.2f %9.2f %9.2f\n", band_rows, a, b, c, d);
+    const double e = time_it([&](int s) { launch_i21<64>(s, band_rows, sets[s].Xo); });
+    const double f = time_it([&](int s) { launch_i21<65>(s, band_rows, sets[s].Xo); });
+    const double g = time_it([&](int s) { launch_i21<66>(s, band_rows, sets[s].Xo); });
+    const double h = time_it([&](int s) { launch_i21<67>(s, band_rows, sets[s].Xo); });
+    printf("k_inv21m PLANAR pyramid, band_rows=%3d    %9.2f %9.2f %9.2f %9.2f\n", band_rows, e, f, g, h);
+    fflush(stdout);
+}
 template <int P, int WPS = 2>
 static void run_f12(int band_rows) {
     const double a = time_it([&](int s) { launch_f12<P, 0, WPS>(s, band_rows); });
@@ -344,6 +358,32 @@ int main(int argc, char **argv) {
         }
         for (int s2 = 1; s2 < NSET; ++s2) { launch_ref(s2, sets[s2].L1, sets[s2].Y0); launch_ref2(sets[s2].L1, sets[s2].L2, sets[s2].Y1); }
     }
+    {   // the planar-pyramid variants: forward against the records (permuted on the host), inverse from the planes
+        float *Y0p, *Y1p, *y0 = sets[0].Y0, *y1 = sets[0].Y1;
+        CK(hipMalloc(&Y0p, px * 12)); CK(hipMalloc(&Y1p, px * 3)); CK(hipMemset(Y0p, 0, px * 12)); CK(hipMemset(Y1p, 0, px * 3));
+        sets[0].Y0 = Y0p; sets[0].Y1 = Y1p;
+        launch_f12<2, 64>(0, 40);
+        CK(hipMemset(sets[0].Xo, 0, px * 4));
+        launch_i21<64>(0, 40, sets[0].Xo);
+        CK(hipStreamSynchronize(st));
+        sets[0].Y0 = y0; sets[0].Y1 = y1;
+        double e[2] = {0, 0};
+        for (int lev = 0; lev < 2; ++lev) {
+            const int h = N >> (lev + 1), w = N >> (lev + 1);
+            std::vector<float> rec((size_t)h * w * 12), pla((size_t)h * w * 12);
+            CK(hipMemcpy(rec.data(), lev ? y1 : y0, rec.size() * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(pla.data(), lev ? Y1p : Y0p, pla.size() * 4, hipMemcpyDeviceToHost));
+            for (int sb = 0; sb < 6; ++sb)
+                for (int i = 0; i < h; ++i)
+                    for (int j = 0; j < w; ++j)
+                        for (int c = 0; c < 2; ++c)
+                            e[lev] = fmax(e[lev], fabs((double)pla[((size_t)sb * h + i) * w * 2 + 2 * j + c] - rec[((size_t)i * w + j) * 12 + 2 * sb + c]));
+        }
+        double ma;
+        const double ex = maxdiff(sets[0].Xo, sets[0].Xor, px, &ma);
+        printf("planar pyramid (KO 64): forward planes vs records Yh0 %.3g, Yh1 %.3g; inverse from planes vs tile programs X %.3g (max %.3g)\n", e[0], e[1], ex, ma);
+        CK(hipFree(Y0p)); CK(hipFree(Y1p));
+    }
     if (argc > 3) {     // profile mode: a few launches of the marching kernels, whole and with loads / stores knocked out
         for (int s2 = 1; s2 < NSET; ++s2) { launch_ref(s2, sets[s2].L1, sets[s2].Y0); launch_ref2(sets[s2].L1, sets[s2].L2, sets[s2].Y1); }
         for (int i = 0; i < 12; ++i) {
@@ -365,6 +405,7 @@ int main(int argc, char **argv) {
         run_f12<2>(40);
         printf("%-40s %9.2f\n", "k_inv2 + k_inv1 tile programs", time_it([&](int s) { launch_ref_inv(s, sets[s].L1, sets[s].Xo); }));
         for (int br : {40, 48, 64}) run_i21(br);
+        run_planar(40);
         printf("k_fwd12m bands of 40: plain record stores %.2f, nt loads %.2f, both %.2f\n", time_it([&](int s) { launch_f12<2, 16>(s, 40); }), time_it([&](int s) { launch_f12<2, 32>(s, 40); }), time_it([&](int s) { launch_f12<2, 48>(s, 40); }));
         run_f12w<2>(40);
         printf("two streams, us per image: tile fwd1 + fwd2 %.2f", time_two_streams([&](int s) { launch_ref(s, sets[s].L1, sets[s].Y0); launch_ref2(sets[s].L1, sets[s].L2, sets[s].Y1); }));
