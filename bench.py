@@ -39,8 +39,8 @@ share of c5, c4 -- as sub-runs of this script after its own measurement and befo
 them under `other_configs` (`--no-other-configs` skips them).
 
 `--config c4` (BASELINE configs[3], one volume: it does not shard, N = 1 only) times the 3-D transform the same way:
-a step = Transform3d forward + inverse of one 256^3 float32 volume, nlevels=3, rotating over `--sets` volumes on one
-stream; the roofline object is for k_fwd3_l1 (level 1 of the forward, 36 B/voxel), timed by a raw event pair around
+a step = Transform3d forward + inverse of one 256^3 float32 volume, nlevels=3, rotating over `--sets` volumes on
+`--streams` streams (independent volumes in flight; `ms_per_step_one_stream` = one at a time); the roofline object is for k_fwd3_l1 (level 1 of the forward, 36 B/voxel), timed by a raw event pair around
 its own C entry.
 """
 import argparse

@@ -273,13 +273,14 @@ def test_bench_config_c4_line():
     env.pop('WORLD_SIZE', None)
     env.pop('RANK', None)
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--config', 'c4', '--rows', '64', '--steps', '3',
-                        '--warmup', '1', '--settle-ms', '0', '--sets', '2'],
+                        '--warmup', '1', '--settle-ms', '0', '--sets', '2', '--streams', '2'],
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = r.stdout.strip().splitlines()
     assert len(lines) == 1
     line = json.loads(lines[0])
     assert line['unit'] == 'Mvoxels/s' and line['n_gpus'] == 1 and line['config']['buffer_sets'] == 2
+    assert line['config']['streams'] == 2 and line['ms_per_step_one_stream'] > 0
     assert line['roofline']['kernel'].startswith('k_fwd3_l1') and 0 < line['roofline']['frac'] < 1
     assert line['recon_max_abs_err'] < 1e-4 and line['gpu_vs_cpu_recon_max_abs_diff'] < 1e-4
     assert line['cpu_baseline']['kind'] == 'port'
