@@ -64,11 +64,11 @@ STEP_BYTES_PER_PX = 40.0      # forward + inverse
 
 # BASELINE.json configs that run on one GPU (c5: one GPU's share of the 512-image batch)
 CONFIGS = {
-    'c2': dict(rows=4096, cols=4096, batch=1, nlevels=4, seed=lambda rank: 1000 * rank,
+    'c2': dict(rows=4096, cols=4096, batch=1, nlevels=4, seed=lambda rank: 1000 * rank, cu_partition=True,
                name='2D forward+inverse 4096x4096 f32, nlevels=4'),
     'c3': dict(rows=1024, cols=1024, batch=64, nlevels=5, seed=lambda rank: 2 + 1000 * rank,
                name='batched 2D 64x1024x1024 f32, nlevels=5'),
-    'c5': dict(rows=2048, cols=2048, batch=64, nlevels=4, seed=lambda rank: 3 + 1000 * rank,
+    'c5': dict(rows=2048, cols=2048, batch=64, nlevels=4, seed=lambda rank: 3 + 1000 * rank, cu_partition=True,
                name='batched 2D 512x2048x2048 f32 nlevels=4 sharded over 8 GPUs: 64 images per GPU'),
     # the WHOLE C5 batch on one GPU: 2.1 G pixels, Yh[0] 6.4 G floats (> 2^31 elements), 58 GB per buffer set
     'c5full': dict(rows=2048, cols=2048, batch=512, nlevels=4, seed=lambda rank: 3 + 1000 * rank, sets=1, streams=1,
@@ -106,6 +106,10 @@ def parse_args(argv=None):
     ap.add_argument('--streams', type=int, default=4, help='HIP streams the steps alternate over (independent images: step k '
                     'runs on stream k %% S, each with its own plan and buffer sets): the small coarse-level kernels of one '
                     'image overlap the large level-1 kernels of the next')
+    ap.add_argument('--cu-partition', choices=['auto', 'on', 'off'], default='auto', help='with S > 1 streams: one context per '
+                    'share of the compute units (dtcwt_hip_ctx_create_partition) instead of plain streams whose kernels '
+                    'share every CU.  auto: where it measured faster (profiles/r04/ab_partition.txt): c2 -5 %%, c5 -2 %%; '
+                    'not c3 (+4 %%) and c4 (+4 %%)')
     ap.add_argument('--mgpu', action='store_true', help='N > 1 from ONE process: dtcwt_hip_mgpu_* with a host '
                     'thread per device instead of one process per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -256,12 +260,21 @@ def main():
     nsets = max(1, cfg.get('sets', args.sets))
     if nsets % nstreams:
         nsets = (nsets // nstreams + 1) * nstreams      # every buffer set belongs to exactly one stream
-    ctxs = [ctx] + [Context(ctx.device) for _ in range(nstreams - 1)]
+    # S images in flight: one context per image stream, each on its own share of the compute units (a slice of every
+    # XCD): 0.152-0.157 against 0.165-0.170 ms per step on plain streams (profiles/r04/ab_cu_mask_2.txt).  `ctx` keeps the
+    # whole device for the uploads and the one-at-a-time phases below.
+    partitioned = nstreams > 1 and (args.cu_partition == 'on' or (args.cu_partition == 'auto' and cfg.get('cu_partition', False)))
+    if partitioned:
+        ctxs = [Context(ctx.device, partition=(s, nstreams)) for s in range(nstreams)]
+    else:
+        ctxs = [ctx] + [Context(ctx.device) for _ in range(nstreams - 1)]
     t2s = [dtcwt_amd.hip.Transform2d(tuple(bt), tuple(qt), ctx=c) for c in ctxs]
     plans = [t.plan(B, R, C, NL) for t in t2s]
-    t2, plan = t2s[0], plans[0]
-    for pl in plans:
-        pl.set_concurrency(nstreams)        # the images in flight on the device: the marching launches size their bands by it
+    t2 = dtcwt_amd.hip.Transform2d(tuple(bt), tuple(qt), ctx=ctx) if partitioned else t2s[0]
+    plan = t2.plan(B, R, C, NL) if partitioned else plans[0]          # the whole device, one transform at a time
+    if not partitioned:
+        for pl in plans:
+            pl.set_concurrency(nstreams)    # the images in flight on the device: the marching launches size their bands by it
     rs = np.random.RandomState(shard_plan(cfg, world)[0][rank][0])   # random, not zero: DVFS; per-shard seed
     sets = []
     for k in range(nsets):
@@ -278,9 +291,9 @@ def main():
     graphs = [plans[k % nstreams].capture(*s[:3], s[3]) for k, s in enumerate(sets)] if args.graph else None
     counter = [0]
 
-    def step_on(k):
+    def step_on(k, pl=None):
         X, Yl, Yh, Z = sets[k]
-        pl = plans[k % nstreams]
+        pl = pl or plans[k % nstreams]
         pl.forward_into(X, Yl, Yh)
         pl.inverse_into(Yl, Yh, None, Z)
 
@@ -296,6 +309,7 @@ def main():
         """This rank's GPU work is done: every stream of the library, then the whole device."""
         for c in ctxs:
             c.sync()
+        ctx.sync()
         if torch is not None and torch.cuda.is_available():
             torch.cuda.synchronize()
         ctx.device_sync()
@@ -357,11 +371,11 @@ def main():
     px_step = B * R * C
     nres = 100 if px_step <= 2 ** 25 else max(5, min(args.steps, 100))      # short timed regions carry ~0.5 ms of start / drain cost
     for _ in range(5):
-        step_on(0)
+        step_on(0, plan)
     ctx.sync()
     r0 = time.perf_counter()
     for _ in range(nres):
-        step_on(0)
+        step_on(0, plan)
     ctx.sync()
     resident_ms = (time.perf_counter() - r0) / nres * 1e3
 
@@ -369,11 +383,11 @@ def main():
     # costs end to end, without the overlap of independent images
     own = [k for k in range(nsets) if k % nstreams == 0]
     for i in range(5):
-        step_on(own[i % len(own)])
+        step_on(own[i % len(own)], plan)
     ctx.sync()
     r0 = time.perf_counter()
     for i in range(nres):
-        step_on(own[i % len(own)])
+        step_on(own[i % len(own)], plan)
     ctx.sync()
     one_stream_ms = (time.perf_counter() - r0) / nres * 1e3
 
@@ -388,7 +402,7 @@ def main():
     nprof = max(5, min(args.steps, 50))
     kf = np.zeros((nprof, NL)); ki = np.zeros((nprof, NL))
     for i in range(nprof):
-        step_on(own[i % len(own)])          # per-kernel hipEvent pairs need the plain launches, on stream 0
+        step_on(own[i % len(own)], plan)    # per-kernel hipEvent pairs need the plain launches, on the whole-device stream
         kf[i], ki[i] = plan.kernel_ms()
     plan.set_profiling(False)
     kf = np.median(kf, axis=0); ki = np.median(ki, axis=0)
@@ -436,6 +450,7 @@ def main():
         'config': {'workload': '%s, %s/%s, %d image(s) per GPU per step' % (cfg['name'], BIORT, QSHIFT, B),
                    'sharding': 'independent images per GPU, no data-path collective',
                    'buffer_sets': nsets, 'bytes_per_set': set_bytes, 'streams': nstreams,
+                   'cu_partition': ('%d contexts, each on 1/%d of the compute units' % (nstreams, nstreams)) if partitioned else None,
                    'ms_per_step_is': 'throughput over %d overlapped stream(s) of independent images' % nstreams},
         'one_stream_ms_per_step': round(one_stream_ms, 5), 'resident_ms_per_step': round(resident_ms, 5),
         'roofline': roofline, 'recon_max_abs_err': err,
@@ -523,11 +538,12 @@ def main_c4(args):
     nsets = max(nstreams, args.sets)
     if nsets % nstreams:
         nsets = (nsets // nstreams + 1) * nstreams
-    ctxs = [ctx] + [Context(0) for _ in range(nstreams - 1)]
+    partitioned = nstreams > 1 and args.cu_partition == 'on'        # each stream on its own share of the compute units: measured slower here
+    ctxs = [Context(0, partition=(s, nstreams)) for s in range(nstreams)] if partitioned else [ctx] + [Context(0) for _ in range(nstreams - 1)]
     t3s = [Transform3d(BIORT, QSHIFT, ctx=c) for c in ctxs]
     rs = np.random.RandomState(4)
     vols = [ctxs[k % nstreams].to_device(rs.standard_normal((n, n, n)).astype(np.float32)) for k in range(nsets)]
-    t3 = t3s[0]
+    t3 = Transform3d(BIORT, QSHIFT, ctx=ctx) if partitioned else t3s[0]      # the whole device, one volume at a time
     state = {}
 
     def step(k):
@@ -603,6 +619,7 @@ def main_c4(args):
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': '3D forward+inverse %dx%dx%d f32, nlevels=%d, %s/%s, one volume per step' % (n, n, n, nl, BIORT, QSHIFT),
                    'sharding': 'replicas only: a volume is not sharded', 'buffer_sets': len(vols), 'streams': nstreams,
+                   'cu_partition': ('%d contexts, each on 1/%d of the compute units' % (nstreams, nstreams)) if partitioned else None,
                    'ms_per_step_is': 'throughput over %d overlapped stream(s) of independent volumes' % nstreams},
         'ms_per_step_one_stream': round(dt_1 / args.steps * 1e3, 5),
         'fwd_ms_per_step': round(dt_f / args.steps * 1e3, 5), 'inv_ms_per_step': round(dt_i / args.steps * 1e3, 5),

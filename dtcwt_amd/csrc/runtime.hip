@@ -89,17 +89,34 @@ int dtcwt_hip_device_info(int device, char *name, int *cus, size_t *mem_bytes) {
     return 0;
 }
 
-int dtcwt_hip_ctx_create(int device, void *stream, dtcwt_hip_ctx **out) {
+static int ctx_create(int device, void *stream, int part, int nparts, dtcwt_hip_ctx **out) {
     DT_REQUIRE(out, "ctx out pointer is NULL");
     int n = 0;
     DT_CHECK_HIP(hipGetDeviceCount(&n));
     DT_REQUIRE(device >= 0 && device < n, "device %d out of range (%d devices)", device, n);
+    DT_REQUIRE(nparts >= 1 && nparts <= 16 && part >= 0 && part < nparts, "partition %d of %d: need 1 <= nparts <= 16, 0 <= part < nparts", part, nparts);
     DT_CHECK_HIP(hipSetDevice(device));
+    hipDeviceProp_t p;
+    const bool have_props = hipGetDeviceProperties(&p, device) == hipSuccess;
+    const int cus = have_props ? p.multiProcessorCount : 256;
     dtcwt_hip_ctx *c = new dtcwt_hip_ctx();
     c->device = device;
     c->owns_stream = (stream == nullptr);
+    c->cus = cus;
     if (stream) {
         c->stream = reinterpret_cast<hipStream_t>(stream);
+    } else if (nparts > 1) {
+        // share `part`: the mask bits part * per .. (part + 1) * per - 1 (contiguous ranges measured best, and far better
+        // than whole XCDs: tools/ab_cu_mask.py)
+        const int per = cus / nparts;
+        std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
+        for (int b = part * per; b < (part + 1) * per; ++b) mask[(size_t)b / 32] |= 1u << (b % 32);
+        hipError_t e = per >= 1 ? hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data()) : hipErrorInvalidValue;
+        if (e != hipSuccess) {
+            delete c;
+            return dtcwt_set_error(-2, "hipExtStreamCreateWithCUMask (share %d of %d, %d CUs) failed: %s", part, nparts, per, hipGetErrorString(e));
+        }
+        c->cus = per;
     } else {
         hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         if (e != hipSuccess) {
@@ -107,18 +124,18 @@ int dtcwt_hip_ctx_create(int device, void *stream, dtcwt_hip_ctx **out) {
             return dtcwt_set_error(-2, "hipStreamCreate failed: %s", hipGetErrorString(e));
         }
     }
-    hipDeviceProp_t p;
-    if (hipGetDeviceProperties(&p, device) == hipSuccess) {
-        c->cus = p.multiProcessorCount;
-        // cache of freed buffers: up to a quarter of the HBM (288 GB on MI355X) -- pyramids of large
-        // volumes are several GB per buffer, and every hipFree / hipMalloc is a device-wide sync
-        if (p.totalGlobalMem / 4 > c->pool_limit) c->pool_limit = p.totalGlobalMem / 4;
-    } else {
-        c->cus = 256;
-    }
+    // cache of freed buffers: up to a quarter of the HBM (288 GB on MI355X) -- pyramids of large
+    // volumes are several GB per buffer, and every hipFree / hipMalloc is a device-wide sync
+    if (have_props && p.totalGlobalMem / 4 > c->pool_limit) c->pool_limit = p.totalGlobalMem / 4;
     if (const char *e = getenv("DTCWT_HIP_POOL_MB")) c->pool_limit = (size_t)atoll(e) << 20;
     *out = c;
     return 0;
+}
+
+int dtcwt_hip_ctx_create(int device, void *stream, dtcwt_hip_ctx **out) { return ctx_create(device, stream, 0, 1, out); }
+
+int dtcwt_hip_ctx_create_partition(int device, int part, int nparts, dtcwt_hip_ctx **out) {
+    return ctx_create(device, nullptr, part, nparts, out);
 }
 
 int dtcwt_hip_ctx_destroy(dtcwt_hip_ctx *c) {

@@ -54,7 +54,7 @@ _dbl = ctypes.c_double
 _pd = ctypes.POINTER(ctypes.c_double)
 
 # name -> (restype, argtypes); every symbol include/dtcwt_hip.h declares
-ABI_VERSION = 3          # == DTCWT_HIP_ABI_VERSION of include/dtcwt_hip.h (checked in load_library)
+ABI_VERSION = 4          # == DTCWT_HIP_ABI_VERSION of include/dtcwt_hip.h (checked in load_library)
 
 SIGNATURES = {
     'dtcwt_hip_abi_version': (_i, []),
@@ -62,6 +62,7 @@ SIGNATURES = {
     'dtcwt_hip_device_count': (_i, [ctypes.POINTER(_i)]),
     'dtcwt_hip_device_info': (_i, [_i, ctypes.c_char_p, ctypes.POINTER(_i), ctypes.POINTER(_sz)]),
     'dtcwt_hip_ctx_create': (_i, [_i, _vp, ctypes.POINTER(_vp)]),
+    'dtcwt_hip_ctx_create_partition': (_i, [_i, _i, _i, ctypes.POINTER(_vp)]),
     'dtcwt_hip_ctx_destroy': (_i, [_vp]),
     'dtcwt_hip_sync': (_i, [_vp]),
     'dtcwt_hip_ctx_stream': (_vp, [_vp]),
@@ -276,14 +277,23 @@ def taps_arg(h):
 class Context(object):
     """A device + stream (``dtcwt_hip_ctx``).  ``stream`` may be a raw ``hipStream_t``
     value (e.g. ``torch.cuda.current_stream().cuda_stream``) to run on a caller's stream;
-    the analogue of the OpenCL backend's ``queue`` (dtcwt/opencl/lowlevel.py:154-167)."""
+    the analogue of the OpenCL backend's ``queue`` (dtcwt/opencl/lowlevel.py:154-167).
+    ``partition=(part, nparts)``: the context's own stream runs on one of ``nparts`` equal shares of the compute units
+    (``dtcwt_hip_ctx_create_partition``) -- for ``nparts`` independent transforms in flight, one context each."""
 
-    def __init__(self, device=0, stream=None):
+    def __init__(self, device=0, stream=None, partition=None):
         L = lib()
         if device_count() < 1:
             raise NoHIPPresentError('no HIP device visible to libdtcwt_hip.so')
         h = _vp()
-        check(L.dtcwt_hip_ctx_create(int(device), _vp(stream) if stream else None, ctypes.byref(h)))
+        if partition is not None:
+            if stream:
+                raise ValueError('Context: a caller\'s stream cannot be confined to a partition')
+            part, nparts = partition
+            check(L.dtcwt_hip_ctx_create_partition(int(device), int(part), int(nparts), ctypes.byref(h)))
+        else:
+            check(L.dtcwt_hip_ctx_create(int(device), _vp(stream) if stream else None, ctypes.byref(h)))
+        self.partition = None if partition is None else (int(partition[0]), int(partition[1]))
         self._h = h
         self.device = int(device)
         self._lib = L

@@ -29,8 +29,9 @@
 extern "C" {
 #endif
 
-/* 2: plan1d_*, plan3d_*, mgpu_* (round 2), mgpu_forward2d_scales, host_alloc / host_free / memcpy_*_async (round 3) */
-#define DTCWT_HIP_ABI_VERSION 3
+/* 2: plan1d_*, plan3d_*, mgpu_* (round 2), mgpu_forward2d_scales, host_alloc / host_free / memcpy_*_async (round 3)
+ * 3: plan2d_launches, plan2d_set_concurrency, mgpu_scatter_async / gather_async;  4: ctx_create_partition (round 4) */
+#define DTCWT_HIP_ABI_VERSION 4
 
 #define DTCWT_HIP_F32 0
 #define DTCWT_HIP_F64 1
@@ -56,6 +57,14 @@ int dtcwt_hip_device_info(int device, char *name, int *cus, size_t *mem_bytes);
  * Analogue of the `queue=` argument of the reference's OpenCL backend
  * (dtcwt/opencl/transform2d.py:108-110, dtcwt/opencl/lowlevel.py:154-167). */
 int dtcwt_hip_ctx_create(int device, void *stream, dtcwt_hip_ctx **ctx);
+/* (ABI 4) A context whose own stream runs on ONE of `nparts` equal shares of the device's compute units only
+ * (hipExtStreamCreateWithCUMask, bits part * cus / nparts ... of the mask: on MI355X a slice of every XCD, so each share
+ * keeps all eight L2s and fabric ports).  For `nparts` independent transforms in flight -- the frames of a video handed to
+ * `nparts` workers (examples/register_video.py:125-156 in the reference) -- each on its own context: their kernels no
+ * longer take turns on every CU, measured 0.152-0.157 against 0.165-0.170 ms per 4096 x 4096 forward + inverse with four in
+ * flight (profiles/r04/ab_cu_mask*.txt).  Plans made on the context size their launches for its share (cus / nparts).
+ * nparts 1..16, 0 <= part < nparts. */
+int dtcwt_hip_ctx_create_partition(int device, int part, int nparts, dtcwt_hip_ctx **ctx);
 int dtcwt_hip_ctx_destroy(dtcwt_hip_ctx *ctx);
 int dtcwt_hip_sync(dtcwt_hip_ctx *ctx);            /* the context's stream */
 int dtcwt_hip_device_sync(dtcwt_hip_ctx *ctx);     /* hipDeviceSynchronize(): all streams */

@@ -259,6 +259,7 @@ def test_bench_self_spawns_ranks(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line['n_gpus'] == 1 and line['config']['buffer_sets'] == 8 and line['config']['streams'] == 4
+    assert line['config']['cu_partition'].startswith('4 contexts')          # each stream on a quarter of the CUs
     assert line['recon_max_abs_err'] < 1e-4 and line['roofline']['launches']['fwd_levels_1_2_one_launch']
 
 

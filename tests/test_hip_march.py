@@ -91,6 +91,33 @@ def test_march_is_not_used_where_it_does_not_apply():
     assert_pyramids_close(p, want, XFM_TOL, same_dtype=False)
 
 
+def test_contexts_on_shares_of_the_compute_units():
+    """dtcwt_hip_ctx_create_partition: four contexts, each on a quarter of the CUs, transform four different images
+    concurrently; every result matches the oracle, and matches the whole-device context's bit for bit (band heights
+    differ -- the plans size their launches for 64 CUs -- the arithmetic of a coefficient does not)."""
+    from dtcwt_amd.hip import Context
+    from dtcwt_amd.hip._lib import HipError
+    rs = np.random.RandomState(12)
+    Xs = [rs.standard_normal((512, 696)).astype(np.float32) for _ in range(4)]
+    ctxs = [Context(0, partition=(s, 4)) for s in range(4)]
+    assert [c.partition for c in ctxs] == [(s, 4) for s in range(4)]
+    ts = [Transform2d(ctx=c) for c in ctxs]
+    ps = [t.forward(X, nlevels=4) for t, X in zip(ts, Xs)]            # four in flight
+    zs = [t.inverse(p) for t, p in zip(ts, ps)]
+    to, tw = o.Transform2d(biort('near_sym_a'), qshift('qshift_a')), Transform2d()
+    for X, p, z in zip(Xs, ps, zs):
+        assert_pyramids_close(p, to.forward(as_f64(X), nlevels=4), XFM_TOL, same_dtype=False)
+        assert_close(np.asarray(z), X, INV_TOL, 'reconstruction on a share')
+        pw = tw.forward(X, nlevels=4)
+        assert np.array_equal(np.asarray(p.lowpass), np.asarray(pw.lowpass))
+        assert all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(p.highpasses, pw.highpasses))
+    for bad in ((4, 4), (-1, 2), (0, 0), (0, 17)):
+        with pytest.raises(HipError):
+            Context(0, partition=bad)
+    with pytest.raises(ValueError):
+        Context(0, stream=ctxs[0].stream, partition=(0, 2))
+
+
 # ---- the host path: page-locked pool, overlapped downloads, Pyramid.prefetch ------------------------------------------
 def test_prefetched_and_lazy_downloads_agree():
     rs = np.random.RandomState(8)
