@@ -23,7 +23,9 @@ marching kernels, which run one or two wavefronts to a SIMD, four images in flig
 against 0.187 ms per step, profiles/r04/ab_streams.txt) HIP streams of independent
 images (the coarse-level kernels of one image overlap the level-1 kernels of the next); it is not
 the latency of one forward + inverse: `one_stream_ms_per_step` in the same line is the same
-rotating-buffer protocol on ONE stream.
+rotating-buffer protocol on ONE stream.  For c2 and c5 each of the streams belongs to a context on its own share of the
+compute units (`--cu-partition`, dtcwt_hip_ctx_create_partition: -5 to -7 % per step, profiles/r04/ab_partition.txt); the
+one-at-a-time phases and the roofline object's kernel times use a context on the whole device.
 
 The roofline object is for the dominant kernel (the launch with the longest median duration: the
 forward's levels 1 + 2, which run as ONE marching launch k_fwd12m when the geometry allows, or the
@@ -263,7 +265,8 @@ def main():
     # S images in flight: one context per image stream, each on its own share of the compute units (a slice of every
     # XCD): 0.152-0.157 against 0.165-0.170 ms per step on plain streams (profiles/r04/ab_cu_mask_2.txt).  `ctx` keeps the
     # whole device for the uploads and the one-at-a-time phases below.
-    partitioned = nstreams > 1 and (args.cu_partition == 'on' or (args.cu_partition == 'auto' and cfg.get('cu_partition', False)))
+    # (two and four shares measured faster than plain streams, three slower: 85 CUs do not divide the XCDs evenly)
+    partitioned = nstreams > 1 and (args.cu_partition == 'on' or (args.cu_partition == 'auto' and cfg.get('cu_partition', False) and nstreams in (2, 4)))
     if partitioned:
         ctxs = [Context(ctx.device, partition=(s, nstreams)) for s in range(nstreams)]
     else:
