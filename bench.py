@@ -268,8 +268,12 @@ def main():
     # (two and four shares measured faster than plain streams, three slower: 85 CUs do not divide the XCDs evenly)
     partitioned = nstreams > 1 and (args.cu_partition == 'on' or (args.cu_partition == 'auto' and cfg.get('cu_partition', False) and nstreams in (2, 4)))
     if partitioned:
-        ctxs = [Context(ctx.device, partition=(s, nstreams)) for s in range(nstreams)]
-    else:
+        try:
+            ctxs = [Context(ctx.device, partition=(s, nstreams)) for s in range(nstreams)]
+        except _lib.HipError as exc:        # a runtime that refuses CU masks: plain streams, and the line says so
+            print('bench.py: no CU partition (%s); plain streams' % exc, file=sys.stderr)
+            partitioned = False
+    if not partitioned:
         ctxs = [ctx] + [Context(ctx.device) for _ in range(nstreams - 1)]
     t2s = [dtcwt_amd.hip.Transform2d(tuple(bt), tuple(qt), ctx=c) for c in ctxs]
     plans = [t.plan(B, R, C, NL) for t in t2s]
