@@ -371,6 +371,25 @@ def main():
     done = sets[:min(nsets, counter[0])]         # a very short run does not reach every buffer set
     err = max(float(np.abs(first_image(s[3], plan.ext)[:64, :64] - first_image(s[0], (R, C))[:64, :64]).max()) for s in done)
 
+    # the level kernels as they run in the timed region -- S images in flight, each stream on its share of the compute
+    # units: event pairs around the launches of the LAST step of bursts of three steps per stream (the other streams are in
+    # their own last steps meanwhile; the host reads the events between bursts, so the figure is approximate)
+    in_flight = None
+    if nstreams > 1 and graphs is None:
+        fence()
+        for pl in plans:
+            pl.set_profiling(True)
+        F, I = [], []
+        for rep in range(8):
+            for _ in range(3 * nstreams):
+                step()
+            for pl in plans:
+                f_, i_ = pl.kernel_ms()
+                F.append(f_); I.append(i_)
+        for pl in plans:
+            pl.set_profiling(False)
+        in_flight = (np.median(np.array(F), axis=0), np.median(np.array(I), axis=0))
+
     # the same step on one buffer set and one stream only (input and pyramid may stay in the Infinity Cache): ONE
     # transform in flight, and the plan is told so
     fence()
@@ -432,6 +451,17 @@ def main():
                              'note': 'a shared launch is timed under the level it starts with; the other level shows an empty event pair'},
                 'sum_kernel_ms': round(float(kf.sum() + ki.sum()), 5), 'event_pair_overhead_ms': round(null_ms, 5),
                 'step_frac': round(STEP_BYTES_PER_PX * px / (dt / args.steps) / HBM_PEAK, 4)}
+    if in_flight is not None:
+        share = 1.0 / nstreams if partitioned else None
+        kms4 = float(in_flight[0][0] if name.startswith('k_fwd') else in_flight[1][1 if inv21 else 0])
+        roofline['in_flight'] = {
+            'streams': nstreams, 'cu_share': share, 'kernel_ms': round(kms4, 5),
+            'achieved': round(bpp * px / (kms4 * 1e-3) / 1e9, 1),
+            'frac_of_share': None if share is None else round(bpp * px / (kms4 * 1e-3) / (HBM_PEAK * share), 4),
+            'fwd_kernel_ms': [round(float(x), 5) for x in in_flight[0]], 'inv_kernel_ms': [round(float(x), 5) for x in in_flight[1]],
+            'is': 'the same kernels as the timed region runs them: %d images in flight%s; `achieved` = algorithmic bytes / kernel_ms, '
+                  '`frac_of_share` = achieved / (peak x cu_share) -- bandwidth is not partitioned, so this is an occupancy-normalised '
+                  'figure, not a roofline fraction' % (nstreams, ', each stream on 1/%d of the compute units' % nstreams if partitioned else '')}
     tr = os.path.join(ROOT, 'profiles', 'traffic.json')
     if os.path.exists(tr) and args.config == 'c2':
         try:

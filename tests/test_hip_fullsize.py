@@ -260,6 +260,7 @@ def test_bench_self_spawns_ranks(tmp_path):
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line['n_gpus'] == 1 and line['config']['buffer_sets'] == 8 and line['config']['streams'] == 4
     assert line['config']['cu_partition'].startswith('4 contexts')          # each stream on a quarter of the CUs
+    assert line['roofline']['in_flight']['streams'] == 4 and line['roofline']['in_flight']['kernel_ms'] > 0
     assert line['recon_max_abs_err'] < 1e-4 and line['roofline']['launches']['fwd_levels_1_2_one_launch']
 
 
