@@ -19,14 +19,14 @@ using namespace dt2d;
 int dtcwt_dispatch_inv1(int m0, int m1, int m2, dt2d::Inv1Params &p, hipStream_t s);
 int dtcwt_dispatch_inv2(int m, bool bp, dt2d::Inv2Params &p, hipStream_t s, bool small);
 // levels 1 + 2 of the forward transform as one marching launch (march2d.hip)
-bool dtcwt_march_fwd12_ok(int rows, int cols, const std::vector<double> &h0o, const std::vector<double> &h1o,
-                          const std::vector<double> &h0a);
+bool dtcwt_march_fwd12_ok(int batch, int rows, int cols, const std::vector<double> &h0o, const std::vector<double> &h1o,
+                          const std::vector<double> &h0a, int cus, int in_flight);
 int dtcwt_march_fwd12(const float *X, float *Yh0, float *Yh1, float *LoLo2, int B, int R, int C,
                       const std::vector<double> &h0o, const std::vector<double> &h1o,
                       const float *l_a, const float *l_b, const float *h_a, const float *h_b, int m,
                       int lo_a_first, int hi_a_first, int cus, int in_flight, hipStream_t s);
 bool dtcwt_march_inv21_ok(int batch, int rows, int cols, const std::vector<double> &g0o, const std::vector<double> &g1o,
-                          const std::vector<double> &g0a, bool lo_pos, bool hi_pos, int cus);
+                          const std::vector<double> &g0a, bool lo_pos, bool hi_pos, int cus, int in_flight);
 int dtcwt_march_inv21(const float *Z2, const float *Yh1, const float *Yh0, float *X, int B, int R, int C,
                       const std::vector<double> &g0o, const std::vector<double> &g1o, const float *l_a, const float *l_b,
                       const float *h_a, const float *h_b, const float *gain1, const float *gain2, int cus, int in_flight, hipStream_t s);
@@ -185,12 +185,12 @@ static bool plan_march_geometry(const dtcwt_hip_plan2d *p) {
 }
 static bool plan_march_fwd12(const dtcwt_hip_plan2d *p) {
     return plan_march_geometry(p) && p->bp1[0].empty() && p->bp2[0].empty() &&
-           dtcwt_march_fwd12_ok(p->lv[0].LR, p->lv[0].LC, p->biort[0], p->biort[2], p->qshift[0]);
+           dtcwt_march_fwd12_ok(p->batch, p->lv[0].LR, p->lv[0].LC, p->biort[0], p->biort[2], p->qshift[0], p->ctx->cus, p->concurrency);
 }
 static bool plan_march_inv21(const dtcwt_hip_plan2d *p) {
     return plan_march_geometry(p) && p->bp1[1].empty() && p->bp2[2].empty() &&
            dtcwt_march_inv21_ok(p->batch, p->lv[0].LR, p->lv[0].LC, p->biort[1], p->biort[3], p->qshift[2],
-                                dotd(p->qshift[3], p->qshift[2]) > 0, dotd(p->qshift[7], p->qshift[6]) > 0, p->ctx->cus);
+                                dotd(p->qshift[3], p->qshift[2]) > 0, dotd(p->qshift[7], p->qshift[6]) > 0, p->ctx->cus, p->concurrency);
 }
 
 extern "C" {

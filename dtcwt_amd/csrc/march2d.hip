@@ -43,11 +43,27 @@ int pick_band_rows(int B, int R, int nstrip, int M, int cus) {
 
 }  // namespace
 
+// DTCWT_HIP_MARCH: 0 = never, 1 = wherever the geometry and the filters allow, unset = where it also pays (below).
+// Read on every call, not cached: the tests switch it between two transforms of one process.
+static int march_mode() { const char *e = getenv("DTCWT_HIP_MARCH"); return e ? (e[0] == '0' ? 0 : 1) : -1; }
+
+// Does the one-launch form pay?  A marching job is one wavefront running 20-80 dependent steps: a launch takes ~30 us
+// however small the image, where the tile programs -- hundreds of short-lived workgroups -- take 5-10 us per level.  One
+// transform at a time on the whole device (profiles/r04/ab_march_sizes.txt, forward + inverse, march / tiles): 512^2 2.07,
+// 1024^2 1.42, 1536^2 1.13, 1792^2 1.06 | 2048^2 0.95, 4 x 1024^2 0.93, 32 x 512^2 0.93, 4096^2 0.89; 16 x 512^2 -- as many
+// pixels as 2048^2, but a third of the lanes of its three strips idle -- 1.17.  So: pixels in flight x the share of a
+// strip's lanes that own columns >= 3.5 M on 256 compute units, in proportion on a share of them.
+static bool march_pays(int batch, int rows, int cols, int cus, int in_flight) {
+    const int nstrip = cdiv(cols, 4 * dtm::Fwd12m<5, 7, 10>::VL);
+    const double useful = (double)batch * (in_flight > 1 ? in_flight : 1) * rows * cols * ((double)cols / (nstrip * 4.0 * dtm::Fwd12m<5, 7, 10>::VL));
+    return useful >= 3.5e6 * (cus > 0 ? cus : 256) / 256.0;
+}
+
 // the geometry / filters the one-launch levels 1 + 2 handle; everything else stays with the tile programs
-bool dtcwt_march_fwd12_ok(int rows, int cols, const std::vector<double> &h0o, const std::vector<double> &h1o,
-                          const std::vector<double> &h0a) {
-    // (read on every call, not cached: the tests switch it between two transforms of one process)
-    { const char *e = getenv("DTCWT_HIP_MARCH"); if (e && e[0] == '0') return false; }
+bool dtcwt_march_fwd12_ok(int batch, int rows, int cols, const std::vector<double> &h0o, const std::vector<double> &h1o,
+                          const std::vector<double> &h0a, int cus, int in_flight) {
+    const int mm = march_mode();
+    if (mm == 0 || (mm < 0 && !march_pays(batch, rows, cols, cus, in_flight))) return false;
     const int m0 = (int)h0o.size(), m1 = (int)h1o.size(), m = (int)h0a.size();
     if (!((m0 == 5 && m1 == 7) || (m0 == 5 && m1 == 3)) || m != 10) return false;       // near_sym_a, legall + qshift_a / _06
     if (!symmetric(h0o) || !symmetric(h1o)) return false;     // mirrored halo lanes: see march2d.hpp
@@ -59,7 +75,7 @@ bool dtcwt_march_fwd12_ok(int rows, int cols, const std::vector<double> &h0o, co
 // levels 2 + 1 of the inverse in one launch: the same geometry rules as the forward, the synthesis filters of near_sym_a
 // (7, 5 taps), 10-tap q-shift filters with the standard phases
 bool dtcwt_march_inv21_ok(int batch, int rows, int cols, const std::vector<double> &g0o, const std::vector<double> &g1o,
-                          const std::vector<double> &g0a, bool lo_pos, bool hi_pos, int cus) {
+                          const std::vector<double> &g0a, bool lo_pos, bool hi_pos, int cus, int in_flight) {
     // DTCWT_HIP_MARCH_INV=0: never.  A band re-reads the rows its windows reach into above and below -- for the inverse
     // those are level-1 RECORD rows, 12 of its 16 bytes per pixel -- so with the 40-row bands a single 4096^2 image has
     // to be cut into, the one launch alone is no faster than the two it replaces (97 against 94 us, 1.2 x the
@@ -67,13 +83,12 @@ bool dtcwt_march_inv21_ok(int batch, int rows, int cols, const std::vector<doubl
     // call, profiles/r04/ab_inv_march.txt; fewer launches, 64 MB less traffic), and a batch affords tall bands
     // (64 x 2048^2: levels 2 + 1 in 1.27 ms against 1.08 + 0.44).
     const int mode = [] { const char *e = getenv("DTCWT_HIP_MARCH_INV"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-    const bool off_all = [] { const char *e = getenv("DTCWT_HIP_MARCH"); return e && e[0] == '0'; }();
-    if (mode == 0 || off_all) return false;
+    const int mm = march_mode();
+    if (mode == 0 || mm == 0 || (mm < 0 && !march_pays(batch, rows, cols, cus, in_flight))) return false;
     if (g0o.size() != 7 || g1o.size() != 5 || g0a.size() != 10 || !lo_pos || hi_pos) return false;
     if (!symmetric(g0o) || !symmetric(g1o)) return false;       // the row filters fold the mirror pairs
     if (rows % 4 || cols % 4 || rows < 32 || cols < 32) return false;
     if ((int64_t)rows * cols * 4 >= ((int64_t)1 << 31)) return false;
-    (void)batch; (void)cus;
     return true;
 }
 

@@ -254,7 +254,7 @@ def test_bench_self_spawns_ranks(tmp_path):
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode != 0 and 'visible' in (r.stderr + r.stdout)
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1',
-                        '--settle-ms', '0', '--no-cpu-baseline', '--no-other-configs', '--rows', '512', '--cols', '512'],
+                        '--settle-ms', '0', '--no-cpu-baseline', '--no-other-configs', '--rows', '2048', '--cols', '2048'],
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])

@@ -60,6 +60,7 @@ def test_march_matches_tile_programs_and_oracle(shape, band, monkeypatch):
 
 
 def test_march_on_a_batch_and_other_level1_filters(monkeypatch):
+    monkeypatch.setenv('DTCWT_HIP_MARCH', '1')              # wherever it applies, not only where it pays
     monkeypatch.setenv('DTCWT_HIP_MARCH_INV', '1')
     rs = np.random.RandomState(6)
     X = rs.standard_normal((3, 128, 248)).astype(np.float32)
@@ -76,7 +77,30 @@ def test_march_on_a_batch_and_other_level1_filters(monkeypatch):
         assert_close(t.inverse_channels(p, 'nhw'), X, INV_TOL, '%s reconstruction' % bn)
 
 
-def test_march_is_not_used_where_it_does_not_apply():
+def test_march_is_used_where_it_pays(monkeypatch):
+    """Unset, DTCWT_HIP_MARCH leaves the choice to the plan: the one-launch form needs ~3.5 M useful pixels in flight on
+    the whole device (a marching launch takes ~30 us however small the image; profiles/r04/ab_march_sizes.txt)."""
+    from dtcwt_amd.hip import Context
+    monkeypatch.delenv('DTCWT_HIP_MARCH', raising=False)
+    t = Transform2d()
+    assert t.plan(1, 512, 512, 3).launches() == (False, False)
+    assert t.plan(1, 1792, 1792, 4).launches() == (False, False)
+    assert t.plan(16, 512, 512, 4).launches() == (False, False)          # 4.2 M pixels, a third of the lanes idle
+    assert t.plan(1, 2048, 2048, 4).launches() == (True, True)
+    assert t.plan(32, 512, 512, 4).launches() == (True, True)
+    pl = t.plan(1, 1024, 1024, 4)
+    assert pl.launches() == (False, False)
+    pl.set_concurrency(4)                                                # four of them in flight
+    assert pl.launches() == (True, True)
+    assert Transform2d(ctx=Context(0, partition=(0, 4))).plan(1, 1024, 1024, 4).launches() == (True, True)   # on 64 CUs
+    monkeypatch.setenv('DTCWT_HIP_MARCH', '1')
+    assert t.plan(1, 512, 512, 3).launches() == (True, True)
+    monkeypatch.setenv('DTCWT_HIP_MARCH', '0')
+    assert t.plan(1, 4096, 4096, 4).launches() == (False, False)
+
+
+def test_march_is_not_used_where_it_does_not_apply(monkeypatch):
+    monkeypatch.setenv('DTCWT_HIP_MARCH', '1')
     t = Transform2d()
     assert t.plan(1, 254, 256, 3).launches() == (False, False)           # level-2 padding (254 % 4)
     assert t.plan(1, 255, 256, 3).launches() == (False, False)           # odd-size extension
@@ -91,7 +115,8 @@ def test_march_is_not_used_where_it_does_not_apply():
     assert_pyramids_close(p, want, XFM_TOL, same_dtype=False)
 
 
-def test_contexts_on_shares_of_the_compute_units():
+def test_contexts_on_shares_of_the_compute_units(monkeypatch):
+    monkeypatch.setenv('DTCWT_HIP_MARCH', '1')
     """dtcwt_hip_ctx_create_partition: four contexts, each on a quarter of the CUs, transform four different images
     concurrently; every result matches the oracle, and matches the whole-device context's bit for bit (band heights
     differ -- the plans size their launches for 64 CUs -- the arithmetic of a coefficient does not)."""

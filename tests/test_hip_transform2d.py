@@ -260,7 +260,7 @@ def test_compat_wrappers_follow_backend():
     assert np.abs(compat.dtwaveifm3(Yl3, Yh3) - V).max() < 1e-10
 
 
-def test_batched_config_c3_shape():
+def test_batched_config_c3_shape(monkeypatch):
     """BASELINE config[2] (batched 64 x 1024 x 1024 f32, nlevels=5), reduced to 6 images for the
     oracle comparison; the full batch is checked through per-image consistency + PR."""
     rs = np.random.RandomState(1)
@@ -284,11 +284,18 @@ def test_batched_config_c3_shape():
     Xb = rs.standard_normal((64, 1024, 1024)).astype(np.float32)
     pb = t.forward_channels(ctx.to_device(Xb), 'nhw', nlevels=5)
     low, high = pb.lowpass, pb.highpasses
+    # (left alone, the plan of ONE 1024^2 image takes the per-level tile programs and the batch the marching launches --
+    # profiles/r04/ab_march_sizes.txt -- which agree to rounding, not to the bit: first as chosen, then the same program)
+    single = t.forward(Xb[7], nlevels=5)
+    assert_close(low[7], single.lowpass, XFM_TOL, 'batch vs one image, programs as chosen')
+    assert t.plan(1, 1024, 1024, 5).launches() == (False, False) and t.plan(64, 1024, 1024, 5).launches() == (True, True)
+    monkeypatch.setenv('DTCWT_HIP_MARCH', '1')
     for i in range(64):
         single = t.forward(Xb[i], nlevels=5)
         assert np.array_equal(low[i], single.lowpass), i
         for l in range(5):
             assert np.array_equal(high[l][i], single.highpasses[l]), (i, l)
+    monkeypatch.delenv('DTCWT_HIP_MARCH')
     for i in (0, 31, 63):
         want = to.forward(as_f64(Xb[i]), nlevels=5)
         assert_close(low[i], want.lowpass, XFM_TOL, 'image %d Yl' % i)
