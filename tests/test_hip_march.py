@@ -47,10 +47,10 @@ def test_march_matches_tile_programs_and_oracle(shape, band, monkeypatch):
     assert f12 and i21
     yl1, ys1, z1 = _fwd_inv(X, nl, gm)
     # the two paths sum in different orders (mirror pairs first, rows before columns): not bit-identical, both right
-    assert_close(yl1, yl0, 2e-6, 'Yl march vs tiles')
+    assert_close(yl1, yl0, 1e-6, 'Yl march vs tiles')
     for a, b in zip(ys1, ys0):
-        assert_close(a, b, 2e-6, 'Yh march vs tiles')
-    assert_close(z1, z0, 2e-6, 'inverse march vs tiles')
+        assert_close(a, b, 1e-6, 'Yh march vs tiles')
+    assert_close(z1, z0, 1e-6, 'inverse march vs tiles')
     to = o.Transform2d(biort('near_sym_a'), qshift('qshift_a'))
     want = to.forward(as_f64(X), nlevels=nl)
     assert_close(yl1, want.lowpass, XFM_TOL, 'Yl')

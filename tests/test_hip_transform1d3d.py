@@ -335,4 +335,4 @@ def test_c4_whole_pyramid_vs_oracle_256cubed():
     q = t.forward(W, nlevels=3)
     r = t.forward(1.5 * V - 0.25 * W, nlevels=3)
     for l in range(3):
-        assert_close(r.highpasses[l], 1.5 * p.highpasses[l] - 0.25 * q.highpasses[l], 3e-6, 'linearity Yh[%d]' % l)
+        assert_close(r.highpasses[l], 1.5 * p.highpasses[l] - 0.25 * q.highpasses[l], 1e-6, 'linearity Yh[%d]' % l)
