@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: rocprofv3 kernel-trace stats + HBM-traffic PMC passes of THE DRIVER'S bench command
-# (`python bench.py --gpus 1 --steps 20 --warmup 5`: two streams, rotating buffer sets), then the per-kernel
+# (`python bench.py --gpus 1 --steps 20 --warmup 5`: four streams on quarters of the compute units, rotating buffer sets), then the per-kernel
 # medians / traffic as JSON (tools/roofline_from_trace.py).
 # Usage: tools/profile_round.sh <outdir under gpurun_out>      e.g. gpurun_out/r03prof
 # Copy <outdir>/{kernel_stats.csv,roofline.json,pmc_hbm_traffic.txt,bench_*.json} into profiles/rNN/ afterwards.

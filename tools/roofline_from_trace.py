@@ -3,7 +3,7 @@
     python tools/roofline_from_trace.py <outdir of tools/profile_round.sh> [--write profiles/traffic.json]
 
 Reads the rocprofv3 outputs that tools/profile_round.sh leaves under <outdir>:
-  trace/      --kernel-trace --stats        -> duration of every dispatch (the driver's command: two streams,
+  trace/      --kernel-trace --stats        -> duration of every dispatch (the driver's command: four streams,
               so kernels of two images overlap in time)
   trace1/     the same with --streams 1     -> durations of kernels that run alone (what bench.py's hipEvent
               pairs measure)
@@ -13,7 +13,7 @@ Dispatches are grouped by (kernel, grid size); the untimed settle phase of bench
 kernels, so every statistic is taken over the LAST `--last` dispatches of a group (default 60: the
 one-stream phases at the end of a `--steps 20` run -- the resident / one-stream re-runs and the steps
 with per-kernel event pairs -- in which kernels do not overlap) -- the clock ramp at the start of the
-process and the two-stream phases, where kernels of two images share the chip, are excluded.  Bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE
+process and the multi-stream phases, where kernels of several images share the chip, are excluded.  Bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE
 counts 128-byte read requests as 64 B on gfx950 (MI355X_MICROARCH.md, HBM section).
 """
 import argparse
@@ -89,7 +89,7 @@ def main():
         side = {'_method': 'tools/profile_round.sh: rocprofv3 --kernel-trace --stats, and --pmc FETCH_SIZE / --pmc WRITE_SIZE in '
                            'separate passes, over the driver\'s command `python bench.py --gpus 1 --steps 20 --warmup 5` (two '
                            'streams); statistics over the last %d dispatches of each kernel = the one-stream phases at the end of the run '
-                           '(settle phase and overlapped two-stream steps excluded); bytes per '
+                           '(settle phase and overlapped multi-stream steps excluded); bytes per '
                            'launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md). '
                            'Counts fabric requests, Infinity-Cache hits included.' % a.last,
                 '_algorithmic_bytes_per_launch': 20 * px, 'source': a.source or a.outdir, 'rocprof_median_us': {},
