@@ -51,12 +51,17 @@ static int march_mode() { const char *e = getenv("DTCWT_HIP_MARCH"); return e ? 
 // however small the image, where the tile programs -- hundreds of short-lived workgroups -- take 5-10 us per level.  One
 // transform at a time on the whole device (profiles/r04/ab_march_sizes.txt, forward + inverse, march / tiles): 512^2 2.07,
 // 1024^2 1.42, 1536^2 1.13, 1792^2 1.06 | 2048^2 0.95, 4 x 1024^2 0.93, 32 x 512^2 0.93, 4096^2 0.89; 16 x 512^2 -- as many
-// pixels as 2048^2, but a third of the lanes of its three strips idle -- 1.17.  So: pixels in flight x the share of a
-// strip's lanes that own columns >= 3.5 M on 256 compute units, in proportion on a share of them.
+// pixels as 2048^2, but a third of the lanes of its three strips idle -- 1.17.  So, for ONE transform at a time on the
+// whole device: pixels of the call x the share of a strip's lanes that own columns >= 3.5 M.  With other transforms in
+// flight beside it the launch's latency is partly hidden and the crossover comes down, but not in proportion (hipGraph
+// replay, so that the host is out of it; four in flight, us per image, march / tiles, profiles/r04/hint_sizes*.txt): on
+// plain streams 1024^2 25.7 / 19.6, 1536^2 32.7 / 33.1, 1792^2 38.9 / 42.6 -- 2.2 M; on quarters of the compute units
+// 1024^2 26.2 / 21.9, 1080 x 1920 30.8 / 35.6, 1536^2 31.8 / 39.0 -- 1.4 M.
 static bool march_pays(int batch, int rows, int cols, int cus, int in_flight) {
     const int nstrip = cdiv(cols, 4 * dtm::Fwd12m<5, 7, 10>::VL);
-    const double useful = (double)batch * (in_flight > 1 ? in_flight : 1) * rows * cols * ((double)cols / (nstrip * 4.0 * dtm::Fwd12m<5, 7, 10>::VL));
-    return useful >= 3.5e6 * (cus > 0 ? cus : 256) / 256.0;
+    const double useful = (double)batch * rows * cols * ((double)cols / (nstrip * 4.0 * dtm::Fwd12m<5, 7, 10>::VL));
+    const bool on_a_share = cus > 0 && cus < 200;
+    return useful >= (on_a_share ? 1.4e6 : (in_flight > 1 ? 2.2e6 : 3.5e6));
 }
 
 // the geometry / filters the one-launch levels 1 + 2 handle; everything else stays with the tile programs
