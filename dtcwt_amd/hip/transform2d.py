@@ -139,7 +139,8 @@ class _Plan2d(object):
 
     def set_concurrency(self, transforms_in_flight):
         """Hint: how many independent transforms are kept in flight on this device at a time (other plans on other
-        streams included); the marching launches choose their band height by it.  Results do not depend on it."""
+        streams included); the marching launches choose their band height by it, and the plan the size from which it uses them
+        (:meth:`launches`).  The two programs agree to rounding, not to the bit; ``DTCWT_HIP_MARCH=0`` / ``=1`` pins one."""
         check(self._lib.dtcwt_hip_plan2d_set_concurrency(self._h, int(transforms_in_flight)))
 
     def launches(self):

@@ -354,7 +354,9 @@ int dtcwt_hip_plan2d_launches(const dtcwt_hip_plan2d *plan, int *fwd12, int *inv
  * plans on other streams -- the images of a video, the members of a batch handed over one by one; default 1).  The
  * marching launches cut an image into bands of rows, each of which re-reads the rows its filters reach into above
  * and below: one image alone needs ~40-row bands to fill the GPU, four in flight are served better by ~150-row bands
- * (4096^2 fwd + inv: 0.152 against 0.167 ms per image).  A hint only: results do not depend on it. */
+ * (4096^2 fwd + inv: 0.152 against 0.167 ms per image).  A hint only: it moves the size from
+ * which levels 1 + 2 run as one launch (dtcwt_hip_plan2d_launches), and the two programs agree to rounding (2e-7), not to the bit;
+ * DTCWT_HIP_MARCH=0 / =1 pins one. */
 int dtcwt_hip_plan2d_set_concurrency(dtcwt_hip_plan2d *plan, int transforms_in_flight);
 
 /* A plan's level loop as a hipGraph on fixed buffers: the forward transform of X into (Yl, Yh[, Ys])
