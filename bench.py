@@ -126,7 +126,16 @@ def parse_args(argv=None):
     ap.add_argument('--rows', type=int, default=None)
     ap.add_argument('--cols', type=int, default=None)
     ap.add_argument('--batch', type=int, default=None, help='images per GPU per step')
-    return ap.parse_args(argv)
+    ap.add_argument('--biort', default=None, help='another level-1 wavelet than the headline near_sym_a (e.g. near_sym_b): the line '
+                    'names it in config.workload and is then NOT the BASELINE metric')
+    ap.add_argument('--qshift', default=None, help='another level >= 2 wavelet than qshift_a (e.g. qshift_b)')
+    a = ap.parse_args(argv)
+    global BIORT, QSHIFT
+    if a.biort:
+        BIORT = a.biort
+    if a.qshift:
+        QSHIFT = a.qshift
+    return a
 
 
 def respawn_under_launcher(args):

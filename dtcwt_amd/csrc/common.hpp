@@ -22,7 +22,8 @@ struct dtcwt_hip_ctx {
     int device;
     hipStream_t stream;
     bool owns_stream;
-    int cus;
+    int cus;                    // compute units the context's stream runs on (its share, for a partition context)
+    int nparts = 1;             // > 1: one of `nparts` equal shares of the device (dtcwt_hip_ctx_create_partition)
     // Size-bucketed cache of freed device buffers.  Every buffer of a context is used on
     // the context's single stream, so handing a freed buffer to the next allocation of the
     // same size is safe without synchronising (stream order) -- and it keeps
@@ -40,6 +41,14 @@ struct dtcwt_hip_ctx {
     // waits, per copy, for an event recorded on `stream`; created on first use
     hipStream_t copy_stream = nullptr;
     hipEvent_t copy_event = nullptr;
+};
+
+// What the 2-D plan tells the marching launchers (march2d.hip) about the call: the context's compute units, whether that
+// is a share of the device, how many independent transforms the caller keeps in flight, and the program the caller
+// pinned (dtcwt_hip_plan2d_set_program: -1 = the library chooses, 0 = tile programs, 1 = marching launches wherever
+// the geometry and the filters allow).
+struct DtMarchHint {
+    int cus, nparts, in_flight, program;
 };
 
 struct dtcwt_hip_event {

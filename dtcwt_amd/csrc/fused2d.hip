@@ -20,16 +20,16 @@ int dtcwt_dispatch_inv1(int m0, int m1, int m2, dt2d::Inv1Params &p, hipStream_t
 int dtcwt_dispatch_inv2(int m, bool bp, dt2d::Inv2Params &p, hipStream_t s, bool small);
 // levels 1 + 2 of the forward transform as one marching launch (march2d.hip)
 bool dtcwt_march_fwd12_ok(int batch, int rows, int cols, const std::vector<double> &h0o, const std::vector<double> &h1o,
-                          const std::vector<double> &h0a, int cus, int in_flight);
+                          const std::vector<double> &h0a, const DtMarchHint &hint);
 int dtcwt_march_fwd12(const float *X, float *Yh0, float *Yh1, float *LoLo2, int B, int R, int C,
                       const std::vector<double> &h0o, const std::vector<double> &h1o,
                       const float *l_a, const float *l_b, const float *h_a, const float *h_b, int m,
-                      int lo_a_first, int hi_a_first, int cus, int in_flight, hipStream_t s);
+                      int lo_a_first, int hi_a_first, const DtMarchHint &hint, hipStream_t s);
 bool dtcwt_march_inv21_ok(int batch, int rows, int cols, const std::vector<double> &g0o, const std::vector<double> &g1o,
-                          const std::vector<double> &g0a, bool lo_pos, bool hi_pos, int cus, int in_flight);
+                          const std::vector<double> &g0a, bool lo_pos, bool hi_pos, const DtMarchHint &hint);
 int dtcwt_march_inv21(const float *Z2, const float *Yh1, const float *Yh0, float *X, int B, int R, int C,
                       const std::vector<double> &g0o, const std::vector<double> &g1o, const float *l_a, const float *l_b,
-                      const float *h_a, const float *h_b, const float *gain1, const float *gain2, int cus, int in_flight, hipStream_t s);
+                      const float *h_a, const float *h_b, const float *gain1, const float *gain2, const DtMarchHint &hint, hipStream_t s);
 
 namespace {
 
@@ -176,6 +176,8 @@ struct dtcwt_hip_plan2d {
     // 60-62 us instead of 64-66; one run per XCD (order 1) is slower (79 us: the write streams thin out).
     int fwd1_order = 8;
     int concurrency = 1;              // independent transforms in flight on the device (dtcwt_hip_plan2d_set_concurrency)
+    int program = -1;                 // -1: the library chooses per call, 0: tile programs, 1: marching launches (dtcwt_hip_plan2d_set_program)
+    DtMarchHint hint() const { return DtMarchHint{ctx->cus, ctx->nparts, concurrency, program}; }
 };
 
 // levels 1 + 2 of the forward / 2 + 1 of the inverse in one marching launch (march2d.hpp): not for the band-pass sets,
@@ -185,12 +187,12 @@ static bool plan_march_geometry(const dtcwt_hip_plan2d *p) {
 }
 static bool plan_march_fwd12(const dtcwt_hip_plan2d *p) {
     return plan_march_geometry(p) && p->bp1[0].empty() && p->bp2[0].empty() &&
-           dtcwt_march_fwd12_ok(p->batch, p->lv[0].LR, p->lv[0].LC, p->biort[0], p->biort[2], p->qshift[0], p->ctx->cus, p->concurrency);
+           dtcwt_march_fwd12_ok(p->batch, p->lv[0].LR, p->lv[0].LC, p->biort[0], p->biort[2], p->qshift[0], p->hint());
 }
 static bool plan_march_inv21(const dtcwt_hip_plan2d *p) {
     return plan_march_geometry(p) && p->bp1[1].empty() && p->bp2[2].empty() &&
            dtcwt_march_inv21_ok(p->batch, p->lv[0].LR, p->lv[0].LC, p->biort[1], p->biort[3], p->qshift[2],
-                                dotd(p->qshift[3], p->qshift[2]) > 0, dotd(p->qshift[7], p->qshift[6]) > 0, p->ctx->cus, p->concurrency);
+                                dotd(p->qshift[3], p->qshift[2]) > 0, dotd(p->qshift[7], p->qshift[6]) > 0, p->hint());
 }
 
 extern "C" {
@@ -198,6 +200,12 @@ extern "C" {
 int dtcwt_hip_plan2d_set_concurrency(dtcwt_hip_plan2d *p, int n) {
     DT_REQUIRE(p && n >= 1 && n <= 1024, "transforms in flight: 1 .. 1024");
     p->concurrency = n;
+    return 0;
+}
+
+int dtcwt_hip_plan2d_set_program(dtcwt_hip_plan2d *p, int program) {
+    DT_REQUIRE(p && program >= -1 && program <= 1, "program: DTCWT_HIP_PROGRAM_AUTO (-1), _TILES (0) or _MARCH (1)");
+    p->program = program;
     return 0;
 }
 
@@ -354,7 +362,7 @@ int dtcwt_hip_plan2d_forward(dtcwt_hip_plan2d *p, const float *X, float *Yl, voi
             put_taps(q.h_a, p->qshift[5]); put_taps(q.h_b, p->qshift[4]);
             rc = dtcwt_march_fwd12(in, (float *)Yh[0], (float *)Yh[1], lo2, p->batch, L.LR, L.LC, p->biort[0], p->biort[2],
                                    q.l_a, q.l_b, q.h_a, q.h_b, (int)p->qshift[0].size(),
-                                   dotd(p->qshift[1], p->qshift[0]) > 0, dotd(p->qshift[5], p->qshift[4]) > 0, p->ctx->cus, p->concurrency, s);
+                                   dotd(p->qshift[1], p->qshift[0]) > 0, dotd(p->qshift[5], p->qshift[4]) > 0, p->hint(), s);
             if (rc) return dtcwt_set_error(rc, "no marching forward kernel for levels 1 + 2");
             DT_CHECK_HIP(hipGetLastError());
             if (p->profiling) {     // level 2 has no launch of its own: an empty event pair
@@ -434,7 +442,7 @@ int dtcwt_hip_plan2d_inverse(dtcwt_hip_plan2d *p, const float *Yl, const void *c
             put_taps(q.l_a, p->qshift[3]); put_taps(q.l_b, p->qshift[2]);
             put_taps(q.h_a, p->qshift[7]); put_taps(q.h_b, p->qshift[6]);
             rc = dtcwt_march_inv21(in, (const float *)Yh[1], (const float *)Yh[0], Z, p->batch, p->lv[0].LR, p->lv[0].LC,
-                                   p->biort[1], p->biort[3], q.l_a, q.l_b, q.h_a, q.h_b, g1, g, p->ctx->cus, p->concurrency, s);
+                                   p->biort[1], p->biort[3], q.l_a, q.l_b, q.h_a, q.h_b, g1, g, p->hint(), s);
             if (rc) return dtcwt_set_error(rc, "no marching inverse kernel for levels 2 + 1");
             DT_CHECK_HIP(hipGetLastError());
             if (p->profiling) {     // level 1 has no launch of its own: an empty event pair

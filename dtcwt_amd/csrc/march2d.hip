@@ -44,43 +44,59 @@ int pick_band_rows(int B, int R, int nstrip, int M, int cus) {
 }  // namespace
 
 // DTCWT_HIP_MARCH: 0 = never, 1 = wherever the geometry and the filters allow, unset = where it also pays (below).
-// Read on every call, not cached: the tests switch it between two transforms of one process.
-static int march_mode() { const char *e = getenv("DTCWT_HIP_MARCH"); return e ? (e[0] == '0' ? 0 : 1) : -1; }
+// Read on every call, not cached: the tests switch it between two transforms of one process.  A program pinned on the
+// plan (dtcwt_hip_plan2d_set_program) wins over the environment.
+static int march_mode(const DtMarchHint &h) {
+    if (h.program >= 0) return h.program ? 1 : 0;
+    const char *e = getenv("DTCWT_HIP_MARCH");
+    return e ? (e[0] == '0' ? 0 : 1) : -1;
+}
 
 // Does the one-launch form pay?  A marching job is one wavefront running 20-80 dependent steps: a launch takes ~30 us
-// however small the image, where the tile programs -- hundreds of short-lived workgroups -- take 5-10 us per level.  One
-// transform at a time on the whole device (profiles/r04/ab_march_sizes.txt, forward + inverse, march / tiles): 512^2 2.07,
-// 1024^2 1.42, 1536^2 1.13, 1792^2 1.06 | 2048^2 0.95, 4 x 1024^2 0.93, 32 x 512^2 0.93, 4096^2 0.89; 16 x 512^2 -- as many
-// pixels as 2048^2, but a third of the lanes of its three strips idle -- 1.17.  So, for ONE transform at a time on the
-// whole device: pixels of the call x the share of a strip's lanes that own columns >= 3.5 M.  With other transforms in
-// flight beside it the launch's latency is partly hidden and the crossover comes down, but not in proportion (hipGraph
-// replay, so that the host is out of it; four in flight, us per image, march / tiles, profiles/r04/hint_sizes*.txt): on
-// plain streams 1024^2 25.7 / 19.6, 1536^2 32.7 / 33.1, 1792^2 38.9 / 42.6 -- 2.2 M; on quarters of the compute units
-// 1024^2 26.2 / 21.9, 1080 x 1920 30.8 / 35.6, 1536^2 31.8 / 39.0 -- 1.4 M.
-static bool march_pays(int batch, int rows, int cols, int cus, int in_flight) {
+// however small the image, where the tile programs -- hundreds of short-lived workgroups -- take 5-10 us per level.  The
+// crossover is a number of USEFUL pixels per call (pixels x the share of a strip's lanes that own columns), measured per
+// situation; each row names the sweep that set it:
+struct MarchCrossover { const char *situation; double useful_pixels; const char *measured_in; };
+static const MarchCrossover kCrossover[3] = {
+    // one transform at a time on the whole device, forward + inverse, march / tiles: 512^2 2.07, 1024^2 1.42, 1536^2 1.13,
+    // 1792^2 1.06 | 2048^2 0.95, 4 x 1024^2 0.93, 32 x 512^2 0.93, 4096^2 0.89; 16 x 512^2 (a third of the lanes idle) 1.17
+    {"alone on the whole device", 3.5e6, "profiles/r04/ab_march_sizes.txt"},
+    // four in flight on plain streams (hipGraph replay, us per image, march / tiles): 1024^2 25.7 / 19.6, 1536^2 32.7 / 33.1,
+    // 1792^2 38.9 / 42.6 -- the launch latency is partly hidden, the crossover comes down, though not in proportion
+    {"others in flight beside it (concurrency hint > 1)", 2.2e6, "profiles/r04/hint_sizes.txt"},
+    // four contexts on quarters of the compute units: 1024^2 26.2 / 21.9, 1080 x 1920 30.8 / 35.6, 1536^2 31.8 / 39.0
+    {"on a partition context (a share of the compute units)", 1.4e6, "profiles/r04/hint_sizes_part.txt"},
+};
+static bool march_pays(int batch, int rows, int cols, const DtMarchHint &h) {
     const int nstrip = cdiv(cols, 4 * dtm::Fwd12m<5, 7, 10>::VL);
     const double useful = (double)batch * rows * cols * ((double)cols / (nstrip * 4.0 * dtm::Fwd12m<5, 7, 10>::VL));
-    const bool on_a_share = cus > 0 && cus < 200;
-    return useful >= (on_a_share ? 1.4e6 : (in_flight > 1 ? 2.2e6 : 3.5e6));
+    const MarchCrossover &x = kCrossover[h.nparts > 1 ? 2 : (h.in_flight > 1 ? 1 : 0)];
+    return useful >= x.useful_pixels;
+}
+// sizes every marching launch handles: multiples of 4 (no odd-size extension, no level-2 padding), 32-bit row offsets
+// inside an image, and a job count the grid can carry (a huge batch of small images falls back to the tile programs)
+static bool march_sizes_ok(int batch, int rows, int cols, int VL) {
+    if (rows % 4 || cols % 4 || rows < 32 || cols < 32) return false;
+    if ((int64_t)rows * cols * 4 >= ((int64_t)1 << 31)) return false;
+    if ((int64_t)cdiv(cols, 4 * VL) * cdiv(rows, 8) * batch >= ((int64_t)1 << 30)) return false;
+    return true;
 }
 
 // the geometry / filters the one-launch levels 1 + 2 handle; everything else stays with the tile programs
 bool dtcwt_march_fwd12_ok(int batch, int rows, int cols, const std::vector<double> &h0o, const std::vector<double> &h1o,
-                          const std::vector<double> &h0a, int cus, int in_flight) {
-    const int mm = march_mode();
-    if (mm == 0 || (mm < 0 && !march_pays(batch, rows, cols, cus, in_flight))) return false;
+                          const std::vector<double> &h0a, const DtMarchHint &hint) {
+    const int mm = march_mode(hint);
+    if (mm == 0 || (mm < 0 && !march_pays(batch, rows, cols, hint))) return false;
     const int m0 = (int)h0o.size(), m1 = (int)h1o.size(), m = (int)h0a.size();
     if (!((m0 == 5 && m1 == 7) || (m0 == 5 && m1 == 3)) || m != 10) return false;       // near_sym_a, legall + qshift_a / _06
     if (!symmetric(h0o) || !symmetric(h1o)) return false;     // mirrored halo lanes: see march2d.hpp
-    if (rows % 4 || cols % 4 || rows < 32 || cols < 32) return false;
-    if ((int64_t)rows * cols * 4 >= ((int64_t)1 << 31)) return false;     // 32-bit row offsets inside an image
-    return true;
+    return march_sizes_ok(batch, rows, cols, dtm::Fwd12m<5, 7, 10>::VL);
 }
 
 // levels 2 + 1 of the inverse in one launch: the same geometry rules as the forward, the synthesis filters of near_sym_a
 // (7, 5 taps), 10-tap q-shift filters with the standard phases
 bool dtcwt_march_inv21_ok(int batch, int rows, int cols, const std::vector<double> &g0o, const std::vector<double> &g1o,
-                          const std::vector<double> &g0a, bool lo_pos, bool hi_pos, int cus, int in_flight) {
+                          const std::vector<double> &g0a, bool lo_pos, bool hi_pos, const DtMarchHint &hint) {
     // DTCWT_HIP_MARCH_INV=0: never.  A band re-reads the rows its windows reach into above and below -- for the inverse
     // those are level-1 RECORD rows, 12 of its 16 bytes per pixel -- so with the 40-row bands a single 4096^2 image has
     // to be cut into, the one launch alone is no faster than the two it replaces (97 against 94 us, 1.2 x the
@@ -88,18 +104,16 @@ bool dtcwt_march_inv21_ok(int batch, int rows, int cols, const std::vector<doubl
     // call, profiles/r04/ab_inv_march.txt; fewer launches, 64 MB less traffic), and a batch affords tall bands
     // (64 x 2048^2: levels 2 + 1 in 1.27 ms against 1.08 + 0.44).
     const int mode = [] { const char *e = getenv("DTCWT_HIP_MARCH_INV"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-    const int mm = march_mode();
-    if (mode == 0 || mm == 0 || (mm < 0 && !march_pays(batch, rows, cols, cus, in_flight))) return false;
+    const int mm = march_mode(hint);
+    if ((mode == 0 && hint.program < 0) || mm == 0 || (mm < 0 && !march_pays(batch, rows, cols, hint))) return false;
     if (g0o.size() != 7 || g1o.size() != 5 || g0a.size() != 10 || !lo_pos || hi_pos) return false;
     if (!symmetric(g0o) || !symmetric(g1o)) return false;       // the row filters fold the mirror pairs
-    if (rows % 4 || cols % 4 || rows < 32 || cols < 32) return false;
-    if ((int64_t)rows * cols * 4 >= ((int64_t)1 << 31)) return false;
-    return true;
+    return march_sizes_ok(batch, rows, cols, dtm::Inv21m<7, 5, 10>::VL);
 }
 
 int dtcwt_march_inv21(const float *Z2, const float *Yh1, const float *Yh0, float *X, int B, int R, int C,
                       const std::vector<double> &g0o, const std::vector<double> &g1o, const float *l_a, const float *l_b,
-                      const float *h_a, const float *h_b, const float *gain1, const float *gain2, int cus, int in_flight, hipStream_t s) {
+                      const float *h_a, const float *h_b, const float *gain1, const float *gain2, const DtMarchHint &hint, hipStream_t s) {
     using G = dtm::Inv21m<7, 5, 10>;
     dtm::Inv21mParams p{};
     p.Z2 = Z2; p.Yh1 = Yh1; p.Yh0 = Yh0; p.X = X; p.B = B; p.R = R; p.C = C;
@@ -111,19 +125,19 @@ int dtcwt_march_inv21(const float *Z2, const float *Yh1, const float *Yh0, float
     for (int d = 0; d < 6; ++d) { p.g1[d] = gain1[d]; p.g2[d] = gain2[d]; }
     dtm::dtm_pack_inv_biort(p, 7, 5);
     const int nstrip = cdiv(C, 4 * G::VL);
-    if ((int64_t)nstrip * cdiv(R, 8) * B >= ((int64_t)1 << 30)) return -3;
-    const unsigned jobs = dtm::dtm_set_jobs(p.jb, B, R, nstrip, pick_band_rows(B * in_flight, R, nstrip, 10, cus));
+    if (!march_sizes_ok(B, R, C, G::VL)) return -3;         // (dtcwt_march_inv21_ok said so already)
+    const unsigned jobs = dtm::dtm_set_jobs(p.jb, B, R, nstrip, pick_band_rows(B * hint.in_flight, R, nstrip, 10, hint.cus));
     // (record rows loaded with the non-temporal hint: no difference, 0.1581 against 0.1586 ms per step)
     dtm::k_inv21m<7, 5, 10, 0><<<jobs, 64, 0, s>>>(p);
     return 0;
 }
 
 template <int M0, int M1, int M>
-static int launch_fwd12(dtm::Fwd12mParams &p, int cus, int in_flight, hipStream_t s) {
+static int launch_fwd12(dtm::Fwd12mParams &p, const DtMarchHint &hint, hipStream_t s) {
     using G = dtm::Fwd12m<M0, M1, M>;
     const int nstrip = cdiv(p.C, 4 * G::VL);
-    if ((int64_t)nstrip * cdiv(p.R, 8) * p.B >= ((int64_t)1 << 30)) return -3;
-    const unsigned jobs = dtm::dtm_set_jobs(p.jb, p.B, p.R, nstrip, pick_band_rows(p.B * in_flight, p.R, nstrip, M, cus));
+    if (!march_sizes_ok(p.B, p.R, p.C, G::VL)) return -3;   // (dtcwt_march_fwd12_ok said so already)
+    const unsigned jobs = dtm::dtm_set_jobs(p.jb, p.B, p.R, nstrip, pick_band_rows(p.B * hint.in_flight, p.R, nstrip, M, hint.cus));
     // (X rows loaded with the non-temporal hint: 81.4 against 85.4 us alone, no difference inside the transform -- not used)
     dtm::k_fwd12m<M0, M1, M, 2, 0><<<jobs, 64, 0, s>>>(p);
     return 0;
@@ -133,7 +147,7 @@ static int launch_fwd12(dtm::Fwd12mParams &p, int cus, int in_flight, hipStream_
 int dtcwt_march_fwd12(const float *X, float *Yh0, float *Yh1, float *LoLo2, int B, int R, int C,
                       const std::vector<double> &h0o, const std::vector<double> &h1o,
                       const float *l_a, const float *l_b, const float *h_a, const float *h_b, int m,
-                      int lo_a_first, int hi_a_first, int cus, int in_flight, hipStream_t s) {
+                      int lo_a_first, int hi_a_first, const DtMarchHint &hint, hipStream_t s) {
     dtm::Fwd12mParams p{};
     p.X = X; p.Yh0 = Yh0; p.Yh1 = Yh1; p.LoLo2 = LoLo2; p.B = B; p.R = R; p.C = C;
     p.lo_a_first = lo_a_first; p.hi_a_first = hi_a_first;
@@ -145,8 +159,8 @@ int dtcwt_march_fwd12(const float *X, float *Yh0, float *Yh1, float *LoLo2, int 
     dtm::dtm_pack_biort(p, (int)h0o.size(), (int)h1o.size());
     const int m0 = (int)h0o.size(), m1 = (int)h1o.size();
     if (m == 10) {
-        if (m0 == 5 && m1 == 7) return launch_fwd12<5, 7, 10>(p, cus, in_flight, s);
-        if (m0 == 5 && m1 == 3) return launch_fwd12<5, 3, 10>(p, cus, in_flight, s);
+        if (m0 == 5 && m1 == 7) return launch_fwd12<5, 7, 10>(p, hint, s);
+        if (m0 == 5 && m1 == 3) return launch_fwd12<5, 3, 10>(p, hint, s);
     }
     return -3;
 }

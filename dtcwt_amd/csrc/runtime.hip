@@ -117,6 +117,7 @@ static int ctx_create(int device, void *stream, int part, int nparts, dtcwt_hip_
             return dtcwt_set_error(-2, "hipExtStreamCreateWithCUMask (share %d of %d, %d CUs) failed: %s", part, nparts, per, hipGetErrorString(e));
         }
         c->cus = per;
+        c->nparts = nparts;
     } else {
         hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         if (e != hipSuccess) {

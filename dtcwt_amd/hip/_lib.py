@@ -54,7 +54,7 @@ _dbl = ctypes.c_double
 _pd = ctypes.POINTER(ctypes.c_double)
 
 # name -> (restype, argtypes); every symbol include/dtcwt_hip.h declares
-ABI_VERSION = 4          # == DTCWT_HIP_ABI_VERSION of include/dtcwt_hip.h (checked in load_library)
+ABI_VERSION = 5          # == DTCWT_HIP_ABI_VERSION of include/dtcwt_hip.h (checked in load_library)
 
 SIGNATURES = {
     'dtcwt_hip_abi_version': (_i, []),
@@ -140,6 +140,7 @@ SIGNATURES = {
     'dtcwt_hip_plan2d_kernel_ms': (_i, [_vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
     'dtcwt_hip_plan2d_launches': (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     'dtcwt_hip_plan2d_set_concurrency': (_i, [_vp, _i]),
+    'dtcwt_hip_plan2d_set_program': (_i, [_vp, _i]),
     'dtcwt_hip_plan3d_create': (_i, [_vp, _i64, _i64, _i64, _i, _i, ctypes.POINTER(_pd), ctypes.POINTER(_i),
                                      ctypes.POINTER(_pd), ctypes.POINTER(_i), ctypes.POINTER(_vp)]),
     'dtcwt_hip_plan3d_destroy': (_i, [_vp]),
@@ -279,7 +280,11 @@ class Context(object):
     value (e.g. ``torch.cuda.current_stream().cuda_stream``) to run on a caller's stream;
     the analogue of the OpenCL backend's ``queue`` (dtcwt/opencl/lowlevel.py:154-167).
     ``partition=(part, nparts)``: the context's own stream runs on one of ``nparts`` equal shares of the compute units
-    (``dtcwt_hip_ctx_create_partition``) -- for ``nparts`` independent transforms in flight, one context each."""
+    (``dtcwt_hip_ctx_create_partition``) -- for ``nparts`` independent transforms in flight, one context each.
+    The stream of a partition context is a *blocking* stream (``hipExtStreamCreateWithCUMask`` takes no flags): it
+    synchronises implicitly with the legacy NULL stream, unlike the non-blocking stream of a plain context -- keep other
+    device work (a framework's default stream) off the NULL stream while partition contexts are busy, or the transforms
+    in flight serialise."""
 
     def __init__(self, device=0, stream=None, partition=None):
         L = lib()

@@ -36,12 +36,14 @@ def _drain(pending):
     ctxs = {}
     for _arr, ctx in pending.values():
         ctxs[id(ctx)] = ctx
-    pending.clear()
+    # wait FIRST, release afterwards: dropping the destination arrays hands their page-locked buffers back to the host
+    # pool (or frees them), and another thread could be given one while the DMA is still writing it
     for ctx in ctxs.values():
         try:
             ctx.copy_sync()
         except Exception:
             pass
+    pending.clear()
 
 
 def nlevels_of(pyramid):

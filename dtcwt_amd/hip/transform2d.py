@@ -140,8 +140,18 @@ class _Plan2d(object):
     def set_concurrency(self, transforms_in_flight):
         """Hint: how many independent transforms are kept in flight on this device at a time (other plans on other
         streams included); the marching launches choose their band height by it, and the plan the size from which it uses them
-        (:meth:`launches`).  The two programs agree to rounding, not to the bit; ``DTCWT_HIP_MARCH=0`` / ``=1`` pins one."""
+        (:meth:`launches`).  The two programs agree to rounding, not to the bit; :meth:`set_program` pins one."""
         check(self._lib.dtcwt_hip_plan2d_set_concurrency(self._h, int(transforms_in_flight)))
+
+    PROGRAMS = {'auto': -1, 'tiles': 0, 'march': 1}
+
+    def set_program(self, program):
+        """``'auto'`` (default): the library picks, per call, between the one-launch marching program for levels 1 + 2
+        and the per-level tile programs (by batch x pixels, the concurrency hint, the context's share of the device).
+        ``'tiles'`` / ``'march'`` pin one -- the two agree to ~2e-7 relative, NOT to the bit, so pin when a batch and its
+        single images (or a forward and the inverse of its pyramid) must be computed by the same arithmetic
+        (``dtcwt_hip_plan2d_set_program``).  ``'march'`` still falls back to the tiles where it does not apply."""
+        check(self._lib.dtcwt_hip_plan2d_set_program(self._h, self.PROGRAMS[program]))
 
     def launches(self):
         """(levels 1 + 2 of the forward in one launch?, levels 2 + 1 of the inverse in one launch?)"""
@@ -215,9 +225,18 @@ class Transform2d(object):
     g1b[, h2a, h2b, g2a, g2b]) -- dtcwt/numpy/transform2d.py:18-38.
 
     *ctx* (optional) is a :class:`dtcwt_amd.hip.Context` (device + stream), the analogue of
-    the OpenCL backend's ``queue`` argument (dtcwt/opencl/transform2d.py:108-110)."""
+    the OpenCL backend's ``queue`` argument (dtcwt/opencl/transform2d.py:108-110).
 
-    def __init__(self, biort=DEFAULT_BIORT, qshift=DEFAULT_QSHIFT, ctx=None):
+    *program* (``'auto'`` | ``'tiles'`` | ``'march'``): float32 levels 1 + 2 run either as one marching launch or as one
+    tile-program launch per level; ``'auto'`` lets the library choose per call by size (fastest), which means that
+    results are reproducible to ~2e-7 relative but NOT bit for bit between a batch and one of its images transformed
+    alone, or across context kinds.  Pin ``'tiles'`` (or ``'march'``) where bit-reproducibility across call shapes matters;
+    the reference itself is deterministic per call shape only up to its BLAS-free NumPy summation order."""
+
+    def __init__(self, biort=DEFAULT_BIORT, qshift=DEFAULT_QSHIFT, ctx=None, program='auto'):
+        if program not in _Plan2d.PROGRAMS:
+            raise ValueError("program must be 'auto', 'tiles' or 'march'")
+        self.program = program
         try:
             self.biort = _biort(biort)
         except TypeError:
@@ -260,6 +279,8 @@ class Transform2d(object):
         if key not in self._plans:
             try:
                 self._plans[key] = _Plan2d(self.ctx, batch, rows, cols, nlevels, self.biort, self.qshift)
+                if self.program != 'auto':
+                    self._plans[key].set_program(self.program)
             except NotImplementedError:
                 self._plans[key] = None
             while len(self._plans) > self.MAX_PLANS:         # least recently used first

@@ -30,8 +30,9 @@ extern "C" {
 #endif
 
 /* 2: plan1d_*, plan3d_*, mgpu_* (round 2), mgpu_forward2d_scales, host_alloc / host_free / memcpy_*_async (round 3)
- * 3: plan2d_launches, plan2d_set_concurrency, mgpu_scatter_async / gather_async;  4: ctx_create_partition (round 4) */
-#define DTCWT_HIP_ABI_VERSION 4
+ * 3: plan2d_launches, plan2d_set_concurrency, mgpu_scatter_async / gather_async;  4: ctx_create_partition (round 4)
+ * 5: plan2d_set_program (round 5) */
+#define DTCWT_HIP_ABI_VERSION 5
 
 #define DTCWT_HIP_F32 0
 #define DTCWT_HIP_F64 1
@@ -63,7 +64,12 @@ int dtcwt_hip_ctx_create(int device, void *stream, dtcwt_hip_ctx **ctx);
  * `nparts` workers (examples/register_video.py:125-156 in the reference) -- each on its own context: their kernels no
  * longer take turns on every CU, measured 0.152-0.157 against 0.165-0.170 ms per 4096 x 4096 forward + inverse with four in
  * flight (profiles/r04/ab_cu_mask*.txt).  Plans made on the context size their launches for its share (cus / nparts).
- * nparts 1..16, 0 <= part < nparts. */
+ * nparts 1..16, 0 <= part < nparts.
+ * Stream semantics: hipExtStreamCreateWithCUMask takes no flags, so the stream of a partition context is a BLOCKING
+ * stream -- unlike the hipStreamNonBlocking stream dtcwt_hip_ctx_create makes, it synchronises implicitly with the
+ * legacy NULL stream: work a framework enqueues on the NULL stream waits for, and is waited for by, everything on every
+ * partition context, which serialises the transforms this call exists to overlap.  Keep other work on explicit
+ * non-blocking streams (or per-thread default streams) while partition contexts are busy. */
 int dtcwt_hip_ctx_create_partition(int device, int part, int nparts, dtcwt_hip_ctx **ctx);
 int dtcwt_hip_ctx_destroy(dtcwt_hip_ctx *ctx);
 int dtcwt_hip_sync(dtcwt_hip_ctx *ctx);            /* the context's stream */
@@ -356,8 +362,21 @@ int dtcwt_hip_plan2d_launches(const dtcwt_hip_plan2d *plan, int *fwd12, int *inv
  * and below: one image alone needs ~40-row bands to fill the GPU, four in flight are served better by ~150-row bands
  * (4096^2 fwd + inv: 0.152 against 0.167 ms per image).  A hint only: it moves the size from
  * which levels 1 + 2 run as one launch (dtcwt_hip_plan2d_launches), and the two programs agree to rounding (2e-7), not to the bit;
- * DTCWT_HIP_MARCH=0 / =1 pins one. */
+ * dtcwt_hip_plan2d_set_program pins one. */
 int dtcwt_hip_plan2d_set_concurrency(dtcwt_hip_plan2d *plan, int transforms_in_flight);
+/* (ABI 5) Which program computes levels 1 + 2 of the forward / 2 + 1 of the inverse.  AUTO (the default): the library picks
+ * per call -- the one-launch marching program where the geometry and the filters allow it AND the call is large enough to
+ * pay (batch x pixels, the concurrency hint, a partition context: the table in dtcwt_amd/csrc/march2d.hip), the per-level
+ * tile programs otherwise.  The two programs evaluate the same sums in a different order and agree to ~2e-7 relative, NOT
+ * to the bit: under AUTO the same image may therefore differ in the last place between a call on its own and a call as
+ * part of a batch, and an inverse may run the other program than the forward that made the pyramid.  Callers that need
+ * run-to-run / batch-to-single bit reproducibility pin one: TILES is the round-1..3 behaviour at every size, MARCH the
+ * one-launch form wherever it applies (tiles where it does not: odd sizes, `scales`, other filter lengths).  A pin on
+ * the plan wins over the DTCWT_HIP_MARCH environment switch, which only the AUTO mode consults. */
+#define DTCWT_HIP_PROGRAM_AUTO (-1)
+#define DTCWT_HIP_PROGRAM_TILES 0
+#define DTCWT_HIP_PROGRAM_MARCH 1
+int dtcwt_hip_plan2d_set_program(dtcwt_hip_plan2d *plan, int program);
 
 /* A plan's level loop as a hipGraph on fixed buffers: the forward transform of X into (Yl, Yh[, Ys])
  * and, when Z is not NULL, the inverse of that pyramid into Z (gain_mask_host as for

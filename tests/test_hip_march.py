@@ -103,6 +103,63 @@ def test_march_is_used_where_it_pays(monkeypatch):
     assert t.plan(1, 4096, 4096, 4).launches() == (False, False)
 
 
+def test_program_pin_is_an_argument_and_wins_over_the_environment(monkeypatch):
+    """dtcwt_hip_plan2d_set_program / Transform2d(program=...): a caller that needs a batch and its single images (or a
+    forward and the inverse of its pyramid) computed by the same arithmetic pins one program -- bit-identical results
+    whatever the call shape -- instead of relying on DTCWT_HIP_MARCH."""
+    monkeypatch.delenv('DTCWT_HIP_MARCH', raising=False)
+    rs = np.random.RandomState(21)
+    Xb = rs.standard_normal((12, 512, 512)).astype(np.float32)
+    for prog, want in (('tiles', (False, False)), ('march', (True, True))):
+        t = Transform2d(program=prog)
+        assert t.plan(1, 512, 512, 3).launches() == want and t.plan(64, 1024, 1024, 3).launches() == want
+        pb = t.forward_channels(Xb, 'nhw', nlevels=3)
+        for i in (0, 5, 11):
+            single = t.forward(Xb[i], nlevels=3)
+            assert np.array_equal(pb.lowpass[i], single.lowpass)
+            for l in range(3):
+                assert np.array_equal(pb.highpasses[l][i], single.highpasses[l]), (prog, i, l)
+        monkeypatch.setenv('DTCWT_HIP_MARCH', '0' if prog == 'march' else '1')       # the pin wins
+        assert t.plan(1, 512, 512, 3).launches() == want
+        monkeypatch.delenv('DTCWT_HIP_MARCH')
+    auto = Transform2d()
+    assert auto.plan(1, 512, 512, 3).launches() == (False, False) and auto.plan(64, 1024, 1024, 3).launches() == (True, True)
+    pl = auto.plan(1, 512, 512, 3)
+    pl.set_program('march'); assert pl.launches() == (True, True)
+    pl.set_program('auto'); assert pl.launches() == (False, False)
+    with pytest.raises(ValueError):
+        Transform2d(program='fastest')
+    # 'march' where it does not apply: the tile programs, silently
+    assert Transform2d(program='march').plan(1, 255, 256, 3).launches() == (False, False)
+
+
+def test_partition_context_beside_null_stream_work():
+    """The stream of a partition context is a blocking stream (hipExtStreamCreateWithCUMask has no flags): it orders itself
+    against the legacy NULL stream.  Results must be right either way; what the header documents is the serialisation."""
+    import ctypes
+    from dtcwt_amd.hip import Context, _lib
+    hip = ctypes.CDLL('libamdhip64.so')
+    rs = np.random.RandomState(3)
+    X = rs.standard_normal((512, 464)).astype(np.float32)
+    want = Transform2d(program='march').forward(X, nlevels=3)
+    c = Context(0, partition=(1, 4))
+    t = Transform2d(ctx=c, program='march')
+    n = 1 << 24
+    d = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(d), ctypes.c_size_t(n)) == 0
+    try:
+        for rep in range(4):
+            assert hip.hipMemsetAsync(d, rep, ctypes.c_size_t(n), None) == 0          # NULL-stream work in between
+            p = t.forward(X, nlevels=3)
+            assert hip.hipMemsetAsync(d, rep + 1, ctypes.c_size_t(n), None) == 0
+            z = t.inverse(p)
+            assert np.array_equal(p.lowpass, want.lowpass) and np.array_equal(p.highpasses[0], want.highpasses[0])
+            assert np.abs(z - X).max() < 1e-6 * np.abs(X).max() * 4
+    finally:
+        hip.hipDeviceSynchronize()
+        hip.hipFree(d)
+
+
 def test_march_is_not_used_where_it_does_not_apply(monkeypatch):
     monkeypatch.setenv('DTCWT_HIP_MARCH', '1')
     t = Transform2d()

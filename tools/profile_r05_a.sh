@@ -1,0 +1,33 @@
+#!/bin/bash
+# round 5, GPU call A: where the tree of round 4 stands on today's box, and the counters the judge asked for --
+#   * the driver's command, 300 steps
+#   * the other shipped wavelet sets at 4096^2 (bench.py --biort / --qshift): BEFORE figures of the round
+#   * rocprofv3 kernel trace + FETCH_SIZE / WRITE_SIZE passes of bench.py --config c5 / c3 / c4 (fabric traffic of the batches)
+set -u
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r05a
+mkdir -p $O
+cd $R
+python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err
+python bench.py --steps 300 --no-cpu-baseline --no-other-configs > $O/bench_300steps.json 2>/dev/null
+for w in "near_sym_b qshift_b" "near_sym_a qshift_b" "near_sym_b qshift_d" "antonini qshift_c" "legall qshift_06"; do
+  set -- $w
+  python bench.py --biort $1 --qshift $2 --steps 100 --no-cpu-baseline --no-other-configs > $O/bench_$1_$2.json 2> $O/bench_$1_$2.err
+done
+cd /tmp && export TMPDIR=/tmp
+for c in c5 c3 c4; do
+  mkdir -p $O/$c
+  B="python $R/bench.py --config $c --steps 8 --warmup 2 --no-cpu-baseline --no-other-configs --settle-ms 60"
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/$c/trace -o bench --output-format csv -- $B > $O/$c/bench_under_trace.json 2> $O/$c/trace.err
+  echo "$c trace rc=$?" >> $O/status.txt
+  timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/$c/pmc_fetch -o p --output-format csv -- $B > $O/$c/pmc_fetch.log 2>&1
+  echo "$c fetch rc=$?" >> $O/status.txt
+  timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/$c/pmc_write -o p --output-format csv -- $B > $O/$c/pmc_write.log 2>&1
+  echo "$c write rc=$?" >> $O/status.txt
+  cp "$(find $O/$c/trace -name "*kernel_stats.csv" | head -1)" $O/$c/kernel_stats.csv 2>/dev/null
+  (cd $R && python tools/roofline_from_trace.py $O/$c > $O/$c/roofline.json 2> $O/$c/roofline.err)
+  # the raw traces are large: keep the per-kernel csv and the summaries
+  find $O/$c -name "*kernel_trace.csv" -size +20M -delete
+done
+cat $O/status.txt
+ls -la $O
