@@ -61,6 +61,7 @@ if ROOT not in sys.path:
 
 BIORT, QSHIFT = 'near_sym_a', 'qshift_a'
 HBM_PEAK = 8.0e12             # B/s, MI355X spec (MI355X_MICROARCH.md)
+HBM_COPY = 6.29e12            # B/s, what a float4 copy kernel reaches on this part (MI355X_MICROARCH.md): SURVEY 8(d) asks for both
 FWD_BYTES_PER_PX = 20.0       # read X, write Yl + all Yh
 STEP_BYTES_PER_PX = 40.0      # forward + inverse
 
@@ -363,6 +364,16 @@ def main():
     dt = time.perf_counter() - t0
     fence()
     rank_ms = [dt / args.steps * 1e3]
+    # the same region over >= 300 steps (bounded to ~0.5 s for the big batches): the 20-step figure of the driver's command
+    # carries the start / drain of the streams (profiles/r04/stream_timeline.txt), this one does not
+    n_sus = max(args.steps, min(300, int(0.5 / max(dt / args.steps, 1e-6)) + 1))
+    sustained_ms = None
+    if n_sus > args.steps and not use_dist:
+        t1 = time.perf_counter()
+        for _ in range(n_sus):
+            step()
+        drain()
+        sustained_ms = (time.perf_counter() - t1) / n_sus * 1e3
     nccl_ranks = 1
     if use_dist:
         nccl_ranks = rccl_ranks
@@ -378,7 +389,8 @@ def main():
     def first_image(a, shape):      # image 0 of a batch without downloading the whole batch
         return DeviceArray(a.ctx, (1,) + tuple(shape), np.float32, ptr=a.ptr, owner=a).get()[0]
     done = sets[:min(nsets, counter[0])]         # a very short run does not reach every buffer set
-    err = max(float(np.abs(first_image(s[3], plan.ext)[:64, :64] - first_image(s[0], (R, C))[:64, :64]).max()) for s in done)
+    # the WHOLE first image of every buffer set the timed steps wrote (a wrong band anywhere in it shows)
+    err = max(float(np.abs(first_image(s[3], plan.ext)[:R, :C] - first_image(s[0], (R, C))).max()) for s in done)
 
     # the level kernels as they run in the timed region -- S images in flight, each stream on its share of the compute
     # units: event pairs around the launches of the LAST step of bursts of three steps per stream (the other streams are in
@@ -451,7 +463,8 @@ def main():
     name, ms, bpp = max(cand, key=lambda c: c[1])
     achieved = bpp * px / (ms * 1e-3) / 1e9       # GB/s
     roofline = {'bound': 'hbm', 'kernel': name, 'achieved': round(achieved, 1), 'peak': HBM_PEAK / 1e9,
-                'unit': 'GB/s', 'frac': round(achieved * 1e9 / HBM_PEAK, 4), 'traffic': None,
+                'unit': 'GB/s', 'frac': round(achieved * 1e9 / HBM_PEAK, 4),
+                'frac_of_copy_ceiling': round(achieved * 1e9 / HBM_COPY, 4), 'copy_ceiling': HBM_COPY / 1e9, 'traffic': None,
                 'kernel_ms': round(float(ms), 5), 'kernel_ms_is': 'median raw hipEvent pair, %d steps' % nprof,
                 'rocprof_kernel_ms': None, 'algorithmic_bytes_per_launch': bpp * px,
                 'fwd_kernel_ms': [round(float(x), 5) for x in kf],
@@ -459,7 +472,8 @@ def main():
                 'launches': {'fwd_levels_1_2_one_launch': bool(fwd12), 'inv_levels_2_1_one_launch': bool(inv21),
                              'note': 'a shared launch is timed under the level it starts with; the other level shows an empty event pair'},
                 'sum_kernel_ms': round(float(kf.sum() + ki.sum()), 5), 'event_pair_overhead_ms': round(null_ms, 5),
-                'step_frac': round(STEP_BYTES_PER_PX * px / (dt / args.steps) / HBM_PEAK, 4)}
+                'step_frac': round(STEP_BYTES_PER_PX * px / (dt / args.steps) / HBM_PEAK, 4),
+                'step_frac_of_copy_ceiling': round(STEP_BYTES_PER_PX * px / (dt / args.steps) / HBM_COPY, 4)}
     if in_flight is not None:
         share = 1.0 / nstreams if partitioned else None
         kms4 = float(in_flight[0][0] if name.startswith('k_fwd') else in_flight[1][1 if inv21 else 0])
@@ -472,9 +486,12 @@ def main():
                   '`frac_of_share` = achieved / (peak x cu_share) -- bandwidth is not partitioned, so this is an occupancy-normalised '
                   'figure, not a roofline fraction' % (nstreams, ', each stream on 1/%d of the compute units' % nstreams if partitioned else '')}
     tr = os.path.join(ROOT, 'profiles', 'traffic.json')
-    if os.path.exists(tr) and args.config == 'c2':
+    default_shape = all(getattr(args, k) is None for k in ('rows', 'cols', 'batch', 'nlevels', 'biort', 'qshift'))
+    if os.path.exists(tr) and default_shape and args.config in ('c2', 'c3', 'c5'):
         try:
             tj = json.load(open(tr))
+            if args.config != 'c2':
+                tj = tj.get(args.config) or {}
             short = name.split(' ')[0]
             roofline['traffic'] = tj.get(short)
             for key, src in (('rocprof_kernel_ms', 'rocprof_median_us_one_stream'), ('rocprof_kernel_ms_two_streams', 'rocprof_median_us')):
@@ -498,6 +515,7 @@ def main():
                    'buffer_sets': nsets, 'bytes_per_set': set_bytes, 'streams': nstreams,
                    'cu_partition': ('%d contexts, each on 1/%d of the compute units' % (nstreams, nstreams)) if partitioned else None,
                    'ms_per_step_is': 'throughput over %d overlapped stream(s) of independent images' % nstreams},
+        'sustained_ms_per_step': None if sustained_ms is None else round(sustained_ms, 5), 'sustained_steps': n_sus if sustained_ms is not None else None,
         'one_stream_ms_per_step': round(one_stream_ms, 5), 'resident_ms_per_step': round(resident_ms, 5),
         'roofline': roofline, 'recon_max_abs_err': err,
     }
@@ -559,7 +577,10 @@ def other_configs():
                 keep['step_frac'] = d.get('step_frac')
             else:
                 keep['one_stream_ms_per_step'] = d.get('one_stream_ms_per_step')
+                keep['sustained_ms_per_step'] = d.get('sustained_ms_per_step')
                 keep['launches'] = d['roofline'].get('launches')
+            keep['roofline'] = {k: d['roofline'].get(k) for k in ('kernel', 'kernel_ms', 'rocprof_kernel_ms', 'frac', 'frac_of_copy_ceiling',
+                                                                  'algorithmic_bytes_per_launch', 'traffic', 'traffic_source')}
             res[name] = keep
         except Exception as exc:            # a failed sub-run must not cost the headline line
             res[name] = {'error': '%s: %s' % (type(exc).__name__, exc)}
@@ -675,9 +696,20 @@ def main_c4(args):
                      'frac': round(36.0 * vox / (kms * 1e-3) / HBM_PEAK, 4), 'traffic': None,
                      'kernel_ms': round(kms, 5), 'kernel_ms_is': 'median raw hipEvent pair around dtcwt_hip_fwd3_level1, 20 launches',
                      'event_pair_overhead_ms': round(float(np.median(empty)), 5),
-                     'algorithmic_bytes_per_launch': 36.0 * vox},
+                     'frac_of_copy_ceiling': round(36.0 * vox / (kms * 1e-3) / HBM_COPY, 4), 'copy_ceiling': HBM_COPY / 1e9,
+                     'rocprof_kernel_ms': None, 'algorithmic_bytes_per_launch': 36.0 * vox},
         'recon_max_abs_err': err,
     }
+    tr = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if os.path.exists(tr) and n == 256:
+        try:
+            tj = json.load(open(tr)).get('c4') or {}
+            out['roofline']['traffic'] = tj.get('k_fwd3_l1')
+            v = (tj.get('rocprof_median_us_one_stream') or {}).get('k_fwd3_l1')
+            out['roofline']['rocprof_kernel_ms'] = None if v is None else round(v / 1e3, 5)
+            out['roofline']['traffic_source'] = tj.get('source')
+        except Exception:
+            pass
     if not args.no_cpu_baseline:
         # the NumPy oracle (one core) on the first volume: ~15 s at 256^3
         from oracle import dtcwt_oracle as o
@@ -715,13 +747,19 @@ def main_mgpu(args):
     sys.stdout.flush()
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
+    # the engine of the one-process-per-GPU path: `--streams` batches in flight per device, each lane's contexts on a share of
+    # the compute units where that measured faster (the library's rule; --cu-partition on / off forces it)
+    lanes = max(1, cfg.get('streams', args.streams))
     m = MultiGPUTransform2d(biort(BIORT), qshift(QSHIFT), devices=list(range(N)), batch=N * B, rows=R, cols=C,
-                            nlevels=NL, broadcast_taps=True)
-    nsets = max(1, args.sets)
+                            nlevels=NL, broadcast_taps=True, lanes=lanes,
+                            partition=None if args.cu_partition == 'auto' else args.cu_partition == 'on')
+    nsets = max(1, cfg.get('sets', args.sets))
+    if nsets % lanes:
+        nsets = (nsets // lanes + 1) * lanes
     sets = []
     for k in range(nsets):
         rs = np.random.RandomState(cfg['seed'](0) + 17 * k)
-        bufs = m.alloc()
+        bufs = m.alloc(lane=k % lanes)
         m.scatter(rs.standard_normal((N * B, R, C)).astype(np.float32), bufs.X)
         sets.append(bufs)
     counter = [0]
@@ -750,7 +788,7 @@ def main_mgpu(args):
     dt = time.perf_counter() - t0
     px = float(N * B) * R * C
     Zh, Xh = m.gather(sets[0].Z, (R + (R & 1), C + (C & 1)), np.float32), m.gather(sets[0].X, (R, C), np.float32)
-    err = float(np.abs(Zh[:, :64, :64] - Xh[:, :64, :64]).max())
+    err = float(np.abs(Zh[:, :R, :C] - Xh).max())          # every image of the first buffer set, whole
     out = {
         'metric': 'Mpixels/s 2D DT-CWT fwd+inv, 4096^2 f32 nlevels=4' if args.config == 'c2' else
                   'Mpixels/s 2D DT-CWT fwd+inv, %s' % cfg['name'],
@@ -760,7 +798,9 @@ def main_mgpu(args):
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': '%s, %s/%s, %d image(s) per GPU per step' % (cfg['name'], BIORT, QSHIFT, B),
                    'sharding': 'contiguous batch split over %d device(s), no data-path collective' % N,
-                   'buffer_sets': nsets, 'taps_broadcast_with_rccl': bool(m.taps_broadcast)},
+                   'buffer_sets': nsets, 'taps_broadcast_with_rccl': bool(m.taps_broadcast), 'streams': lanes,
+                   'cu_partition': ('%d lanes per device, each on 1/%d of the compute units' % (lanes, m.shares)) if m.shares > 1 else None,
+                   'ms_per_step_is': 'throughput over %d overlapped lane(s) of independent batches per device' % lanes},
         'roofline': {'bound': 'hbm', 'kernel': 'whole step', 'achieved': round(STEP_BYTES_PER_PX * px / dt * args.steps / N / 1e9, 1),
                      'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                      'frac': round(STEP_BYTES_PER_PX * px / N / (dt / args.steps) / HBM_PEAK, 4), 'traffic': None},

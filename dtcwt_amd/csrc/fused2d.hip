@@ -20,7 +20,7 @@ int dtcwt_dispatch_inv1(int m0, int m1, int m2, dt2d::Inv1Params &p, hipStream_t
 int dtcwt_dispatch_inv2(int m, bool bp, dt2d::Inv2Params &p, hipStream_t s, bool small);
 // levels 1 + 2 of the forward transform as one marching launch (march2d.hip)
 bool dtcwt_march_fwd12_ok(int batch, int rows, int cols, const std::vector<double> &h0o, const std::vector<double> &h1o,
-                          const std::vector<double> &h0a, const DtMarchHint &hint);
+                          const std::vector<double> &h0a, bool lo_a_first, bool hi_a_first, const DtMarchHint &hint);
 int dtcwt_march_fwd12(const float *X, float *Yh0, float *Yh1, float *LoLo2, int B, int R, int C,
                       const std::vector<double> &h0o, const std::vector<double> &h1o,
                       const float *l_a, const float *l_b, const float *h_a, const float *h_b, int m,
@@ -187,7 +187,8 @@ static bool plan_march_geometry(const dtcwt_hip_plan2d *p) {
 }
 static bool plan_march_fwd12(const dtcwt_hip_plan2d *p) {
     return plan_march_geometry(p) && p->bp1[0].empty() && p->bp2[0].empty() &&
-           dtcwt_march_fwd12_ok(p->batch, p->lv[0].LR, p->lv[0].LC, p->biort[0], p->biort[2], p->qshift[0], p->hint());
+           dtcwt_march_fwd12_ok(p->batch, p->lv[0].LR, p->lv[0].LC, p->biort[0], p->biort[2], p->qshift[0],
+                                dotd(p->qshift[1], p->qshift[0]) > 0, dotd(p->qshift[5], p->qshift[4]) > 0, p->hint());
 }
 static bool plan_march_inv21(const dtcwt_hip_plan2d *p) {
     return plan_march_geometry(p) && p->bp1[1].empty() && p->bp2[2].empty() &&

@@ -84,12 +84,13 @@ static bool march_sizes_ok(int batch, int rows, int cols, int VL) {
 
 // the geometry / filters the one-launch levels 1 + 2 handle; everything else stays with the tile programs
 bool dtcwt_march_fwd12_ok(int batch, int rows, int cols, const std::vector<double> &h0o, const std::vector<double> &h1o,
-                          const std::vector<double> &h0a, const DtMarchHint &hint) {
+                          const std::vector<double> &h0a, bool lo_a_first, bool hi_a_first, const DtMarchHint &hint) {
     const int mm = march_mode(hint);
     if (mm == 0 || (mm < 0 && !march_pays(batch, rows, cols, hint))) return false;
     const int m0 = (int)h0o.size(), m1 = (int)h1o.size(), m = (int)h0a.size();
     if (!((m0 == 5 && m1 == 7) || (m0 == 5 && m1 == 3)) || m != 10) return false;       // near_sym_a, legall + qshift_a / _06
     if (!symmetric(h0o) || !symmetric(h1o)) return false;     // mirrored halo lanes: see march2d.hpp
+    if (!lo_a_first || hi_a_first) return false;               // the phases the kernel is compiled for: every shipped set
     return march_sizes_ok(batch, rows, cols, dtm::Fwd12m<5, 7, 10>::VL);
 }
 
@@ -157,6 +158,7 @@ int dtcwt_march_fwd12(const float *X, float *Yh0, float *Yh1, float *LoLo2, int 
     }
     dtm::dtm_pack_qshift(p, m, l_a, l_b, h_a, h_b);
     dtm::dtm_pack_biort(p, (int)h0o.size(), (int)h1o.size());
+    dtm::dtm_pack_biort_scaled(p, (int)h0o.size(), (int)h1o.size(), h0o.data(), h1o.data());
     const int m0 = (int)h0o.size(), m1 = (int)h1o.size();
     if (m == 10) {
         if (m0 == 5 && m1 == 7) return launch_fwd12<5, 7, 10>(p, hint, s);

@@ -150,11 +150,28 @@ __device__ __forceinline__ void row_lohi(const pk2 *wc_, const pk2 *hp, pk2 &ol,
     for (int d = 1; d <= HH; ++d) { const pk2 sm = wc_[-d] + wc_[d]; a += hp[d] * DTM_BX(sm); b += hp[d] * DTM_BY(sm); }
     ol = a; oh = b;
 }
+// the same with the 1/sqrt2 of q2c folded into the taps: hpl = (h0, h1 / sqrt2) over the Lo row -> (ll, lh / sqrt2),
+// hph = (h0, h1) / sqrt2 over the Hi row -> (hl, hh) / sqrt2; 24 multiplications per step less
+template <int HH>
+__device__ __forceinline__ void row_lohi_s(const pk2 *wc_, const pk2 *hpl, const pk2 *hph, pk2 &ol, pk2 &oh) {
+    pk2 a = hpl[0] * DTM_BX(wc_[0]), b = hph[0] * DTM_BY(wc_[0]);
+#pragma unroll
+    for (int d = 1; d <= HH; ++d) { const pk2 sm = wc_[-d] + wc_[d]; a += hpl[d] * DTM_BX(sm); b += hph[d] * DTM_BY(sm); }
+    ol = a; oh = b;
+}
 
 // q2c of the lane's two quads of a plane (rows e0 / e1; the 1/sqrt2 is already in the row taps)
 //   z0 = (a - d) + j(b + c), z1 = (a + d) + j(b - c)  for  a b / c d
 struct Zq { float z0r, z0i, z1r, z1i; };
 __device__ __forceinline__ Zq q2c_s(float a, float b, float c, float d) { return Zq{a - d, b + c, a + d, b - c}; }
+// the same with every result pinned as a scalar: four v_add / v_sub that write straight into their places in the record.
+// Left alone, the compiler pairs them into v_pk_add_f32 (operands swapped and negated by modifiers) and then needs a v_mov
+// per component to lay the record out for its 16-byte LDS write -- more instructions than it saved.
+__device__ __forceinline__ Zq q2c_p(float a, float b, float c, float d) {
+    Zq z{a - d, b + c, a + d, b - c};
+    asm("" : "+v"(z.z0r)); asm("" : "+v"(z.z0i)); asm("" : "+v"(z.z1r)); asm("" : "+v"(z.z1i));
+    return z;
+}
 
 #endif  // __HIP_DEVICE_COMPILE__
 
@@ -191,6 +208,8 @@ struct Fwd12mParams {
     // position -- and the level-1 taps by distance d from the centre as (h0, h1) pairs (h0 zero beyond its half length)
     float ta2[2 * MAXT2] __attribute__((aligned(8))), tb2[2 * MAXT2] __attribute__((aligned(8)));
     float hp[2 * (MAXT1 / 2 + 1)] __attribute__((aligned(8)));
+    // the row-pass taps with the 1/sqrt2 of q2c folded in: over the Lo plane (h0, h1 / sqrt2), over the Hi plane (h0, h1) / sqrt2
+    float hpl[2 * (MAXT1 / 2 + 1)] __attribute__((aligned(8))), hph[2 * (MAXT1 / 2 + 1)] __attribute__((aligned(8)));
 };
 
 // ha / hb: the FIRST / SECOND filter argument of coldfilt (Fwd2Params::l_a, l_b and h_a, h_b)
@@ -215,6 +234,16 @@ inline void dtm_pack_biort(Pm &p, int m0, int m1) {
     for (int d = 0; d <= MAXT1 / 2; ++d) {
         p.hp[2 * d] = d <= m0 / 2 ? p.h0[m0 / 2 - d] : 0.f;
         p.hp[2 * d + 1] = d <= m1 / 2 ? p.h1[m1 / 2 - d] : 0.f;
+    }
+}
+// h0d / h1d: the level-1 taps in double precision (the products with 1/sqrt2 are rounded once)
+template <class Pm>
+inline void dtm_pack_biort_scaled(Pm &p, int m0, int m1, const double *h0d, const double *h1d) {
+    const double rs = 0.70710678118654752440;
+    for (int d = 0; d <= MAXT1 / 2; ++d) {
+        const double a = d <= m0 / 2 ? h0d[m0 / 2 - d] : 0.0, b = d <= m1 / 2 ? h1d[m1 / 2 - d] : 0.0;
+        p.hpl[2 * d] = (float)a; p.hpl[2 * d + 1] = (float)(b * rs);
+        p.hph[2 * d] = (float)(a * rs); p.hph[2 * d + 1] = (float)(b * rs);
     }
 }
 
@@ -331,6 +360,7 @@ __global__ void __launch_bounds__(64, WPS) k_fwd12m(const Fwd12mParams p) {
 #pragma unroll
             for (int j = 0; j < WR; ++j) { wp[0][j] = pk2{w[j].x, w[j].y}; wp[1][j] = pk2{w[j].z, w[j].w}; }
             const pk2 *hpp = reinterpret_cast<const pk2 *>(p.hp);
+            const pk2 *hpl = reinterpret_cast<const pk2 *>(p.hpl), *hph = reinterpret_cast<const pk2 *>(p.hph);
             f4 ll[2];
             f4 pv[6];                                   // (KO & 64) planar pyramid: a lane's two coefficients of each subband
             if (in_band) {
@@ -348,27 +378,27 @@ __global__ void __launch_bounds__(64, WPS) k_fwd12m(const Fwd12mParams p) {
                     }
                     pk2 ol[4], oh[4];           // (ll, lh) and (hl, hh) of the four columns
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) row_lohi<HH>(&W[c + HH], hpp, ol[c], oh[c]);
+                    for (int c = 0; c < 4; ++c) row_lohi_s<HH>(&W[c + HH], hpl, hph, ol[c], oh[c]);
                     ll[q] = f4{ol[0].x, ol[1].x, ol[2].x, ol[3].x}; lh[q] = f4{ol[0].y, ol[1].y, ol[2].y, ol[3].y};
                     hl[q] = f4{oh[0].x, oh[1].x, oh[2].x, oh[3].x}; hh[q] = f4{oh[0].y, oh[1].y, oh[2].y, oh[3].y};
                 }
                 {
-                    const Zq a0 = q2c_s(hl[0].x, hl[0].y, hl[1].x, hl[1].y), a1 = q2c_s(hl[0].z, hl[0].w, hl[1].z, hl[1].w);
-                    const Zq b0 = q2c_s(hh[0].x, hh[0].y, hh[1].x, hh[1].y), b1 = q2c_s(hh[0].z, hh[0].w, hh[1].z, hh[1].w);
-                    const Zq c0q = q2c_s(lh[0].x, lh[0].y, lh[1].x, lh[1].y), c1q = q2c_s(lh[0].z, lh[0].w, lh[1].z, lh[1].w);
+                    const Zq a0 = q2c_p(hl[0].x, hl[0].y, hl[1].x, hl[1].y), a1 = q2c_p(hl[0].z, hl[0].w, hl[1].z, hl[1].w);
+                    const Zq b0 = q2c_p(hh[0].x, hh[0].y, hh[1].x, hh[1].y), b1 = q2c_p(hh[0].z, hh[0].w, hh[1].z, hh[1].w);
+                    const Zq c0q = q2c_p(lh[0].x, lh[0].y, lh[1].x, lh[1].y), c1q = q2c_p(lh[0].z, lh[0].w, lh[1].z, lh[1].w);
                     if constexpr ((KO & 64) != 0) {
-                        pv[0] = f4{sq * a0.z0r, sq * a0.z0i, sq * a1.z0r, sq * a1.z0i}; pv[1] = f4{sq * b0.z0r, sq * b0.z0i, sq * b1.z0r, sq * b1.z0i};
-                        pv[2] = f4{sq * c0q.z0r, sq * c0q.z0i, sq * c1q.z0r, sq * c1q.z0i}; pv[3] = f4{sq * c0q.z1r, sq * c0q.z1i, sq * c1q.z1r, sq * c1q.z1i};
-                        pv[4] = f4{sq * b0.z1r, sq * b0.z1i, sq * b1.z1r, sq * b1.z1i}; pv[5] = f4{sq * a0.z1r, sq * a0.z1i, sq * a1.z1r, sq * a1.z1i};
+                        pv[0] = f4{a0.z0r, a0.z0i, a1.z0r, a1.z0i}; pv[1] = f4{b0.z0r, b0.z0i, b1.z0r, b1.z0i};
+                        pv[2] = f4{c0q.z0r, c0q.z0i, c1q.z0r, c1q.z0i}; pv[3] = f4{c0q.z1r, c0q.z1i, c1q.z1r, c1q.z1i};
+                        pv[4] = f4{b0.z1r, b0.z1i, b1.z1r, b1.z1i}; pv[5] = f4{a0.z1r, a0.z1i, a1.z1r, a1.z1i};
                     }
                     f4 *o = slab + lane * 6;
                     if constexpr ((KO & 64) == 0) {
-                    o[0] = f4{sq * a0.z0r, sq * a0.z0i, sq * b0.z0r, sq * b0.z0i};
-                    o[1] = f4{sq * c0q.z0r, sq * c0q.z0i, sq * c0q.z1r, sq * c0q.z1i};
-                    o[2] = f4{sq * b0.z1r, sq * b0.z1i, sq * a0.z1r, sq * a0.z1i};
-                    o[3] = f4{sq * a1.z0r, sq * a1.z0i, sq * b1.z0r, sq * b1.z0i};
-                    o[4] = f4{sq * c1q.z0r, sq * c1q.z0i, sq * c1q.z1r, sq * c1q.z1i};
-                    o[5] = f4{sq * b1.z1r, sq * b1.z1i, sq * a1.z1r, sq * a1.z1i};
+                    o[0] = f4{a0.z0r, a0.z0i, b0.z0r, b0.z0i};
+                    o[1] = f4{c0q.z0r, c0q.z0i, c0q.z1r, c0q.z1i};
+                    o[2] = f4{b0.z1r, b0.z1i, a0.z1r, a0.z1i};
+                    o[3] = f4{a1.z0r, a1.z0i, b1.z0r, b1.z0i};
+                    o[4] = f4{c1q.z0r, c1q.z0i, c1q.z1r, c1q.z1i};
+                    o[5] = f4{b1.z1r, b1.z1i, a1.z1r, a1.z1i};
                     }
                 }
             } else {
@@ -450,8 +480,21 @@ __global__ void __launch_bounds__(64, WPS) k_fwd12m(const Fwd12mParams p) {
                 for (int a = 0; a < NP2; ++a) {
                     const int tt = (phi + 8 * HL2 - 4 * a) >> 1;
                     const pk2 cc = (phi & 1) ? tb2[tt] : ta2[tt];
-                    S2[a][phi & 1][0] += cc * DTM_BX(rA); S2[a][phi & 1][1] += cc * DTM_BX(rB);
-                    S2[a][phi & 1][2] += cc * DTM_BY(rA); S2[a][phi & 1][3] += cc * DTM_BY(rB);
+                    if (phi < 2) {
+                        // rows 4n, 4n + 1 are the first to touch the A / B halves after pair n - HL2 - 1 has left: slot a
+                        // continues what slot a + 1 held, the last slot starts afresh -- the pairs move up without a v_mov
+                        // (v_pk_fma_f32 has a destination of its own)
+                        if (a + 1 < NP2) {
+                            S2[a][phi & 1][0] = cc * DTM_BX(rA) + S2[a + 1][phi & 1][0]; S2[a][phi & 1][1] = cc * DTM_BX(rB) + S2[a + 1][phi & 1][1];
+                            S2[a][phi & 1][2] = cc * DTM_BY(rA) + S2[a + 1][phi & 1][2]; S2[a][phi & 1][3] = cc * DTM_BY(rB) + S2[a + 1][phi & 1][3];
+                        } else {
+                            S2[a][phi & 1][0] = cc * DTM_BX(rA); S2[a][phi & 1][1] = cc * DTM_BX(rB);
+                            S2[a][phi & 1][2] = cc * DTM_BY(rA); S2[a][phi & 1][3] = cc * DTM_BY(rB);
+                        }
+                    } else {
+                        S2[a][phi & 1][0] += cc * DTM_BX(rA); S2[a][phi & 1][1] += cc * DTM_BX(rB);
+                        S2[a][phi & 1][2] += cc * DTM_BY(rA); S2[a][phi & 1][3] += cc * DTM_BY(rB);
+                    }
                 }
             }
             if (k & 1) {
@@ -459,7 +502,9 @@ __global__ void __launch_bounds__(64, WPS) k_fwd12m(const Fwd12mParams p) {
                 const int i2 = (r - 2) / 4 - HL2;
                 const bool pair_ok = 4 * i2 >= rb && 4 * i2 < rb + nrow;        // uniform; otherwise the stores are dropped
                 {
-                    const bool la = p.lo_a_first != 0, ha = p.hi_a_first != 0;
+                    // sum(ha * hb) > 0 for the lowpass pair, < 0 for the highpass pair: every shipped q-shift set
+                    // (dtcwt_march_fwd12_ok sends anything else to the tile programs)
+                    constexpr bool la = true, ha = false;
                     // column-lowpass plane rows (A lo / B lo), column-highpass plane rows (A hi / B hi)
                     float pl[2][4], ph[2][4];
 #pragma unroll
@@ -507,16 +552,6 @@ __global__ void __launch_bounds__(64, WPS) k_fwd12m(const Fwd12mParams p) {
                     DT_WAVE_LDS_SYNC();
                     }
                 }
-#pragma unroll
-                for (int a = 0; a + 1 < NP2; ++a)
-#pragma unroll
-                    for (int c = 0; c < 2; ++c)
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) S2[a][c][v] = S2[a + 1][c][v];
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) S2[NP2 - 1][c][v] = pk2{0.f, 0.f};
             }
             f4 e0 = in0, e1 = in1;
             fix(e0); fix(e1);
@@ -665,11 +700,13 @@ __global__ void __launch_bounds__(64) k_inv21m(const Inv21mParams p) {
     const int j0 = rb / 4 - 1, j1 = (rb + nrow) / 4;      // groups of Z1 rows level 1 reads
     const int nfirst = j0 - 2, nms = j1 - j0 + 5;         // level-2 pairs j0 - 2 .. j1 + 2
 
+    // the level-1 taps of the column pass are the low halves of the (g, g) pairs the row pass holds (the filters are
+    // symmetric: g[k] = gd[|k - H|]): no scalar registers of their own -- the kernel was spilling 47 of them
     float g0o[M0], g1o[M1];
 #pragma unroll
-    for (int k = 0; k < M0; ++k) g0o[k] = p.g0o[k];
+    for (int k = 0; k < M0; ++k) g0o[k] = p.gd0[2 * (k < H0 ? H0 - k : k - H0)];
 #pragma unroll
-    for (int k = 0; k < M1; ++k) g1o[k] = p.g1o[k];
+    for (int k = 0; k < M1; ++k) g1o[k] = p.gd1[2 * (k < H1 ? H1 - k : k - H1)];
 
     // ---- requests -----------------------------------------------------------------------------------------------
     auto zrow = [&](int u) { u = u < 0 ? -1 - u : u; u = u >= R / 2 ? R - 1 - u : u; u = u < 0 ? 0 : (u > R / 2 - 1 ? R / 2 - 1 : u); return (KO & 1) ? (u & 7) : u; };
@@ -794,10 +831,20 @@ __global__ void __launch_bounds__(64) k_inv21m(const Inv21mParams p) {
 #pragma unroll
             for (int a = 0; a < NG; ++a) {          // slot a = group n - 2 + a, tap pair k = a
                 if (e == 0) {       // the even ("lo") row of the pair: rows (0, 2) through g0, rows (1, 3) through g1
-                    PzE[a][0] += la2[a] * DTM_BX(U0E); PzE[a][2] += la2[a] * DTM_BY(U0E);
-                    PzE[a][1] += la2[a] * DTM_BX(U0O); PzE[a][3] += la2[a] * DTM_BY(U0O);
-                    PzO[a][0] += hb2[a] * DTM_BX(U1E); PzO[a][2] += hb2[a] * DTM_BY(U1E);
-                    PzO[a][1] += hb2[a] * DTM_BX(U1O); PzO[a][3] += hb2[a] * DTM_BY(U1O);
+                    // The first touch of a slot in this macro-step also moves the groups up by one: slot a continues the
+                    // sums that slot a + 1 held during the previous macro-step (whose slot 0 level 1 has consumed), the last
+                    // slot starts from nothing -- the shift costs no instruction of its own (it was 64 v_mov per macro-step)
+                    if (a + 1 < NG) {
+                        PzE[a][0] = la2[a] * DTM_BX(U0E) + PzE[a + 1][0]; PzE[a][2] = la2[a] * DTM_BY(U0E) + PzE[a + 1][2];
+                        PzE[a][1] = la2[a] * DTM_BX(U0O) + PzE[a + 1][1]; PzE[a][3] = la2[a] * DTM_BY(U0O) + PzE[a + 1][3];
+                        PzO[a][0] = hb2[a] * DTM_BX(U1E) + PzO[a + 1][0]; PzO[a][2] = hb2[a] * DTM_BY(U1E) + PzO[a + 1][2];
+                        PzO[a][1] = hb2[a] * DTM_BX(U1O) + PzO[a + 1][1]; PzO[a][3] = hb2[a] * DTM_BY(U1O) + PzO[a + 1][3];
+                    } else {
+                        PzE[a][0] = la2[a] * DTM_BX(U0E); PzE[a][2] = la2[a] * DTM_BY(U0E);
+                        PzE[a][1] = la2[a] * DTM_BX(U0O); PzE[a][3] = la2[a] * DTM_BY(U0O);
+                        PzO[a][0] = hb2[a] * DTM_BX(U1E); PzO[a][2] = hb2[a] * DTM_BY(U1E);
+                        PzO[a][1] = hb2[a] * DTM_BX(U1O); PzO[a][3] = hb2[a] * DTM_BY(U1O);
+                    }
                 } else {
                     PzO[a][0] += lb2[a] * DTM_BX(U0E); PzO[a][2] += lb2[a] * DTM_BY(U0E);
                     PzO[a][1] += lb2[a] * DTM_BX(U0O); PzO[a][3] += lb2[a] * DTM_BY(U0O);
@@ -893,13 +940,32 @@ __global__ void __launch_bounds__(64) k_inv21m(const Inv21mParams p) {
                         V[c] = a_;
                     }
                     const float v0[4] = {V[0].x, V[1].x, V[2].x, V[3].x}, v1[4] = {V[0].y, V[1].y, V[2].y, V[3].y};
-                    // columns, transposed: PX[i] is row rho - H0 + i
+                    // columns, transposed: PX[i] is row rho - H0 + i.  The first row of a half-step (e == 0) also moves
+                    // the pending rows up by the two that left at the end of the previous half-step: row i continues what
+                    // row i + 2 held (no v_mov for the shift; it was 48 + 16 per macro-step)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
+                        if (e == 0) {
 #pragma unroll
-                        for (int k = 0; k < M0; ++k) PX[e + k][c] += g0o[k] * v0[c];
+                            for (int i = 0; i < NPX; ++i) {
+                                float acc;
+                                if (i + 2 < NPX && i < M0) {
+                                    // three-address form spelled out: left to itself the compiler takes the two-address
+                                    // v_fmac and copies row i + 2 into place first -- the very v_mov this is about
+                                    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(acc) : "s"(g0o[i]), "v"(v0[c]), "v"(PX[i + 2][c]));
+                                } else {
+                                    acc = i + 2 < NPX ? PX[i + 2][c] : 0.f;
+                                    if (i < M0) acc += g0o[i] * v0[c];
+                                }
+                                if (i >= H0 - H1 && i - (H0 - H1) < M1) acc += g1o[i - (H0 - H1)] * v1[c];
+                                PX[i][c] = acc;
+                            }
+                        } else {
 #pragma unroll
-                        for (int k = 0; k < M1; ++k) PX[e + (H0 - H1) + k][c] += g1o[k] * v1[c];
+                            for (int k = 0; k < M0; ++k) PX[e + k][c] += g0o[k] * v0[c];
+#pragma unroll
+                            for (int k = 0; k < M1; ++k) PX[e + (H0 - H1) + k][c] += g1o[k] * v1[c];
+                        }
                     }
                 }
             }
@@ -912,20 +978,8 @@ __global__ void __launch_bounds__(64) k_inv21m(const Inv21mParams p) {
                 const DtBuf bo = dt_buf_n(Xb + (int64_t)xo * C, ok ? 16u * nv : 0u);
                 dt2d::dt_buf_st4<true>(bo, xv, 0u, f4{PX[e][0], PX[e][1], PX[e][2], PX[e][3]});
             }
-#pragma unroll
-            for (int i = 0; i + 2 < NPX; ++i)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) PX[i][c] = PX[i + 2][c];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { PX[NPX - 2][c] = 0.f; PX[NPX - 1][c] = 0.f; }
         }
         DT_WAVE_LDS_SYNC();
-#pragma unroll
-        for (int a = 0; a + 1 < NG; ++a)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { PzE[a][c] = PzE[a + 1][c]; PzO[a][c] = PzO[a + 1][c]; }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { PzE[NG - 1][c] = pk2{0.f, 0.f}; PzO[NG - 1][c] = pk2{0.f, 0.f}; }
     }
 #endif
 }

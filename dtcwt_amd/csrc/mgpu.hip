@@ -122,6 +122,7 @@ struct dtcwt_hip_mgpu {
     std::vector<Shard> sh;
     std::vector<Worker *> workers;
     int taps_broadcast = 0;            // 1: the plans were built from taps that travelled through RCCL
+    int on_shares = 1;                 // > 1: every shard's context runs on 1 / on_shares of its device (a lane)
 };
 
 namespace {
@@ -209,11 +210,30 @@ int broadcast_taps(dtcwt_hip_mgpu *m, const std::vector<double> &flat, std::vect
 
 extern "C" {
 
+// Does a lane's shard run on a share of its device?  Measured under the bench protocol with four in flight
+// (profiles/r04/ab_partition.txt): images of 2048^2 and more gain from contexts on quarters of the compute units
+// (4096^2 -5 .. -7 %, 64 x 2048^2 -2 %), 64 x 1024^2 with five levels loses 4 % (its coarse levels are too small for 64
+// CUs); two and four shares divide the XCDs evenly, three do not.
+static bool lane_on_a_share(int flags, int nlanes, int rows, int cols) {
+    if (nlanes < 2 || (flags & DTCWT_HIP_MGPU_NO_PARTITION)) return false;
+    if (flags & DTCWT_HIP_MGPU_PARTITION) return nlanes <= 16;
+    return (nlanes == 2 || nlanes == 4) && (int64_t)rows * cols >= (int64_t)2048 * 2048;
+}
+
 int dtcwt_hip_mgpu_create(int ndev, const int *devices, int batch, int rows, int cols, int nlevels,
                           const double *const *biort_host, const int *biort_len,
                           const double *const *qshift_host, const int *qshift_len, int flags,
                           dtcwt_hip_mgpu **out) {
+    return dtcwt_hip_mgpu_create_lane(ndev, devices, batch, rows, cols, nlevels, biort_host, biort_len, qshift_host, qshift_len,
+                                      flags, 0, 1, out);
+}
+
+int dtcwt_hip_mgpu_create_lane(int ndev, const int *devices, int batch, int rows, int cols, int nlevels,
+                               const double *const *biort_host, const int *biort_len,
+                               const double *const *qshift_host, const int *qshift_len, int flags,
+                               int lane, int nlanes, dtcwt_hip_mgpu **out) {
     DT_REQUIRE(out && devices && biort_host && biort_len && qshift_host && qshift_len, "NULL argument");
+    DT_REQUIRE(nlanes >= 1 && nlanes <= 16 && lane >= 0 && lane < nlanes, "lane %d of %d: need 1 <= nlanes <= 16, 0 <= lane < nlanes", lane, nlanes);
     DT_REQUIRE(ndev >= 1 && ndev <= 64, "bad device count %d", ndev);
     DT_REQUIRE(batch >= 1 && rows >= 1 && cols >= 1 && nlevels >= 1, "bad extents");
     // the tables are copied below, before any plan looks at them: lengths first
@@ -253,14 +273,21 @@ int dtcwt_hip_mgpu_create(int ndev, const int *devices, int batch, int rows, int
     if (!rc)
         rc = on_all(m, [&](int d) -> int {
             Shard &s = m->sh[d];
-            int r = dtcwt_hip_ctx_create(s.device, nullptr, &s.ctx);
+            // one of `nlanes` objects in flight on the same devices: the engine of the one-process-per-GPU path (bench.py)
+            // -- each lane's context on its own share of the compute units where that measured faster, otherwise plain
+            // contexts whose plans are told how many transforms share the device
+            const bool share = lane_on_a_share(flags, nlanes, rows, cols);
+            int r = share ? dtcwt_hip_ctx_create_partition(s.device, lane, nlanes, &s.ctx) : dtcwt_hip_ctx_create(s.device, nullptr, &s.ctx);
             if (r || s.count == 0) return r;
             const double *bp[4], *qp[8];
             const double *p = taps[d].data();
             for (int i = 0; i < 4; ++i) { bp[i] = p; p += lens[i]; }
             for (int i = 0; i < 8; ++i) { qp[i] = p; p += lens[4 + i]; }
-            return dtcwt_hip_plan2d_create(s.ctx, s.count, rows, cols, nlevels, bp, biort_len, qp, qshift_len, &s.plan);
+            r = dtcwt_hip_plan2d_create(s.ctx, s.count, rows, cols, nlevels, bp, biort_len, qp, qshift_len, &s.plan);
+            if (!r && nlanes > 1 && !share) r = dtcwt_hip_plan2d_set_concurrency(s.plan, nlanes);
+            return r;
         });
+    m->on_shares = lane_on_a_share(flags, nlanes, rows, cols) ? nlanes : 1;
     if (rc) {
         std::string keep = dtcwt_hip_last_error();
         dtcwt_hip_mgpu_destroy(m);
@@ -284,6 +311,8 @@ int dtcwt_hip_mgpu_destroy(dtcwt_hip_mgpu *m) {
 int dtcwt_hip_mgpu_ndev(const dtcwt_hip_mgpu *m) { return m ? (int)m->sh.size() : 0; }
 
 int dtcwt_hip_mgpu_taps_broadcast(const dtcwt_hip_mgpu *m) { return m ? m->taps_broadcast : 0; }
+
+int dtcwt_hip_mgpu_shares(const dtcwt_hip_mgpu *m) { return m ? m->on_shares : 0; }
 
 int dtcwt_hip_mgpu_shard(const dtcwt_hip_mgpu *m, int d, int *device, int *start, int *count) {
     DT_REQUIRE(m && d >= 0 && d < (int)m->sh.size(), "bad shard index");

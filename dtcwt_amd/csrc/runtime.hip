@@ -37,6 +37,8 @@ static int to_float_dispatch(dtcwt_hip_ctx *c, int src_kind, const void *src, D 
         case 6: DT_TF(uint64_t); break;
         case 7: DT_TF(int64_t); break;
         case 8: DT_TF(bool); break;
+        case 9: DT_TF(float); break;        // float32 <-> float64: degenerate float32 shapes are computed in float64
+        case 10: DT_TF(double); break;
         default: return dtcwt_set_error(-1, "bad integer kind %d", src_kind);
     }
 #undef DT_TF

@@ -155,6 +155,9 @@ SIGNATURES = {
     'dtcwt_hip_plan1d_inverse': (_i, [_vp, _vp, ctypes.POINTER(_vp), _pd, _vp]),
     'dtcwt_hip_mgpu_create': (_i, [_i, ctypes.POINTER(_i), _i, _i, _i, _i, ctypes.POINTER(_pd), ctypes.POINTER(_i),
                                    ctypes.POINTER(_pd), ctypes.POINTER(_i), _i, ctypes.POINTER(_vp)]),
+    'dtcwt_hip_mgpu_create_lane': (_i, [_i, ctypes.POINTER(_i), _i, _i, _i, _i, ctypes.POINTER(_pd), ctypes.POINTER(_i),
+                                   ctypes.POINTER(_pd), ctypes.POINTER(_i), _i, _i, _i, ctypes.POINTER(_vp)]),
+    'dtcwt_hip_mgpu_shares': (_i, [_vp]),
     'dtcwt_hip_mgpu_destroy': (_i, [_vp]),
     'dtcwt_hip_mgpu_ndev': (_i, [_vp]),
     'dtcwt_hip_mgpu_taps_broadcast': (_i, [_vp]),
@@ -362,6 +365,20 @@ class Context(object):
         raw = self.to_device(X)
         out = DeviceArray(self, X.shape, np.float64)
         check(self._lib.dtcwt_hip_to_float(self._h, kind, raw.ptr, F64, out.ptr, X.size))
+        return out
+
+    def convert(self, a, dtype):
+        """A device array in another floating-point precision (float32 <-> float64, complex64 <-> complex128), converted
+        on the device (dtcwt_hip_to_float kinds 9 / 10)."""
+        dtype = np.dtype(dtype)
+        if a.dtype == dtype:
+            return a
+        pairs = {(np.dtype(np.float32), np.dtype(np.float64)): (9, F64, 1), (np.dtype(np.float64), np.dtype(np.float32)): (10, F32, 1),
+                 (np.dtype(np.complex64), np.dtype(np.complex128)): (9, F64, 2), (np.dtype(np.complex128), np.dtype(np.complex64)): (10, F32, 2)}
+        kind, dst, mul = pairs[(np.dtype(a.dtype), dtype)]
+        out = DeviceArray(self, a.shape, dtype)
+        if a.size:
+            check(self._lib.dtcwt_hip_to_float(self._h, kind, a.ptr, dst, out.ptr, a.size * mul))
         return out
 
     def event(self):

@@ -218,6 +218,20 @@ def _fused_levels(rows, cols, nlevels):
     return k
 
 
+_DEGENERATE_DIM = 8
+
+
+def _degenerate(rows, cols, nlevels):
+    """A float32 image some level of which is `_DEGENERATE_DIM` samples or fewer along an axis: its filters reflect
+    several times and sum the same few samples over and over, and float32 arithmetic leaves up to 1e-6 of a subband's own
+    maximum against the float64 oracle (profiles/r04/parity_worst.json: 9.9e-7 for a 2 x 2 image through four levels).
+    Such transforms run in float64 on the device and are rounded to float32 once, at the end."""
+    if nlevels < 1:
+        return False
+    _, lv = _level_geometry(rows, cols, nlevels)
+    return any(min(g['LR'], g['LC']) <= _DEGENERATE_DIM for g in lv[:nlevels])
+
+
 class Transform2d(object):
     """An implementation of the 2D DT-CWT on AMD Instinct GPUs via HIP.  *biort* and
     *qshift* are wavelet names (:py:func:`dtcwt_amd.coeffs.biort`/``qshift``) or tuples of
@@ -302,6 +316,11 @@ class Transform2d(object):
         """Xd: DeviceArray [B, r, c] float32/float64.  Returns (Yl, [Yh], [Ys]|None) with
         a leading batch axis."""
         B, r, c = Xd.shape
+        if Xd.dtype == np.float32 and _degenerate(r, c, nlevels):
+            ctx = Xd.ctx
+            Yl, Yh, Ys = self._forward_generic(ctx.convert(Xd, np.float64), nlevels, include_scale)
+            return (ctx.convert(Yl, np.float32), [ctx.convert(y, np.complex64) for y in Yh],
+                    [ctx.convert(y, np.float32) for y in Ys] if include_scale else None)
         if Xd.dtype == np.float32:
             k = _fused_levels(r, c, nlevels)
             plan = self._plan(B, r, c, k) if k > 0 else None
@@ -483,6 +502,10 @@ class Transform2d(object):
         B = Yl.shape[0]
         crops = self._check_shapes(Yl.shape[1:], [y.shape[1:] for y in Yh])
         R, C = 2 * Yh[0].shape[1], 2 * Yh[0].shape[2]
+        if Yl.dtype == np.float32 and _degenerate(R, C, nl):
+            ctx = Yl.ctx
+            Z = self._inverse_generic(ctx.convert(Yl, np.float64), [ctx.convert(y, np.complex128) for y in Yh], gain_mask, crops)
+            return ctx.convert(Z, np.float32)
         if Yl.dtype == np.float32:
             k = _fused_levels(R, C, nl)
             plan = self._plan(B, R, C, k) if k > 0 else None

@@ -31,7 +31,7 @@ extern "C" {
 
 /* 2: plan1d_*, plan3d_*, mgpu_* (round 2), mgpu_forward2d_scales, host_alloc / host_free / memcpy_*_async (round 3)
  * 3: plan2d_launches, plan2d_set_concurrency, mgpu_scatter_async / gather_async;  4: ctx_create_partition (round 4)
- * 5: plan2d_set_program (round 5) */
+ * 5: plan2d_set_program, mgpu_create_lane, mgpu_shares, to_float kinds 9 / 10 (round 5) */
 #define DTCWT_HIP_ABI_VERSION 5
 
 #define DTCWT_HIP_F32 0
@@ -97,7 +97,10 @@ int dtcwt_hip_memcpy_d2h_overlapped(dtcwt_hip_ctx *ctx, void *dst_host, const vo
 int dtcwt_hip_copy_sync(dtcwt_hip_ctx *ctx);
 /* Integer / bool samples -> float32 / float64 on the device: `asfarray` of dtcwt/utils.py:98-105 (every
  * non-float input becomes float64) done after the upload, so that an 8-bit image crosses the host link
- * as 1 byte per sample.  src_kind: 0 u8, 1 i8, 2 u16, 3 i16, 4 u32, 5 i32, 6 u64, 7 i64, 8 bool. */
+ * as 1 byte per sample.  src_kind: 0 u8, 1 i8, 2 u16, 3 i16, 4 u32, 5 i32, 6 u64, 7 i64, 8 bool; (ABI 5) 9 float32,
+ * 10 float64 -- a plain precision change on the device (complex arrays: count both components): float32 images with a
+ * level of 8 samples or fewer are transformed in float64 and rounded once (their multi-bounce reflections sum the same
+ * few samples many times; in float32 the error against the float64 oracle reached 9.9e-7 of a subband's maximum). */
 int dtcwt_hip_to_float(dtcwt_hip_ctx *ctx, int src_kind, const void *src, int dst_dtype, void *dst,
                        int64_t count);
 
@@ -449,6 +452,22 @@ int dtcwt_hip_mgpu_create(int ndev, const int *devices, int batch, int rows, int
                           const double *const *biort_host, const int *biort_len,
                           const double *const *qshift_host, const int *qshift_len, int flags,
                           dtcwt_hip_mgpu **mgpu);
+/* (ABI 5) The same object as one of `nlanes` the caller keeps in flight on the same devices, each with batches of its own
+ * (the frames of a video handed to the node group by group; bench.py --mgpu rotates its steps over four): lane `lane`'s
+ * shard contexts are share `lane` of `nlanes` of their device's compute units (dtcwt_hip_ctx_create_partition) where that
+ * measured faster -- two or four lanes, images of 2048 x 2048 and more (profiles/r04/ab_partition.txt) -- and plain
+ * contexts whose plans carry the concurrency hint `nlanes` otherwise; DTCWT_HIP_MGPU_PARTITION / _NO_PARTITION in `flags`
+ * force one or the other.  This gives the one-process path the engine of the one-process-per-GPU path: one 4096 x 4096
+ * image per device per call runs at the four-in-flight rate (0.15-0.16 ms) instead of the one-at-a-time rate (0.19 ms).
+ * dtcwt_hip_mgpu_create is lane 0 of 1.  dtcwt_hip_mgpu_shares: the number of shares a lane's contexts divide their
+ * device into (1: whole devices). */
+#define DTCWT_HIP_MGPU_PARTITION 2
+#define DTCWT_HIP_MGPU_NO_PARTITION 4
+int dtcwt_hip_mgpu_create_lane(int ndev, const int *devices, int batch, int rows, int cols, int nlevels,
+                               const double *const *biort_host, const int *biort_len,
+                               const double *const *qshift_host, const int *qshift_len, int flags,
+                               int lane, int nlanes, dtcwt_hip_mgpu **mgpu);
+int dtcwt_hip_mgpu_shares(const dtcwt_hip_mgpu *mgpu);
 int dtcwt_hip_mgpu_destroy(dtcwt_hip_mgpu *mgpu);
 int dtcwt_hip_mgpu_ndev(const dtcwt_hip_mgpu *mgpu);
 int dtcwt_hip_mgpu_taps_broadcast(const dtcwt_hip_mgpu *mgpu);          /* 1: plans built from RCCL-delivered taps */

@@ -12,7 +12,6 @@
 #include "fused2d_tiles.hpp"
 #include "fused2d_tiles_v2.hpp"
 #include "march2d.hpp"
-#include "../../tools/kbench/fused2d_l12.hpp"      /* measurement-only tile program (not in the library) */
 #include "fused2d_table.hpp"
 #include "fused3d_tiles.hpp"
 #include "fused3d_inv_tiles.hpp"
@@ -67,43 +66,6 @@ static int run_fwd2(Fwd2Params p) {
                 for (int q = 0; q < C::TI * C::TJ; q += DT_NT) {
                     for (int t = 0; t < DT_NT; ++t) fwd2s_rows_compute<C>(p, sLo, sHi, stage, t, q, b, r0, c0, sBa);
                     for (int t = 0; t < DT_NT; ++t) fwd2s_rows_flush<C>(p, stage, t, q, b, r0, c0);
-                }
-            }
-    return 0;
-}
-
-template <class C>
-static int run_fwd12(Fwd1Params p1, Fwd2Params p2) {
-    p2.tilesR = cdiv(p2.LR / 2, C::T2R); p2.tilesC = cdiv(p2.LC / 2, C::T2C);
-    dt_pack_lh(p2);
-    std::vector<float> smem(C::LDS_FLOATS + 4);
-    float *base = smem.data();
-    while (((uintptr_t)base) & 15) ++base;
-    float *sLo = base, *sHi = sLo + C::SLO, *stage = sHi + C::SB;
-    float *sLo2 = sHi, *sHi2 = sHi + C::S2;
-    static Fwd12State<C> st[C::NT];
-    alignas(16) static float rec[C::NT][2][12];
-    for (int b = 0; b < p2.B; ++b)
-        for (int tr = 0; tr < p2.tilesR; ++tr)
-            for (int tc = 0; tc < p2.tilesC; ++tc) {
-                for (int i = 0; i < C::LDS_FLOATS; ++i) base[i] = NAN;     // stale LDS must never be read
-                const int r2 = tr * C::T2R, c2 = tc * C::T2C, r1 = 2 * r2, c1 = 2 * c2;
-                for (int t = 0; t < C::NT; ++t) fwd12_cols<C>(p1, sLo, sHi, t, b, r1, c1);
-                for (int round = 0; round < C::NCR; ++round) {
-                    for (int t = 0; t < C::NT; ++t) fwd12_core_compute<C>(p1, sLo, sHi, lds128_perm(t), round, st[t], rec[t]);
-                    for (int half = 0; half < 2; ++half) {      // a wave's two steps run as two passes over its lanes
-                        for (int t = 0; t < C::NT; ++t) fwd12_core_deposit<C>(stage, lds128_perm(t), round, half, rec[t]);
-                        for (int t = 0; t < C::NT; ++t) fwd12_core_flush<C>(p1, stage, t, round, half, b, r1, c1);
-                    }
-                }
-                for (int t = 0; t < C::NT; ++t) fwd12_halo_compute<C>(p1, sLo, lds128_perm(t), st[t]);
-                for (int t = 0; t < C::NT; ++t) fwd12_writeback<C>(p1, sLo, lds128_perm(t), b, r1, c1, st[t]);
-                if (fwd12_needs_fix<C>(p1, r1, c1))
-                    for (int t = 0; t < C::NT; ++t) fwd12_fix<C>(p1, sLo, t, r1, c1);
-                for (int t = 0; t < C::NT; ++t) fwd12_cols2<C>(p2, sLo, sLo2, sHi2, t);
-                for (int q = 0; q < C::TI * C::TJ; q += C::NT) {
-                    for (int t = 0; t < C::NT; ++t) fwd2s_rows_compute<typename C::L2View>(p2, sLo2, sHi2, stage, lds128_perm(t), q, b, r2, c2);
-                    for (int t = 0; t < C::NT; ++t) fwd2s_rows_flush<typename C::L2View>(p2, stage, t, q, b, r2, c2);
                 }
             }
     return 0;
@@ -473,26 +435,6 @@ int emu_inv2_large(int m, const float *Z, const float *Yh, float *Out, int B, in
     put_taps(p.l_a, la, m); put_taps(p.l_b, lb, m); put_taps(p.h_a, ha, m); put_taps(p.h_b, hb, m);
     p.lo_pos = dotd(la, lb, m) > 0; p.hi_pos = dotd(ha, hb, m) > 0;
     DT_INV2_TABLE(EMU_INV2)
-    return -3;
-}
-
-// levels 1 + 2 forward in one tile program (fused2d_l12.hpp); LoLo1 may be NULL
-#define DT_FWD12_TABLE(X) X(16, 32, 8, 4, 5, 7, 10) X(16, 28, 8, 4, 9, 7, 10) X(16, 32, 8, 4, 5, 3, 10)      /* == tools/kbench/fwd12_kernel.hpp */
-#define EMU_FWD12(T2R, T2C, RS, PS, A, B, M) if (m0 == A && m1 == B && m == M) return run_fwd12<Fwd12Cfg<T2R, T2C, RS, PS, A, B, M>>(p1, p2);
-int emu_fwd12(int m0, int m1, int m, const float *X, float *LoLo1, float *Yh0, float *LoLo2, float *Yh1, int B,
-              int inR, int inC, const double *h0, const double *h1, const double *la, const double *lb,
-              const double *ha, const double *hb) {
-    Fwd1Params p1{};
-    p1.X = X; p1.LoLo = LoLo1; p1.Yh = Yh0; p1.B = B; p1.inR = inR; p1.inC = inC;
-    p1.LR = inR + (inR & 1); p1.LC = inC + (inC & 1);
-    put_taps(p1.h0, h0, m0); put_taps(p1.h1, h1, m1);
-    if (p1.LR % 4 || p1.LC % 4) return -1;
-    Fwd2Params p2{};
-    p2.X = nullptr; p2.LoLo = LoLo2; p2.Yh = Yh1; p2.B = B; p2.inR = p1.LR; p2.inC = p1.LC;
-    p2.LR = p1.LR; p2.LC = p1.LC;
-    put_taps(p2.l_a, la, m); put_taps(p2.l_b, lb, m); put_taps(p2.h_a, ha, m); put_taps(p2.h_b, hb, m);
-    p2.lo_a_first = dotd(la, lb, m) > 0; p2.hi_a_first = dotd(ha, hb, m) > 0;
-    DT_FWD12_TABLE(EMU_FWD12)
     return -3;
 }
 

@@ -25,7 +25,7 @@ TOL = 2e-6
 
 
 def _build():
-    deps = [EMU_SRC, os.path.join(ROOT, 'tools', 'kbench', 'fused2d_l12.hpp')] + [
+    deps = [EMU_SRC] + [
         os.path.join(ROOT, 'dtcwt_amd', 'csrc', f) for f in
         ('fused2d_tiles.hpp', 'fused2d_tiles_v2.hpp', 'fused2d_table.hpp', 'fused3d_tiles.hpp', 'fused3d_inv_tiles.hpp',
          'march2d.hpp')]
@@ -101,42 +101,6 @@ def emu_inv2(emu, Z, Yh, q, gain, cropR, cropC, large=False):
     rc = fn(len(la), _f(Z), _f(yh), _f(out), B, zr, zc, cropR, cropC, pg, pla, plb, pha, phb)
     assert rc == 0
     return out
-
-
-def emu_fwd12(emu, X, b, q, want_scale=False):
-    B, r, c = X.shape
-    R, C = r + (r & 1), c + (c & 1)
-    lolo1 = np.full((B, R, C), np.nan, np.float32) if want_scale else None
-    yh0 = np.full((B, R // 2, C // 2, 12), np.nan, np.float32)
-    lolo2 = np.full((B, R // 2, C // 2), np.nan, np.float32)
-    yh1 = np.full((B, R // 4, C // 4, 12), np.nan, np.float32)
-    h0a, h0b, g0a, g0b, h1a, h1b, g1a, g1b = q[:8]
-    h0, p0 = _d(b[0]); h1, p1 = _d(b[2])
-    la, pla = _d(h0b); lb, plb = _d(h0a); ha, pha = _d(h1b); hb, phb = _d(h1a)
-    rc = emu.emu_fwd12(len(h0), len(h1), len(la), _f(X), _f(lolo1) if want_scale else None, _f(yh0), _f(lolo2),
-                       _f(yh1), B, r, c, p0, p1, pla, plb, pha, phb)
-    assert rc == 0
-    return lolo1, yh0.view(np.complex64), lolo2, yh1.view(np.complex64)
-
-
-@pytest.mark.parametrize('bn', ['near_sym_a', 'antonini', 'legall'])
-@pytest.mark.parametrize('shape', [(64, 128), (128, 64), (63, 68), (72, 100), (132, 196)])
-def test_emu_levels12_forward_fused(emu, bn, shape):
-    """Levels 1 and 2 in one tile program (LoLo1 never leaves LDS) against the oracle's two levels,
-    odd sizes (bottom row replicated) and tiles hanging over the image edge included."""
-    rs = np.random.RandomState(11)
-    X = rs.standard_normal((2,) + shape).astype(np.float32)
-    b, q = biort(bn), qshift('qshift_a')
-    scale = shape == (72, 100)
-    lolo1, yh0, lolo2, yh1 = emu_fwd12(emu, X, b, q, want_scale=scale)
-    t = o.Transform2d(b, q)
-    for i in range(2):
-        p = t.forward(X[i], nlevels=2, include_scale=True)
-        assert rel(yh0[i], p.highpasses[0]) < TOL
-        assert rel(lolo2[i], p.lowpass) < TOL
-        assert rel(yh1[i], p.highpasses[1]) < TOL
-        if scale:
-            assert rel(lolo1[i], p.scales[0]) < TOL
 
 
 BIORTS = ['near_sym_a', 'antonini', 'legall', 'near_sym_b']

@@ -166,6 +166,40 @@ def test_mgpu_batch_split_matches_single_plan(devices, bcast):
     m.sync()
 
 
+@pytest.mark.parametrize('lanes,partition,shape', [(4, None, (512, 464)), (4, True, (512, 464)), (2, None, (2048, 2048)), (3, None, (256, 328))])
+def test_mgpu_lanes_in_flight(lanes, partition, shape):
+    """dtcwt_hip_mgpu_create_lane / MultiGPUTransform2d(lanes=K): K batches in flight per device, lane k's shard contexts on
+    share k of K of their device where the library's rule (or the caller) says so -- the engine of the one-process-per-GPU
+    path.  Different batches on different lanes at the same time; every result equals the unsharded batch of the same
+    program bit for bit."""
+    from dtcwt_amd.hip.multigpu import MultiGPUTransform2d
+    rs = np.random.RandomState(lanes)
+    nb = 3
+    m = MultiGPUTransform2d(B, Q, devices=[0, 0], batch=nb, rows=shape[0], cols=shape[1], nlevels=3, lanes=lanes, partition=partition)
+    want_shares = lanes if (partition or (partition is None and lanes in (2, 4) and shape[0] * shape[1] >= 2048 * 2048)) else 1
+    assert m.shares == want_shares and m.lanes == lanes
+    sets = [m.alloc() for _ in range(2 * lanes)]
+    assert [s.lane for s in sets] == [k % lanes for k in range(2 * lanes)]
+    Xs = [rs.standard_normal((nb,) + shape).astype(np.float32) for _ in sets]
+    for s, X in zip(sets, Xs):            # everything enqueued before anything is read back
+        m.scatter(X, s.X)
+        m.forward_into(s)
+        m.inverse_into(s)
+    m.sync()
+    t = Transform2d(B, Q, program='march')
+    tt = Transform2d(B, Q, program='tiles')
+    for s, X in zip(sets, Xs):
+        low, high = m.gather_pyramid(s)
+        # which program a lane's plan picked depends on its share of the device and the hint: compare with that program
+        ref_m, ref_t = t.forward_channels(X, 'nhw', nlevels=3), tt.forward_channels(X, 'nhw', nlevels=3)
+        ref = ref_m if np.array_equal(low, ref_m.lowpass) else ref_t
+        assert np.array_equal(low, ref.lowpass)
+        for l in range(3):
+            assert np.array_equal(high[l], ref.highpasses[l]), (s.lane, l)
+        z = m.gather(s.Z, m.ext, np.float32)
+        assert np.abs(z - X).max() < 4e-6 * np.abs(X).max()
+
+
 def test_mgpu_async_scatter_gather():
     """dtcwt_hip_mgpu_scatter_async / gather_async: page-locked host arrays, every shard's upload on its own stream and
     its download on its copy stream, complete at sync() -- the same numbers as the blocking pageable copies."""

@@ -138,7 +138,15 @@ def test_partition_context_beside_null_stream_work():
     against the legacy NULL stream.  Results must be right either way; what the header documents is the serialisation."""
     import ctypes
     from dtcwt_amd.hip import Context, _lib
-    hip = ctypes.CDLL('libamdhip64.so')
+    # the HIP runtime this process already has (the library's dependency): dlopen of the same file returns the same handle
+    default_context()
+    path = next((ln.split()[-1] for ln in open('/proc/self/maps') if 'libamdhip64.so' in ln), None)
+    if path is None:
+        pytest.skip('no libamdhip64 mapped: cannot enqueue NULL-stream work')
+    hip = ctypes.CDLL(path)
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemsetAsync.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
     rs = np.random.RandomState(3)
     X = rs.standard_normal((512, 464)).astype(np.float32)
     want = Transform2d(program='march').forward(X, nlevels=3)

@@ -174,7 +174,7 @@ static void launch_f12(int s, int band_rows) {
     const unsigned jobs = dtm::dtm_set_jobs(p.jb, 1, N, cdiv(N, 4 * G::VL), band_rows);
     put(p.h0, H0O, 5, dtm::MAXT1); put(p.h1, H1O, 7, dtm::MAXT1);
     Fwd2Params q{}; fill_fwd2(q);
-    dtm::dtm_pack_qshift(p, 10, q.l_a, q.l_b, q.h_a, q.h_b); dtm::dtm_pack_biort(p, 5, 7); p.lo_a_first = q.lo_a_first; p.hi_a_first = q.hi_a_first;
+    dtm::dtm_pack_qshift(p, 10, q.l_a, q.l_b, q.h_a, q.h_b); dtm::dtm_pack_biort(p, 5, 7); dtm::dtm_pack_biort_scaled(p, 5, 7, H0O, H1O); p.lo_a_first = q.lo_a_first; p.hi_a_first = q.hi_a_first;
     dtm::k_fwd12m<5, 7, 10, P, KO, WPS><<<jobs, 64, 0, st>>>(p);
 }
 using I1 = Inv1RCfg<16, 120, 8, 7, 5>;
@@ -222,7 +222,7 @@ static void launch_f12w(int s, int band_rows) {
     const unsigned jobs = dtm::dtm_set_jobs(p.jb, 1, N, cdiv(N, 4 * G::VL), band_rows);
     put(p.h0, H0O, 5, dtm::MAXT1); put(p.h1, H1O, 7, dtm::MAXT1);
     Fwd2Params q{}; fill_fwd2(q);
-    dtm::dtm_pack_qshift(p, 10, q.l_a, q.l_b, q.h_a, q.h_b); dtm::dtm_pack_biort(p, 5, 7); p.lo_a_first = q.lo_a_first; p.hi_a_first = q.hi_a_first;
+    dtm::dtm_pack_qshift(p, 10, q.l_a, q.l_b, q.h_a, q.h_b); dtm::dtm_pack_biort(p, 5, 7); dtm::dtm_pack_biort_scaled(p, 5, 7, H0O, H1O); p.lo_a_first = q.lo_a_first; p.hi_a_first = q.hi_a_first;
     dtm::k_fwd12w<5, 7, 10, P, KO><<<jobs, 128, 0, st>>>(p);
 }
 template <int P>
