@@ -31,6 +31,14 @@ int dtcwt_march_inv21(const float *Z2, const float *Yh1, const float *Yh0, float
                       const std::vector<double> &g0o, const std::vector<double> &g1o, const float *l_a, const float *l_b,
                       const float *h_a, const float *h_b, const float *gain1, const float *gain2, const DtMarchHint &hint, hipStream_t s);
 
+// level 1 alone as a march, for the biort sets the fused launches are not built for (march2d_l1.hpp)
+bool dtcwt_march_fwd1_ok(int batch, int rows, int cols, const std::vector<double> &h0o, const std::vector<double> &h1o, const DtMarchHint &hint);
+int dtcwt_march_fwd1(const float *X, float *LoLo, float *Yh0, int B, int R, int C, const std::vector<double> &h0o,
+                     const std::vector<double> &h1o, const DtMarchHint &hint, hipStream_t s);
+bool dtcwt_march_inv1_ok(int batch, int rows, int cols, const std::vector<double> &g0o, const std::vector<double> &g1o, const DtMarchHint &hint);
+int dtcwt_march_inv1(const float *Z, const float *Yh0, float *X, int B, int R, int C, const std::vector<double> &g0o,
+                     const std::vector<double> &g1o, const float *gain1, const DtMarchHint &hint, hipStream_t s);
+
 namespace {
 
 // record arrays at least this big leave with the non-temporal hint (DTCWT_HIP_STREAM_RECORDS_MB; default 32)
@@ -196,7 +204,26 @@ static bool plan_march_inv21(const dtcwt_hip_plan2d *p) {
                                 dotd(p->qshift[3], p->qshift[2]) > 0, dotd(p->qshift[7], p->qshift[6]) > 0, p->hint());
 }
 
+// level 1 alone as a march (near_sym_b, antonini): no odd-size extension, columns in fours, no band-pass set
+static bool plan_march_fwd1(const dtcwt_hip_plan2d *p) {
+    const Level &L = p->lv[0];
+    return L.inR == L.LR && L.inC == L.LC && p->bp1[0].empty() &&
+           dtcwt_march_fwd1_ok(p->batch, L.LR, L.LC, p->biort[0], p->biort[2], p->hint());
+}
+static bool plan_march_inv1(const dtcwt_hip_plan2d *p) {
+    const Level &L = p->lv[0];
+    return L.inR == L.LR && L.inC == L.LC && p->bp1[1].empty() &&
+           dtcwt_march_inv1_ok(p->batch, L.LR, L.LC, p->biort[1], p->biort[3], p->hint());
+}
+
 extern "C" {
+
+int dtcwt_hip_plan2d_level1_march(const dtcwt_hip_plan2d *p, int *fwd1, int *inv1) {
+    DT_REQUIRE(p, "NULL plan");
+    if (fwd1) *fwd1 = plan_march_fwd1(p) ? 1 : 0;
+    if (inv1) *inv1 = plan_march_inv1(p) ? 1 : 0;
+    return 0;
+}
 
 int dtcwt_hip_plan2d_set_concurrency(dtcwt_hip_plan2d *p, int n) {
     DT_REQUIRE(p && n >= 1 && n <= 1024, "transforms in flight: 1 .. 1024");
@@ -375,7 +402,9 @@ int dtcwt_hip_plan2d_forward(dtcwt_hip_plan2d *p, const float *X, float *Yl, voi
             l = 1;
             continue;
         }
-        if (l == 0) {
+        if (l == 0 && plan_march_fwd1(p)) {
+            rc = dtcwt_march_fwd1(in, lo, (float *)Yh[0], p->batch, L.LR, L.LC, p->biort[0], p->biort[2], p->hint(), s);
+        } else if (l == 0) {
             Fwd1Params q{};
             q.X = in; q.LoLo = lo; q.Yh = (float *)Yh[l];
             q.B = p->batch; q.inR = L.inR; q.inC = L.inC; q.LR = L.LR; q.LC = L.LC;
@@ -453,7 +482,9 @@ int dtcwt_hip_plan2d_inverse(dtcwt_hip_plan2d *p, const float *Yl, const void *c
             }
             break;
         }
-        if (l == 0) {
+        if (l == 0 && plan_march_inv1(p)) {
+            rc = dtcwt_march_inv1(in, (const float *)Yh[0], Z, p->batch, L.LR, L.LC, p->biort[1], p->biort[3], g, p->hint(), s);
+        } else if (l == 0) {
             Inv1Params q{};
             q.Z = in; q.Yh = (const float *)Yh[0]; q.X = Z;
             q.B = p->batch; q.R = L.LR; q.C = L.LC; q.xcd_order = p->xcd_order < 0 ? 1 : p->xcd_order;

@@ -9,6 +9,7 @@
 
 #include "common.hpp"
 #include "march2d.hpp"
+#include "march2d_l1.hpp"
 
 namespace {
 
@@ -36,6 +37,21 @@ int pick_band_rows(int B, int R, int nstrip, int M, int cus) {
         const int64_t jobs = (int64_t)B * nstrip * cdiv(R, br);
         const int64_t rounds = (jobs + slots - 1) / slots;
         const double cost = (double)rounds * (br / 2 + 0.45 * (M - 2));
+        if (cost < best_cost * 0.999) { best_cost = cost; best = br; }
+    }
+    return best;
+}
+// the level-1 marches (march2d_l1.hpp): bands in multiples of `quant` rows (the forward runs whole periods of its register
+// ring: 2 x (HH + 1) rows), `warm` extra steps per band (the inverse reads (HM + 1) / 2 record rows above and below)
+int pick_band_rows_l1(int B, int R, int nstrip, int quant, double warm, int cus) {
+    if (const char *e = getenv("DTCWT_HIP_MARCH_BAND")) { const int v = atoi(e) / quant * quant; if (v >= quant) return v; }
+    const int64_t slots = (int64_t)cus * 8;
+    int best = quant; double best_cost = 1e30;
+    for (int br = quant; br <= 640; br += quant) {
+        if (br < 16) continue;
+        const int64_t jobs = (int64_t)B * nstrip * cdiv(R, br);
+        const int64_t rounds = (jobs + slots - 1) / slots;
+        const double cost = (double)rounds * (br / 2 + warm);
         if (cost < best_cost * 0.999) { best_cost = cost; best = br; }
     }
     return best;
@@ -164,5 +180,85 @@ int dtcwt_march_fwd12(const float *X, float *Yh0, float *Yh1, float *LoLo2, int 
         if (m0 == 5 && m1 == 7) return launch_fwd12<5, 7, 10>(p, hint, s);
         if (m0 == 5 && m1 == 3) return launch_fwd12<5, 3, 10>(p, hint, s);
     }
+    return -3;
+}
+
+// ---- level 1 alone as a march (march2d_l1.hpp): the biort sets the fused launches above are not built for --------------
+// forward: (len h0o, len h1o) = (13, 19) near_sym_b, (9, 7) antonini; inverse: (len g0o, len g1o) = (19, 13), (7, 9)
+static bool l1_sizes_ok(int batch, int rows, int cols, int VL) {
+    if (rows % 2 || cols % 4 || rows < 32 || cols < 32) return false;
+    if ((int64_t)rows * cols * 4 >= ((int64_t)1 << 31)) return false;
+    if ((int64_t)cdiv(cols, 4 * VL) * cdiv(rows, 8) * batch >= ((int64_t)1 << 30)) return false;
+    return true;
+}
+static bool l1_pays(int batch, int rows, int cols, int VL, const DtMarchHint &h) {
+    const int nstrip = cdiv(cols, 4 * VL);
+    const double useful = (double)batch * rows * cols * ((double)cols / (nstrip * 4.0 * VL));
+    return useful >= kCrossover[h.nparts > 1 ? 2 : (h.in_flight > 1 ? 1 : 0)].useful_pixels;
+}
+
+bool dtcwt_march_fwd1_ok(int batch, int rows, int cols, const std::vector<double> &h0o, const std::vector<double> &h1o,
+                         const DtMarchHint &hint) {
+    const int m0 = (int)h0o.size(), m1 = (int)h1o.size();
+    if (!((m0 == 13 && m1 == 19) || (m0 == 9 && m1 == 7))) return false;
+    if (!symmetric(h0o) || !symmetric(h1o)) return false;
+    const int VL = m0 == 13 ? dtm::Fwd1m<13, 19>::VL : dtm::Fwd1m<9, 7>::VL;
+    if (!l1_sizes_ok(batch, rows, cols, VL)) return false;
+    const int mm = march_mode(hint);
+    // antonini (9 / 7 taps): the tile programs re-filter 8 halo rows per 32-row tile only, and the march measured no faster
+    // (4096^2 forward 67 against 63.5 us alone, the step 0.240 against 0.250 ms with four in flight: profiles/r05/level1_march.txt)
+    // -- it runs where the caller pins the marching program, near_sym_b wherever it pays
+    return mm > 0 || (mm < 0 && m0 == 13 && l1_pays(batch, rows, cols, VL, hint));
+}
+
+template <int M0, int M1, int P>
+static int launch_fwd1m(dtm::Fwd1mParams &p, const DtMarchHint &hint, hipStream_t s) {
+    using G = dtm::Fwd1m<M0, M1>;
+    const int nstrip = cdiv(p.C, 4 * G::VL);
+    const unsigned jobs = dtm::dtm_set_jobs(p.jb, p.B, p.R, nstrip, pick_band_rows_l1(p.B * hint.in_flight, p.R, nstrip, 2 * G::PER, 0.5 * G::HH, hint.cus));
+    dtm::k_fwd1m<M0, M1, P><<<jobs, 64, 0, s>>>(p);
+    return 0;
+}
+
+int dtcwt_march_fwd1(const float *X, float *LoLo, float *Yh0, int B, int R, int C, const std::vector<double> &h0o,
+                     const std::vector<double> &h1o, const DtMarchHint &hint, hipStream_t s) {
+    dtm::Fwd1mParams p{};
+    p.X = X; p.LoLo = LoLo; p.Yh0 = Yh0; p.B = B; p.R = R; p.C = C;
+    const int m0 = (int)h0o.size(), m1 = (int)h1o.size();
+    dtm::dtm_pack_fwd1m(p, m0, m1, h0o.data(), h1o.data());
+    if (m0 == 13 && m1 == 19) return launch_fwd1m<13, 19, 2>(p, hint, s);
+    if (m0 == 9 && m1 == 7) return launch_fwd1m<9, 7, 1>(p, hint, s);
+    return -3;
+}
+
+bool dtcwt_march_inv1_ok(int batch, int rows, int cols, const std::vector<double> &g0o, const std::vector<double> &g1o,
+                         const DtMarchHint &hint) {
+    const int m0 = (int)g0o.size(), m1 = (int)g1o.size();
+    if (!((m0 == 19 && m1 == 13) || (m0 == 7 && m1 == 9))) return false;
+    if (!symmetric(g0o) || !symmetric(g1o)) return false;
+    const int VL = m0 == 19 ? dtm::Inv1m<19, 13>::VL : dtm::Inv1m<7, 9>::VL;
+    if (!l1_sizes_ok(batch, rows, cols, VL)) return false;
+    const int mm = march_mode(hint);
+    return mm > 0 || (mm < 0 && m0 == 19 && l1_pays(batch, rows, cols, VL, hint));        // (antonini: see the forward)
+}
+
+template <int M0, int M1>
+static int launch_inv1m(dtm::Inv1mParams &p, const DtMarchHint &hint, hipStream_t s) {
+    using G = dtm::Inv1m<M0, M1>;
+    const int nstrip = cdiv(p.C, 4 * G::VL);
+    const unsigned jobs = dtm::dtm_set_jobs(p.jb, p.B, p.R, nstrip, pick_band_rows_l1(p.B * hint.in_flight, p.R, nstrip, 4, 2.0 * G::WARM, hint.cus));
+    dtm::k_inv1m<M0, M1><<<jobs, 64, 0, s>>>(p);
+    return 0;
+}
+
+int dtcwt_march_inv1(const float *Z, const float *Yh0, float *X, int B, int R, int C, const std::vector<double> &g0o,
+                     const std::vector<double> &g1o, const float *gain1, const DtMarchHint &hint, hipStream_t s) {
+    dtm::Inv1mParams p{};
+    p.Z = Z; p.Yh0 = Yh0; p.X = X; p.B = B; p.R = R; p.C = C;
+    for (int d = 0; d < 6; ++d) p.g1[d] = gain1[d];
+    const int m0 = (int)g0o.size(), m1 = (int)g1o.size();
+    dtm::dtm_pack_inv1m(p, m0, m1, g0o.data(), g1o.data());
+    if (m0 == 19 && m1 == 13) return launch_inv1m<19, 13>(p, hint, s);
+    if (m0 == 7 && m1 == 9) return launch_inv1m<7, 9>(p, hint, s);
     return -3;
 }

@@ -141,6 +141,7 @@ SIGNATURES = {
     'dtcwt_hip_plan2d_launches': (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     'dtcwt_hip_plan2d_set_concurrency': (_i, [_vp, _i]),
     'dtcwt_hip_plan2d_set_program': (_i, [_vp, _i]),
+    'dtcwt_hip_plan2d_level1_march': (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     'dtcwt_hip_plan3d_create': (_i, [_vp, _i64, _i64, _i64, _i, _i, ctypes.POINTER(_pd), ctypes.POINTER(_i),
                                      ctypes.POINTER(_pd), ctypes.POINTER(_i), ctypes.POINTER(_vp)]),
     'dtcwt_hip_plan3d_destroy': (_i, [_vp]),

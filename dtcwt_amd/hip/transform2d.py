@@ -159,6 +159,13 @@ class _Plan2d(object):
         check(self._lib.dtcwt_hip_plan2d_launches(self._h, ctypes.byref(a), ctypes.byref(b)))
         return bool(a.value), bool(b.value)
 
+    def level1_march(self):
+        """(level 1 of the forward as a marching launch of its own?, of the inverse?) -- near_sym_b and antonini, whose
+        filters are too long for the fused levels 1 + 2 (``dtcwt_hip_plan2d_level1_march``)."""
+        a, b = ctypes.c_int(0), ctypes.c_int(0)
+        check(self._lib.dtcwt_hip_plan2d_level1_march(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return bool(a.value), bool(b.value)
+
     def __del__(self):
         # The plan dereferences its context when it is destroyed.  When both die in one garbage
         # cycle (typically at interpreter exit) the finalisers run in arbitrary order: if the

@@ -31,7 +31,7 @@ extern "C" {
 
 /* 2: plan1d_*, plan3d_*, mgpu_* (round 2), mgpu_forward2d_scales, host_alloc / host_free / memcpy_*_async (round 3)
  * 3: plan2d_launches, plan2d_set_concurrency, mgpu_scatter_async / gather_async;  4: ctx_create_partition (round 4)
- * 5: plan2d_set_program, mgpu_create_lane, mgpu_shares, to_float kinds 9 / 10 (round 5) */
+ * 5: plan2d_set_program, plan2d_level1_march, mgpu_create_lane, mgpu_shares, to_float kinds 9 / 10 (round 5) */
 #define DTCWT_HIP_ABI_VERSION 5
 
 #define DTCWT_HIP_F32 0
@@ -359,6 +359,10 @@ int dtcwt_hip_plan2d_kernel_ms(dtcwt_hip_plan2d *plan, float *fwd_ms, float *inv
  * *inv21 = 1 likewise for levels 2 + 1 of the inverse (:242-293).  kernel_ms() then reports the shared launch under
  * the level it starts with (fwd_ms[0], inv_ms[1]) and an empty event pair under the other.  Either pointer may be NULL. */
 int dtcwt_hip_plan2d_launches(const dtcwt_hip_plan2d *plan, int *fwd12, int *inv21);
+/* (ABI 5) *fwd1 / *inv1 = 1 when level 1 of the forward / inverse runs as a marching launch of its own (near_sym_b's 13 / 19
+ * taps and antonini's 9 / 7 need a window the fused launch above has no registers for; dtcwt_amd/csrc/march2d_l1.hpp); the
+ * levels >= 2 then stay with the tile programs.  Same choice rules and pin as dtcwt_hip_plan2d_launches. */
+int dtcwt_hip_plan2d_level1_march(const dtcwt_hip_plan2d *plan, int *fwd1, int *inv1);
 /* How many independent transforms the caller keeps in flight on this device at a time (this plan's included; other
  * plans on other streams -- the images of a video, the members of a batch handed over one by one; default 1).  The
  * marching launches cut an image into bands of rows, each of which re-reads the rows its filters reach into above

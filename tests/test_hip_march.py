@@ -59,6 +59,65 @@ def test_march_matches_tile_programs_and_oracle(shape, band, monkeypatch):
     assert_close(z1, to.inverse(want, gm), INV_TOL, 'inverse')
 
 
+L1_SHAPES = [(64, 64), (256, 320), (96, 1036), (520, 236), (1024, 232), (200, 464), (44, 940), (62, 468), (40, 224)]
+
+
+@pytest.mark.parametrize('shape', L1_SHAPES)
+@pytest.mark.parametrize('bn,qn', [('near_sym_b', 'qshift_b'), ('antonini', 'qshift_a'), ('near_sym_b', 'qshift_d')])
+@pytest.mark.parametrize('band', [None, 20, 40])
+def test_level1_march_matches_tile_programs_and_oracle(shape, bn, qn, band, monkeypatch):
+    """Level 1 alone as a marching launch (march2d_l1.hpp: near_sym_b's 13 / 19 taps, antonini's 9 / 7) against the tile
+    programs it replaces and against the oracle, at sizes that put strip and band boundaries, the three mirrored halo lanes
+    and the reflected rows everywhere (rows not a multiple of 4 included: level 1 needs even rows only), with gains."""
+    rs = np.random.RandomState(15)
+    X = rs.standard_normal(shape).astype(np.float32)
+    nl = 2 if min(shape) < 160 else 3
+    gm = rs.uniform(0.3, 1.4, size=(6, nl)) * (rs.uniform(size=(6, nl)) > 0.2)
+    tt, tm = Transform2d(bn, qn, program='tiles'), Transform2d(bn, qn, program='march')
+    if band:
+        monkeypatch.setenv('DTCWT_HIP_MARCH_BAND', str(band))
+    assert tt.plan(1, shape[0], shape[1], nl).level1_march() == (False, False)
+    assert tm.plan(1, shape[0], shape[1], nl).level1_march() == (True, True)
+    assert tm.plan(1, shape[0], shape[1], nl).launches() == (False, False)        # the fused levels 1 + 2 are not built for these
+    p0, p1 = tt.forward(X, nlevels=nl, include_scale=True), tm.forward(X, nlevels=nl, include_scale=True)
+    assert_close(p1.lowpass, p0.lowpass, 1e-6, 'Yl march vs tiles')
+    for a, b in zip(p1.highpasses, p0.highpasses):
+        assert_close(a, b, 1e-6, 'Yh march vs tiles')
+    assert_close(p1.scales[0], p0.scales[0], 1e-6, 'level-1 lowpass march vs tiles')
+    to = o.Transform2d(biort(bn), qshift(qn))
+    want = to.forward(as_f64(X), nlevels=nl, include_scale=True)
+    assert_pyramids_close(p1, want, XFM_TOL, same_dtype=False)
+    pw = Pyramid(np.asarray(want.lowpass, np.float32), tuple(np.asarray(y, np.complex64) for y in want.highpasses))
+    z0, z1 = tt.inverse(pw, gm), tm.inverse(pw, gm)
+    assert_close(z1, z0, 1e-6, 'inverse march vs tiles')
+    assert_close(z1, to.inverse(want, gm), INV_TOL, 'inverse')
+    assert_close(tm.inverse(p1), X, INV_TOL, 'reconstruction')
+
+
+def test_level1_march_on_a_batch_and_where_it_is_chosen(monkeypatch):
+    monkeypatch.delenv('DTCWT_HIP_MARCH', raising=False)
+    t = Transform2d('near_sym_b', 'qshift_b')
+    assert t.plan(1, 512, 512, 3).level1_march() == (False, False)             # below the crossover: the tile programs
+    assert t.plan(1, 2048, 2048, 4).level1_march() == (True, True)
+    assert t.plan(1, 2047, 2048, 4).level1_march() == (False, False)           # odd-size extension: tiles
+    assert t.plan(1, 2048, 2046, 4).level1_march() == (False, False)           # columns in fours
+    assert Transform2d('near_sym_b_bp', 'qshift_b_bp').plan(1, 2048, 2048, 3).level1_march() == (False, False)
+    assert Transform2d().plan(1, 2048, 2048, 4).level1_march() == (False, False)       # near_sym_a: the fused levels 1 + 2
+    rs = np.random.RandomState(16)
+    X = rs.standard_normal((5, 160, 476)).astype(np.float32)
+    tm = Transform2d('near_sym_b', 'qshift_b', program='march')
+    to = o.Transform2d(biort('near_sym_b'), qshift('qshift_b'))
+    p = tm.forward_channels(X, 'nhw', nlevels=3)
+    for b in (0, 4):
+        want = to.forward(as_f64(X[b]), nlevels=3)
+        assert_close(p.lowpass[b], want.lowpass, XFM_TOL, 'Yl')
+        for l in range(3):
+            assert_close(p.highpasses[l][b], want.highpasses[l], XFM_TOL, 'Yh[%d]' % l)
+    single = tm.forward(X[3], nlevels=3)
+    assert np.array_equal(single.highpasses[0], p.highpasses[0][3]) and np.array_equal(single.lowpass, p.lowpass[3])
+    assert_close(tm.inverse_channels(p, 'nhw'), X, INV_TOL, 'reconstruction')
+
+
 def test_march_on_a_batch_and_other_level1_filters(monkeypatch):
     monkeypatch.setenv('DTCWT_HIP_MARCH', '1')              # wherever it applies, not only where it pays
     monkeypatch.setenv('DTCWT_HIP_MARCH_INV', '1')

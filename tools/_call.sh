@@ -1,14 +1,14 @@
-cd $GRAFT_REPO_ROOT; O=gpurun_out/r05d; mkdir -p $O
-timeout 1500 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.txt 2>&1; tail -8 $O/pytest_gpu.txt
-cp gpurun_out/parity_worst.json $O/ 2>/dev/null
-python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > $O/bench_default.json 2>$O/bench_default.err
-python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --mgpu > $O/bench_mgpu.json 2>$O/bench_mgpu.err
-python bench.py --gpus 1 --steps 300 --warmup 5 --no-cpu-baseline --mgpu > $O/bench_mgpu_300.json 2>>$O/bench_mgpu.err
-python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --mgpu --config c5 > $O/bench_mgpu_c5.json 2>>$O/bench_mgpu.err
-python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs --config c5 > $O/bench_c5.json 2>>$O/bench_default.err
-for f in bench_default bench_mgpu bench_mgpu_300 bench_mgpu_c5 bench_c5; do python -c "
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r05f; mkdir -p $O
+timeout 1500 python -m pytest tests/test_hip_march.py -x -q -m gpu -k "level1" > $O/pytest_l1.txt 2>&1; tail -5 $O/pytest_l1.txt
+for w in "near_sym_b qshift_b" "near_sym_b qshift_d"; do set -- $w
+for prog in 0 1; do
+  echo "== $1 $2 DTCWT_HIP_MARCH=$prog"
+  DTCWT_HIP_MARCH=$prog python bench.py --biort $1 --qshift $2 --steps 60 --no-cpu-baseline --no-other-configs 2>/dev/null | python -c "
 import json,sys
-d=json.loads(open('$O/$f.json').read().strip().splitlines()[-1])
-print('$f', d['ms_per_step'], d.get('sustained_ms_per_step'), d.get('one_stream_ms_per_step'), d['recon_max_abs_err'], d['config'].get('cu_partition'))
-"; done
-tail -3 $O/bench_mgpu.err
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
+print(d['ms_per_step'], d['sustained_ms_per_step'], d['one_stream_ms_per_step'], r['step_frac'], r['fwd_kernel_ms'], r['inv_kernel_ms'], d['recon_max_abs_err'])"
+done; done 2>&1 | tee $O/bench_l1.txt
+for br in 20 40 60 80 120 160; do echo "band $br: $(DTCWT_HIP_MARCH_BAND=$br python bench.py --biort near_sym_b --qshift qshift_b --steps 40 --streams 1 --no-cpu-baseline --no-other-configs 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
+print(d['one_stream_ms_per_step'], r['fwd_kernel_ms'][0], r['inv_kernel_ms'][0])")"; done 2>&1 | tee $O/band_l1.txt
