@@ -9,6 +9,7 @@
 #include "fused2d_table.hpp"
 #include "fused3d_tiles.hpp"
 #include "fused3d_inv_tiles.hpp"
+#include "fused3d_march.hpp"
 
 using namespace dt3d;
 
@@ -233,6 +234,37 @@ void put_centred(float *dst, const double *src, int m, int to) {
 
 #define DT_FWD3_L1_TABLE(X) X(5, 7) X(9, 7) X(7, 5) X(7, 9)
 
+// Level 1 as a marching pair of wavefronts (fused3d_march.hpp): filters of at most 7 taps (near_sym_a, legall), rows of
+// axis 2 in fours and wide enough to fill most of a strip's lanes; DTCWT_HIP_FWD3_MARCH=0 / =1 forces the tile program / the
+// march wherever it applies.
+static bool fwd3m_ok(int64_t n0, int64_t n1, int64_t n2, int m0, int m1) {
+    const int mode = [] { const char *e = getenv("DTCWT_HIP_FWD3_MARCH"); return e ? atoi(e) : -1; }();    // read per call: the tests switch it
+    if (mode == 0 || m0 > 7 || m1 > 7 || m0 % 2 == 0 || m1 % 2 == 0) return false;
+    if (n2 % 4 || n0 % 2 || n1 % 2 || n0 < 8 || n1 < 8 || n2 < 16) return false;
+    if (n0 * n1 * n2 * 4 >= ((int64_t)1 << 31)) return false;          // 32-bit byte offsets inside the volume
+    if (mode == 1) return true;
+    const int nstrip = dt3m::fwd3m_nstrip((int)n2);
+    return (double)(n2 / 4) / (64.0 * nstrip) >= 0.7;                   // lanes that own columns
+}
+static int launch_fwd3m(const float *X, float *LLL, float *Yh, int n0, int n1, int n2, const double *h0, int m0,
+                        const double *h1, int m1, int cus, hipStream_t s) {
+    dt3m::Fwd3mParams p{};
+    p.X = X; p.LLL = LLL; p.Yh = Yh; p.n0 = n0; p.n1 = n1; p.n2 = n2;
+    p.nstrip = dt3m::fwd3m_nstrip(n2); p.nrp = n1 / 2;
+    // slices per job: long marches amortise the six warm-up slices (loads + the axis-1 pass only), but a launch should
+    // fill the wave slots (four pairs per CU)
+    int chunk = 64;
+    while (chunk > 8 && (int64_t)p.nstrip * p.nrp * cdiv(n0, chunk) < 4 * (int64_t)cus) chunk /= 2;
+    if (const char *e = getenv("DTCWT_HIP_FWD3_CHUNK")) { const int v = atoi(e) / 8 * 8; if (v >= 8) chunk = v; }
+    p.chunk = chunk; p.nchunk = cdiv(n0, chunk);
+    dt3m::pack_fwd3m(p, h0, m0, h1, m1);
+    const int per = (p.nrp + 7) / 8;
+    const int occ = [] { const char *e = getenv("DTCWT_HIP_FWD3_OCC"); return e ? atoi(e) : 1; }();
+    if (occ == 2) dt3m::k_fwd3m_l1<5, 7, 2><<<(unsigned)(8 * per * p.nstrip * p.nchunk), 128, 0, s>>>(p);
+    else dt3m::k_fwd3m_l1<5, 7, 1><<<(unsigned)(8 * per * p.nstrip * p.nchunk), 128, 0, s>>>(p);
+    return 0;
+}
+
 extern "C" int dtcwt_hip_fwd3_level1(dtcwt_hip_ctx *ctx, const float *X, int64_t n0, int64_t n1, int64_t n2,
                                      const double *h0o, int m0, const double *h1o, int m1, float *LLL,
                                      float *Yh) {
@@ -246,10 +278,16 @@ extern "C" int dtcwt_hip_fwd3_level1(dtcwt_hip_ctx *ctx, const float *X, int64_t
     p.X = X; p.LLL = LLL; p.Yh = Yh;
     p.n0 = (int)n0; p.n1 = (int)n1; p.n2 = (int)n2;
     put_taps(p.h0, h0o, m0); put_taps(p.h1, h1o, m1);
+    const int m0_in = m0, m1_in = m1;
     // 3-tap filters (legall) run as centred zero-padded 7-tap ones on the 5/7 kernels
     if (m0 == 5 && m1 == 3) { put_centred(p.h1, h1o, 3, 7); m1 = 7; }
     if (m0 == 3 && m1 == 5) { put_centred(p.h0, h0o, 3, 7); m0 = 7; }
     DT_CHECK_HIP(hipSetDevice(ctx->device));
+    if (fwd3m_ok(n0, n1, n2, m0_in, m1_in)) {
+        launch_fwd3m(X, LLL, Yh, (int)n0, (int)n1, (int)n2, h0o, m0_in, h1o, m1_in, ctx->cus, ctx->stream);
+        DT_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
 #define X_(A, B)                                                                           \
     if (m0 == A && m1 == B) {                                                              \
         launch_fwd3_l1<Fwd3L1Cfg<A, B>>(p, ctx->cus, ctx->stream);                         \

@@ -7,7 +7,7 @@ from oracle import dtcwt_oracle as o
 from dtcwt_amd.coeffs import biort, qshift
 from dtcwt_amd.hip import Transform1d, Transform3d, Pyramid
 from tests import _golden as G
-from tests._hip import assert_close, assert_pyramids_close, XFM_TOL, INV_TOL, F64_TOL
+from tests._hip import assert_close, assert_pyramids_close, as_f64, XFM_TOL, INV_TOL, F64_TOL
 
 pytestmark = pytest.mark.gpu
 
@@ -216,6 +216,30 @@ def test_3d_fused_level1_matches_generic_and_oracle(shape, bname):
         z = t.inverse(p)
         assert_close(z, X, INV_TOL, 'PR')
         assert_close(z, g.inverse(p), INV_TOL, 'fused vs generic inverse')
+
+
+@pytest.mark.parametrize('shape', [(8, 8, 16), (14, 10, 72), (40, 12, 252), (26, 34, 256), (10, 8, 260), (18, 6, 520), (72, 20, 128),
+                                   (16, 130, 64)])
+@pytest.mark.parametrize('bname', ['near_sym_a', 'legall'])
+def test_3d_level1_march_matches_tile_program_and_oracle(shape, bname, monkeypatch):
+    """k_fwd3m_l1 (fused3d_march.hpp: level 1 as a marching pair of wavefronts) against the tile program k_fwd3_l1 and the
+    oracle: one strip with and without idle lanes (16 .. 256 columns), two and three strips (260, 520: halo lanes at the
+    interior boundaries, the mirror columns taken in-lane at the faces), slice counts that are not whole chunks or ring
+    periods, both wavefront occupancies."""
+    X = np.random.RandomState(31).standard_normal(shape).astype(np.float32)
+    t = Transform3d(biort=bname)
+    monkeypatch.setenv('DTCWT_HIP_FWD3_MARCH', '0')
+    p0 = t.forward(X, nlevels=1)
+    monkeypatch.setenv('DTCWT_HIP_FWD3_MARCH', '1')
+    for occ, chunk in (('1', None), ('2', '8')):
+        monkeypatch.setenv('DTCWT_HIP_FWD3_OCC', occ)
+        if chunk:
+            monkeypatch.setenv('DTCWT_HIP_FWD3_CHUNK', chunk)
+        p1 = t.forward(X, nlevels=1)
+        assert_pyramids_close(p1, p0, XFM_TOL)
+        want = o.Transform3d(biort(bname), qshift('qshift_a')).forward(as_f64(X), nlevels=1)
+        assert_pyramids_close(p1, want, XFM_TOL, same_dtype=False)
+        assert_close(t.inverse(p1), X, INV_TOL, 'PR')
 
 
 @pytest.mark.parametrize('shape,ext', [((42, 46, 90), 4), ((44, 52, 84), 8), ((80, 80, 80), 4), ((48, 40, 200), 8)])
