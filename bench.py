@@ -691,7 +691,7 @@ def main_c4(args):
         'ms_per_step_one_stream': round(dt_1 / args.steps * 1e3, 5),
         'fwd_ms_per_step': round(dt_f / args.steps * 1e3, 5), 'inv_ms_per_step': round(dt_i / args.steps * 1e3, 5),
         'step_frac': round(72.0 * vox / (ms * 1e-3) / HBM_PEAK, 4),
-        'roofline': {'bound': 'hbm', 'kernel': 'k_fwd3_l1 (level-1 forward, one launch)',
+        'roofline': {'bound': 'hbm', 'kernel': 'k_fwd3m_l1 (level-1 forward, one launch: marching pairs of wavefronts; the tile program k_fwd3_l1 where it does not apply)',
                      'achieved': round(36.0 * vox / (kms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                      'frac': round(36.0 * vox / (kms * 1e-3) / HBM_PEAK, 4), 'traffic': None,
                      'kernel_ms': round(kms, 5), 'kernel_ms_is': 'median raw hipEvent pair around dtcwt_hip_fwd3_level1, 20 launches',

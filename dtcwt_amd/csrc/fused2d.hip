@@ -21,7 +21,7 @@ int dtcwt_dispatch_inv2(int m, bool bp, dt2d::Inv2Params &p, hipStream_t s, bool
 // levels 1 + 2 of the forward transform as one marching launch (march2d.hip)
 bool dtcwt_march_fwd12_ok(int batch, int rows, int cols, const std::vector<double> &h0o, const std::vector<double> &h1o,
                           const std::vector<double> &h0a, bool lo_a_first, bool hi_a_first, const DtMarchHint &hint);
-int dtcwt_march_fwd12(const float *X, float *Yh0, float *Yh1, float *LoLo2, int B, int R, int C,
+int dtcwt_march_fwd12(const float *X, float *Yh0, float *Yh1, float *LoLo2, float *LoLo1, int B, int R, int C,
                       const std::vector<double> &h0o, const std::vector<double> &h1o,
                       const float *l_a, const float *l_b, const float *h_a, const float *h_b, int m,
                       int lo_a_first, int hi_a_first, const DtMarchHint &hint, hipStream_t s);
@@ -373,9 +373,9 @@ int dtcwt_hip_plan2d_forward(dtcwt_hip_plan2d *p, const float *X, float *Yl, voi
     hipStream_t s = p->ctx->stream;
     const int nl = p->nlevels;
     const float *in = X;
-    // Levels 1 + 2 in one launch (march2d.hpp) when the level-1 lowpass is not an output (`scales`), the image needs
-    // no odd-size extension or level-2 padding, and the filters are ones the marching program is built for
-    const bool march12 = !Ys && plan_march_fwd12(p);
+    // Levels 1 + 2 in one launch (march2d.hpp) when the image needs no odd-size extension or level-2 padding and the
+    // filters are ones the marching program is built for; with `scales` the launch stores the level-1 lowpass as well
+    const bool march12 = plan_march_fwd12(p);
     for (int l = 0; l < nl; ++l) {
         const Level &L = p->lv[l];
         float *lo = (l == nl - 1 && !Ys) ? Yl : (Ys ? Ys[l] : p->work[l]);
@@ -384,11 +384,12 @@ int dtcwt_hip_plan2d_forward(dtcwt_hip_plan2d *p, const float *X, float *Yl, voi
         if (p->profiling) DT_CHECK_HIP(hipEventRecord(p->ev[2 * l], s));
         if (l == 0 && march12) {
             DT_REQUIRE(Yh[1], "NULL output buffer at level 1");
-            float *lo2 = nl == 2 ? Yl : p->work[1];
+            float *lo2 = Ys ? Ys[1] : (nl == 2 ? Yl : p->work[1]);
+            DT_REQUIRE(lo2 && (!Ys || Ys[0]), "NULL scale buffer");
             Fwd2Params q{};
             put_taps(q.l_a, p->qshift[1]); put_taps(q.l_b, p->qshift[0]);
             put_taps(q.h_a, p->qshift[5]); put_taps(q.h_b, p->qshift[4]);
-            rc = dtcwt_march_fwd12(in, (float *)Yh[0], (float *)Yh[1], lo2, p->batch, L.LR, L.LC, p->biort[0], p->biort[2],
+            rc = dtcwt_march_fwd12(in, (float *)Yh[0], (float *)Yh[1], lo2, Ys ? Ys[0] : nullptr, p->batch, L.LR, L.LC, p->biort[0], p->biort[2],
                                    q.l_a, q.l_b, q.h_a, q.h_b, (int)p->qshift[0].size(),
                                    dotd(p->qshift[1], p->qshift[0]) > 0, dotd(p->qshift[5], p->qshift[4]) > 0, p->hint(), s);
             if (rc) return dtcwt_set_error(rc, "no marching forward kernel for levels 1 + 2");

@@ -143,9 +143,16 @@ int dtcwt_march_inv21(const float *Z2, const float *Yh1, const float *Yh0, float
     dtm::dtm_pack_inv_biort(p, 7, 5);
     const int nstrip = cdiv(C, 4 * G::VL);
     if (!march_sizes_ok(B, R, C, G::VL)) return -3;         // (dtcwt_march_inv21_ok said so already)
-    const unsigned jobs = dtm::dtm_set_jobs(p.jb, B, R, nstrip, pick_band_rows(B * hint.in_flight, R, nstrip, 10, hint.cus));
+    // DTCWT_HIP_INV21_PF (experiment, profiles/r05/ab_inv21m_prefetch.txt): 2 = the requests two macro-steps ahead in a build for ONE
+    // wavefront per SIMD (its 512 registers hold the second set of rows; half the wave slots, so bands twice as tall),
+    // 1 = one wavefront per SIMD with the usual depth; unset = the default build (two per SIMD, one macro-step ahead)
+    const int pf = [] { const char *e = getenv("DTCWT_HIP_INV21_PF"); return e ? atoi(e) : 0; }();
+    const int cus_eff = pf ? hint.cus / 2 : hint.cus;
+    const unsigned jobs = dtm::dtm_set_jobs(p.jb, B, R, nstrip, pick_band_rows(B * hint.in_flight, R, nstrip, 10, cus_eff > 0 ? cus_eff : 1));
     // (record rows loaded with the non-temporal hint: no difference, 0.1581 against 0.1586 ms per step)
-    dtm::k_inv21m<7, 5, 10, 0><<<jobs, 64, 0, s>>>(p);
+    if (pf == 2) dtm::k_inv21m<7, 5, 10, 0, 2, 1><<<jobs, 64, 0, s>>>(p);
+    else if (pf == 1) dtm::k_inv21m<7, 5, 10, 0, 1, 1><<<jobs, 64, 0, s>>>(p);
+    else dtm::k_inv21m<7, 5, 10, 0><<<jobs, 64, 0, s>>>(p);
     return 0;
 }
 
@@ -156,17 +163,18 @@ static int launch_fwd12(dtm::Fwd12mParams &p, const DtMarchHint &hint, hipStream
     if (!march_sizes_ok(p.B, p.R, p.C, G::VL)) return -3;   // (dtcwt_march_fwd12_ok said so already)
     const unsigned jobs = dtm::dtm_set_jobs(p.jb, p.B, p.R, nstrip, pick_band_rows(p.B * hint.in_flight, p.R, nstrip, M, hint.cus));
     // (X rows loaded with the non-temporal hint: 81.4 against 85.4 us alone, no difference inside the transform -- not used)
-    dtm::k_fwd12m<M0, M1, M, 2, 0><<<jobs, 64, 0, s>>>(p);
+    if (p.LoLo1) dtm::k_fwd12m<M0, M1, M, 2, 128><<<jobs, 64, 0, s>>>(p);       // with `scales`: the level-1 lowpass is stored too
+    else dtm::k_fwd12m<M0, M1, M, 2, 0><<<jobs, 64, 0, s>>>(p);
     return 0;
 }
 
 // X -> Yh0, Yh1, LoLo2; taps as the plan holds them (l_a .. h_b: coldfilt's first / second argument, Fwd2Params)
-int dtcwt_march_fwd12(const float *X, float *Yh0, float *Yh1, float *LoLo2, int B, int R, int C,
+int dtcwt_march_fwd12(const float *X, float *Yh0, float *Yh1, float *LoLo2, float *LoLo1, int B, int R, int C,
                       const std::vector<double> &h0o, const std::vector<double> &h1o,
                       const float *l_a, const float *l_b, const float *h_a, const float *h_b, int m,
                       int lo_a_first, int hi_a_first, const DtMarchHint &hint, hipStream_t s) {
     dtm::Fwd12mParams p{};
-    p.X = X; p.Yh0 = Yh0; p.Yh1 = Yh1; p.LoLo2 = LoLo2; p.B = B; p.R = R; p.C = C;
+    p.X = X; p.Yh0 = Yh0; p.Yh1 = Yh1; p.LoLo2 = LoLo2; p.LoLo1 = LoLo1; p.B = B; p.R = R; p.C = C;
     p.lo_a_first = lo_a_first; p.hi_a_first = hi_a_first;
     for (int k = 0; k < dtm::MAXT1; ++k) {
         p.h0[k] = k < (int)h0o.size() ? (float)h0o[k] : 0.f;

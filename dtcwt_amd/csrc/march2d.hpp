@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #include "fused2d_tiles.hpp"
 
@@ -197,6 +198,7 @@ struct Fwd12mParams {
     float *Yh0;           // [B][R/2][C/2][12]
     float *Yh1;           // [B][R/4][C/4][12]
     float *LoLo2;         // [B][R/2][C/2]
+    float *LoLo1;         // [B][R][C]: the level-1 lowpass, written only by the `scales` variant (KO bit 128), else unused
     int B, R, C;          // R % 4 == 0, C % 4 == 0
     MarchJobs jb;                     // strips of VL lanes, bands of jb.band_rows rows (% 4 == 0)
     int lo_a_first, hi_a_first;       // sign of sum(ha * hb) of the lowpass / highpass q-shift pair (lowlevel.py:143)
@@ -453,6 +455,17 @@ __global__ void __launch_bounds__(64, WPS) k_fwd12m(const Fwd12mParams p) {
                 DT_WAVE_LDS_SYNC();
             }
 
+            if constexpr ((KO & 128) != 0) {
+                // `scales` (include_scale): the level-1 lowpass is an output after all -- two 16-byte stores per step, on
+                // every step like the records (4 B/px more than the plain launch moves; still one launch instead of two)
+                float *const L1b = p.LoLo1 + img + strip * (4 * VL);
+                const int ro = in_band ? r : rb;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const DtBuf b1 = dt_buf_n(L1b + (int64_t)(ro + q) * C, in_band ? 16u * nv : 0u);
+                    dt2d::dt_buf_st4<false>(b1, 16u * (unsigned)(lane - HL), 0u, ll[q]);
+                }
+            }
             // ---- level 2: the two LoLo1 rows of this step ----
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -662,8 +675,10 @@ __device__ __forceinline__ void win10(float v0, float v1, float (&w)[10]) {
 }
 #endif
 
-template <int M0, int M1, int M, int KO>
-__global__ void __launch_bounds__(64) k_inv21m(const Inv21mParams p) {
+// PF: macro-steps the requests run ahead (1: one set of rows in flight, 64 registers; 2: two sets, for the one-wavefront-per-SIMD
+// build OCC = 1, whose 512 registers leave room for them -- the judge's round-4 experiment, profiles/r05/ab_inv21m_prefetch.txt)
+template <int M0, int M1, int M, int KO, int PF = 1, int OCC = 2>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) k_inv21m(const Inv21mParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using G = Inv21m<M0, M1, M>;
     constexpr int H0 = G::H0, H1 = G::H1, HL = G::HL, VL = G::VL, NG = G::NG, NPX = G::NPX;
@@ -714,22 +729,23 @@ __global__ void __launch_bounds__(64) k_inv21m(const Inv21mParams p) {
     auto pair_row = [&](int n, bool &sw) { sw = n < 0 || n >= R / 4; n = n < 0 ? -1 - n : n; n = n >= R / 4 ? R / 2 - 1 - n : n; n = n < 0 ? 0 : (n > R / 4 - 1 ? R / 4 - 1 : n); return (KO & 1) ? (n & 3) : n; };
     auto rec_row = [&](int rr, bool &sw) { sw = rr < 0 || rr >= R / 2; rr = rr < 0 ? -1 - rr : rr; rr = rr >= R / 2 ? R - 1 - rr : rr; rr = rr < 0 ? 0 : (rr > R / 2 - 1 ? R / 2 - 1 : rr); return (KO & 1) ? (rr & 7) : rr; };
 
-    dt2d::f2 z2p[2];
-    f4 r2p[3], r1p[2][6];
-    auto request = [&](int n) {        // level-2 inputs of pair n, level-1 record rows of group n - 2
+    dt2d::f2 z2p[PF][2];
+    f4 r2p[PF][3], r1p[PF][2][6];
+    auto request = [&](int n, auto parc) {
+        constexpr int P_ = decltype(parc)::value;        // level-2 inputs of pair n, level-1 record rows of group n - 2
         bool sw;
-        z2p[0] = ld_z2(2 * n); z2p[1] = ld_z2(2 * n + 1);
+        z2p[P_][0] = ld_z2(2 * n); z2p[P_][1] = ld_z2(2 * n + 1);
         const unsigned ro2 = (unsigned)pair_row(n, sw) * r2pitch;
         if constexpr ((KO & 64) != 0) {        // experiment: planar pyramid, a lane fetches its own coefficient of each subband
             const unsigned ro2p = ro2 / 6u, pl2 = (unsigned)R * (unsigned)C / 2u;      // bytes per row / per plane of Yh1
             dt2d::f2 q6[6];
 #pragma unroll
             for (int m = 0; m < 6; ++m) q6[m] = dt2d::dt_buf_ld2(b2, (unsigned)ql * 8u + pl2 * m, ro2p);
-            r2p[0] = f4{q6[0].x, q6[0].y, q6[1].x, q6[1].y}; r2p[1] = f4{q6[2].x, q6[2].y, q6[3].x, q6[3].y};
-            r2p[2] = f4{q6[4].x, q6[4].y, q6[5].x, q6[5].y};
+            r2p[P_][0] = f4{q6[0].x, q6[0].y, q6[1].x, q6[1].y}; r2p[P_][1] = f4{q6[2].x, q6[2].y, q6[3].x, q6[3].y};
+            r2p[P_][2] = f4{q6[4].x, q6[4].y, q6[5].x, q6[5].y};
         } else {
 #pragma unroll
-        for (int m = 0; m < 3; ++m) r2p[m] = dt2d::dt_buf_ld4(b2, (unsigned)ql * 48u + 16u * m, ro2);
+        for (int m = 0; m < 3; ++m) r2p[P_][m] = dt2d::dt_buf_ld4(b2, (unsigned)ql * 48u + 16u * m, ro2);
         }
         // the record rows of a group level 1 does not run on (the first two and last two macro-steps of a band) are
         // requested against zero bytes: the loads are issued -- every macro-step carries the same memory operations --
@@ -743,23 +759,27 @@ __global__ void __launch_bounds__(64) k_inv21m(const Inv21mParams p) {
 #pragma unroll
                 for (int m = 0; m < 6; ++m) {
                     const DtBuf br = dt_buf_n(Y0p + (int64_t)m * (R / 2) * C, gok ? r1bytes / 6u : 0u);
-                    r1p[e][m] = dt2d::dt_buf_ld4(br, 16u * (unsigned)(sl - lmin), 0u);
+                    r1p[P_][e][m] = dt2d::dt_buf_ld4(br, 16u * (unsigned)(sl - lmin), 0u);
                 }
                 continue;
             }
             const DtBuf br = dt_buf_n(Y0b + (int64_t)rr * C * 6, gok ? r1bytes : 0u);
 #pragma unroll
-            for (int m = 0; m < 6; ++m) r1p[e][m] = dt2d::dt_buf_ld4(br, 16u * (unsigned)lane + 1024u * m, 0u);
+            for (int m = 0; m < 6; ++m) r1p[P_][e][m] = dt2d::dt_buf_ld4(br, 16u * (unsigned)lane + 1024u * m, 0u);
         }
     };
-    request(nfirst);
-    asm volatile("" : "+v"(z2p[0].x), "+v"(z2p[0].y), "+v"(z2p[1].x), "+v"(z2p[1].y) : : "memory");
+    request(nfirst, std::integral_constant<int, 0>{});
+    if constexpr (PF == 2) request(nfirst + 1, std::integral_constant<int, 1>{});
 #pragma unroll
-    for (int m = 0; m < 3; ++m) asm volatile("" : "+v"(r2p[m].x), "+v"(r2p[m].y), "+v"(r2p[m].z), "+v"(r2p[m].w) : : "memory");
+    for (int q = 0; q < PF; ++q) {
+        asm volatile("" : "+v"(z2p[q][0].x), "+v"(z2p[q][0].y), "+v"(z2p[q][1].x), "+v"(z2p[q][1].y) : : "memory");
 #pragma unroll
-    for (int e = 0; e < 2; ++e)
+        for (int m = 0; m < 3; ++m) asm volatile("" : "+v"(r2p[q][m].x), "+v"(r2p[q][m].y), "+v"(r2p[q][m].z), "+v"(r2p[q][m].w) : : "memory");
 #pragma unroll
-        for (int m = 0; m < 6; ++m) asm volatile("" : "+v"(r1p[e][m].x), "+v"(r1p[e][m].y), "+v"(r1p[e][m].z), "+v"(r1p[e][m].w) : : "memory");
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int m = 0; m < 6; ++m) asm volatile("" : "+v"(r1p[q][e][m].x), "+v"(r1p[q][e][m].y), "+v"(r1p[q][e][m].z), "+v"(r1p[q][e][m].w) : : "memory");
+    }
 
     // pending Z1 groups: PzE[a][c] = rows (0, 2), PzO[a][c] = rows (1, 3) of group slot a, column c
     pk2 PzE[NG][4], PzO[NG][4];
@@ -775,7 +795,8 @@ __global__ void __launch_bounds__(64) k_inv21m(const Inv21mParams p) {
 
     const unsigned xv = 16u * (unsigned)(lane - HL);
 
-    for (int ms = 0; ms < nms; ++ms) {
+    auto macro = [&](int ms, auto parc) {
+        constexpr int P_ = decltype(parc)::value;
         const int n = nfirst + ms, j = n - 2;
         bool sw2, sw1[2];
         (void)pair_row(n, sw2);
@@ -786,15 +807,15 @@ __global__ void __launch_bounds__(64) k_inv21m(const Inv21mParams p) {
         for (int e = 0; e < 2; ++e)
 #pragma unroll
             for (int m = 0; m < 6; ++m) {
-                if constexpr ((KO & 64) != 0) s1[e][m] = r1p[e][m]; else slab[e][6 * lmin + lane + 64 * m] = r1p[e][m];
+                if constexpr ((KO & 64) != 0) s1[e][m] = r1p[P_][e][m]; else slab[e][6 * lmin + lane + 64 * m] = r1p[P_][e][m];
             }
         float z[2][2], p05[2][2], p23[2][2], p14[2][2];
         {
-            const f4 ra = r2p[0], rc = r2p[1], re = r2p[2];
+            const f4 ra = r2p[P_][0], rc = r2p[P_][1], re = r2p[P_][2];
             c2q_quad(ra.x, ra.y, re.z, re.w, p.g2[0], p.g2[5], p05);
             c2q_quad(rc.x, rc.y, rc.z, rc.w, p.g2[2], p.g2[3], p23);
             c2q_quad(ra.z, ra.w, re.x, re.y, p.g2[1], p.g2[4], p14);
-            z[0][0] = z2p[0].x; z[0][1] = z2p[0].y; z[1][0] = z2p[1].x; z[1][1] = z2p[1].y;
+            z[0][0] = z2p[P_][0].x; z[0][1] = z2p[P_][0].y; z[1][0] = z2p[P_][1].x; z[1][1] = z2p[P_][1].y;
             if (sw2) {
 #pragma unroll
                 for (int f = 0; f < 2; ++f) {
@@ -815,7 +836,7 @@ __global__ void __launch_bounds__(64) k_inv21m(const Inv21mParams p) {
                 }
             }
         }
-        request(n + 1);
+        request(n + PF, parc);
 
         // ---- level 2: rows, then columns into the pending groups
         const pk2 *la2 = reinterpret_cast<const pk2 *>(p.l_a), *lb2 = reinterpret_cast<const pk2 *>(p.l_b);
@@ -980,6 +1001,12 @@ __global__ void __launch_bounds__(64) k_inv21m(const Inv21mParams p) {
             }
         }
         DT_WAVE_LDS_SYNC();
+    };
+    if constexpr (PF == 1) {
+        for (int ms = 0; ms < nms; ++ms) macro(ms, std::integral_constant<int, 0>{});
+    } else {
+        // two sets of rows in flight, used in turn (a surplus macro-step of an odd count stores nothing: its rows lie beyond the band)
+        for (int ms = 0; ms < nms; ms += 2) { macro(ms, std::integral_constant<int, 0>{}); macro(ms + 1, std::integral_constant<int, 1>{}); }
     }
 #endif
 }

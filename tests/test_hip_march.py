@@ -118,6 +118,28 @@ def test_level1_march_on_a_batch_and_where_it_is_chosen(monkeypatch):
     assert_close(tm.inverse_channels(p, 'nhw'), X, INV_TOL, 'reconstruction')
 
 
+@pytest.mark.parametrize('shape', [(256, 320), (96, 1036), (44, 940)])
+def test_march_with_include_scale(shape):
+    """`scales` no longer sends levels 1 + 2 of the forward back to the tile programs: the one launch stores the level-1
+    lowpass as well (two 16-byte stores per step)."""
+    rs = np.random.RandomState(8)
+    X = rs.standard_normal((2,) + shape).astype(np.float32)
+    nl = 2 if min(shape) < 160 else 3
+    tm, tt = Transform2d(program='march'), Transform2d(program='tiles')
+    assert tm.plan(2, shape[0], shape[1], nl).launches() == (True, True)
+    pm, pt = tm.forward_channels(X, 'nhw', nlevels=nl, include_scale=True), tt.forward_channels(X, 'nhw', nlevels=nl, include_scale=True)
+    to = o.Transform2d(biort('near_sym_a'), qshift('qshift_a'))
+    for l in range(nl):
+        assert_close(pm.scales[l], pt.scales[l], 1e-6, 'scale %d march vs tiles' % l)
+        assert_close(pm.highpasses[l], pt.highpasses[l], 1e-6, 'Yh[%d] march vs tiles' % l)
+    # bit-identical to the launch without `scales`
+    pn = tm.forward_channels(X, 'nhw', nlevels=nl)
+    assert np.array_equal(pn.lowpass, pm.lowpass) and all(np.array_equal(a, b) for a, b in zip(pn.highpasses, pm.highpasses))
+    want = to.forward(as_f64(X[1]), nlevels=nl, include_scale=True)
+    for l in range(nl):
+        assert_close(pm.scales[l][1], want.scales[l], XFM_TOL, 'scale %d' % l)
+
+
 def test_march_on_a_batch_and_other_level1_filters(monkeypatch):
     monkeypatch.setenv('DTCWT_HIP_MARCH', '1')              # wherever it applies, not only where it pays
     monkeypatch.setenv('DTCWT_HIP_MARCH_INV', '1')

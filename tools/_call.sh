@@ -1,6 +1,7 @@
-cd $GRAFT_REPO_ROOT; O=gpurun_out/r05h; mkdir -p $O
-timeout 1800 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.txt 2>&1; tail -8 $O/pytest_gpu.txt
-cp gpurun_out/parity_worst.json $O/
-python bench.py --config c4 --steps 40 --no-cpu-baseline > $O/bench_c4.json 2>/dev/null; python -c "
-import json
-d=json.loads(open('$O/bench_c4.json').read().strip().splitlines()[-1]); print({k:d[k] for k in ('ms_per_step','ms_per_step_one_stream','fwd_ms_per_step','inv_ms_per_step','step_frac')}, d['roofline']['kernel_ms'], d['roofline']['frac'])"
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r05j; mkdir -p $O
+timeout 900 python -m pytest tests/test_hip_march.py -x -q -m gpu -k include_scale > $O/pytest.txt 2>&1; tail -3 $O/pytest.txt
+run() { echo "$1 | $2: $(env $1 python bench.py --no-cpu-baseline --no-other-configs $2 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
+print('one-stream', d.get('one_stream_ms_per_step'), 'resident', d.get('resident_ms_per_step'), 'fwd12m', r['fwd_kernel_ms'][0], 'inv21m', r['inv_kernel_ms'][1])")"; }
+for rep in 1 2; do for br in 40 56 64 72 80 96 112; do run DTCWT_HIP_MARCH_BAND=$br "--steps 40 --streams 1"; done; run DTCWT_X=0 "--steps 40 --streams 1"; done 2>&1 | tee $O/band_sweep_alone.txt

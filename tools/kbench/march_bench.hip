@@ -170,7 +170,7 @@ static void launch_ref2(float *L1, float *L2, float *Y1) {
 template <int P, int KO, int WPS = 2>
 static void launch_f12(int s, int band_rows) {
     using G = dtm::Fwd12m<5, 7, 10>;
-    dtm::Fwd12mParams p{}; p.X = sets[s].X; p.Yh0 = sets[s].Y0; p.Yh1 = sets[s].Y1; p.LoLo2 = sets[s].L2; p.B = 1; p.R = p.C = N;
+    dtm::Fwd12mParams p{}; p.X = sets[s].X; p.LoLo1 = nullptr; p.Yh0 = sets[s].Y0; p.Yh1 = sets[s].Y1; p.LoLo2 = sets[s].L2; p.B = 1; p.R = p.C = N;
     const unsigned jobs = dtm::dtm_set_jobs(p.jb, 1, N, cdiv(N, 4 * G::VL), band_rows);
     put(p.h0, H0O, 5, dtm::MAXT1); put(p.h1, H1O, 7, dtm::MAXT1);
     Fwd2Params q{}; fill_fwd2(q);
@@ -218,7 +218,7 @@ static void run_i21(int band_rows) {
 template <int P, int KO>
 static void launch_f12w(int s, int band_rows) {
     using G = dtm::Fwd12m<5, 7, 10>;
-    dtm::Fwd12mParams p{}; p.X = sets[s].X; p.Yh0 = sets[s].Y0; p.Yh1 = sets[s].Y1; p.LoLo2 = sets[s].L2; p.B = 1; p.R = p.C = N;
+    dtm::Fwd12mParams p{}; p.X = sets[s].X; p.LoLo1 = nullptr; p.Yh0 = sets[s].Y0; p.Yh1 = sets[s].Y1; p.LoLo2 = sets[s].L2; p.B = 1; p.R = p.C = N;
     const unsigned jobs = dtm::dtm_set_jobs(p.jb, 1, N, cdiv(N, 4 * G::VL), band_rows);
     put(p.h0, H0O, 5, dtm::MAXT1); put(p.h1, H1O, 7, dtm::MAXT1);
     Fwd2Params q{}; fill_fwd2(q);
