@@ -1,7 +1,10 @@
-cd $GRAFT_REPO_ROOT; O=gpurun_out/r05j; mkdir -p $O
-timeout 900 python -m pytest tests/test_hip_march.py -x -q -m gpu -k include_scale > $O/pytest.txt 2>&1; tail -3 $O/pytest.txt
-run() { echo "$1 | $2: $(env $1 python bench.py --no-cpu-baseline --no-other-configs $2 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
-print('one-stream', d.get('one_stream_ms_per_step'), 'resident', d.get('resident_ms_per_step'), 'fwd12m', r['fwd_kernel_ms'][0], 'inv21m', r['inv_kernel_ms'][1])")"; }
-for rep in 1 2; do for br in 40 56 64 72 80 96 112; do run DTCWT_HIP_MARCH_BAND=$br "--steps 40 --streams 1"; done; run DTCWT_X=0 "--steps 40 --streams 1"; done 2>&1 | tee $O/band_sweep_alone.txt
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r05l; mkdir -p $O
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -2 $O/smoke.txt
+timeout 1800 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.txt 2>&1; tail -4 $O/pytest_gpu.txt
+cp gpurun_out/parity_worst.json $O/
+python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench.err; python -c "
+import json
+d=json.loads(open('$O/bench_driver_cmd.json').read().strip().splitlines()[-1])
+print(d['value'], d['ms_per_step'], d['sustained_ms_per_step'], d['one_stream_ms_per_step'], d['roofline']['frac'], d['roofline']['traffic'])
+for k,v in d['other_configs'].items(): print(k, v.get('ms_per_step'), v.get('roofline'))
+"

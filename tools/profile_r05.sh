@@ -38,3 +38,7 @@ python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --mgpu > $O/ben
 python bench.py --biort near_sym_b --qshift qshift_b --steps 100 --no-cpu-baseline --no-other-configs > $O/bench_near_sym_b_qshift_b.json 2>/dev/null
 DTCWT_HIP_MARCH=0 python bench.py --cu-partition off --no-cpu-baseline --no-other-configs --steps 100 > $O/bench_march_off.json 2>/dev/null
 cat $O/status.txt; cat $O/c2/status.txt
+# SQ counters of the kernels that are new this round (VALU / LDS / wait shares): C4's marching pair and the level-1 marches
+bash $R/tools/pmc_cmd.sh gpurun_out/r05prof/pmc_c4 python $R/bench.py --config c4 --steps 6 --warmup 2 --no-cpu-baseline --streams 1 --cu-partition off --settle-ms 60 > $O/pmc_c4.log 2>&1
+bash $R/tools/pmc_cmd.sh gpurun_out/r05prof/pmc_nsb python $R/bench.py --biort near_sym_b --qshift qshift_b --steps 6 --warmup 2 --no-cpu-baseline --no-other-configs --streams 1 --settle-ms 60 > $O/pmc_nsb.log 2>&1
+find $O/pmc_c4 $O/pmc_nsb -name "*.csv" -size +5M -delete
