@@ -317,7 +317,7 @@ def test_bench_config_c4_line():
     line = json.loads(lines[0])
     assert line['unit'] == 'Mvoxels/s' and line['n_gpus'] == 1 and line['config']['buffer_sets'] == 2
     assert line['config']['streams'] == 2 and line['ms_per_step_one_stream'] > 0
-    assert line['roofline']['kernel'].startswith('k_fwd3_l1') and 0 < line['roofline']['frac'] < 1
+    assert line['roofline']['kernel'].startswith('k_fwd3m_l1') and 0 < line['roofline']['frac'] < 1
     assert line['recon_max_abs_err'] < 1e-4 and line['gpu_vs_cpu_recon_max_abs_diff'] < 1e-4
     assert line['cpu_baseline']['kind'] == 'port'
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--config', 'c4', '--gpus', '2', '--steps', '1'],
