@@ -39,6 +39,14 @@ bool dtcwt_march_inv1_ok(int batch, int rows, int cols, const std::vector<double
 int dtcwt_march_inv1(const float *Z, const float *Yh0, float *X, int B, int R, int C, const std::vector<double> &g0o,
                      const std::vector<double> &g1o, const float *gain1, const DtMarchHint &hint, hipStream_t s);
 
+// levels 1 + 2 of the forward as a marching pair of wavefronts (march2d_pair.hpp)
+bool dtcwt_march_fwd12p_ok(int batch, int rows, int cols, const std::vector<double> &h0o, const std::vector<double> &h1o,
+                           const std::vector<double> &h0a, bool lo_a_first, bool hi_a_first, const DtMarchHint &hint);
+int dtcwt_march_fwd12p(const float *X, float *Yh0, float *Yh1, float *LoLo2, int B, int R, int C,
+                       const std::vector<double> &h0o, const std::vector<double> &h1o,
+                       const float *l_a, const float *l_b, const float *h_a, const float *h_b, int m,
+                       const DtMarchHint &hint, hipStream_t s);
+
 namespace {
 
 // record arrays at least this big leave with the non-temporal hint (DTCWT_HIP_STREAM_RECORDS_MB; default 32)
@@ -198,6 +206,12 @@ static bool plan_march_fwd12(const dtcwt_hip_plan2d *p) {
            dtcwt_march_fwd12_ok(p->batch, p->lv[0].LR, p->lv[0].LC, p->biort[0], p->biort[2], p->qshift[0],
                                 dotd(p->qshift[1], p->qshift[0]) > 0, dotd(p->qshift[5], p->qshift[4]) > 0, p->hint());
 }
+// ... or as a marching PAIR of wavefronts, for the sets one wavefront's registers do not hold (near_sym_b; 14- / 18-tap q-shift)
+static bool plan_march_fwd12p(const dtcwt_hip_plan2d *p) {
+    return plan_march_geometry(p) && p->bp1[0].empty() && p->bp2[0].empty() &&
+           dtcwt_march_fwd12p_ok(p->batch, p->lv[0].LR, p->lv[0].LC, p->biort[0], p->biort[2], p->qshift[0],
+                                 dotd(p->qshift[1], p->qshift[0]) > 0, dotd(p->qshift[5], p->qshift[4]) > 0, p->hint());
+}
 static bool plan_march_inv21(const dtcwt_hip_plan2d *p) {
     return plan_march_geometry(p) && p->bp1[1].empty() && p->bp2[2].empty() &&
            dtcwt_march_inv21_ok(p->batch, p->lv[0].LR, p->lv[0].LC, p->biort[1], p->biort[3], p->qshift[2],
@@ -220,7 +234,7 @@ extern "C" {
 
 int dtcwt_hip_plan2d_level1_march(const dtcwt_hip_plan2d *p, int *fwd1, int *inv1) {
     DT_REQUIRE(p, "NULL plan");
-    if (fwd1) *fwd1 = plan_march_fwd1(p) ? 1 : 0;
+    if (fwd1) *fwd1 = (plan_march_fwd1(p) && !plan_march_fwd12p(p)) ? 1 : 0;
     if (inv1) *inv1 = plan_march_inv1(p) ? 1 : 0;
     return 0;
 }
@@ -239,7 +253,7 @@ int dtcwt_hip_plan2d_set_program(dtcwt_hip_plan2d *p, int program) {
 
 int dtcwt_hip_plan2d_launches(const dtcwt_hip_plan2d *p, int *fwd12, int *inv21) {
     DT_REQUIRE(p, "NULL plan");
-    if (fwd12) *fwd12 = plan_march_fwd12(p) ? 1 : 0;
+    if (fwd12) *fwd12 = (plan_march_fwd12(p) || plan_march_fwd12p(p)) ? 1 : 0;
     if (inv21) *inv21 = plan_march_inv21(p) ? 1 : 0;
     return 0;
 }
@@ -395,6 +409,25 @@ int dtcwt_hip_plan2d_forward(dtcwt_hip_plan2d *p, const float *X, float *Yl, voi
             if (rc) return dtcwt_set_error(rc, "no marching forward kernel for levels 1 + 2");
             DT_CHECK_HIP(hipGetLastError());
             if (p->profiling) {     // level 2 has no launch of its own: an empty event pair
+                DT_CHECK_HIP(hipEventRecord(p->ev[1], s));
+                DT_CHECK_HIP(hipEventRecord(p->ev[2], s));
+                DT_CHECK_HIP(hipEventRecord(p->ev[3], s));
+            }
+            in = lo2;
+            l = 1;
+            continue;
+        }
+        if (l == 0 && !Ys && plan_march_fwd12p(p)) {
+            DT_REQUIRE(Yh[1], "NULL output buffer at level 1");
+            float *lo2 = nl == 2 ? Yl : p->work[1];
+            Fwd2Params q{};
+            put_taps(q.l_a, p->qshift[1]); put_taps(q.l_b, p->qshift[0]);
+            put_taps(q.h_a, p->qshift[5]); put_taps(q.h_b, p->qshift[4]);
+            rc = dtcwt_march_fwd12p(in, (float *)Yh[0], (float *)Yh[1], lo2, p->batch, L.LR, L.LC, p->biort[0], p->biort[2],
+                                    q.l_a, q.l_b, q.h_a, q.h_b, (int)p->qshift[0].size(), p->hint(), s);
+            if (rc) return dtcwt_set_error(rc, "no marching-pair forward kernel for levels 1 + 2");
+            DT_CHECK_HIP(hipGetLastError());
+            if (p->profiling) {
                 DT_CHECK_HIP(hipEventRecord(p->ev[1], s));
                 DT_CHECK_HIP(hipEventRecord(p->ev[2], s));
                 DT_CHECK_HIP(hipEventRecord(p->ev[3], s));

@@ -10,6 +10,7 @@
 #include "common.hpp"
 #include "march2d.hpp"
 #include "march2d_l1.hpp"
+#include "march2d_pair.hpp"
 
 namespace {
 
@@ -268,5 +269,63 @@ int dtcwt_march_inv1(const float *Z, const float *Yh0, float *X, int B, int R, i
     dtm::dtm_pack_inv1m(p, m0, m1, g0o.data(), g1o.data());
     if (m0 == 19 && m1 == 13) return launch_inv1m<19, 13>(p, hint, s);
     if (m0 == 7 && m1 == 9) return launch_inv1m<7, 9>(p, hint, s);
+    return -3;
+}
+
+// ---- levels 1 + 2 of the forward as a marching PAIR of wavefronts (march2d_pair.hpp) ------------------------------------------
+// near_sym_a / legall-length level-1 filters (5, 7) with the 14- / 18-tap q-shift sets (qshift_b, qshift_d): 112 / 144 registers
+// of pending sums that one wavefront cannot hold beside level 1.  Measured (profiles/r05/pair_forward.txt, pair / level-1 tile
+// launch + level-2 tile launch): 64 x 2048^2 3.12 / 3.47 ms per step, 64 x 1024^2 0.756 / 0.869, 4096^2 with four in flight 0.214 /
+// 0.232 -- and 0.251 / 0.237 for ONE 4096^2 image at a time: the level-1 wavefront of a pair issues all of level 1's
+// instructions while its partner waits for rows, and a launch that cannot fill the chip twice over feels that.  So: wherever
+// other work shares the device (concurrency hint, partition context) from the usual crossover, alone from 60 M useful pixels.
+// near_sym_b was built too and lost everywhere (146 us against 72 + 28 alone, 451 against 245 + 157 in flight: its level-1
+// wavefront carries 573 instructions per step, the partner 130): its level 1 stays a march of its own (march2d_l1.hpp).
+// DTCWT_HIP_MARCH_PAIR=0: never.
+bool dtcwt_march_fwd12p_ok(int batch, int rows, int cols, const std::vector<double> &h0o, const std::vector<double> &h1o,
+                           const std::vector<double> &h0a, bool lo_a_first, bool hi_a_first, const DtMarchHint &hint) {
+    if (const char *e = getenv("DTCWT_HIP_MARCH_PAIR")) { if (e[0] == '0') return false; }
+    const int m0 = (int)h0o.size(), m1 = (int)h1o.size(), m = (int)h0a.size();
+    if (!(m0 == 5 && m1 == 7 && (m == 14 || m == 18))) return false;
+    if (!symmetric(h0o) || !symmetric(h1o) || !lo_a_first || hi_a_first) return false;
+    const int VL = m == 14 ? dtm::Fwd12p<5, 7, 14>::VL : dtm::Fwd12p<5, 7, 18>::VL;
+    if (!march_sizes_ok(batch, rows, cols, VL)) return false;
+    const int mm = march_mode(hint);
+    if (mm == 0) return false;
+    if (mm > 0) return true;
+    const int nstrip = cdiv(cols, 4 * VL);
+    const double useful = (double)batch * rows * cols * ((double)cols / (nstrip * 4.0 * VL));
+    const bool shared = hint.nparts > 1 || hint.in_flight > 1;
+    return useful >= (shared ? kCrossover[hint.nparts > 1 ? 2 : 1].useful_pixels : 6.0e7);
+}
+
+template <int M0, int M1, int M>
+static int launch_fwd12p(dtm::Fwd12pParams &p, const DtMarchHint &hint, hipStream_t s) {
+    using G = dtm::Fwd12p<M0, M1, M>;
+    const int nstrip = cdiv(p.C, 4 * G::VL);
+    // a job is a PAIR of wavefronts: half as many fit the chip as single-wavefront jobs
+    const int cus = hint.cus / 2 > 0 ? hint.cus / 2 : 1;
+    const unsigned jobs = dtm::dtm_set_jobs(p.jb, p.B, p.R, nstrip, pick_band_rows(p.B * hint.in_flight, p.R, nstrip, M, cus));
+    dtm::k_fwd12p<M0, M1, M, 2><<<jobs, 128, 0, s>>>(p);
+    return 0;
+}
+
+int dtcwt_march_fwd12p(const float *X, float *Yh0, float *Yh1, float *LoLo2, int B, int R, int C,
+                       const std::vector<double> &h0o, const std::vector<double> &h1o,
+                       const float *l_a, const float *l_b, const float *h_a, const float *h_b, int m,
+                       const DtMarchHint &hint, hipStream_t s) {
+    dtm::Fwd12pParams p{};
+    p.X = X; p.Yh0 = Yh0; p.Yh1 = Yh1; p.LoLo2 = LoLo2; p.B = B; p.R = R; p.C = C;
+    const int m0 = (int)h0o.size(), m1 = (int)h1o.size();
+    const double rs = 0.70710678118654752440;
+    for (int d = 0; d <= dtm::MAXH1; ++d) {
+        const double a = d <= m0 / 2 ? h0o[m0 / 2 - d] : 0.0, b = d <= m1 / 2 ? h1o[m1 / 2 - d] : 0.0;
+        p.hp[2 * d] = (float)a; p.hp[2 * d + 1] = (float)b;
+        p.hpl[2 * d] = (float)a; p.hpl[2 * d + 1] = (float)(b * rs);
+        p.hph[2 * d] = (float)(a * rs); p.hph[2 * d + 1] = (float)(b * rs);
+    }
+    dtm::dtm_pack_qshift(p, m, l_a, l_b, h_a, h_b);
+    if (m0 == 5 && m == 14) return launch_fwd12p<5, 7, 14>(p, hint, s);
+    if (m0 == 5 && m == 18) return launch_fwd12p<5, 7, 18>(p, hint, s);
     return -3;
 }

@@ -99,6 +99,7 @@ def test_level1_march_on_a_batch_and_where_it_is_chosen(monkeypatch):
     t = Transform2d('near_sym_b', 'qshift_b')
     assert t.plan(1, 512, 512, 3).level1_march() == (False, False)             # below the crossover: the tile programs
     assert t.plan(1, 2048, 2048, 4).level1_march() == (True, True)
+    assert t.plan(1, 2050, 2048, 4).level1_march() == (True, True)             # even rows suffice: level 2 pads
     assert t.plan(1, 2047, 2048, 4).level1_march() == (False, False)           # odd-size extension: tiles
     assert t.plan(1, 2048, 2046, 4).level1_march() == (False, False)           # columns in fours
     assert Transform2d('near_sym_b_bp', 'qshift_b_bp').plan(1, 2048, 2048, 3).level1_march() == (False, False)
@@ -138,6 +139,52 @@ def test_march_with_include_scale(shape):
     want = to.forward(as_f64(X[1]), nlevels=nl, include_scale=True)
     for l in range(nl):
         assert_close(pm.scales[l][1], want.scales[l], XFM_TOL, 'scale %d' % l)
+
+
+@pytest.mark.parametrize('shape', SHAPES + [(48, 212), (1024, 208)])
+@pytest.mark.parametrize('bn,qn', [('near_sym_a', 'qshift_b'), ('near_sym_a', 'qshift_d')])
+@pytest.mark.parametrize('band', [None, 8, 24])
+def test_forward_pair_matches_tile_programs_and_oracle(shape, bn, qn, band, monkeypatch):
+    """Levels 1 + 2 of the forward as a marching PAIR of wavefronts (march2d_pair.hpp: k_fwd12p; near_sym_a with the 14- / 18-tap
+    q-shift sets) against the tile programs and the oracle, at sizes that put the strip boundaries (224- / 216-column strips), band
+    boundaries, mirrored halo lanes and reflected rows everywhere."""
+    rs = np.random.RandomState(25)
+    X = rs.standard_normal(shape).astype(np.float32)
+    nl = 2 if min(shape) < 160 else 3
+    tt, tm = Transform2d(bn, qn, program='tiles'), Transform2d(bn, qn, program='march')
+    if band:
+        monkeypatch.setenv('DTCWT_HIP_MARCH_BAND', str(band))
+    assert tm.plan(1, shape[0], shape[1], nl).launches()[0] is True
+    p0, p1 = tt.forward(X, nlevels=nl), tm.forward(X, nlevels=nl)
+    assert_close(p1.lowpass, p0.lowpass, 1e-6, 'Yl pair vs tiles')
+    for a, b in zip(p1.highpasses, p0.highpasses):
+        assert_close(a, b, 1e-6, 'Yh pair vs tiles')
+    want = o.Transform2d(biort(bn), qshift(qn)).forward(as_f64(X), nlevels=nl)
+    assert_pyramids_close(p1, want, XFM_TOL, same_dtype=False)
+    assert_close(tm.inverse(p1), X, INV_TOL, 'reconstruction')
+    monkeypatch.setenv('DTCWT_HIP_MARCH_PAIR', '0')              # the switch: back to level 1 alone + a level-2 tile launch
+    assert tm.plan(1, shape[0], shape[1], nl).launches()[0] is False
+
+
+def test_forward_pair_on_a_batch():
+    rs = np.random.RandomState(26)
+    X = rs.standard_normal((5, 128, 424)).astype(np.float32)
+    tm = Transform2d('near_sym_a', 'qshift_b', program='march')
+    to = o.Transform2d(biort('near_sym_a'), qshift('qshift_b'))
+    assert tm.plan(5, 128, 424, 3).launches() == (True, False)
+    # where the library chooses by itself: batches and shared devices, not one image alone (profiles/r05/pair_forward.txt)
+    ta = Transform2d('near_sym_a', 'qshift_b')
+    assert ta.plan(1, 4096, 4096, 4).launches()[0] is False and ta.plan(64, 1024, 1024, 4).launches()[0] is True
+    pl = ta.plan(1, 4096, 4096, 4); pl.set_concurrency(4); assert pl.launches()[0] is True; pl.set_concurrency(1)
+    p = tm.forward_channels(X, 'nhw', nlevels=3)
+    for b in (0, 4):
+        want = to.forward(as_f64(X[b]), nlevels=3)
+        assert_close(p.lowpass[b], want.lowpass, XFM_TOL, 'Yl')
+        for l in range(3):
+            assert_close(p.highpasses[l][b], want.highpasses[l], XFM_TOL, 'Yh[%d]' % l)
+    single = tm.forward(X[2], nlevels=3)
+    assert all(np.array_equal(a, b[2]) for a, b in zip(single.highpasses, p.highpasses))
+    assert_close(tm.inverse_channels(p, 'nhw'), X, INV_TOL, 'reconstruction')
 
 
 def test_march_on_a_batch_and_other_level1_filters(monkeypatch):
@@ -254,7 +301,10 @@ def test_march_is_not_used_where_it_does_not_apply(monkeypatch):
     t = Transform2d()
     assert t.plan(1, 254, 256, 3).launches() == (False, False)           # level-2 padding (254 % 4)
     assert t.plan(1, 255, 256, 3).launches() == (False, False)           # odd-size extension
-    assert Transform2d('near_sym_b', 'qshift_b').plan(1, 256, 256, 3).launches() == (False, False)
+    assert Transform2d('near_sym_b', 'qshift_b').plan(1, 256, 256, 3).launches() == (False, False)    # level 1 alone as a march instead
+    assert Transform2d('near_sym_a', 'qshift_b').plan(1, 256, 256, 3).launches() == (True, False)     # forward: the marching pair
+    assert Transform2d('near_sym_a', 'qshift_c').plan(1, 256, 256, 3).launches() == (False, False)    # 16 taps: (M - 2) % 4 != 0
+    assert Transform2d('antonini', 'qshift_b').plan(1, 256, 256, 3).launches() == (False, False)
     assert t.plan(1, 4096, 4096, 4).launches() == (True, True)
     assert t.plan(64, 1024, 1024, 3).launches() == (True, True)
     # `scales` needs the level-1 lowpass: the forward then keeps its one launch per level, and says so by being right
