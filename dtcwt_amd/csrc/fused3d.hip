@@ -10,6 +10,7 @@
 #include "fused3d_tiles.hpp"
 #include "fused3d_inv_tiles.hpp"
 #include "fused3d_march.hpp"
+#include "fused3d_long.hpp"
 
 using namespace dt3d;
 
@@ -265,6 +266,41 @@ static int launch_fwd3m(const float *X, float *LLL, float *Yh, int n0, int n1, i
     return 0;
 }
 
+// Level 1 for the long filters (near_sym_b: 13 / 19 taps) as two launches around four plane volumes (fused3d_long.hpp): the
+// in-slice half is the 2-D level-1 march with every slice an image (march2d.hip), then axis 0 + cube2c.
+// DTCWT_HIP_LONG3D=0: never (the axis-by-axis generic kernels, as before round 5).
+int dtcwt_march_fwd1_planes(const float *X, float *P, int64_t pstride, int B, int R, int C, const double *h0o, int m0,
+                            const double *h1o, int m1, int cus, hipStream_t s);
+int dtcwt_march_inv1_planes(const float *P, int64_t pstride, float *X, int B, int R, int C, const double *g0o, int m0,
+                            const double *g1o, int m1, int cus, hipStream_t s);
+static bool long3_ok(int64_t n0, int64_t n1, int64_t n2, int ma, int mb) {
+    if (const char *e = getenv("DTCWT_HIP_LONG3D")) { if (e[0] == '0') return false; }
+    if (!((ma == 13 && mb == 19) || (ma == 19 && mb == 13))) return false;
+    if (n0 % 2 || n1 % 2 || n2 % 4 || n0 < 20 || n1 < 40 || n2 < 40) return false;
+    return 4 * n0 * n1 * n2 * 4 < ((int64_t)1 << 40) && n0 * n1 * n2 * 4 < ((int64_t)1 << 31);      // 32-bit byte offsets inside a plane volume
+}
+static bool symmetric_taps(const double *h, int m) {
+    double mx = 0;
+    for (int k = 0; k < m; ++k) mx = fmax(mx, fabs(h[k]));
+    for (int k = 0; k < m / 2; ++k) if (fabs(h[k] - h[m - 1 - k]) > 1e-12 * mx) return false;
+    return true;
+}
+static int launch_fwd3l_axis0(const float *P, int64_t pstride, float *LLL, float *Yh, int n0, int n1, int n2, const double *h0,
+                              int m0, const double *h1, int m1, int cus, hipStream_t s) {
+    dt3l::Fwd3lParams p{};
+    p.P = P; p.pstride = pstride; p.LLL = LLL; p.Yh = Yh; p.n0 = n0; p.n1 = n1; p.n2 = n2;
+    p.nstrip = cdiv(n2 / 2, 64); p.ncr = n1 / 2;
+    // slices per job in whole periods of the ring (20 slices); every chunk re-reads 18 slices of warm-up
+    constexpr int PERS = 2 * dtm::Fwd1m<13, 19>::PER;
+    int chunk = cdiv(n0, PERS) * PERS;
+    while (chunk > PERS && (int64_t)p.nstrip * p.ncr * cdiv(n0, chunk) < 2 * (int64_t)cus) chunk -= PERS;
+    if (const char *e = getenv("DTCWT_HIP_LONG3D_CHUNK")) { const int v = atoi(e) / PERS * PERS; if (v >= PERS) chunk = v; }
+    p.chunk = chunk; p.nchunk = cdiv(n0, chunk);
+    dt3l::pack_fwd3l(p, h0, m0, h1, m1);
+    dt3l::k_fwd3l_axis0<13, 19><<<(unsigned)(p.ncr * p.nstrip * p.nchunk), 256, 0, s>>>(p);
+    return 0;
+}
+
 extern "C" int dtcwt_hip_fwd3_level1(dtcwt_hip_ctx *ctx, const float *X, int64_t n0, int64_t n1, int64_t n2,
                                      const double *h0o, int m0, const double *h1o, int m1, float *LLL,
                                      float *Yh) {
@@ -296,6 +332,18 @@ extern "C" int dtcwt_hip_fwd3_level1(dtcwt_hip_ctx *ctx, const float *X, int64_t
     }
     DT_FWD3_L1_TABLE(X_)
 #undef X_
+    if (long3_ok(n0, n1, n2, m0, m1) && symmetric_taps(h0o, m0) && symmetric_taps(h1o, m1)) {
+        const int64_t ps = n0 * n1 * n2;
+        void *planes = nullptr;
+        if (int rc = dtcwt_hip_malloc(ctx, (size_t)(4 * ps) * sizeof(float), &planes)) return rc;
+        int rc = dtcwt_march_fwd1_planes(X, (float *)planes, ps, (int)n0, (int)n1, (int)n2, h0o, m0, h1o, m1, ctx->cus, ctx->stream);
+        if (!rc) rc = launch_fwd3l_axis0((const float *)planes, ps, LLL, Yh, (int)n0, (int)n1, (int)n2, h0o, m0, h1o, m1, ctx->cus, ctx->stream);
+        hipError_t e = hipGetLastError();
+        dtcwt_hip_free(ctx, planes);        // stream-ordered reuse (common.hpp)
+        if (rc) return dtcwt_set_error(-3, "the level-1 march does not take this volume");
+        if (e != hipSuccess) return dtcwt_set_error(-2, "3-D level launch failed: %s", hipGetErrorString(e));
+        return 0;
+    }
     return dtcwt_set_error(-3, "no fused 3-D level-1 kernel for %d/%d-tap biort filters", m0, m1);
 }
 
@@ -424,6 +472,55 @@ __global__ void __launch_bounds__(G::NT, 4) k_inv3_l1_axis02(Inv3AParams p, int 
     }
 }
 
+// level 1 for long filters (fused3d_long.hpp), first launch: unpack + axis-0 merge into the four plane volumes -- the march
+// above without the axis-2 exchange
+template <class G>
+DT_HD void i3l_store(const Inv3AParams &p, const float (&out)[2][4], int tid, int cj0, int ck0, int c) {
+    const int v = G::combo(tid), idx = G::cell(tid);
+    const int j = 2 * (cj0 + idx / G::CK), k = 2 * (ck0 + idx % G::CK);
+    if (j >= p.n1 || k >= p.n2) return;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int so = 2 * c + e;
+        if (so < 0 || so >= p.S) continue;
+        float *o = p.P + v * p.pstride + ((int64_t)so * p.n1 + j) * p.n2 + k;
+        *reinterpret_cast<f2 *>(o) = f2{out[e][0], out[e][1]};
+        *reinterpret_cast<f2 *>(o + p.n2) = f2{out[e][2], out[e][3]};
+    }
+}
+template <class F, class G>
+__global__ void __launch_bounds__(G::NT) k_inv3l_axis0(Inv3AParams p, int ntile_xcd) {
+    __shared__ __attribute__((aligned(16))) float slab[2][G::SLAB];
+    const int bid = xcd_tile3(ntile_xcd), tid = threadIdx.x;
+    if (bid < 0) return;
+    const int tk = bid % p.tilesK, tj = (bid / p.tilesK) % p.tilesJ, ch = bid / (p.tilesK * p.tilesJ);
+    const int cj0 = tj * G::CJ, ck0 = tk * G::CK, c0 = ch * p.chunk;
+    const int c1 = min(c0 + p.chunk, p.n0 / 2);
+    const int q0 = c0 - F::HP, q1 = c1 - 1 + F::HP;       // virtual records added by this march
+    Inv3TState<F, G> st;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int t = 0; t < F::NA; ++t) st.acc[q][t] = 0.f;
+    i3a_issue_rec<F, G>(p, st, tid, cj0, ck0, q0);
+    i3a_issue_low<F, G>(p, st, tid, cj0, ck0, q0);
+    i3a_slab_write<F, G>(st, slab[0], tid);
+    i3a_issue_rec<F, G>(p, st, tid, cj0, ck0, q0 + 1);
+    __syncthreads();
+    for (int q = q0; q <= q1; ++q) {
+        const int buf = (q - q0) & 1, c = q - F::HP;        // the output pair this step completes
+        float out[2][4];
+        i3a_accumulate<F, G>(p, st, slab[buf], tid, q, out);
+        i3a_slab_write<F, G>(st, slab[buf ^ 1], tid);
+        if (q < q1) {
+            i3a_issue_rec<F, G>(p, st, tid, cj0, ck0, q + 2);
+            i3a_issue_low<F, G>(p, st, tid, cj0, ck0, q + 1);
+        }
+        if (c >= c0) i3l_store<G>(p, out, tid, cj0, ck0, c);
+        __syncthreads();
+    }
+}
+
 // level 1, second launch: the axis-1 merge
 template <class F, int VEC, int RS>
 __global__ void __launch_bounds__(DT_NT) k_inv3_l1_axis1(Inv3BParams p) {
@@ -494,6 +591,23 @@ void launch_inv3_l1_axis02(Inv3AParams &p, int cus, hipStream_t s) {
     else if (e2 <= 64) launch_inv3_l1_axis02_g<F, I3Geo<512, 64>>(p, cus, s);
     else launch_inv3_l1_axis02_g<F, I3Geo<512, 128>>(p, cus, s);
 }
+template <class F, class G>
+void launch_inv3l_axis0_g(Inv3AParams &p, int cus, hipStream_t s) {
+    p.hal = 0;
+    p.tilesJ = cdiv(p.n1 / 2, G::CJ); p.tilesK = cdiv(p.n2 / 2, G::CK);
+    const int pairs = p.n0 / 2;
+    int chunk = 64;             // long marches amortise the 2 HP warm-up records
+    while (chunk > 16 && (int64_t)p.tilesJ * p.tilesK * cdiv(pairs, chunk) < 2 * (int64_t)cus) chunk /= 2;
+    if (const char *e = getenv("DTCWT_HIP_LONG3D_ICHUNK")) { const int v = atoi(e); if (v >= 4) chunk = v; }
+    p.chunk = chunk; p.chunks = cdiv(pairs, chunk);
+    const int ntile = p.tilesJ * p.tilesK * p.chunks;
+    k_inv3l_axis0<F, G><<<xcd3_grid(ntile, XCD3_INV_AXIS0), G::NT, 0, s>>>(p, xcd3_arg(ntile, XCD3_INV_AXIS0));
+}
+template <class F>
+void launch_inv3l_axis0(Inv3AParams &p, int cus, hipStream_t s) {
+    if (p.n2 / 2 <= 32) launch_inv3l_axis0_g<F, I3GeoA>(p, cus, s);
+    else launch_inv3l_axis0_g<F, I3Geo<256, 64>>(p, cus, s);
+}
 template <class F>
 void launch_inv3_l1_axis1(Inv3BParams &b, hipStream_t s) {
     constexpr int RS = 8;
@@ -531,6 +645,24 @@ extern "C" int dtcwt_hip_inv3_level1(dtcwt_hip_ctx *ctx, const float *LLL, const
 #define X_(A, B) if (m0 == A && m1 == B) have = true;
     DT_INV3_L1_TABLE(X_)
 #undef X_
+    if (!have && long3_ok(n0, n1, n2, m0, m1) && m0 == 19 && symmetric_taps(g0o, m0) && symmetric_taps(g1o, m1)) {
+        // long filters (fused3d_long.hpp): c2cube + axis 0 into four plane volumes, then the 2-D level-1 march slice by slice
+        Inv3AParams a{};
+        a.LLL = LLL; a.Yh = Yh; a.n0 = (int)n0; a.n1 = (int)n1; a.n2 = (int)n2; a.S = (int)n0; a.crop0 = 0;
+        a.pstride = n0 * n1 * n2;
+        put_taps(a.l_a, g0o, m0); put_taps(a.h_a, g1o, m1);
+        void *planes = nullptr;
+        if (int rc = dtcwt_hip_malloc(ctx, (size_t)(4 * a.pstride) * sizeof(float), &planes)) return rc;
+        a.P = (float *)planes;
+        DT_CHECK_HIP(hipSetDevice(ctx->device));
+        launch_inv3l_axis0<Inv3L1<19, 13>>(a, ctx->cus, ctx->stream);
+        const int rc = dtcwt_march_inv1_planes((const float *)planes, a.pstride, Z, (int)n0, (int)n1, (int)n2, g0o, m0, g1o, m1, ctx->cus, ctx->stream);
+        hipError_t er = hipGetLastError();
+        dtcwt_hip_free(ctx, planes);
+        if (rc) return dtcwt_set_error(-3, "the level-1 march does not take this volume");
+        if (er != hipSuccess) return dtcwt_set_error(-2, "3-D inverse launch failed: %s", hipGetErrorString(er));
+        return 0;
+    }
     if (!have) return dtcwt_set_error(-3, "no fused 3-D level-1 inverse for %d/%d-tap biort filters", m0, m1);
     Inv3AParams a{};
     a.LLL = LLL; a.Yh = Yh; a.n0 = (int)n0; a.n1 = (int)n1; a.n2 = (int)n2; a.S = (int)n0; a.crop0 = 0;
@@ -617,7 +749,7 @@ bool dtcwt_fwd3_level1_ok(int64_t n0, int64_t n1, int64_t n2, int m0, int m1) {
 #define X_(A, B) if (m0 == A && m1 == B) return true;
     DT_FWD3_L1_TABLE(X_)
 #undef X_
-    return false;
+    return long3_ok(n0, n1, n2, m0, m1) && m0 == 13;
 }
 bool dtcwt_fwd3_level2_ok(int64_t n0, int64_t n1, int64_t n2, int pad0, int pad1, int pad2, int m) {
     const int64_t L1 = n1 + 2 * pad1, L2 = n2 + 2 * pad2;
@@ -635,7 +767,7 @@ bool dtcwt_inv3_level1_ok(int64_t n0, int64_t n1, int64_t n2, int m0, int m1) {
 #define X_(A, B) if (m0 == A && m1 == B) return true;
     DT_INV3_L1_TABLE(X_)
 #undef X_
-    return false;
+    return long3_ok(n0, n1, n2, m0, m1) && m0 == 19;
 }
 bool dtcwt_inv3_level2_ok(int64_t n0, int64_t n1, int64_t n2, int crop0, int m) {
     const int64_t S = 2 * n0 - 2 * crop0;

@@ -1,0 +1,171 @@
+// Level 1 of the float32 3-D DT-CWT for LONG level-1 filters (near_sym_b: 13 / 19 taps) as two launches per direction (gfx950).
+//
+// The one-launch level 1 of fused3d_march.hpp / fused3d_tiles.hpp keeps a window of 2 H + 2 slices of a tile in registers
+// and filters the other two axes inside the same workgroup: at H = 9 that is a ring of 20 slices and a halo of 9 on every
+// side of a tile, which neither the registers nor the LDS hold.  Until round 5 these filters ran axis by axis on the
+// generic kernels (84 B/voxel in seven launches, the cube2c ones writing 32-byte pieces of the 224-byte records: 755 us
+// forward / 965 us inverse at 256^3 -- profiles/r05/c4_qbgn.txt).  Here a level is TWO launches around four plane volumes
+// P[2 a1 + a2] (the in-slice subbands: a1 = lo | hi along axis 1, a2 = lo | hi along axis 2; 16 B/voxel):
+//
+//   forward   k_fwd1m<.., PLANES>   (march2d_l1.hpp)   X -> P         every slice is an image of the 2-D level-1 march
+//             k_fwd3l_axis0         (this file)        P -> LLL, Yh   axis 0 + cube2c
+//   inverse   k_inv3l_axis0         (fused3d.hip, the march of fused3d_inv_tiles.hpp)   LLL, Yh -> P   c2cube + axis 0
+//             k_inv1m<.., PLANES>   (march2d_l1.hpp)   P -> X
+//
+// 4 + 16 | 16 + 32 = 68 B/voxel each way against the 36 of a one-launch level.
+//
+// k_fwd3l_axis0: a workgroup = four wavefronts = the four planes of one job (a row of cells along axis 1, a strip of 64
+// cells along axis 2, a chunk of slices); a lane owns ONE 2 x 2 cell column.  Axis 2 is the lane axis and needs no
+// neighbours any more, so there are no halo lanes and no DPP: a wavefront marches down axis 0 over a register ring of the
+// last 2 H + 2 slices of its plane (2 rows x 2 columns: 80 registers at H = 9), the loop unrolled over the ring's period,
+// filters (lo0, hi0) with the column filter of the 2-D march (col_lohi2), runs cube2c on its two octants (a0 = 0 / 1) and
+// puts them into the record row the four wavefronts assemble in a shared LDS slab; the row leaves as one contiguous run of
+// 16-byte pieces (two LDS-only barriers per slice pair).  Wavefront 0 stores the lowpass volume.  cube2c's 1/2 rides on
+// the taps (exact).
+//
+// Reference: dtcwt/numpy/transform3d.py:208-289 (level 1: colfilter along axes 2, 1, 0 + cube2c :532-579).
+#pragma once
+#include "fused3d_march.hpp"
+#include "march2d_l1.hpp"
+
+namespace dt3l {
+
+using dt2d::DtBuf;
+using dt2d::f2;
+using dt2d::f4;
+
+struct Fwd3lParams {
+    const float *P;       // [4][n0][n1][n2]
+    int64_t pstride;      // n0 * n1 * n2
+    float *LLL;           // [n0][n1][n2]
+    float *Yh;            // [n0/2][n1/2][n2/2][56 floats]
+    int n0, n1, n2;       // all even
+    int nstrip, ncr, nchunk, chunk;       // strips of 64 cells along axis 2, rows of cells (n1 / 2), chunks of `chunk` slices (even)
+    // axis 0: (h0, h1) pairs by distance from the centre with cube2c's 1/2: [0] plane 0 -- octant (0, 0, 0) is the lowpass
+    // volume and stays unscaled: (h0, h1 / 2) --, [1] planes 1 .. 3: (h0, h1) / 2
+    float hp[2][2 * (dtm::MAXH1 + 1)] __attribute__((aligned(8)));
+};
+inline void pack_fwd3l(Fwd3lParams &p, const double *h0, int m0, const double *h1, int m1) {
+    for (int d = 0; d <= dtm::MAXH1; ++d) {
+        const double a = d <= m0 / 2 ? h0[m0 / 2 - d] : 0.0, b = d <= m1 / 2 ? h1[m1 / 2 - d] : 0.0;
+        p.hp[0][2 * d] = (float)a; p.hp[0][2 * d + 1] = (float)(0.5 * b);
+        p.hp[1][2 * d] = (float)(0.5 * a); p.hp[1][2 * d + 1] = (float)(0.5 * b);
+    }
+}
+
+template <int M0, int M1>
+__global__ void __launch_bounds__(256) k_fwd3l_axis0(const Fwd3lParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using G = dtm::Fwd1m<M0, M1>;
+    using dtm::pk2;
+    constexpr int HH = G::HH, WR = G::WR, PER = G::PER;
+    __shared__ __attribute__((aligned(16))) f4 slab[64 * 15 + 8];           // a record = 14 pieces, 15 apart (bank spread)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int v = __builtin_amdgcn_readfirstlane(tid >> 6);                 // plane 2 a1 + a2
+    const int w = blockIdx.x;
+    const int cr = w % p.ncr, rest = w / p.ncr;
+    const int strip = rest % p.nstrip, chunk = rest / p.nstrip;
+    if (chunk >= p.nchunk) return;
+    const int n0 = p.n0, n1 = p.n1, n2 = p.n2;
+    const int ncell = n2 / 2 - strip * 64 < 64 ? n2 / 2 - strip * 64 : 64;         // cells of this strip
+    const bool owns = lane < ncell;
+    const int k0 = 2 * (strip * 64 + (owns ? lane : 0));
+    const int j0 = 2 * cr;
+    const DtBuf bx = dtm::dt_buf2g(p.P + v * p.pstride);
+    const unsigned voff[2] = {((unsigned)j0 * (unsigned)n2 + (unsigned)k0) * 4u, ((unsigned)(j0 + 1) * (unsigned)n2 + (unsigned)k0) * 4u};
+    const int64_t spitch = (int64_t)n1 * n2;
+    const int s0 = chunk * p.chunk;
+    const int ns = n0 - s0 < p.chunk ? n0 - s0 : p.chunk;           // slices of this job (even)
+    const int nst = (ns / 2 + PER - 1) / PER * PER;                 // whole periods of the ring; surplus steps store nothing
+    const int last_slice = s0 + ns - 1 + HH;
+    auto soff = [&](int s) -> unsigned {
+        s = s > last_slice ? last_slice : s;
+        s = s < 0 ? -1 - s : s; s = s >= n0 ? 2 * n0 - 1 - s : s;
+        return (unsigned)s * (unsigned)spitch * 4u;                 // bytes (a volume is < 2 GiB: launcher)
+    };
+    auto load_slice = [&](int s, pk2 (&o)[2]) {
+        const unsigned so = soff(s);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { const f2 t = dt2d::dt_buf_ld2(bx, voff[h], so); o[h] = pk2{t.x, t.y}; }
+    };
+
+    pk2 ring[WR][2], pre[2][2];
+#pragma unroll
+    for (int i = 0; i < WR; ++i) load_slice(s0 - HH + i, ring[i]);
+    load_slice(s0 - HH + WR, pre[0]);
+    load_slice(s0 - HH + WR + 1, pre[1]);
+#pragma unroll
+    for (int i = 0; i < WR; ++i) asm volatile("" : "+v"(ring[i][0].x), "+v"(ring[i][0].y), "+v"(ring[i][1].x), "+v"(ring[i][1].y) : : "memory");
+#pragma unroll
+    for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(pre[i][0].x), "+v"(pre[i][0].y), "+v"(pre[i][1].x), "+v"(pre[i][1].y) : : "memory");
+
+    const pk2 *hpp = reinterpret_cast<const pk2 *>(p.hp[v == 0 ? 0 : 1]);
+    // record slots of this plane's two octants (oracle _OCTANTS order: (a0, a1, a2) = (0,1,0) (1,0,0) (1,1,0) (0,0,1) (0,1,1)
+    // (1,0,1) (1,1,1)): plane 0 -> (lowpass volume, 1), plane 1 = (a1, a2) = (0, 1) -> (3, 5), plane 2 -> (0, 2), plane 3 -> (4, 6)
+    const int slot_lo = v == 1 ? 3 : (v == 2 ? 0 : 4), slot_hi = v == 0 ? 1 : (v == 1 ? 5 : (v == 2 ? 2 : 6));
+    const int64_t rec_row = (int64_t)(n2 / 2) * 56;                 // floats per row of cells
+    float *const Lb = p.LLL + (int64_t)j0 * n2 + 2 * strip * 64;
+    float *const Yb = p.Yh + (int64_t)cr * rec_row + (int64_t)strip * 64 * 56;
+    const int npiece = ncell * 14;
+    int pslab[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int piece = tid + 256 * i; pslab[i] = (piece / 14) * 15 + piece % 14; }
+
+    for (int t0 = 0; t0 < nst; t0 += PER) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int m = t0 + k, s = s0 + 2 * m;                  // output slices s, s + 1
+            pk2 in0[2] = {pre[0][0], pre[0][1]}, in1[2] = {pre[1][0], pre[1][1]};
+            load_slice(s - HH + WR + 2, pre[0]);
+            load_slice(s - HH + WR + 3, pre[1]);
+            const bool ok = 2 * m < ns;                            // uniform
+            // ---- axis 0: O[q][e][c] = (lo0, hi0) at slice s + q, row j0 + e, column k0 + c
+            pk2 O[2][2][2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                pk2 win[WR];
+#pragma unroll
+                for (int j = 0; j < WR; ++j) win[j] = ring[(2 * k + j) % WR][e];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) dtm::col_lohi2<HH>(&win[q + HH], hpp, O[q][e][0], O[q][e][1]);
+            }
+            // ---- the slab must be free: the flush of the previous step has read it
+            DT3M_LDS_BARRIER();
+            {
+                f4 o0, o1;
+                dt3m::cube2c_cell(O[0][0][0].y, O[0][1][0].y, O[1][0][0].y, O[1][1][0].y, O[0][0][1].y, O[0][1][1].y, O[1][0][1].y, O[1][1][1].y, o0, o1);
+                if (owns) { slab[lane * 15 + 2 * slot_hi] = o0; slab[lane * 15 + 2 * slot_hi + 1] = o1; }
+                dt3m::cube2c_cell(O[0][0][0].x, O[0][1][0].x, O[1][0][0].x, O[1][1][0].x, O[0][0][1].x, O[0][1][1].x, O[1][0][1].x, O[1][1][1].x, o0, o1);
+                if (owns && v != 0) { slab[lane * 15 + 2 * slot_lo] = o0; slab[lane * 15 + 2 * slot_lo + 1] = o1; }
+            }
+            // the lowpass volume (every wavefront issues the same four stores: against zero bytes unless it is wavefront 0)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int so = ok ? s + q : s0;
+                    const DtBuf bl = dtm::dt_buf_n(Lb + (int64_t)so * spitch + (int64_t)e * n2, (ok && v == 0) ? 8u * ncell : 0u);
+                    dt2d::dt_buf_st2<false>(bl, 8u * (unsigned)lane, 0u, f2{O[q][e][0].x, O[q][e][1].x});
+                }
+            DT3M_LDS_BARRIER();
+            // ---- flush: the strip's row of cells as one run of 16-byte pieces
+            {
+                const int so = ok ? s / 2 : s0 / 2;
+                const DtBuf by = dtm::dt_buf_n(Yb + (int64_t)so * (n1 / 2) * rec_row, ok ? 16u * npiece : 0u);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int piece = tid + 256 * i;
+                    if (i < 3 || piece < 64 * 14) {
+                        const f4 val = slab[pslab[i]];
+                        dt2d::dt_buf_st4<true>(by, 16u * (unsigned)piece, 0u, val);
+                    }
+                }
+            }
+            ring[(2 * k) % WR][0] = in0[0]; ring[(2 * k) % WR][1] = in0[1];
+            ring[(2 * k + 1) % WR][0] = in1[0]; ring[(2 * k + 1) % WR][1] = in1[1];
+        }
+    }
+#endif
+}
+
+}  // namespace dt3l

@@ -272,6 +272,33 @@ int dtcwt_march_inv1(const float *Z, const float *Yh0, float *X, int B, int R, i
     return -3;
 }
 
+// ---- the in-slice half of the 3-D level 1 for long filters (fused3d_long.hpp): the level-1 marches above with the four row-
+// filtered planes in place of the lowpass + records; every slice of the volume is an image of the batch.  Called by fused3d.hip.
+int dtcwt_march_fwd1_planes(const float *X, float *P, int64_t pstride, int B, int R, int C, const double *h0o, int m0,
+                            const double *h1o, int m1, int cus, hipStream_t s) {
+    if (!(m0 == 13 && m1 == 19) || !l1_sizes_ok(B, R, C, dtm::Fwd1m<13, 19>::VL)) return -3;
+    dtm::Fwd1mParams p{};
+    p.X = X; p.LoLo = P; p.Yh0 = nullptr; p.pstride = pstride; p.B = B; p.R = R; p.C = C;
+    dtm::dtm_pack_fwd1m_planes(p, m0, m1, h0o, h1o);
+    using G = dtm::Fwd1m<13, 19>;
+    const int nstrip = cdiv(C, 4 * G::VL);
+    const unsigned jobs = dtm::dtm_set_jobs(p.jb, B, R, nstrip, pick_band_rows_l1(B, R, nstrip, 2 * G::PER, 0.5 * G::HH, cus));
+    dtm::k_fwd1m<13, 19, 2, true><<<jobs, 64, 0, s>>>(p);
+    return 0;
+}
+int dtcwt_march_inv1_planes(const float *P, int64_t pstride, float *X, int B, int R, int C, const double *g0o, int m0,
+                            const double *g1o, int m1, int cus, hipStream_t s) {
+    if (!(m0 == 19 && m1 == 13) || !l1_sizes_ok(B, R, C, dtm::Inv1m<19, 13>::VL)) return -3;
+    dtm::Inv1mParams p{};
+    p.Z = P; p.Yh0 = nullptr; p.X = X; p.pstride = pstride; p.B = B; p.R = R; p.C = C;
+    dtm::dtm_pack_inv1m(p, m0, m1, g0o, g1o);
+    using G = dtm::Inv1m<19, 13>;
+    const int nstrip = cdiv(C, 4 * G::VL);
+    const unsigned jobs = dtm::dtm_set_jobs(p.jb, B, R, nstrip, pick_band_rows_l1(B, R, nstrip, 4, 2.0 * G::WARM, cus));
+    dtm::k_inv1m<19, 13, true><<<jobs, 64, 0, s>>>(p);
+    return 0;
+}
+
 // ---- levels 1 + 2 of the forward as a marching PAIR of wavefronts (march2d_pair.hpp) ------------------------------------------
 // near_sym_a / legall-length level-1 filters (5, 7) with the 14- / 18-tap q-shift sets (qshift_b, qshift_d): 112 / 144 registers
 // of pending sums that one wavefront cannot hold beside level 1.  Measured (profiles/r05/pair_forward.txt, pair / level-1 tile

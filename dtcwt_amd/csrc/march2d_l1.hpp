@@ -24,8 +24,9 @@ constexpr int MAXH1 = 9;        // longest half length of a level-1 filter: 19 t
 
 struct Fwd1mParams {
     const float *X;       // [B][R][C]
-    float *LoLo;          // [B][R][C]
-    float *Yh0;           // [B][R/2][C/2][12]
+    float *LoLo;          // [B][R][C]; PLANES build: the first of four plane volumes [4][B][R][C], pstride elements apart
+    float *Yh0;           // [B][R/2][C/2][12]; PLANES build: unused
+    int64_t pstride;
     int B, R, C;          // R even, C % 4 == 0
     MarchJobs jb;
     // taps by distance d from the centre as (h0, h1) pairs, the shorter filter zero beyond its half length: the column
@@ -45,6 +46,12 @@ inline void dtm_pack_fwd1m(Fwd1mParams &p, int m0, int m1, const double *h0, con
     }
 }
 
+// PLANES build: the row taps unscaled
+inline void dtm_pack_fwd1m_planes(Fwd1mParams &p, int m0, int m1, const double *h0, const double *h1) {
+    dtm_pack_fwd1m(p, m0, m1, h0, h1);
+    for (int d = 0; d < 2 * (MAXH1 + 1); ++d) { p.hpl[d] = p.hp[d]; p.hph[d] = p.hp[d]; }
+}
+
 template <int M0, int M1>
 struct Fwd1m {
     static constexpr int H0 = M0 / 2, H1 = M1 / 2, HH = H0 > H1 ? H0 : H1;
@@ -56,9 +63,11 @@ struct Fwd1m {
 };
 
 struct Inv1mParams {
-    const float *Z;       // [B][R][C]          the level-1 lowpass (output of the level-2 inverse, or Yl)
-    const float *Yh0;     // [B][R/2][C/2][12]
+    const float *Z;       // [B][R][C]          the level-1 lowpass (output of the level-2 inverse, or Yl); PLANES build: the
+                          //                    first of four plane volumes [4][B][R][C], pstride elements apart
+    const float *Yh0;     // [B][R/2][C/2][12]  (PLANES build: unused)
     float *X;             // [B][R][C]
+    int64_t pstride;
     int B, R, C;          // R even, C % 4 == 0
     MarchJobs jb;
     float g1[6];          // gain x sqrt(1/2) per subband
@@ -124,7 +133,10 @@ __device__ __forceinline__ pk2 sym_gg(const pk2 *wc_, const pk2 *gd) {
 // on their way; the column pass makes (lo, hi) pairs of the lane's four columns for both rows, the row pass takes the
 // HH columns either side from the neighbouring lanes; q2c is lane-local; the records leave through the slab.
 // ======================================================================================================================
-template <int M0, int M1, int P>
+// PLANES (the in-slice half of the 3-D level 1 for long filters, fused3d_long.hpp): the four row-filtered planes (a1, a2) =
+// (Lo|Hi down the columns, lo|hi along the rows) leave as they are -- plane 2 a1 + a2 of p.LoLo, no q2c, no records -- and the
+// row taps p.hpl / p.hph come without the 1 / sqrt2 (dtm_pack_fwd1m_planes).
+template <int M0, int M1, int P, bool PLANES = false>
 __global__ void __launch_bounds__(64, 2) k_fwd1m(const Fwd1mParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using G = Fwd1m<M0, M1>;
@@ -208,6 +220,16 @@ __global__ void __launch_bounds__(64, 2) k_fwd1m(const Fwd1mParams p) {
                 ll[q] = f4{ol[0].x, ol[1].x, ol[2].x, ol[3].x}; lh[q] = f4{ol[0].y, ol[1].y, ol[2].y, ol[3].y};
                 hl[q] = f4{oh[0].x, oh[1].x, oh[2].x, oh[3].x}; hh[q] = f4{oh[0].y, oh[1].y, oh[2].y, oh[3].y};
             }
+            if constexpr (PLANES) {
+                const int ro = in_band ? r : rb;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const f4 pv[4] = {ll[q], lh[q], hl[q], hh[q]};
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        dt2d::dt_buf_st4<false>(dt_buf_n(Lb + v * p.pstride + (int64_t)(ro + q) * C, in_band ? 16u * nv : 0u), lv, 0u, pv[v]);
+                }
+            } else {
             {
                 const Zq a0 = q2c_p(hl[0].x, hl[0].y, hl[1].x, hl[1].y), a1 = q2c_p(hl[0].z, hl[0].w, hl[1].z, hl[1].w);
                 const Zq b0 = q2c_p(hh[0].x, hh[0].y, hh[1].x, hh[1].y), b1 = q2c_p(hh[0].z, hh[0].w, hh[1].z, hh[1].w);
@@ -232,6 +254,7 @@ __global__ void __launch_bounds__(64, 2) k_fwd1m(const Fwd1mParams p) {
                 dt2d::dt_buf_st4<true>(by, yv + 1024u * m, 0u, v);
             }
             DT_WAVE_LDS_SYNC();
+            }
             f4 e0 = in0, e1 = in1;
             fix(e0); fix(e1);
             ring[(2 * k) % WR] = e0;
@@ -250,7 +273,10 @@ __global__ void __launch_bounds__(64, 2) k_fwd1m(const Fwd1mParams p) {
 // Rows are requested one step ahead.  Symmetric extension: reflected record rows swap the rows of their quads, mirrored
 // lanes take the mirror lane's records in reverse (march2d.hpp: k_inv21m).
 // ======================================================================================================================
-template <int M0, int M1>
+// PLANES (the in-slice half of the 3-D level-1 inverse for long filters, fused3d_long.hpp): the lowpass and the three quad
+// planes arrive as the four plane volumes (a1, a2) = plane 2 a1 + a2 of p.Z -- Z1 = plane 0, q23 = plane 1 (Lo down the columns,
+// hi along the rows), q05 = plane 2, q14 = plane 3 -- instead of c2q of the records; no gains.
+template <int M0, int M1, bool PLANES = false>
 __global__ void __launch_bounds__(64, 2) k_inv1m(const Inv1mParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using G = Inv1m<M0, M1>;
@@ -288,10 +314,22 @@ __global__ void __launch_bounds__(64, 2) k_inv1m(const Inv1mParams p) {
     auto rec_row = [&](int rr, bool &sw) { sw = rr < 0 || rr >= R / 2; rr = rr < 0 ? -1 - rr : rr; rr = rr >= R / 2 ? R - 1 - rr : rr; return rr < 0 ? 0 : (rr > R / 2 - 1 ? R / 2 - 1 : rr); };
 
     f4 zp[2], r1p[6];
+    const DtBuf bq1 = dt_buf2g(p.Z + img + (PLANES ? p.pstride : 0)), bq2 = dt_buf2g(p.Z + img + (PLANES ? 2 * p.pstride : 0)),
+                bq3 = dt_buf2g(p.Z + img + (PLANES ? 3 * p.pstride : 0));
     auto request = [&](int rr) {
         bool sw;
         zp[0] = dt2d::dt_buf_ld4(bz, (unsigned)lc * 4u, (unsigned)zrow(2 * rr) * pitch);
         zp[1] = dt2d::dt_buf_ld4(bz, (unsigned)lc * 4u, (unsigned)zrow(2 * rr + 1) * pitch);
+        if constexpr (PLANES) {           // r1p[2 (plane - 1) + e]: rows 2 rr + e of planes 1, 2, 3
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const unsigned ro = (unsigned)zrow(2 * rr + e) * pitch;
+                r1p[e] = dt2d::dt_buf_ld4(bq1, (unsigned)lc * 4u, ro);
+                r1p[2 + e] = dt2d::dt_buf_ld4(bq2, (unsigned)lc * 4u, ro);
+                r1p[4 + e] = dt2d::dt_buf_ld4(bq3, (unsigned)lc * 4u, ro);
+            }
+            return;
+        }
         const DtBuf br = dt_buf_n(Y0b + (int64_t)rec_row(rr, sw) * C * 6, r1bytes);
 #pragma unroll
         for (int m = 0; m < 6; ++m) r1p[m] = dt2d::dt_buf_ld4(br, 16u * (unsigned)lane + 1024u * m, 0u);
@@ -312,15 +350,28 @@ __global__ void __launch_bounds__(64, 2) k_inv1m(const Inv1mParams p) {
         bool sw;
         (void)rec_row(rr, sw);
         // ---- what was requested a step ago: the records to the slab, the lowpass rows in place
+        f4 qq[6];
+        if constexpr (PLANES) {
+#pragma unroll
+            for (int m = 0; m < 6; ++m) { qq[m] = r1p[m]; if (edge_strip) qq[m] = mir ? rev4(qq[m]) : qq[m]; }
+        } else {
 #pragma unroll
         for (int m = 0; m < 6; ++m) slab[6 * lmin + lane + 64 * m] = r1p[m];
+        }
         f4 zz[2] = {zp[0], zp[1]};
         // (rows 2 rr, 2 rr + 1 reflect to the two rows of the reflected record row in the other order: zrow() did that)
         if (edge_strip) { zz[0] = mir ? rev4(zz[0]) : zz[0]; zz[1] = mir ? rev4(zz[1]) : zz[1]; }
         request(rr + 1);
         DT_WAVE_LDS_SYNC();
         float q05[2][4], q23[2][4], q14[2][4];
-        {
+        if constexpr (PLANES) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                q23[e][0] = qq[e].x; q23[e][1] = qq[e].y; q23[e][2] = qq[e].z; q23[e][3] = qq[e].w;
+                q05[e][0] = qq[2 + e].x; q05[e][1] = qq[2 + e].y; q05[e][2] = qq[2 + e].z; q05[e][3] = qq[2 + e].w;
+                q14[e][0] = qq[4 + e].x; q14[e][1] = qq[4 + e].y; q14[e][2] = qq[4 + e].z; q14[e][3] = qq[4 + e].w;
+            }
+        } else {
             const f4 *sp = slab + 6 * sl;
             f4 s_[6];
 #pragma unroll

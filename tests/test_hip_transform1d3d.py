@@ -242,6 +242,35 @@ def test_3d_level1_march_matches_tile_program_and_oracle(shape, bname, monkeypat
         assert_close(t.inverse(p1), X, INV_TOL, 'PR')
 
 
+@pytest.mark.parametrize('shape', [(20, 40, 40), (24, 44, 132), (64, 48, 256), (42, 40, 260), (100, 64, 64), (36, 130, 72)])
+@pytest.mark.parametrize('chunks', [(None, None), ('20', '4')])
+def test_3d_level1_long_filters_match_generic_and_oracle(shape, chunks, monkeypatch):
+    """near_sym_b (13 / 19 taps: "qbgn-style", the set the reference's own 3-D MATLAB vectors use) through the two-launch level 1
+    of fused3d_long.hpp -- k_fwd1m / k_inv1m with plane volumes, k_fwd3l_axis0, k_inv3l_axis0 -- against the axis-by-axis generic
+    kernels (DTCWT_HIP_LONG3D=0: the path before round 5) and the oracle: one and two strips of cells (a second strip of 2 and of
+    66 cells), two strips of the in-slice march, slice counts that are not whole ring periods or chunks, one chunk and several."""
+    X = np.random.RandomState(37).standard_normal(shape).astype(np.float32)
+    t = Transform3d(biort='near_sym_b', qshift='qshift_b')
+    monkeypatch.setenv('DTCWT_HIP_LONG3D', '0')
+    p0 = t.forward(X, nlevels=1)
+    z0 = t.inverse(p0)
+    monkeypatch.setenv('DTCWT_HIP_LONG3D', '1')
+    if chunks[0]:
+        monkeypatch.setenv('DTCWT_HIP_LONG3D_CHUNK', chunks[0])
+        monkeypatch.setenv('DTCWT_HIP_LONG3D_ICHUNK', chunks[1])
+    p1 = t.forward(X, nlevels=1)
+    assert_pyramids_close(p1, p0, XFM_TOL)
+    if X.size <= 900000:
+        want = o.Transform3d(biort('near_sym_b'), qshift('qshift_b')).forward(as_f64(X), nlevels=1)
+        assert_pyramids_close(p1, want, XFM_TOL, same_dtype=False)
+    z1 = t.inverse(p1)
+    assert_close(z1, X, INV_TOL, 'PR')
+    assert_close(t.inverse(p0), z0, INV_TOL, 'long vs generic inverse')
+    # the whole transform as one native plan: levels >= 2 on the q-shift tile programs
+    p2 = t.forward(X, nlevels=2)
+    assert_close(t.inverse(p2), X, INV_TOL, 'PR, two levels')
+
+
 @pytest.mark.parametrize('shape,ext', [((42, 46, 90), 4), ((44, 52, 84), 8), ((80, 80, 80), 4), ((48, 40, 200), 8)])
 @pytest.mark.parametrize('qname', ['qshift_a', 'qshift_b', 'qshift_d'])
 def test_3d_fused_level2_matches_generic_and_oracle(shape, ext, qname):
