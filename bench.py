@@ -558,8 +558,11 @@ def other_configs():
     (one GPU's share of the 512-image batch: 64 x 2048^2 nl=4) and c4 (3-D 256^3 nl=3).  The reference's own benchmark
     script times every case it names in one run (scripts/benchmark_opencl.py:57-100)."""
     res = {}
-    for name, extra in (('c3', ['--steps', '40']), ('c5_share', ['--config', 'c5', '--steps', '20']), ('c4', ['--steps', '40'])):
-        cfgname = 'c5' if name == 'c5_share' else name
+    # c4_qbgn: BASELINE configs[3] reads "qbgn-style" -- the reference's own 3-D vectors (tests/test_againstmatlab.py:115-124) use
+    # near_sym_b / qshift_b: 13 / 19-tap level-1 filters, two launches per direction around four plane volumes (fused3d_long.hpp)
+    for name, extra in (('c3', ['--steps', '40']), ('c5_share', ['--config', 'c5', '--steps', '20']), ('c4', ['--steps', '40']),
+                        ('c4_qbgn', ['--steps', '40', '--biort', 'near_sym_b', '--qshift', 'qshift_b'])):
+        cfgname = 'c5' if name == 'c5_share' else ('c4' if name == 'c4_qbgn' else name)
         cmd = [sys.executable, os.path.abspath(__file__), '--config', cfgname, '--no-cpu-baseline', '--no-other-configs',
                '--warmup', '5', '--settle-ms', '150'] + [e for e in extra if e not in ('--config', 'c5')]
         t0 = time.perf_counter()
@@ -570,7 +573,7 @@ def other_configs():
             keep = {'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'], 'steps': d['steps'],
                     'workload': d['config']['workload'], 'step_frac': d['roofline'].get('step_frac'),
                     'wall_s': round(time.perf_counter() - t0, 1)}
-            if name == 'c4':
+            if cfgname == 'c4':
                 keep.update({k: d.get(k) for k in ('fwd_ms_per_step', 'inv_ms_per_step', 'ms_per_step_one_stream')})
                 keep['streams'] = d['config'].get('streams')
                 keep['k_fwd3_l1_frac'] = d['roofline'].get('frac')
@@ -699,7 +702,8 @@ def main_c4(args):
         'ms_per_step_one_stream': round(dt_1 / args.steps * 1e3, 5),
         'fwd_ms_per_step': round(dt_f / args.steps * 1e3, 5), 'inv_ms_per_step': round(dt_i / args.steps * 1e3, 5),
         'step_frac': round(72.0 * vox / (ms * 1e-3) / HBM_PEAK, 4),
-        'roofline': {'bound': 'hbm', 'kernel': 'k_fwd3m_l1 (level-1 forward, one launch: marching pairs of wavefronts; the tile program k_fwd3_l1 where it does not apply)' if fused_l1 else 'level-1 forward as Transform3d runs it for this wavelet set (several launches)',
+        'roofline': {'bound': 'hbm', 'kernel': ('k_fwd3m_l1 (level-1 forward, one launch: marching pairs of wavefronts; the tile program k_fwd3_l1 where it does not apply)' if BIORT != 'near_sym_b'
+                                                 else 'k_fwd1m<13,19,PLANES> + k_fwd3l_axis0 (level-1 forward for the 13 / 19-tap filters: two launches around four plane volumes, 68 B/voxel moved)') if fused_l1 else 'level-1 forward as Transform3d runs it for this wavelet set (several launches)',
                      'achieved': round(36.0 * vox / (kms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                      'frac': round(36.0 * vox / (kms * 1e-3) / HBM_PEAK, 4), 'traffic': None,
                      'kernel_ms': round(kms, 5), 'kernel_ms_is': 'median raw hipEvent pair around dtcwt_hip_fwd3_level1, 20 launches',

@@ -290,11 +290,11 @@ static int launch_fwd3l_axis0(const float *P, int64_t pstride, float *LLL, float
     dt3l::Fwd3lParams p{};
     p.P = P; p.pstride = pstride; p.LLL = LLL; p.Yh = Yh; p.n0 = n0; p.n1 = n1; p.n2 = n2;
     p.nstrip = cdiv(n2 / 2, 64); p.ncr = n1 / 2;
-    // slices per job in whole periods of the ring (20 slices); every chunk re-reads 18 slices of warm-up
-    constexpr int PERS = 2 * dtm::Fwd1m<13, 19>::PER;
-    int chunk = cdiv(n0, PERS) * PERS;
-    while (chunk > PERS && (int64_t)p.nstrip * p.ncr * cdiv(n0, chunk) < 2 * (int64_t)cus) chunk -= PERS;
-    if (const char *e = getenv("DTCWT_HIP_LONG3D_CHUNK")) { const int v = atoi(e) / PERS * PERS; if (v >= PERS) chunk = v; }
+    // equal chunks of slices, enough of them for two workgroups per CU; every chunk re-reads 18 slices of warm-up
+    int nchunk = 1;
+    while (nchunk < 8 && n0 / (nchunk + 1) >= 40 && (int64_t)p.nstrip * p.ncr * nchunk < 2 * (int64_t)cus) ++nchunk;
+    int chunk = (cdiv(n0, nchunk) + 1) & ~1;
+    if (const char *e = getenv("DTCWT_HIP_LONG3D_CHUNK")) { const int v = atoi(e) & ~1; if (v >= 2) chunk = v; }
     p.chunk = chunk; p.nchunk = cdiv(n0, chunk);
     dt3l::pack_fwd3l(p, h0, m0, h1, m1);
     dt3l::k_fwd3l_axis0<13, 19><<<(unsigned)(p.ncr * p.nstrip * p.nchunk), 256, 0, s>>>(p);

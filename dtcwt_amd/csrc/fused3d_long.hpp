@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(256) k_fwd3l_axis0(const Fwd3lParams p) {
     const int64_t spitch = (int64_t)n1 * n2;
     const int s0 = chunk * p.chunk;
     const int ns = n0 - s0 < p.chunk ? n0 - s0 : p.chunk;           // slices of this job (even)
-    const int nst = (ns / 2 + PER - 1) / PER * PER;                 // whole periods of the ring; surplus steps store nothing
+    const int nst = ns / 2;                                         // steps; the loop leaves inside a period of the ring (uniform)
     const int last_slice = s0 + ns - 1 + HH;
     auto soff = [&](int s) -> unsigned {
         s = s > last_slice ? last_slice : s;
@@ -115,10 +115,11 @@ __global__ void __launch_bounds__(256) k_fwd3l_axis0(const Fwd3lParams p) {
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int m = t0 + k, s = s0 + 2 * m;                  // output slices s, s + 1
+            if (m >= nst) return;                                  // the whole workgroup at once
             pk2 in0[2] = {pre[0][0], pre[0][1]}, in1[2] = {pre[1][0], pre[1][1]};
             load_slice(s - HH + WR + 2, pre[0]);
             load_slice(s - HH + WR + 3, pre[1]);
-            const bool ok = 2 * m < ns;                            // uniform
+            constexpr bool ok = true;
             // ---- axis 0: O[q][e][c] = (lo0, hi0) at slice s + q, row j0 + e, column k0 + c
             pk2 O[2][2][2];
 #pragma unroll

@@ -274,6 +274,10 @@ int dtcwt_march_inv1(const float *Z, const float *Yh0, float *X, int B, int R, i
 
 // ---- the in-slice half of the 3-D level 1 for long filters (fused3d_long.hpp): the level-1 marches above with the four row-
 // filtered planes in place of the lowpass + records; every slice of the volume is an image of the batch.  Called by fused3d.hip.
+static bool planes_one_strip(int C, int VL) {
+    if (const char *e = getenv("DTCWT_HIP_LONG3D_EDGE")) return e[0] != '0' && C <= 256 && C >= 48;       // tests: force / forbid
+    return C > 4 * VL && C <= 256;
+}
 int dtcwt_march_fwd1_planes(const float *X, float *P, int64_t pstride, int B, int R, int C, const double *h0o, int m0,
                             const double *h1o, int m1, int cus, hipStream_t s) {
     if (!(m0 == 13 && m1 == 19) || !l1_sizes_ok(B, R, C, dtm::Fwd1m<13, 19>::VL)) return -3;
@@ -281,9 +285,12 @@ int dtcwt_march_fwd1_planes(const float *X, float *P, int64_t pstride, int B, in
     p.X = X; p.LoLo = P; p.Yh0 = nullptr; p.pstride = pstride; p.B = B; p.R = R; p.C = C;
     dtm::dtm_pack_fwd1m_planes(p, m0, m1, h0o, h1o);
     using G = dtm::Fwd1m<13, 19>;
-    const int nstrip = cdiv(C, 4 * G::VL);
+    // a row of 236 .. 256 columns: one strip without halo lanes (EDGE build) instead of two strips with 58 owning lanes each
+    const bool edge = planes_one_strip(C, G::VL);
+    const int nstrip = edge ? 1 : cdiv(C, 4 * G::VL);
     const unsigned jobs = dtm::dtm_set_jobs(p.jb, B, R, nstrip, pick_band_rows_l1(B, R, nstrip, 2 * G::PER, 0.5 * G::HH, cus));
-    dtm::k_fwd1m<13, 19, 2, true><<<jobs, 64, 0, s>>>(p);
+    if (edge) dtm::k_fwd1m<13, 19, 2, true, true><<<jobs, 64, 0, s>>>(p);
+    else dtm::k_fwd1m<13, 19, 2, true><<<jobs, 64, 0, s>>>(p);
     return 0;
 }
 int dtcwt_march_inv1_planes(const float *P, int64_t pstride, float *X, int B, int R, int C, const double *g0o, int m0,
@@ -293,9 +300,11 @@ int dtcwt_march_inv1_planes(const float *P, int64_t pstride, float *X, int B, in
     p.Z = P; p.Yh0 = nullptr; p.X = X; p.pstride = pstride; p.B = B; p.R = R; p.C = C;
     dtm::dtm_pack_inv1m(p, m0, m1, g0o, g1o);
     using G = dtm::Inv1m<19, 13>;
-    const int nstrip = cdiv(C, 4 * G::VL);
+    const bool edge = planes_one_strip(C, G::VL);
+    const int nstrip = edge ? 1 : cdiv(C, 4 * G::VL);
     const unsigned jobs = dtm::dtm_set_jobs(p.jb, B, R, nstrip, pick_band_rows_l1(B, R, nstrip, 4, 2.0 * G::WARM, cus));
-    dtm::k_inv1m<19, 13, true><<<jobs, 64, 0, s>>>(p);
+    if (edge) dtm::k_inv1m<19, 13, true, true><<<jobs, 64, 0, s>>>(p);
+    else dtm::k_inv1m<19, 13, true><<<jobs, 64, 0, s>>>(p);
     return 0;
 }
 

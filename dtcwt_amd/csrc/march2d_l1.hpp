@@ -116,6 +116,29 @@ __device__ __forceinline__ void halo_pairs(pk2 (&W)[4 + 2 * HH]) {
     }
 }
 
+// EDGE builds (a row of at most 256 columns is ONE strip, every lane owns columns: no halo lanes): what halo_pairs() took
+// from beyond the image -- lanes that do not exist at the left face, idle lanes at the right one -- is replaced by the
+// mirror columns, which are in the window already.  W[H + r] is column 4 lane + r; at the left face of lane l column
+// 4 l - d < 0 mirrors to d - 4 l - 1, i.e. r = d - 8 l - 1; at the right face of lane nl - 1 - l column 3 + d mirrors to
+// r = 4 + 8 l - d; both for d > 4 l.  (15 + 15 selects of pairs at H = 9.)
+template <int H>
+__device__ __forceinline__ void edge_mirror(pk2 (&W)[4 + 2 * H], int lane, int nl) {
+    constexpr int HLn = (H + 3) / 4;
+    pk2 T[4 + 2 * H];
+#pragma unroll
+    for (int i = 0; i < 4 + 2 * H; ++i) T[i] = W[i];
+#pragma unroll
+    for (int l = 0; l < HLn; ++l) {
+        const bool isl = lane == l, isr = lane == nl - 1 - l;
+#pragma unroll
+        for (int d = 4 * l + 1; d <= H; ++d) {
+            const pk2 ml = T[H + d - 8 * l - 1], mr = T[H + 4 + 8 * l - d];
+            W[H - d] = pk2{isl ? ml.x : W[H - d].x, isl ? ml.y : W[H - d].y};
+            W[H + 3 + d] = pk2{isr ? mr.x : W[H + 3 + d].x, isr ? mr.y : W[H + 3 + d].y};
+        }
+    }
+}
+
 // Symmetric row filters on (plane, plane) pairs with a tap common to both halves: out = g[0] w[0] + sum_d g[d] (w[-d] + w[d])
 template <int H>
 __device__ __forceinline__ pk2 sym_gg(const pk2 *wc_, const pk2 *gd) {
@@ -136,11 +159,13 @@ __device__ __forceinline__ pk2 sym_gg(const pk2 *wc_, const pk2 *gd) {
 // PLANES (the in-slice half of the 3-D level 1 for long filters, fused3d_long.hpp): the four row-filtered planes (a1, a2) =
 // (Lo|Hi down the columns, lo|hi along the rows) leave as they are -- plane 2 a1 + a2 of p.LoLo, no q2c, no records -- and the
 // row taps p.hpl / p.hph come without the 1 / sqrt2 (dtm_pack_fwd1m_planes).
-template <int M0, int M1, int P, bool PLANES = false>
+// EDGE: rows of at most 256 columns as one strip without halo lanes (edge_mirror above).
+template <int M0, int M1, int P, bool PLANES = false, bool EDGE = false>
 __global__ void __launch_bounds__(64, 2) k_fwd1m(const Fwd1mParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using G = Fwd1m<M0, M1>;
-    constexpr int HH = G::HH, WR = G::WR, HL = G::HL, VL = G::VL, PER = G::PER;
+    constexpr int HH = G::HH, WR = G::WR, HL = EDGE ? 0 : G::HL, VL = EDGE ? 64 : G::VL, PER = G::PER;
+    static_assert(!EDGE || PLANES, "the one-strip build writes planes");
     static_assert(PER % P == 0, "prefetch depth divides the ring period");
     __shared__ __attribute__((aligned(16))) f4 slab[64 * 6 + 6 * G::HL + 8];
     const int lane = threadIdx.x;
@@ -152,7 +177,7 @@ __global__ void __launch_bounds__(64, 2) k_fwd1m(const Fwd1mParams p) {
     const bool rev = c0 < 0 || c0 >= C;
     int lc = c0 < 0 ? -c0 - 4 : (c0 >= C ? 2 * C - 4 - c0 : c0);
     lc = lc < 0 ? 0 : (lc > C - 4 ? C - 4 : lc);
-    const bool edge_strip = strip == 0 || (strip + 1) * (4 * VL) + 4 * HL >= C;
+    const bool edge_strip = !EDGE && (strip == 0 || (strip + 1) * (4 * VL) + 4 * HL >= C);
     const int nv = (C - strip * (4 * VL)) / 4 < VL ? (C - strip * (4 * VL)) / 4 : VL;     // owning lanes
 
     const int64_t img = (int64_t)b * R * C;
@@ -214,6 +239,7 @@ __global__ void __launch_bounds__(64, 2) k_fwd1m(const Fwd1mParams p) {
                 col_lohi2<HH>(&wp[0][q + HH], hpp, W[HH], W[HH + 1]);
                 col_lohi2<HH>(&wp[1][q + HH], hpp, W[HH + 2], W[HH + 3]);
                 halo_pairs<HH>(W);
+                if constexpr (EDGE) edge_mirror<HH>(W, lane, nv);
                 pk2 ol[4], oh[4];           // (ll, lh) and (hl, hh) of the four columns, the highpass ones over sqrt2
 #pragma unroll
                 for (int c = 0; c < 4; ++c) row_lohi_s<HH>(&W[c + HH], hpl, hph, ol[c], oh[c]);
@@ -276,11 +302,12 @@ __global__ void __launch_bounds__(64, 2) k_fwd1m(const Fwd1mParams p) {
 // PLANES (the in-slice half of the 3-D level-1 inverse for long filters, fused3d_long.hpp): the lowpass and the three quad
 // planes arrive as the four plane volumes (a1, a2) = plane 2 a1 + a2 of p.Z -- Z1 = plane 0, q23 = plane 1 (Lo down the columns,
 // hi along the rows), q05 = plane 2, q14 = plane 3 -- instead of c2q of the records; no gains.
-template <int M0, int M1, bool PLANES = false>
+template <int M0, int M1, bool PLANES = false, bool EDGE = false>
 __global__ void __launch_bounds__(64, 2) k_inv1m(const Inv1mParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using G = Inv1m<M0, M1>;
-    constexpr int H0 = G::H0, H1 = G::H1, HM = G::HM, HL = G::HL, VL = G::VL, NPX = G::NPX, WARM = G::WARM;
+    constexpr int H0 = G::H0, H1 = G::H1, HM = G::HM, HL = EDGE ? 0 : G::HL, VL = EDGE ? 64 : G::VL, NPX = G::NPX, WARM = G::WARM;
+    static_assert(!EDGE || PLANES, "the one-strip build reads planes");
     __shared__ __attribute__((aligned(16))) f4 slab[64 * 6 + 6 * G::HL + 8];
     const int lane = threadIdx.x;
     int strip, band, b;
@@ -289,7 +316,7 @@ __global__ void __launch_bounds__(64, 2) k_inv1m(const Inv1mParams p) {
     const int cb = strip * (4 * VL) - 4 * HL;             // column of lane 0
     const int c0 = cb + 4 * lane;
     const bool mir = c0 < 0 || c0 >= C;
-    const bool edge_strip = cb < 0 || cb + 256 > C;      // uniform: some lane is mirrored
+    const bool edge_strip = !EDGE && (cb < 0 || cb + 256 > C);      // uniform: some lane is mirrored
     const int nv = (C - strip * (4 * VL)) / 4 < VL ? (C - strip * (4 * VL)) / 4 : VL;
     // where the lane's lowpass samples come from (mirrored lanes: the mirror block, reversed on arrival) and which slab
     // lane holds its records
@@ -424,6 +451,7 @@ __global__ void __launch_bounds__(64, 2) k_inv1m(const Inv1mParams p) {
             }
             halo_pairs<H0>(Wa);
             halo_pairs<H1>(Wb);
+            if constexpr (EDGE) { edge_mirror<H0>(Wa, lane, nv); edge_mirror<H1>(Wb, lane, nv); }
 #pragma unroll
             for (int c = 0; c < 4; ++c) V[c] = sym_gg<H0>(&Wa[H0 + c], gd0) + sym_gg<H1>(&Wb[H1 + c], gd1);
             // columns, transposed, on pairs of neighbouring columns: PX[i][h] = columns (2h, 2h + 1) of row rho - HM + i;

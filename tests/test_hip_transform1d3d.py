@@ -243,12 +243,14 @@ def test_3d_level1_march_matches_tile_program_and_oracle(shape, bname, monkeypat
 
 
 @pytest.mark.parametrize('shape', [(20, 40, 40), (24, 44, 132), (64, 48, 256), (42, 40, 260), (100, 64, 64), (36, 130, 72)])
-@pytest.mark.parametrize('chunks', [(None, None), ('20', '4')])
+@pytest.mark.parametrize('chunks', [(None, None, None), ('20', '4', '1'), ('14', '7', '0')])
 def test_3d_level1_long_filters_match_generic_and_oracle(shape, chunks, monkeypatch):
     """near_sym_b (13 / 19 taps: "qbgn-style", the set the reference's own 3-D MATLAB vectors use) through the two-launch level 1
     of fused3d_long.hpp -- k_fwd1m / k_inv1m with plane volumes, k_fwd3l_axis0, k_inv3l_axis0 -- against the axis-by-axis generic
     kernels (DTCWT_HIP_LONG3D=0: the path before round 5) and the oracle: one and two strips of cells (a second strip of 2 and of
-    66 cells), two strips of the in-slice march, slice counts that are not whole ring periods or chunks, one chunk and several."""
+    66 cells), two strips of the in-slice march, slice counts that are not whole ring periods or chunks, one chunk and several;
+    the in-slice marches as one strip without halo lanes (the EDGE builds: mirror columns selected in-lane at both faces, with
+    and without idle lanes) wherever the rows have at most 256 columns, and with halo lanes everywhere."""
     X = np.random.RandomState(37).standard_normal(shape).astype(np.float32)
     t = Transform3d(biort='near_sym_b', qshift='qshift_b')
     monkeypatch.setenv('DTCWT_HIP_LONG3D', '0')
@@ -258,6 +260,7 @@ def test_3d_level1_long_filters_match_generic_and_oracle(shape, chunks, monkeypa
     if chunks[0]:
         monkeypatch.setenv('DTCWT_HIP_LONG3D_CHUNK', chunks[0])
         monkeypatch.setenv('DTCWT_HIP_LONG3D_ICHUNK', chunks[1])
+        monkeypatch.setenv('DTCWT_HIP_LONG3D_EDGE', chunks[2])
     p1 = t.forward(X, nlevels=1)
     assert_pyramids_close(p1, p0, XFM_TOL)
     if X.size <= 900000:
