@@ -318,6 +318,29 @@ def test_3d_fused_vs_generic_random_sweep():
         assert_close(zt, X, INV_TOL, 'PR')
 
 
+def test_3d_long_filters_random_sweep():
+    """Seeded random volumes through the two-launch level 1 of the 13 / 19-tap filters (fused3d_long.hpp) against the generic
+    axis passes: rows of 40 .. 300 columns (one strip with halo lanes, one strip without -- 236 .. 256 --, two strips), 20 .. 90
+    slices, one to three levels, both ext_modes."""
+    rs = np.random.RandomState(77)
+    for trial in range(14):
+        ext = int(rs.choice([4, 8]))
+        mult = 2 if ext == 4 else 4
+        n0 = int(mult * rs.randint(20 // mult, 92 // mult))
+        n1 = int(mult * rs.randint(40 // mult, 80 // mult))
+        n2 = int(4 * rs.choice([rs.randint(10, 59), rs.randint(59, 65), rs.randint(65, 76)]))
+        qn = ['qshift_b', 'qshift_a', 'qshift_d'][rs.randint(3)]
+        nl = int(rs.randint(1, 4))
+        X = rs.standard_normal((n0, n1, n2)).astype(np.float32)
+        t, g = Transform3d('near_sym_b', qn, ext_mode=ext), Transform3d('near_sym_b', qn, ext_mode=ext)
+        g.fused = False
+        p, q = t.forward(X, nlevels=nl), g.forward(X, nlevels=nl)
+        assert_pyramids_close(p, q, XFM_TOL)
+        zt = t.inverse(p)
+        assert_close(zt, g.inverse(p), INV_TOL, 'inverse %s %s ext%d nl%d' % (X.shape, qn, ext, nl))
+        assert_close(zt, X, INV_TOL, 'PR')
+
+
 def test_native_plans_one_call_per_transform(monkeypatch):
     """Transform3d / Transform1d run as ONE native call (dtcwt_hip_plan3d_* / plan1d_*) and give bit-identical
     results to the level-by-level sequencing from Python (plans switched off)."""
