@@ -104,7 +104,7 @@ int dtcwt_g2_sum(dtcwt_hip_ctx *ctx, int dtype, int kind, const void *X0, const 
                  int packed_x1, double gain1);
 
 // would the fused 3-D level kernels take this level? (fused3d.hip; used by the whole-transform plan)
-bool dtcwt_fwd3_level1_ok(int64_t n0, int64_t n1, int64_t n2, int m0, int m1);
+bool dtcwt_fwd3_level1_ok(int64_t n0, int64_t n1, int64_t n2, int m0, int m1, const double *h0o = nullptr, const double *h1o = nullptr);
 bool dtcwt_fwd3_level2_ok(int64_t n0, int64_t n1, int64_t n2, int pad0, int pad1, int pad2, int m);
-bool dtcwt_inv3_level1_ok(int64_t n0, int64_t n1, int64_t n2, int m0, int m1);
+bool dtcwt_inv3_level1_ok(int64_t n0, int64_t n1, int64_t n2, int m0, int m1, const double *g0o = nullptr, const double *g1o = nullptr);
 bool dtcwt_inv3_level2_ok(int64_t n0, int64_t n1, int64_t n2, int crop0, int m);

@@ -742,14 +742,15 @@ extern "C" int dtcwt_hip_inv3_level2(dtcwt_hip_ctx *ctx, const float *LLL, const
 // ---- "would this level run fused?" for the whole-transform plan (plans13.hip): the same conditions the four
 // entry points above test before launching, so that a plan is only created where every level of a direction runs
 // natively -- a level that declined in the middle of a transform made the host redo the whole transform.
-bool dtcwt_fwd3_level1_ok(int64_t n0, int64_t n1, int64_t n2, int m0, int m1) {
+bool dtcwt_fwd3_level1_ok(int64_t n0, int64_t n1, int64_t n2, int m0, int m1, const double *h0o, const double *h1o) {
     if (n0 < 8 || n1 < 8 || n2 < 8 || n0 >= (1 << 30) || n1 * n2 >= ((int64_t)1 << 31)) return false;
     if (m0 == 5 && m1 == 3) m1 = 7;
     if (m0 == 3 && m1 == 5) m0 = 7;
 #define X_(A, B) if (m0 == A && m1 == B) return true;
     DT_FWD3_L1_TABLE(X_)
 #undef X_
-    return long3_ok(n0, n1, n2, m0, m1) && m0 == 13;
+    // the long filters (fused3d_long.hpp) fold their mirror pairs: symmetric taps only (every shipped set)
+    return long3_ok(n0, n1, n2, m0, m1) && m0 == 13 && h0o && h1o && symmetric_taps(h0o, m0) && symmetric_taps(h1o, m1);
 }
 bool dtcwt_fwd3_level2_ok(int64_t n0, int64_t n1, int64_t n2, int pad0, int pad1, int pad2, int m) {
     const int64_t L1 = n1 + 2 * pad1, L2 = n2 + 2 * pad2;
@@ -760,14 +761,14 @@ bool dtcwt_fwd3_level2_ok(int64_t n0, int64_t n1, int64_t n2, int pad0, int pad1
 #undef X_
     return false;
 }
-bool dtcwt_inv3_level1_ok(int64_t n0, int64_t n1, int64_t n2, int m0, int m1) {
+bool dtcwt_inv3_level1_ok(int64_t n0, int64_t n1, int64_t n2, int m0, int m1, const double *g0o, const double *g1o) {
     const int taps = m0 > m1 ? m0 : m1;
     const int minw = 2 * taps > 16 ? 2 * taps : 16;
     if (n0 < 12 || n1 < minw || n2 < minw || 4 * n0 * n1 * n2 >= ((int64_t)1 << 31)) return false;
 #define X_(A, B) if (m0 == A && m1 == B) return true;
     DT_INV3_L1_TABLE(X_)
 #undef X_
-    return long3_ok(n0, n1, n2, m0, m1) && m0 == 19;
+    return long3_ok(n0, n1, n2, m0, m1) && m0 == 19 && g0o && g1o && symmetric_taps(g0o, m0) && symmetric_taps(g1o, m1);
 }
 bool dtcwt_inv3_level2_ok(int64_t n0, int64_t n1, int64_t n2, int crop0, int m) {
     const int64_t S = 2 * n0 - 2 * crop0;

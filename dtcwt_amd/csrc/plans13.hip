@@ -90,8 +90,8 @@ int dtcwt_hip_plan3d_create(dtcwt_hip_ctx *ctx, int64_t n0, int64_t n1, int64_t 
     }
     // which directions run natively at every level (the conditions of the level entry points, fused3d.hip)
     const int mq = qshift_len[0];
-    p->fwd_ok = dtcwt_fwd3_level1_ok(n0, n1, n2, biort_len[0], biort_len[2]);
-    p->inv_ok = dtcwt_inv3_level1_ok(n0, n1, n2, biort_len[1], biort_len[3]);
+    p->fwd_ok = dtcwt_fwd3_level1_ok(n0, n1, n2, biort_len[0], biort_len[2], biort_host[0], biort_host[2]);
+    p->inv_ok = dtcwt_inv3_level1_ok(n0, n1, n2, biort_len[1], biort_len[3], biort_host[1], biort_host[3]);
     for (int l = 1; l < nlevels; ++l) {
         const Lv3 &L = p->lv[l];
         p->fwd_ok = p->fwd_ok && dtcwt_fwd3_level2_ok(L.in[0], L.in[1], L.in[2], L.pad[0], L.pad[1], L.pad[2], mq);
