@@ -713,6 +713,15 @@ def main_c4(args):
         'recon_max_abs_err': err,
     }
     tr = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if os.path.exists(tr) and n == 256 and fused_l1 and (BIORT, QSHIFT) == ('near_sym_b', 'qshift_b'):
+        try:            # the two launches of the level together
+            tj = json.load(open(tr)).get('c4_qbgn') or {}
+            out['roofline']['traffic'] = tj.get('level1_forward')
+            v = (tj.get('rocprof_median_us_one_stream') or {}).get('level1_forward')
+            out['roofline']['rocprof_kernel_ms'] = None if v is None else round(v / 1e3, 5)
+            out['roofline']['traffic_source'] = tj.get('source')
+        except Exception:
+            pass
     if os.path.exists(tr) and n == 256 and fused_l1 and (BIORT, QSHIFT) == ('near_sym_a', 'qshift_a'):
         try:
             tj = json.load(open(tr)).get('c4') or {}
