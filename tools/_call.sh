@@ -1,3 +1,2 @@
-cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_hip_transform1d3d.py -q -m gpu 2>&1 | tail -4
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r05u
+timeout 400 python tools/soak_long3d.py 150 1 2>&1 | tail -3 | tee gpurun_out/r05u/soak_long3d.txt
