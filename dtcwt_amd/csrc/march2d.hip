@@ -124,7 +124,8 @@ bool dtcwt_march_inv21_ok(int batch, int rows, int cols, const std::vector<doubl
     const int mode = [] { const char *e = getenv("DTCWT_HIP_MARCH_INV"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
     const int mm = march_mode(hint);
     if ((mode == 0 && hint.program < 0) || mm == 0 || (mm < 0 && !march_pays(batch, rows, cols, hint))) return false;
-    if (g0o.size() != 7 || g1o.size() != 5 || g0a.size() != 10 || !lo_pos || hi_pos) return false;
+    // (7, 5): near_sym_a; (3, 5): legall, whose 3-tap g0o runs as a centred zero-padded 7-tap one
+    if (!((g0o.size() == 7 || g0o.size() == 3) && g1o.size() == 5) || g0a.size() != 10 || !lo_pos || hi_pos) return false;
     if (!symmetric(g0o) || !symmetric(g1o)) return false;       // the row filters fold the mirror pairs
     return march_sizes_ok(batch, rows, cols, dtm::Inv21m<7, 5, 10>::VL);
 }
@@ -135,8 +136,9 @@ int dtcwt_march_inv21(const float *Z2, const float *Yh1, const float *Yh0, float
     using G = dtm::Inv21m<7, 5, 10>;
     dtm::Inv21mParams p{};
     p.Z2 = Z2; p.Yh1 = Yh1; p.Yh0 = Yh0; p.X = X; p.B = B; p.R = R; p.C = C;
+    const int off0 = (7 - (int)g0o.size()) / 2;             // legall: 3 taps centred in 7
     for (int k = 0; k < dtm::MAXT1; ++k) {
-        p.g0o[k] = k < (int)g0o.size() ? (float)g0o[k] : 0.f;
+        p.g0o[k] = (k >= off0 && k - off0 < (int)g0o.size()) ? (float)g0o[k - off0] : 0.f;
         p.g1o[k] = k < (int)g1o.size() ? (float)g1o[k] : 0.f;
     }
     for (int k = 0; k < dtm::MAXT2; ++k) { p.l_a[k] = l_a[k]; p.l_b[k] = l_b[k]; p.h_a[k] = h_a[k]; p.h_b[k] = h_b[k]; }
