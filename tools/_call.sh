@@ -1,6 +1,11 @@
-cd $GRAFT_REPO_ROOT
-B="python bench.py --no-cpu-baseline --no-other-configs --config c4 --biort near_sym_b --qshift qshift_b --steps 40 --warmup 10"
-for rep in 1 2; do
-for a in "--streams 2" "--streams 3" "--streams 4" "--streams 6" "--streams 8" "--streams 4 --cu-partition on" "--streams 2 --cu-partition on"; do
-  echo "$a: $(timeout 200 $B $a | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print(d['ms_per_step'], d['fwd_ms_per_step'], d['inv_ms_per_step'])")"
-done; done
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r05v; mkdir -p $O; export TMPDIR=/tmp
+timeout 2400 python -m pytest tests -q -m gpu > $O/pytest_gpu.txt 2>&1; grep -E "passed|failed|FAILED|ERROR" $O/pytest_gpu.txt | tail -8
+cp gpurun_out/parity_worst.json $O/ 2>/dev/null
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+( time python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err ) 2>&1 | grep real
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r05v/bench_driver_cmd.json').read().strip().splitlines()[-1])
+print(d['value'], d['ms_per_step'], d.get('sustained_ms_per_step'), d['roofline']['frac'])
+for k,v in d['other_configs'].items(): print(k, {a:v.get(a) for a in ('ms_per_step','fwd_ms_per_step','inv_ms_per_step','step_frac','wall_s','error')})
+PY
