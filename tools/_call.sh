@@ -1,8 +1,6 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r05w
-timeout 600 python -m pytest tests/test_hip_march.py tests/test_hip_transform2d.py -q -m gpu -x 2>&1 | tail -2
-B="python bench.py --no-cpu-baseline --no-other-configs"
-for rep in 1 2 3; do
-for v in 0 1; do
-  export DTCWT_HIP_INV21_NOGAIN=$v
-  echo "NOGAIN=$v c2 300 steps: $(timeout 200 $B --steps 300 --warmup 50 | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print(d['ms_per_step'], d['one_stream_ms_per_step'])")   c5: $(timeout 200 $B --config c5 --steps 20 --warmup 5 | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print(d['ms_per_step'])")  c3: $(timeout 200 $B --config c3 --steps 60 --warmup 10 | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print(d['ms_per_step'])")"
-done; done | tee gpurun_out/r05w/ab_nogain.txt
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r05x
+( python bench.py --no-cpu-baseline --no-other-configs --steps 150000 --warmup 50 > gpurun_out/r05x/long.json 2>/dev/null ) &
+BP=$!
+for i in $(seq 1 30); do echo "t=$i $(rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|Power" | sed 's/GPU\[0\]\t\t: //' | tr '\n' ' ')"; sleep 1; done | tee gpurun_out/r05x/clocks_c2.txt
+wait $BP
+python -c "import json; d=json.loads(open('gpurun_out/r05x/long.json').read().strip().splitlines()[-1]); print(d['ms_per_step'])"
