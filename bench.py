@@ -116,6 +116,8 @@ def parse_args(argv=None):
     ap.add_argument('--mgpu', action='store_true', help='N > 1 from ONE process: dtcwt_hip_mgpu_* with a host '
                     'thread per device instead of one process per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-probe', action='store_true', help='c2 at N = 1 only: do not run tools/kbench/step_probe (a trivial float4 '
+                    'streaming program moving the algorithmic bytes of a step in the same launch structure) beside the transform')
     ap.add_argument('--no-other-configs', action='store_true', help='c2 at N = 1 only: do not append short runs of '
                     'c3, c5 (the share of one GPU) and c4 as "other_configs"')
     ap.add_argument('--graph', action='store_true', help='replay the level kernels of a step as one hipGraph '
@@ -536,6 +538,11 @@ def main():
         sets.clear()            # hand this run's 1.6 GB of buffers back before the sub-runs allocate theirs
         out['other_configs'] = other_configs()
 
+    # ---- what the device gives a trivial streaming program with the step's bytes and launches (c2 at N = 1, default shape) ----
+    if rank == 0 and world == 1 and args.config == 'c2' and default_shape and not args.no_probe and not args.mgpu:
+        sets.clear()
+        out['streaming_probe'] = streaming_probe(out['ms_per_step'], out.get('sustained_ms_per_step'), out['one_stream_ms_per_step'], partitioned, nstreams)
+
     # ---- CPU baseline: the oracle (a NumPy port of the reference's algorithm), rank 0 ----
     if rank == 0 and not args.no_cpu_baseline:
         out['cpu_baseline'], zc = cpu_baseline(cfg, Xh0)
@@ -550,6 +557,33 @@ def main():
         print(json.dumps(out), flush=True)
         if saved_stdout is not None:
             os.dup2(2, 1)           # what the collective library still has in its stdio buffer (its banner) goes to stderr
+
+
+def streaming_probe(ms20, ms_sus, ms_one, partitioned, nstreams):
+    """tools/kbench/step_probe (built by __graft_entry__.build()): per step and stream six float4 streaming kernels that move the
+    algorithmic bytes of a 4096^2 nlevels=4 forward + inverse (20 B/px per direction + the LoLo2 / LoLo3 round trips of the
+    per-level tail) on eight rotating buffer sets, in the three launch protocols.  Not a roofline: the rate a program with NO
+    arithmetic, no halo and no band warm-up reaches on this box in this run -- what is left between the transform and it is
+    what the kernels themselves cost."""
+    exe = os.path.join(ROOT, 'tools', 'kbench', 'step_probe')
+    if not os.path.exists(exe):
+        return None
+    try:
+        r = subprocess.run([exe, '--json'], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=60)
+        pj = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    except Exception as exc:
+        return {'error': repr(exc)[:200]}
+    key = 'four_streams_on_quarters' if (partitioned and nstreams == 4) else ('four_plain_streams' if nstreams == 4 else 'one_stream')
+    pj['is'] = ('tools/kbench/step_probe.hip in this run: ms per step of a trivial float4 streaming program with the bytes and the six '
+                'launches of a step, 20 / 200 steps between device syncs, eight 403 MB buffer sets; transform_over_probe = this '
+                'line\'s figure / the probe\'s in the same protocol')
+    pj['transform_over_probe'] = {
+        'ms_per_step_%d_streams' % nstreams: round(ms20 / pj[key]['ms_per_step_20'], 4),
+        'sustained': None if ms_sus is None else round(ms_sus / pj[key]['ms_per_step_200'], 4),
+        'one_stream': round(ms_one / pj['one_stream']['ms_per_step_200'], 4)}
+    pj['probe_frac_of_8TBs'] = {k: round(STEP_BYTES_PER_PX * 4096 * 4096 / (pj[k]['ms_per_step_200'] * 1e-3) / HBM_PEAK, 4)
+                                for k in ('one_stream', 'four_plain_streams', 'four_streams_on_quarters')}
+    return pj
 
 
 def other_configs():

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Which wavefront of a marching pair takes level 1 (DTCWT_HIP_PAIR_ROLES, march2d_pair.hpp): the placement probe first, then
+# bench.py lines per role mode, alternating in one call.  Columns: ms_per_step, one_stream_ms_per_step, fwd kernel ms per level.
+cd ${GRAFT_REPO_ROOT:-.}
+tools/kbench/hwid_probe
+line() { python -c 'import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d["roofline"]; print(d["ms_per_step"], d["one_stream_ms_per_step"], r.get("fwd_kernel_ms"), d["recon_max_abs_err"])'; }
+for rep in 1 2; do
+  for roles in 0 1 2 3 4; do
+    echo "near_sym_b/qshift_b PAIR_B=1 roles=$roles: $(DTCWT_HIP_PAIR_B=1 DTCWT_HIP_PAIR_ROLES=$roles python bench.py --no-cpu-baseline --no-other-configs --biort near_sym_b --qshift qshift_b --steps 40 2>/dev/null | line)"
+  done
+  echo "near_sym_b/qshift_b no pair: $(python bench.py --no-cpu-baseline --no-other-configs --biort near_sym_b --qshift qshift_b --steps 40 2>/dev/null | line)"
+  for roles in 0 1 2 3 4; do
+    echo "near_sym_a/qshift_b roles=$roles: $(DTCWT_HIP_PAIR_ROLES=$roles python bench.py --no-cpu-baseline --no-other-configs --qshift qshift_b --steps 40 2>/dev/null | line)"
+  done
+done

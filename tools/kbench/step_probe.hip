@@ -1,0 +1,105 @@
+// What does the device give a TRIVIAL program that moves the algorithmic bytes of a 4096^2 nlevels=4 forward + inverse step
+// in the launch structure bench.py times?  Per step and stream, six float4 streaming kernels on rotating buffer sets:
+//   forward levels 1 + 2   read  67.1 MB (X), write 268.4 MB (Yh[0] 201.3, Yh[1] 50.3, LoLo2 16.8)        non-temporal stores
+//   forward level 3        read  16.8 MB, write 16.8 MB (LoLo3 4.2 + Yh[2] 12.6);  level 4: 4.2 MB -> 4.2 MB
+//   inverse level 4, 3     the same bytes the other way round
+//   inverse levels 2 + 1   read 268.4 MB, write 67.1 MB
+// i.e. 20 B/px per direction + the LoLo2 / LoLo3 round trips the two-launch-per-level tail makes -- what k_fwd12m, k_fwd2 x 2,
+// k_inv2 x 2, k_inv21m move when they move nothing twice.  Protocols: one stream on the whole device; four plain streams; four
+// streams on quarters of the compute units (hipExtStreamCreateWithCUMask, contiguous mask ranges as dtcwt_hip_ctx_create_partition
+// builds them).  Eight buffer sets of 403 MB as in bench.py, so nothing is served by the Infinity Cache from the previous step of
+// the same set.  Prints ms per step over 20 and over 200 steps (host clock between device syncs, as bench.py measures).
+//   hipcc --offload-arch=gfx950 -O3 tools/kbench/step_probe.hip -o tools/kbench/step_probe
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstring>
+#include <unistd.h>
+#include <cstdio>
+#include <vector>
+typedef float v4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+// n float4 per plane; NR planes in, NW planes out
+template <int NR, int NW, bool NT>
+__global__ void __launch_bounds__(256) k_mix(const v4 *__restrict__ in, v4 *__restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    v4 a = in[i];
+#pragma unroll
+    for (int r = 1; r < NR; ++r) a += in[i + r * n];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const v4 b = a * (float)(w + 1);
+        if (NT) __builtin_nontemporal_store(b, out + i + w * n); else out[i + w * n] = b;
+    }
+}
+
+struct Set { v4 *X, *rec, *l2, *l3, *y2, *l4, *y3, *Z; };      // X 67 MB, rec 268 MB (incl. LoLo2 as its last quarter plane), ...
+static const size_t PX = (size_t)4096 * 4096;
+static const size_t NP = PX / 4;          // float4 per 67 MB plane
+
+static void step(const Set &s, hipStream_t st) {
+    const unsigned g1 = (unsigned)((NP + 255) / 256), g3 = (unsigned)((NP / 4 + 255) / 256), g4 = (unsigned)((NP / 16 + 255) / 256);
+    k_mix<1, 4, true><<<g1, 256, 0, st>>>(s.X, s.rec, NP);                 // forward levels 1 + 2
+    k_mix<1, 1, false><<<g3, 256, 0, st>>>(s.l2, s.l3, NP / 4);            // level 3: LoLo2 -> LoLo3 + Yh[2] (16.8 MB each way)
+    k_mix<1, 1, false><<<g4, 256, 0, st>>>(s.l3, s.l4, NP / 16);           // level 4
+    k_mix<1, 1, false><<<g4, 256, 0, st>>>(s.l4, s.l3, NP / 16);           // inverse level 4
+    k_mix<1, 1, false><<<g3, 256, 0, st>>>(s.l3, s.l2, NP / 4);            // inverse level 3
+    k_mix<4, 1, true><<<g1, 256, 0, st>>>(s.rec, s.Z, NP);                 // inverse levels 2 + 1
+}
+
+static double run(const std::vector<Set> &sets, const std::vector<hipStream_t> &sts, int nsteps) {
+    const int S = (int)sts.size();
+    CK(hipDeviceSynchronize());
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < nsteps; ++k) step(sets[k % sets.size()], sts[k % S]);
+    CK(hipDeviceSynchronize());
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / nsteps;
+}
+
+int main(int argc, char **argv) {
+    setvbuf(stdout, nullptr, _IOLBF, 0);
+    const bool quick = argc > 1 && !strcmp(argv[1], "--json");       // one JSON line for bench.py: fewer repetitions
+    const int NSET = 8;
+    std::vector<Set> sets(NSET);
+    for (auto &s : sets) {
+        CK(hipMalloc(&s.X, NP * 16)); CK(hipMalloc(&s.rec, 4 * NP * 16)); CK(hipMalloc(&s.l3, NP / 4 * 16)); CK(hipMalloc(&s.l4, NP / 16 * 16));
+        CK(hipMalloc(&s.Z, NP * 16));
+        s.l2 = s.rec + 4 * NP - NP / 4;        // LoLo2: the last 16.8 MB of the record block
+        CK(hipMemset(s.X, 0x3c, NP * 16)); CK(hipMemset(s.rec, 0, 4 * NP * 16));
+    }
+    hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
+    const int cus = p.multiProcessorCount;
+    for (int proto = 0; proto < 3; ++proto) {
+        std::vector<hipStream_t> sts;
+        const char *name = proto == 0 ? "one stream, whole device" : (proto == 1 ? "four plain streams" : "four streams on quarters of the CUs");
+        const int S = proto == 0 ? 1 : 4;
+        for (int q = 0; q < S; ++q) {
+            hipStream_t st;
+            if (proto == 2) {
+                const int per = cus / 4;
+                std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
+                for (int b = q * per; b < (q + 1) * per; ++b) mask[(size_t)b / 32] |= 1u << (b % 32);
+                CK(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
+            } else CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            sts.push_back(st);
+        }
+        for (int w = 0; w < 3; ++w) run(sets, sts, 200);            // clocks up
+        double b20 = 1e9, b200 = 1e9, s20 = 0, s200 = 0;
+        const int nrep = quick ? 3 : 6;
+        for (int rep = 0; rep < nrep; ++rep) {
+            const double a = run(sets, sts, 20), b = run(sets, sts, 200);
+            b20 = a < b20 ? a : b20; b200 = b < b200 ? b : b200; s20 += a / nrep; s200 += b / nrep;
+        }
+        const double bytes = 40.0 * PX, moved = bytes + 2 * 2 * (16.8e6 + 4.2e6);
+        if (quick) {
+            printf("%s\"%s\": {\"ms_per_step_20\": %.5f, \"ms_per_step_200\": %.5f}%s", proto == 0 ? "{" : " ", proto == 0 ? "one_stream" : (proto == 1 ? "four_plain_streams" : "four_streams_on_quarters"),
+                   s20, s200, proto == 2 ? "}\n" : ",");
+        } else printf("%-40s 20 steps: mean %.4f best %.4f ms   200 steps: mean %.4f best %.4f ms   = %.2f TB/s of algorithmic bytes (%.3f of 8), %.2f TB/s moved\n",
+               name, s20, b20, s200, b200, bytes / (s200 * 1e-3) / 1e12, bytes / (s200 * 1e-3) / 8e12, moved / (s200 * 1e-3) / 1e12);
+    }
+    // no teardown: a process that destroys CU-masked streams and exits normally did not come back on this runtime
+    // (the first run of this probe sat in exit until its 600 s limit)
+    fflush(stdout);
+    _exit(0);
+}
