@@ -38,14 +38,24 @@ struct Set { v4 *X, *rec, *l2, *l3, *y2, *l4, *y3, *Z; };      // X 67 MB, rec 2
 static const size_t PX = (size_t)4096 * 4096;
 static const size_t NP = PX / 4;          // float4 per 67 MB plane
 
+static hipEvent_t g_ev[7];
+static bool g_mark = false;       // record an event before every kernel of the step and after the last
+#define MARK(i) do { if (g_mark) CK(hipEventRecord(g_ev[i], st)); } while (0)
 static void step(const Set &s, hipStream_t st) {
     const unsigned g1 = (unsigned)((NP + 255) / 256), g3 = (unsigned)((NP / 4 + 255) / 256), g4 = (unsigned)((NP / 16 + 255) / 256);
+    MARK(0);
     k_mix<1, 4, true><<<g1, 256, 0, st>>>(s.X, s.rec, NP);                 // forward levels 1 + 2
+    MARK(1);
     k_mix<1, 1, false><<<g3, 256, 0, st>>>(s.l2, s.l3, NP / 4);            // level 3: LoLo2 -> LoLo3 + Yh[2] (16.8 MB each way)
+    MARK(2);
     k_mix<1, 1, false><<<g4, 256, 0, st>>>(s.l3, s.l4, NP / 16);           // level 4
+    MARK(3);
     k_mix<1, 1, false><<<g4, 256, 0, st>>>(s.l4, s.l3, NP / 16);           // inverse level 4
+    MARK(4);
     k_mix<1, 1, false><<<g3, 256, 0, st>>>(s.l3, s.l2, NP / 4);            // inverse level 3
+    MARK(5);
     k_mix<4, 1, true><<<g1, 256, 0, st>>>(s.rec, s.Z, NP);                 // inverse levels 2 + 1
+    MARK(6);
 }
 
 static double run(const std::vector<Set> &sets, const std::vector<hipStream_t> &sts, int nsteps) {
@@ -68,6 +78,7 @@ int main(int argc, char **argv) {
         s.l2 = s.rec + 4 * NP - NP / 4;        // LoLo2: the last 16.8 MB of the record block
         CK(hipMemset(s.X, 0x3c, NP * 16)); CK(hipMemset(s.rec, 0, 4 * NP * 16));
     }
+    for (auto &e : g_ev) CK(hipEventCreate(&e));
     hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
     const int cus = p.multiProcessorCount;
     for (int proto = 0; proto < 3; ++proto) {
@@ -97,6 +108,22 @@ int main(int argc, char **argv) {
                    s20, s200, proto == 2 ? "}\n" : ",");
         } else printf("%-40s 20 steps: mean %.4f best %.4f ms   200 steps: mean %.4f best %.4f ms   = %.2f TB/s of algorithmic bytes (%.3f of 8), %.2f TB/s moved\n",
                name, s20, b20, s200, b200, bytes / (s200 * 1e-3) / 1e12, bytes / (s200 * 1e-3) / 8e12, moved / (s200 * 1e-3) / 1e12);
+        if (!quick) {
+            // the kernels of a step as the protocol runs them: events around the kernels of every fourth step of stream 0, the
+            // other streams busy beside it (level 3 -> 4 and 4 -> 3 come as pairs: the event between them is not recorded)
+            double acc[6] = {0, 0, 0, 0, 0, 0}; int nacc = 0;
+            for (int rep = 0; rep < 40; ++rep) {
+                for (int k = 0; k < 3 * S; ++k) step(sets[k % sets.size()], sts[k % S]);
+                g_mark = true; step(sets[0], sts[0]); g_mark = false;
+                for (int k = 1; k < S; ++k) step(sets[k % sets.size()], sts[k % S]);
+                CK(hipDeviceSynchronize());
+                if (rep < 5) continue;
+                for (int i = 0; i < 6; ++i) { float ms; CK(hipEventElapsedTime(&ms, g_ev[i], g_ev[i + 1])); acc[i] += ms; }
+                ++nacc;
+            }
+            printf("    per kernel on stream 0 (us): fwd 1+2 %.1f | L3 %.1f | L4 %.1f | inv L4 %.1f | inv L3 %.1f | inv 2+1 %.1f\n",
+                   acc[0] / nacc * 1e3, acc[1] / nacc * 1e3, acc[2] / nacc * 1e3, acc[3] / nacc * 1e3, acc[4] / nacc * 1e3, acc[5] / nacc * 1e3);
+        }
     }
     // no teardown: a process that destroys CU-masked streams and exits normally did not come back on this runtime
     // (the first run of this probe sat in exit until its 600 s limit)
