@@ -166,8 +166,12 @@ static int launch_fwd12(dtm::Fwd12mParams &p, const DtMarchHint &hint, hipStream
     if (!march_sizes_ok(p.B, p.R, p.C, G::VL)) return -3;   // (dtcwt_march_fwd12_ok said so already)
     const unsigned jobs = dtm::dtm_set_jobs(p.jb, p.B, p.R, nstrip, pick_band_rows(p.B * hint.in_flight, p.R, nstrip, M, hint.cus));
     // (X rows loaded with the non-temporal hint: 81.4 against 85.4 us alone, no difference inside the transform -- not used)
-    if (p.LoLo1) dtm::k_fwd12m<M0, M1, M, 2, 128><<<jobs, 64, 0, s>>>(p);       // with `scales`: the level-1 lowpass is stored too
-    else dtm::k_fwd12m<M0, M1, M, 2, 0><<<jobs, 64, 0, s>>>(p);
+    // rows requested FOUR steps ahead (P = 4: 249 VGPRs, no scratch) instead of two: k_fwd12m alone 71-74 against 74-77 us, one
+    // transform at a time 0.181 against 0.184 ms per step, nothing with four in flight or on the batches; Yh[1] / LoLo2 written with
+    // the non-temporal hint (KO 256 / 512) cost the inverse its cache hits (80 -> 84 us alone) and bought nothing
+    // (profiles/r05/ab_fwd12_prefetch.txt)
+    if (p.LoLo1) dtm::k_fwd12m<M0, M1, M, 4, 128><<<jobs, 64, 0, s>>>(p);       // with `scales`: the level-1 lowpass is stored too
+    else dtm::k_fwd12m<M0, M1, M, 4, 0><<<jobs, 64, 0, s>>>(p);
     return 0;
 }
 

@@ -536,8 +536,8 @@ __global__ void __launch_bounds__(64, WPS) k_fwd12m(const Fwd12mParams p) {
                     const int io = pair_ok ? ((KO & 2) ? (i2 & 3) : i2) : 0;
                     const DtBuf bl0 = dt_buf_n(L2b + (int64_t)(2 * io) * (C / 2), pair_ok ? 8u * nv : 0u);
                     const DtBuf bl1 = dt_buf_n(L2b + (int64_t)(2 * io + 1) * (C / 2), pair_ok ? 8u * nv : 0u);
-                    dt2d::dt_buf_st2<false>(bl0, l2v, 0u, dt2d::f2{llo[0][0], llo[0][1]});
-                    dt2d::dt_buf_st2<false>(bl1, l2v, 0u, dt2d::f2{llo[1][0], llo[1][1]});
+                    dt2d::dt_buf_st2<(KO & 512) != 0>(bl0, l2v, 0u, dt2d::f2{llo[0][0], llo[0][1]});
+                    dt2d::dt_buf_st2<(KO & 512) != 0>(bl1, l2v, 0u, dt2d::f2{llo[1][0], llo[1][1]});
                     const Zq a = q2c_s(hl2[0][0], hl2[0][1], hl2[1][0], hl2[1][1]);
                     const Zq bq = q2c_s(hh2[0][0], hh2[0][1], hh2[1][0], hh2[1][1]);
                     const Zq c = q2c_s(lh2[0][0], lh2[0][1], lh2[1][0], lh2[1][1]);
@@ -560,7 +560,7 @@ __global__ void __launch_bounds__(64, WPS) k_fwd12m(const Fwd12mParams p) {
 #pragma unroll
                     for (int m = 0; m < 3; ++m) {
                         const f4 v = slab2[3 * HL + lane + 64 * m];
-                        dt2d::dt_buf_st4<false>(by1, yv + 1024u * m, 0u, v);
+                        dt2d::dt_buf_st4<(KO & 256) != 0>(by1, yv + 1024u * m, 0u, v);
                     }
                     DT_WAVE_LDS_SYNC();
                     }
