@@ -38,7 +38,11 @@ reference's algorithm) on the host, rank 0 only, after the process group is gone
 
 At N = 1 the default (c2) run also times short versions of the other single-GPU BASELINE configs -- c3, one GPU's
 share of c5, c4 -- as sub-runs of this script after its own measurement and before the CPU baseline, and reports
-them under `other_configs` (`--no-other-configs` skips them).
+them under `other_configs` (`--no-other-configs` skips them).  It then runs tools/kbench/step_probe (a trivial float4
+streaming program that moves the algorithmic bytes of a step in the same six launches, in the same three protocols:
+one stream / four plain streams / four streams on quarters of the compute units) and reports its ms per step and the
+transform's figures over it as `streaming_probe` (`--no-probe` skips it): not a roofline -- `roofline` quotes the 8 TB/s
+the contract asks for -- but what this box gives a program WITHOUT arithmetic, halo or warm-up rows in this very run.
 
 `--config c4` (BASELINE configs[3], one volume: it does not shard, N = 1 only) times the 3-D transform the same way:
 a step = Transform3d forward + inverse of one 256^3 float32 volume, nlevels=3, rotating over `--sets` volumes on

@@ -272,6 +272,34 @@ def test_mgpu_more_shards_than_images():
     assert np.abs(z - X).max() < 2e-6
 
 
+def test_bench_default_line_carries_the_streaming_probe():
+    """The default configuration's line runs tools/kbench/step_probe (built by __graft_entry__.build()) in the same call: a
+    trivial float4 streaming program with the bytes and launches of a step, in the three protocols, and the transform's
+    figures over it."""
+    import subprocess
+    import sys
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, 'tools', 'kbench', 'step_probe')):
+        pytest.skip('tools/kbench/step_probe is not built')
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    env.pop('RANK', None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '4', '--warmup', '1',
+                        '--settle-ms', '0', '--no-cpu-baseline', '--no-other-configs'], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    sp = line['streaming_probe']
+    assert sp and 'error' not in sp, sp
+    for k in ('one_stream', 'four_plain_streams', 'four_streams_on_quarters'):
+        assert 0.05 < sp[k]['ms_per_step_200'] < 1.0 and 0.05 < sp[k]['ms_per_step_20'] < 1.0
+        assert 0.2 < sp['probe_frac_of_8TBs'][k] < 1.0          # a streaming program cannot beat the spec peak
+    assert sp['transform_over_probe']['one_stream'] > 0.8         # the transform does not beat a program without arithmetic by much
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1', '--settle-ms', '0',
+                        '--no-cpu-baseline', '--no-other-configs', '--no-probe'], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and 'streaming_probe' not in json.loads(r.stdout.strip().splitlines()[-1])
+
+
 def test_bench_self_spawns_ranks(tmp_path):
     """`python bench.py --gpus N` without a launcher starts N ranks itself; with fewer devices than N it
     refuses loudly instead of silently running one rank (round-1 behaviour)."""

@@ -1,5 +1,7 @@
 #!/bin/bash
-# Which wavefront of a marching pair takes level 1 (DTCWT_HIP_PAIR_ROLES, march2d_pair.hpp): the placement probe first, then
+# EXPERIMENT OF RECORD (profiles/r05/pair_roles.txt): the switches DTCWT_HIP_PAIR_ROLES / DTCWT_HIP_PAIR_B it drives lived in
+# march2d_pair.hpp / march2d.hip for one measurement and are gone again (no difference); the probe half still runs.
+# Which wavefront of a marching pair takes level 1: the placement probe first, then
 # bench.py lines per role mode, alternating in one call.  Columns: ms_per_step, one_stream_ms_per_step, fwd kernel ms per level.
 cd ${GRAFT_REPO_ROOT:-.}
 tools/kbench/hwid_probe

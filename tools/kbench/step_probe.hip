@@ -41,8 +41,17 @@ static const size_t NP = PX / 4;          // float4 per 67 MB plane
 static hipEvent_t g_ev[7];
 static bool g_mark = false;       // record an event before every kernel of the step and after the last
 #define MARK(i) do { if (g_mark) CK(hipEventRecord(g_ev[i], st)); } while (0)
-static void step(const Set &s, hipStream_t st) {
+static void step(const Set &s, hipStream_t st, bool inv_first = false) {
     const unsigned g1 = (unsigned)((NP + 255) / 256), g3 = (unsigned)((NP / 4 + 255) / 256), g4 = (unsigned)((NP / 16 + 255) / 256);
+    if (inv_first) {        // the same six kernels, the inverse half of the step first (it reads what the previous step on this set wrote)
+        k_mix<1, 1, false><<<g4, 256, 0, st>>>(s.l4, s.l3, NP / 16);
+        k_mix<1, 1, false><<<g3, 256, 0, st>>>(s.l3, s.l2, NP / 4);
+        k_mix<4, 1, true><<<g1, 256, 0, st>>>(s.rec, s.Z, NP);
+        k_mix<1, 4, true><<<g1, 256, 0, st>>>(s.X, s.rec, NP);
+        k_mix<1, 1, false><<<g3, 256, 0, st>>>(s.l2, s.l3, NP / 4);
+        k_mix<1, 1, false><<<g4, 256, 0, st>>>(s.l3, s.l4, NP / 16);
+        return;
+    }
     MARK(0);
     k_mix<1, 4, true><<<g1, 256, 0, st>>>(s.X, s.rec, NP);                 // forward levels 1 + 2
     MARK(1);
@@ -58,11 +67,12 @@ static void step(const Set &s, hipStream_t st) {
     MARK(6);
 }
 
+static bool g_stagger = false;      // odd streams run the inverse half of their steps first
 static double run(const std::vector<Set> &sets, const std::vector<hipStream_t> &sts, int nsteps) {
     const int S = (int)sts.size();
     CK(hipDeviceSynchronize());
     const auto t0 = std::chrono::steady_clock::now();
-    for (int k = 0; k < nsteps; ++k) step(sets[k % sets.size()], sts[k % S]);
+    for (int k = 0; k < nsteps; ++k) step(sets[k % sets.size()], sts[k % S], g_stagger && ((k % S) & 1));
     CK(hipDeviceSynchronize());
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / nsteps;
 }
@@ -81,13 +91,15 @@ int main(int argc, char **argv) {
     for (auto &e : g_ev) CK(hipEventCreate(&e));
     hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
     const int cus = p.multiProcessorCount;
-    for (int proto = 0; proto < 3; ++proto) {
+    for (int proto = 0; proto < (quick ? 3 : 5); ++proto) {
         std::vector<hipStream_t> sts;
-        const char *name = proto == 0 ? "one stream, whole device" : (proto == 1 ? "four plain streams" : "four streams on quarters of the CUs");
+        const char *name = proto == 0 ? "one stream, whole device" : (proto == 1 ? "four plain streams" : (proto == 2 ? "four streams on quarters of the CUs" :
+                           (proto == 3 ? "four on quarters, odd streams inverse half first" : "four plain streams, odd streams inverse half first")));
         const int S = proto == 0 ? 1 : 4;
+        g_stagger = proto >= 3;
         for (int q = 0; q < S; ++q) {
             hipStream_t st;
-            if (proto == 2) {
+            if (proto == 2 || proto == 3) {
                 const int per = cus / 4;
                 std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
                 for (int b = q * per; b < (q + 1) * per; ++b) mask[(size_t)b / 32] |= 1u << (b % 32);
@@ -108,7 +120,7 @@ int main(int argc, char **argv) {
                    s20, s200, proto == 2 ? "}\n" : ",");
         } else printf("%-40s 20 steps: mean %.4f best %.4f ms   200 steps: mean %.4f best %.4f ms   = %.2f TB/s of algorithmic bytes (%.3f of 8), %.2f TB/s moved\n",
                name, s20, b20, s200, b200, bytes / (s200 * 1e-3) / 1e12, bytes / (s200 * 1e-3) / 8e12, moved / (s200 * 1e-3) / 1e12);
-        if (!quick) {
+        if (!quick && proto < 3) {
             // the kernels of a step as the protocol runs them: events around the kernels of every fourth step of stream 0, the
             // other streams busy beside it (level 3 -> 4 and 4 -> 3 come as pairs: the event between them is not recorded)
             double acc[6] = {0, 0, 0, 0, 0, 0}; int nacc = 0;
