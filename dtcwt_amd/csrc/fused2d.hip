@@ -46,6 +46,12 @@ int dtcwt_march_fwd12p(const float *X, float *Yh0, float *Yh1, float *LoLo2, int
                        const std::vector<double> &h0o, const std::vector<double> &h1o,
                        const float *l_a, const float *l_b, const float *h_a, const float *h_b, int m,
                        const DtMarchHint &hint, hipStream_t s);
+// levels 2 + 1 of the inverse as a marching pair of wavefronts (march2d_ipair.hpp)
+bool dtcwt_march_inv21p_ok(int batch, int rows, int cols, const std::vector<double> &g0o, const std::vector<double> &g1o,
+                           const std::vector<double> &g0a, bool lo_pos, bool hi_pos, const DtMarchHint &hint);
+int dtcwt_march_inv21p(const float *Z2, const float *Yh1, const float *Yh0, float *X, int B, int R, int C,
+                       const std::vector<double> &g0o, const std::vector<double> &g1o, const float *l_a, const float *l_b,
+                       const float *h_a, const float *h_b, int m, const float *gain1, const float *gain2, const DtMarchHint &hint, hipStream_t s);
 
 namespace {
 
@@ -217,6 +223,11 @@ static bool plan_march_inv21(const dtcwt_hip_plan2d *p) {
            dtcwt_march_inv21_ok(p->batch, p->lv[0].LR, p->lv[0].LC, p->biort[1], p->biort[3], p->qshift[2],
                                 dotd(p->qshift[3], p->qshift[2]) > 0, dotd(p->qshift[7], p->qshift[6]) > 0, p->hint());
 }
+static bool plan_march_inv21p(const dtcwt_hip_plan2d *p) {
+    return plan_march_geometry(p) && p->bp1[1].empty() && p->bp2[2].empty() &&
+           dtcwt_march_inv21p_ok(p->batch, p->lv[0].LR, p->lv[0].LC, p->biort[1], p->biort[3], p->qshift[2],
+                                 dotd(p->qshift[3], p->qshift[2]) > 0, dotd(p->qshift[7], p->qshift[6]) > 0, p->hint());
+}
 
 // level 1 alone as a march (near_sym_b, antonini): no odd-size extension, columns in fours, no band-pass set
 static bool plan_march_fwd1(const dtcwt_hip_plan2d *p) {
@@ -254,7 +265,7 @@ int dtcwt_hip_plan2d_set_program(dtcwt_hip_plan2d *p, int program) {
 int dtcwt_hip_plan2d_launches(const dtcwt_hip_plan2d *p, int *fwd12, int *inv21) {
     DT_REQUIRE(p, "NULL plan");
     if (fwd12) *fwd12 = (plan_march_fwd12(p) || plan_march_fwd12p(p)) ? 1 : 0;
-    if (inv21) *inv21 = plan_march_inv21(p) ? 1 : 0;
+    if (inv21) *inv21 = (plan_march_inv21(p) || plan_march_inv21p(p)) ? 1 : 0;
     return 0;
 }
 
@@ -491,6 +502,7 @@ int dtcwt_hip_plan2d_inverse(dtcwt_hip_plan2d *p, const float *Yl, const void *c
     const float *in = Yl;
     // levels 2 + 1 in one launch (march2d.hpp) under the same conditions as the forward's levels 1 + 2
     const bool march21 = plan_march_inv21(p);
+    const bool march21p = !march21 && plan_march_inv21p(p);        // ... as a marching pair of wavefronts (the 14- / 18-tap q-shift sets)
     for (int l = nl - 1; l >= 0; --l) {
         const Level &L = p->lv[l];
         DT_REQUIRE(Yh[l], "NULL Yh at level %d", l);
@@ -498,13 +510,17 @@ int dtcwt_hip_plan2d_inverse(dtcwt_hip_plan2d *p, const float *Yl, const void *c
         for (int d = 0; d < 6; ++d) g[d] = (float)(rs * (gain ? gain[d * nl + l] : 1.0));
         int rc;
         if (p->profiling) DT_CHECK_HIP(hipEventRecord(p->ev[2 * (nl + l)], s));
-        if (l == 1 && march21) {
+        if (l == 1 && (march21 || march21p)) {
             DT_REQUIRE(Yh[0], "NULL Yh at level 0");
             float g1[6];
             for (int d = 0; d < 6; ++d) g1[d] = (float)(rs * (gain ? gain[d * nl + 0] : 1.0));
             Inv2Params q{};
             put_taps(q.l_a, p->qshift[3]); put_taps(q.l_b, p->qshift[2]);
             put_taps(q.h_a, p->qshift[7]); put_taps(q.h_b, p->qshift[6]);
+            if (march21p)
+                rc = dtcwt_march_inv21p(in, (const float *)Yh[1], (const float *)Yh[0], Z, p->batch, p->lv[0].LR, p->lv[0].LC,
+                                        p->biort[1], p->biort[3], q.l_a, q.l_b, q.h_a, q.h_b, (int)p->qshift[2].size(), g1, g, p->hint(), s);
+            else
             rc = dtcwt_march_inv21(in, (const float *)Yh[1], (const float *)Yh[0], Z, p->batch, p->lv[0].LR, p->lv[0].LC,
                                    p->biort[1], p->biort[3], q.l_a, q.l_b, q.h_a, q.h_b, g1, g, p->hint(), s);
             if (rc) return dtcwt_set_error(rc, "no marching inverse kernel for levels 2 + 1");

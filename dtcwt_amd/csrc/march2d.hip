@@ -11,6 +11,7 @@
 #include "march2d.hpp"
 #include "march2d_l1.hpp"
 #include "march2d_pair.hpp"
+#include "march2d_ipair.hpp"
 
 namespace {
 
@@ -369,5 +370,56 @@ int dtcwt_march_fwd12p(const float *X, float *Yh0, float *Yh1, float *LoLo2, int
     dtm::dtm_pack_qshift(p, m, l_a, l_b, h_a, h_b);
     if (m0 == 5 && m == 14) return launch_fwd12p<5, 7, 14>(p, hint, s);
     if (m0 == 5 && m == 18) return launch_fwd12p<5, 7, 18>(p, hint, s);
+    return -3;
+}
+
+// ---- levels 2 + 1 of the inverse as a marching PAIR of wavefronts (march2d_ipair.hpp) -----------------------------------------
+// The synthesis filters of near_sym_a (7, 5) / legall (3, 5) with the 14- / 18-tap q-shift sets, standard phases; chosen like the
+// forward pair: wherever other work shares the device from the usual crossover, alone from 60 M useful pixels
+// (profiles/r05/pair_inverse.txt).  DTCWT_HIP_MARCH_PAIR=0: never (both directions); DTCWT_HIP_MARCH_IPAIR=0: not the inverse.
+bool dtcwt_march_inv21p_ok(int batch, int rows, int cols, const std::vector<double> &g0o, const std::vector<double> &g1o,
+                           const std::vector<double> &g0a, bool lo_pos, bool hi_pos, const DtMarchHint &hint) {
+    if (const char *e = getenv("DTCWT_HIP_MARCH_PAIR")) { if (e[0] == '0') return false; }
+    if (const char *e = getenv("DTCWT_HIP_MARCH_IPAIR")) { if (e[0] == '0') return false; }
+    const int m = (int)g0a.size();
+    if (!((g0o.size() == 7 || g0o.size() == 3) && g1o.size() == 5) || !(m == 14 || m == 18) || !lo_pos || hi_pos) return false;
+    if (!symmetric(g0o) || !symmetric(g1o)) return false;
+    const int VL = m == 14 ? dtm::Inv21p<7, 5, 14>::VL : dtm::Inv21p<7, 5, 18>::VL;
+    if (!march_sizes_ok(batch, rows, cols, VL)) return false;
+    const int mm = march_mode(hint);
+    if (mm == 0) return false;
+    if (mm > 0) return true;
+    const int nstrip = cdiv(cols, 4 * VL);
+    const double useful = (double)batch * rows * cols * ((double)cols / (nstrip * 4.0 * VL));
+    const bool shared = hint.nparts > 1 || hint.in_flight > 1;
+    return useful >= (shared ? kCrossover[hint.nparts > 1 ? 2 : 1].useful_pixels : 6.0e7);
+}
+
+template <int M>
+static int launch_inv21p(dtm::Inv21mParams &p, const DtMarchHint &hint, hipStream_t s) {
+    using G = dtm::Inv21p<7, 5, M>;
+    const int nstrip = cdiv(p.C, 4 * G::VL);
+    if (!march_sizes_ok(p.B, p.R, p.C, G::VL)) return -3;
+    const int cus = hint.cus / 2 > 0 ? hint.cus / 2 : 1;      // a job is a PAIR of wavefronts
+    const unsigned jobs = dtm::dtm_set_jobs(p.jb, p.B, p.R, nstrip, pick_band_rows(p.B * hint.in_flight, p.R, nstrip, M, cus));
+    dtm::k_inv21p<7, 5, M><<<jobs, 128, 0, s>>>(p);
+    return 0;
+}
+
+int dtcwt_march_inv21p(const float *Z2, const float *Yh1, const float *Yh0, float *X, int B, int R, int C,
+                       const std::vector<double> &g0o, const std::vector<double> &g1o, const float *l_a, const float *l_b,
+                       const float *h_a, const float *h_b, int m, const float *gain1, const float *gain2, const DtMarchHint &hint, hipStream_t s) {
+    dtm::Inv21mParams p{};
+    p.Z2 = Z2; p.Yh1 = Yh1; p.Yh0 = Yh0; p.X = X; p.B = B; p.R = R; p.C = C;
+    const int off0 = (7 - (int)g0o.size()) / 2;             // legall: 3 taps centred in 7
+    for (int k = 0; k < dtm::MAXT1; ++k) {
+        p.g0o[k] = (k >= off0 && k - off0 < (int)g0o.size()) ? (float)g0o[k - off0] : 0.f;
+        p.g1o[k] = k < (int)g1o.size() ? (float)g1o[k] : 0.f;
+    }
+    for (int k = 0; k < dtm::MAXT2; ++k) { p.l_a[k] = l_a[k]; p.l_b[k] = l_b[k]; p.h_a[k] = h_a[k]; p.h_b[k] = h_b[k]; }
+    for (int d = 0; d < 6; ++d) { p.g1[d] = gain1[d]; p.g2[d] = gain2[d]; }
+    dtm::dtm_pack_inv_biort(p, 7, 5);
+    if (m == 14) return launch_inv21p<14>(p, hint, s);
+    if (m == 18) return launch_inv21p<18>(p, hint, s);
     return -3;
 }

@@ -166,12 +166,39 @@ def test_forward_pair_matches_tile_programs_and_oracle(shape, bn, qn, band, monk
     assert tm.plan(1, shape[0], shape[1], nl).launches()[0] is False
 
 
+@pytest.mark.parametrize('shape', SHAPES + [(48, 212), (1024, 208)])
+@pytest.mark.parametrize('bn,qn', [('near_sym_a', 'qshift_b'), ('near_sym_a', 'qshift_d'), ('legall', 'qshift_b')])
+@pytest.mark.parametrize('band', [None, 8, 24])
+def test_inverse_pair_matches_tile_programs_and_oracle(shape, bn, qn, band, monkeypatch):
+    """Levels 2 + 1 of the inverse as a marching PAIR of wavefronts (march2d_ipair.hpp: k_inv21p; the 14- / 18-tap q-shift sets with
+    the 7 / 5-tap synthesis filters of near_sym_a and legall's 3 / 5) against the tile programs and the oracle, with a gain mask, at
+    sizes that put the strip boundaries (224- / 216-column strips), band boundaries, mirrored lanes and reflected rows everywhere."""
+    rs = np.random.RandomState(27)
+    X = rs.standard_normal(shape).astype(np.float32)
+    nl = 2 if min(shape) < 160 else 3
+    gm = rs.uniform(0.3, 1.4, size=(6, nl)) * (rs.uniform(size=(6, nl)) > 0.2)
+    tt, tm = Transform2d(bn, qn, program='tiles'), Transform2d(bn, qn, program='march')
+    if band:
+        monkeypatch.setenv('DTCWT_HIP_MARCH_BAND', str(band))
+    assert tm.plan(1, shape[0], shape[1], nl).launches()[1] is True
+    p0 = tt.forward(X, nlevels=nl)
+    pyr = Pyramid(np.array(p0.lowpass), tuple(np.array(y) for y in p0.highpasses))
+    z0, z1 = np.array(tt.inverse(pyr, gm)), np.array(tm.inverse(pyr, gm))
+    assert_close(z1, z0, 1e-6, 'inverse pair vs tiles')
+    to = o.Transform2d(biort(bn), qshift(qn))
+    want = to.forward(as_f64(X), nlevels=nl)
+    assert_close(z1, to.inverse(want, gm), INV_TOL, 'inverse')
+    assert_close(tm.inverse(tm.forward(X, nlevels=nl)), X, INV_TOL, 'reconstruction')
+    monkeypatch.setenv('DTCWT_HIP_MARCH_PAIR', '0')              # the switch: back to a level-2 tile launch + a level-1 tile launch
+    assert tm.plan(1, shape[0], shape[1], nl).launches()[1] is False
+
+
 def test_forward_pair_on_a_batch():
     rs = np.random.RandomState(26)
     X = rs.standard_normal((5, 128, 424)).astype(np.float32)
     tm = Transform2d('near_sym_a', 'qshift_b', program='march')
     to = o.Transform2d(biort('near_sym_a'), qshift('qshift_b'))
-    assert tm.plan(5, 128, 424, 3).launches() == (True, False)
+    assert tm.plan(5, 128, 424, 3).launches() == (True, True)
     # where the library chooses by itself: batches and shared devices, not one image alone (profiles/r05/pair_forward.txt)
     ta = Transform2d('near_sym_a', 'qshift_b')
     assert ta.plan(1, 4096, 4096, 4).launches()[0] is False and ta.plan(64, 1024, 1024, 4).launches()[0] is True
@@ -302,7 +329,7 @@ def test_march_is_not_used_where_it_does_not_apply(monkeypatch):
     assert t.plan(1, 254, 256, 3).launches() == (False, False)           # level-2 padding (254 % 4)
     assert t.plan(1, 255, 256, 3).launches() == (False, False)           # odd-size extension
     assert Transform2d('near_sym_b', 'qshift_b').plan(1, 256, 256, 3).launches() == (False, False)    # level 1 alone as a march instead
-    assert Transform2d('near_sym_a', 'qshift_b').plan(1, 256, 256, 3).launches() == (True, False)     # forward: the marching pair
+    assert Transform2d('near_sym_a', 'qshift_b').plan(1, 256, 256, 3).launches() == (True, True)      # both directions: marching pairs
     assert Transform2d('near_sym_a', 'qshift_c').plan(1, 256, 256, 3).launches() == (False, False)    # 16 taps: (M - 2) % 4 != 0
     assert Transform2d('antonini', 'qshift_b').plan(1, 256, 256, 3).launches() == (False, False)
     assert t.plan(1, 4096, 4096, 4).launches() == (True, True)

@@ -19,7 +19,11 @@ def rel(a, b):
 
 
 WAVES = [('near_sym_a', 'qshift_a'), ('near_sym_a', 'qshift_a'), ('near_sym_b', 'qshift_b'), ('near_sym_b', 'qshift_d'),
-         ('antonini', 'qshift_c'), ('legall', 'qshift_06')]
+         ('antonini', 'qshift_c'), ('legall', 'qshift_06'),
+         # the marching PAIRS (march2d_pair.hpp / march2d_ipair.hpp): both directions for near_sym_a, the inverse for legall
+         ('near_sym_a', 'qshift_b'), ('near_sym_a', 'qshift_d'), ('legall', 'qshift_b')]
+if os.environ.get('SOAK_PAIRS_ONLY'):
+    WAVES = WAVES[-3:]
 
 
 def run(X, nl, gm, batch, wave=WAVES[0]):
@@ -65,7 +69,7 @@ def main():
         worst = max(worst, max(errs))
         assert max(errs) < 2e-6, (wave, R, C, B, nl, band, errs)
         n += 1
-    print('%d random 2-D transforms in %.0f s (near_sym_a / legall: fused levels 1 + 2; near_sym_b / antonini: level 1 alone), marching launches vs '
+    print('%d random 2-D transforms in %.0f s (near_sym_a / legall: fused levels 1 + 2, marching pairs with the 14- / 18-tap q-shift sets; near_sym_b / antonini: level 1 alone), marching launches vs '
           'tile programs: worst relative difference %.3g' % (n, time.time() - t0, worst))
     # ---- 3-D: level 1 as a marching pair of wavefronts (fused3d_march.hpp) against the tile program
     from dtcwt_amd.hip import Transform3d
