@@ -131,6 +131,7 @@ bool dtcwt_march_inv21_ok(int batch, int rows, int cols, const std::vector<doubl
     return march_sizes_ok(batch, rows, cols, dtm::Inv21m<7, 5, 10>::VL);
 }
 
+static int launch_inv21p_m10(dtm::Inv21mParams &p, const DtMarchHint &hint, hipStream_t s);
 int dtcwt_march_inv21(const float *Z2, const float *Yh1, const float *Yh0, float *X, int B, int R, int C,
                       const std::vector<double> &g0o, const std::vector<double> &g1o, const float *l_a, const float *l_b,
                       const float *h_a, const float *h_b, const float *gain1, const float *gain2, const DtMarchHint &hint, hipStream_t s) {
@@ -151,6 +152,18 @@ int dtcwt_march_inv21(const float *Z2, const float *Yh1, const float *Yh0, float
     // wavefront per SIMD (its 512 registers hold the second set of rows; half the wave slots, so bands twice as tall),
     // 1 = one wavefront per SIMD with the usual depth; unset = the default build (two per SIMD, one macro-step ahead)
     const int pf = [] { const char *e = getenv("DTCWT_HIP_INV21_PF"); return e ? atoi(e) : 0; }();
+    // ONE transform at a time on the whole device, up to a 4096^2 image: the same macro-steps as a marching PAIR of wavefronts
+    // (k_inv21p<7, 5, 10>, march2d_ipair.hpp; bit-identical output).  Such a launch does not fill the wave slots -- a pair puts two
+    // wavefronts on every job and, where the slots are all taken (4096^2), affords bands twice as tall (72 rows instead of 40: 1.15 x
+    // instead of 1.28 x the algorithmic bytes).  Inverse launch alone 2048^2 35.9 -> 29.6 us, 3072^2 55 -> 45.7, 4096^2 84 -> 80.6;
+    // 5120^2 163 -> 172 (no longer chosen); with four in flight on quarters it loses outright (231 -> 338 us per image-share) and on
+    // batches it is level (profiles/r05/pair_headline_inverse.txt).  DTCWT_HIP_INV21_PAIR=0 / 1: never / always.
+    {
+        const char *e = getenv("DTCWT_HIP_INV21_PAIR");
+        const double useful = (double)B * R * C * ((double)C / (nstrip * 4.0 * G::VL));
+        const bool alone = hint.in_flight <= 1 && hint.nparts <= 1;
+        if (!pf && (e ? e[0] == '1' : (alone && useful <= 1.8e7))) return launch_inv21p_m10(p, hint, s);
+    }
     const int cus_eff = pf ? hint.cus / 2 : hint.cus;
     const unsigned jobs = dtm::dtm_set_jobs(p.jb, B, R, nstrip, pick_band_rows(B * hint.in_flight, R, nstrip, 10, cus_eff > 0 ? cus_eff : 1));
     // (record rows loaded with the non-temporal hint: no difference, 0.1581 against 0.1586 ms per step)
@@ -405,6 +418,8 @@ static int launch_inv21p(dtm::Inv21mParams &p, const DtMarchHint &hint, hipStrea
     dtm::k_inv21p<7, 5, M><<<jobs, 128, 0, s>>>(p);
     return 0;
 }
+
+static int launch_inv21p_m10(dtm::Inv21mParams &p, const DtMarchHint &hint, hipStream_t s) { return launch_inv21p<10>(p, hint, s); }
 
 int dtcwt_march_inv21p(const float *Z2, const float *Yh1, const float *Yh0, float *X, int B, int R, int C,
                        const std::vector<double> &g0o, const std::vector<double> &g1o, const float *l_a, const float *l_b,

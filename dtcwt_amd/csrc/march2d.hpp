@@ -635,9 +635,13 @@ struct Inv21m {
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // c2q of one subband pair (A.4): quad a b / c d from w0, w1 (complex) and their gains (x sqrt(1/2))
+// The two products of every sum are NOT left to the compiler's contraction (a * b + c * d becomes a multiply and a fused multiply-add,
+// and WHICH product is rounded first differed between kernels that inline this -- k_inv21m and the same macro-steps as a marching
+// pair, march2d_ipair.hpp, disagreed in the last bit): the second subband's products are rounded, the first's are fused.
 __device__ __forceinline__ void c2q_quad(float w0r, float w0i, float w1r, float w1i, float ga, float gb, float (&q)[2][2]) {
-    const float pr = ga * w0r, pi = ga * w0i, qr = gb * w1r, qi = gb * w1i;
-    q[0][0] = pr + qr; q[0][1] = pi + qi; q[1][0] = pi - qi; q[1][1] = qr - pr;
+    const float qr = gb * w1r, qi = gb * w1i;
+    q[0][0] = __builtin_fmaf(ga, w0r, qr); q[0][1] = __builtin_fmaf(ga, w0i, qi);
+    q[1][0] = __builtin_fmaf(ga, w0i, -qi); q[1][1] = __builtin_fmaf(-ga, w0r, qr);
 }
 // interpolating row filter (colifilt along a row), standard phases: four outputs from the 10-sample window w
 // (element j = sample 2 jx - 4 + j); POS: sum(ha hb) > 0
@@ -865,6 +869,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OCC, OC
                         PzE[a][1] = la2[a] * DTM_BX(U0O); PzE[a][3] = la2[a] * DTM_BY(U0O);
                         PzO[a][0] = hb2[a] * DTM_BX(U1E); PzO[a][2] = hb2[a] * DTM_BY(U1E);
                         PzO[a][1] = hb2[a] * DTM_BX(U1O); PzO[a][3] = hb2[a] * DTM_BY(U1O);
+                        // the last slot starts from a PRODUCT, and the odd row adds another product to it: pinned as a rounded product here, so that
+                        // the sum is fma(odd-row product's factors, this) in every kernel that inlines these lines (left alone, WHICH of the two
+                        // products is rounded first differed between k_inv21m and the marching pair: their outputs disagreed in the last bit)
+#ifndef DTM_NO_PIN      /* (A/B builds only: tools/build_variant.sh) */
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) { asm("" : "+v"(PzE[a][c])); asm("" : "+v"(PzO[a][c])); }
+#endif
                     }
                 } else {
                     PzO[a][0] += lb2[a] * DTM_BX(U0E); PzO[a][2] += lb2[a] * DTM_BY(U0E);

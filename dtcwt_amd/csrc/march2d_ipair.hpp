@@ -166,6 +166,13 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
                             PzE[a][1] = la2[a] * DTM_BX(U0O); PzE[a][3] = la2[a] * DTM_BY(U0O);
                             PzO[a][0] = hb2[a] * DTM_BX(U1E); PzO[a][2] = hb2[a] * DTM_BY(U1E);
                             PzO[a][1] = hb2[a] * DTM_BX(U1O); PzO[a][3] = hb2[a] * DTM_BY(U1O);
+                            // the last slot starts from a PRODUCT, and the odd row adds another product to it: pinned as a rounded product here, so that
+                            // the sum is fma(odd-row product's factors, this) in every kernel that inlines these lines (left alone, WHICH of the two
+                            // products is rounded first differed between k_inv21m and the marching pair: their outputs disagreed in the last bit)
+#ifndef DTM_NO_PIN      /* (A/B builds only: tools/build_variant.sh) */
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) { asm("" : "+v"(PzE[a][c])); asm("" : "+v"(PzO[a][c])); }
+#endif
                         }
                     } else {
                         PzO[a][0] += lb2[a] * DTM_BX(U0E); PzO[a][2] += lb2[a] * DTM_BY(U0E);

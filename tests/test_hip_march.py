@@ -193,6 +193,32 @@ def test_inverse_pair_matches_tile_programs_and_oracle(shape, bn, qn, band, monk
     assert tm.plan(1, shape[0], shape[1], nl).launches()[1] is False
 
 
+@pytest.mark.parametrize('shape', [(64, 64), (256, 320), (96, 1036), (520, 236), (1024, 232), (44, 940)])
+@pytest.mark.parametrize('bn', ['near_sym_a', 'legall'])
+def test_headline_inverse_as_a_pair_is_bit_identical(shape, bn, monkeypatch):
+    """One transform at a time on the whole device (up to 4096^2) runs levels 2 + 1 of the inverse as a marching pair of wavefronts
+    (k_inv21p<7, 5, 10>) instead of k_inv21m: the same sums in the same order, whatever the band heights -- not a bit differs."""
+    monkeypatch.setenv('DTCWT_HIP_MARCH', '1')
+    monkeypatch.setenv('DTCWT_HIP_MARCH_INV', '1')
+    rs = np.random.RandomState(29)
+    X = rs.standard_normal(shape).astype(np.float32)
+    nl = 2 if min(shape) < 160 else 3
+    gm = rs.uniform(0.3, 1.4, size=(6, nl)) * (rs.uniform(size=(6, nl)) > 0.2)
+    t = Transform2d(bn, 'qshift_a' if bn == 'near_sym_a' else 'qshift_06')
+    assert t.plan(1, shape[0], shape[1], nl).launches()[1] is True
+    p = t.forward(X, nlevels=nl)
+    pyr = Pyramid(np.array(p.lowpass), tuple(np.array(y) for y in p.highpasses))
+    out = {}
+    for arm in ('0', '1'):
+        monkeypatch.setenv('DTCWT_HIP_INV21_PAIR', arm)
+        out[arm] = np.array(t.inverse(pyr, gm))
+    assert np.array_equal(out['0'], out['1'])
+    monkeypatch.delenv('DTCWT_HIP_INV21_PAIR')
+    assert np.array_equal(np.array(t.inverse(pyr, gm)), out['0'])           # the library's own choice
+    to = o.Transform2d(biort(bn), qshift('qshift_a' if bn == 'near_sym_a' else 'qshift_06'))
+    assert_close(out['1'], to.inverse(to.forward(as_f64(X), nlevels=nl), gm), INV_TOL, 'inverse')
+
+
 def test_forward_pair_on_a_batch():
     rs = np.random.RandomState(26)
     X = rs.standard_normal((5, 128, 424)).astype(np.float32)
