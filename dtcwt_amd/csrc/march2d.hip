@@ -79,8 +79,8 @@ static const MarchCrossover kCrossover[3] = {
     // one transform at a time on the whole device, forward + inverse, march / tiles: 512^2 2.07, 1024^2 1.42, 1536^2 1.13,
     // 1792^2 1.06 | 2048^2 0.95, 4 x 1024^2 0.93, 32 x 512^2 0.93, 4096^2 0.89; 16 x 512^2 (a third of the lanes idle) 1.17
     // re-measured per direction with the round-5 kernels (the inverse up to 4096^2 is the marching pair): 1536^2 1.07 / 1.12,
-    // 1792^2 0.97 / 0.97, 2048^2 0.87 / 0.92 (profiles/r05/march_sizes_dir.txt): the crossover is 3.0 M useful pixels now
-    {"alone on the whole device", 3.0e6, "profiles/r04/ab_march_sizes.txt, profiles/r05/march_sizes_dir.txt"},
+    // 1792^2 0.97 / 0.97, 2048^2 0.87 / 0.92 (profiles/r05/march_sizes_dir.txt): the crossover is 3.1 M useful pixels now (16 x 512^2, a third of its lanes idle, 3.09 M: stays on the tiles, 1.17)
+    {"alone on the whole device", 3.1e6, "profiles/r04/ab_march_sizes.txt, profiles/r05/march_sizes_dir.txt"},
     // four in flight on plain streams (hipGraph replay, us per image, march / tiles): 1024^2 25.7 / 19.6, 1536^2 32.7 / 33.1,
     // 1792^2 38.9 / 42.6 -- the launch latency is partly hidden, the crossover comes down, though not in proportion
     {"others in flight beside it (concurrency hint > 1)", 2.2e6, "profiles/r04/hint_sizes.txt"},

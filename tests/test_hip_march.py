@@ -259,18 +259,19 @@ def test_march_on_a_batch_and_other_level1_filters(monkeypatch):
 
 
 def test_march_is_used_where_it_pays(monkeypatch):
-    """Unset, DTCWT_HIP_MARCH leaves the choice to the plan: the one-launch form needs ~3.5 M useful pixels per call on
-    the whole device (a marching launch takes ~30 us however small the image; profiles/r04/ab_march_sizes.txt), fewer with
+    """Unset, DTCWT_HIP_MARCH leaves the choice to the plan: the one-launch form needs ~3.1 M useful pixels per call on
+    the whole device (a marching launch takes ~30 us however small the image; profiles/r04/ab_march_sizes.txt, profiles/r05/march_sizes_dir.txt), fewer with
     other transforms in flight beside it (profiles/r04/hint_sizes*.txt)."""
     from dtcwt_amd.hip import Context
     monkeypatch.delenv('DTCWT_HIP_MARCH', raising=False)
     t = Transform2d()
     assert t.plan(1, 512, 512, 3).launches() == (False, False)
-    assert t.plan(1, 1792, 1792, 4).launches() == (False, False)
+    assert t.plan(1, 1536, 1536, 4).launches() == (False, False)
+    assert t.plan(1, 1792, 1792, 4).launches() == (True, True)
     assert t.plan(16, 512, 512, 4).launches() == (False, False)          # 4.2 M pixels, a third of the lanes idle
     assert t.plan(1, 2048, 2048, 4).launches() == (True, True)
     assert t.plan(32, 512, 512, 4).launches() == (True, True)
-    pl = t.plan(1, 1792, 1792, 4)
+    pl = t.plan(1, 1536, 1536, 4)
     assert pl.launches() == (False, False)
     pl.set_concurrency(4)                                                # others in flight beside it: from 2.2 M pixels
     assert pl.launches() == (True, True)
