@@ -464,8 +464,14 @@ def main():
     #   level-1 kernels              X 4 + LoLo1 4 + Yh[0] 12            = 20 B/px
     #   levels 1 + 2 in one launch   X 4 + Yh[0] 12 + Yh[1] 3 + LoLo2 1  = 20 B/px (LoLo1 stays in registers)
     fwd12, inv21 = plan.launches() if NL >= 2 else (False, False)
+    # one transform at a time up to 4096^2 (18 M useful pixels) the library runs levels 2 + 1 of the inverse as a marching PAIR of
+    # wavefronts (k_inv21p, march2d.hip: dtcwt_march_inv21) -- that is the launch the one-at-a-time event pairs below time
+    nstrip58 = -(-C // 232)
+    alone_pair = BIORT in ('near_sym_a', 'legall') and QSHIFT in ('qshift_a', 'qshift_06') and px * C / (nstrip58 * 232.0) <= 1.8e7
+    inv21_name = ('k_inv21p (levels 2+1 inverse, one launch: the marching pair one transform at a time; k_inv21m with several in flight)'
+                  if alone_pair else 'k_inv21m (levels 2+1 inverse, one launch)')
     cand = [('k_fwd12m (levels 1+2 forward, one launch)', kf[0], 20.0) if fwd12 else ('k_fwd1 (level-1 forward)', kf[0], 20.0),
-            ('k_inv21m (levels 2+1 inverse, one launch)', ki[1], 20.0) if inv21 else ('k_inv1 (level-1 inverse)', ki[0], 20.0)]
+            (inv21_name, ki[1], 20.0) if inv21 else ('k_inv1 (level-1 inverse)', ki[0], 20.0)]
     name, ms, bpp = max(cand, key=lambda c: c[1])
     achieved = bpp * px / (ms * 1e-3) / 1e9       # GB/s
     roofline = {'bound': 'hbm', 'kernel': name, 'achieved': round(achieved, 1), 'peak': HBM_PEAK / 1e9,

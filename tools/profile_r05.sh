@@ -13,7 +13,7 @@ bash $R/tools/profile_round.sh gpurun_out/r05prof/c2 r05 > $O/profile_round.log 
 cd /tmp && export TMPDIR=/tmp
 for c in c3 c5 c4; do
   mkdir -p $O/$c
-  B="python $R/bench.py --config $c --steps 8 --warmup 2 --no-cpu-baseline --no-other-configs --settle-ms 60"
+  B="python $R/bench.py --config $c --steps 8 --warmup 2 --no-cpu-baseline --no-other-configs --no-probe --settle-ms 60"
   timeout 300 rocprofv3 --kernel-trace --stats -d $O/$c/trace -o bench --output-format csv -- $B > $O/$c/bench_under_trace.json 2> $O/$c/trace.err
   echo "$c trace rc=$?" >> $O/status.txt
   timeout 300 rocprofv3 --kernel-trace --stats -d $O/$c/trace1 -o bench --output-format csv -- $B --streams 1 --cu-partition off > $O/$c/bench_under_trace1.json 2> $O/$c/trace1.err

@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/${1:-gpurun_out/prof}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs"
+BENCH="python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs --no-probe"
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o bench --output-format csv -- $BENCH > "$OUT/bench_under_trace.json" 2> "$OUT/trace.err"
 echo "trace rc=$?" > "$OUT/status.txt"
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace1" -o bench --output-format csv -- $BENCH --streams 1 > "$OUT/bench_under_trace_streams1.json" 2> "$OUT/trace1.err"
