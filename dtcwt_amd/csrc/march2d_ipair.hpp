@@ -55,8 +55,9 @@ __device__ __forceinline__ void ifilt_row_n(const pk2 (&W)[NW], const pk2 *ha2, 
 }
 #endif
 
-template <int M0, int M1, int M>
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) k_inv21p(const Inv21mParams p) {
+// WPS: wavefronts per SIMD the registers are allocated for (162 VGPRs at M = 14: three fit, i.e. six pairs per CU)
+template <int M0, int M1, int M, int WPS = 2>
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, WPS))) k_inv21p(const Inv21mParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using G = Inv21p<M0, M1, M>;
     constexpr int H0 = G::H0, H1 = G::H1, HL = G::HL, HL2 = G::HL2, VL = G::VL, NG = G::NG, NPX = G::NPX;

@@ -219,6 +219,24 @@ def test_headline_inverse_as_a_pair_is_bit_identical(shape, bn, monkeypatch):
     assert_close(out['1'], to.inverse(to.forward(as_f64(X), nlevels=nl), gm), INV_TOL, 'inverse')
 
 
+def test_inverse_pair_on_a_share_of_the_compute_units():
+    """On a partition context k_inv21p<7, 5, 14> is the build for three wavefronts per SIMD: the same arithmetic as on the whole
+    device, bit for bit, and right."""
+    from dtcwt_amd.hip import Context
+    rs = np.random.RandomState(33)
+    X = rs.standard_normal((520, 696)).astype(np.float32)
+    gm = rs.uniform(0.3, 1.4, size=(6, 3))
+    tw = Transform2d('near_sym_a', 'qshift_b', program='march')
+    tq = Transform2d('near_sym_a', 'qshift_b', program='march', ctx=Context(0, partition=(1, 4)))
+    assert tq.plan(1, 520, 696, 3).launches() == (True, True)
+    p = tw.forward(X, nlevels=3)
+    pyr = Pyramid(np.array(p.lowpass), tuple(np.array(y) for y in p.highpasses))
+    zw, zq = np.array(tw.inverse(pyr, gm)), np.array(tq.inverse(pyr, gm))
+    assert np.array_equal(zw, zq)
+    to = o.Transform2d(biort('near_sym_a'), qshift('qshift_b'))
+    assert_close(zq, to.inverse(to.forward(as_f64(X), nlevels=3), gm), INV_TOL, 'inverse on a share')
+
+
 def test_forward_pair_on_a_batch():
     rs = np.random.RandomState(26)
     X = rs.standard_normal((5, 128, 424)).astype(np.float32)
