@@ -418,7 +418,8 @@ static int launch_inv21p(dtm::Inv21mParams &p, const DtMarchHint &hint, hipStrea
     // A job is a PAIR of wavefronts: half as many are resident as single-wavefront jobs.  At M = 14 the registers (162) allow a third
     // wavefront per SIMD: on a partition context (a share of the CUs, the other shares busy) that measured -8 % per step (four 4096^2 in
     // flight 0.202 -> 0.186 ms, 64 x 2048^2 on quarters -2 %), on the whole device +3.5 % (64 x 1024^2): profiles/r05/ab_ipair_occ.txt
-    const int wps = (M == 14 && hint.nparts > 1) ? 3 : 2;
+    static const int wps_env = [] { const char *e = getenv("DTCWT_HIP_IPAIR_WPS"); return e ? atoi(e) : 0; }();       // 2 / 3: force (M = 14 only; at M = 10 three measured no faster alone: profiles/r05/ab_ipair_occ.txt)
+    const int wps = wps_env ? wps_env : ((M == 14 && hint.nparts > 1) ? 3 : 2);
     const int cus = hint.cus * wps / 4 > 0 ? hint.cus * wps / 4 : 1;
     const unsigned jobs = dtm::dtm_set_jobs(p.jb, p.B, p.R, nstrip, pick_band_rows(p.B * hint.in_flight, p.R, nstrip, M, cus));
     if constexpr (M == 14) { if (wps == 3) { dtm::k_inv21p<7, 5, M, 3><<<jobs, 128, 0, s>>>(p); return 0; } }
