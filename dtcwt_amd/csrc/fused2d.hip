@@ -53,6 +53,10 @@ int dtcwt_march_inv21p(const float *Z2, const float *Yh1, const float *Yh0, floa
                        const std::vector<double> &g0o, const std::vector<double> &g1o, const float *l_a, const float *l_b,
                        const float *h_a, const float *h_b, int m, const float *gain1, const float *gain2, const DtMarchHint &hint, hipStream_t s);
 
+// level 2 of the inverse alone as a march (march2d_ipair.hpp: k_inv2m)
+bool dtcwt_march_inv2_ok(int batch, int rows, int cols, const std::vector<double> &g0a, bool lo_pos, bool hi_pos, const DtMarchHint &hint);
+int dtcwt_march_inv2(const float *Z2, const float *Yh1, float *Z1, int B, int R, int C, const float *l_a, const float *l_b,
+                     const float *h_a, const float *h_b, int m, const float *gain2, const DtMarchHint &hint, hipStream_t s);
 namespace {
 
 // record arrays at least this big leave with the non-temporal hint (DTCWT_HIP_STREAM_RECORDS_MB; default 32)
@@ -227,6 +231,12 @@ static bool plan_march_inv21p(const dtcwt_hip_plan2d *p) {
     return plan_march_geometry(p) && p->bp1[1].empty() && p->bp2[2].empty() &&
            dtcwt_march_inv21p_ok(p->batch, p->lv[0].LR, p->lv[0].LC, p->biort[1], p->biort[3], p->qshift[2],
                                  dotd(p->qshift[3], p->qshift[2]) > 0, dotd(p->qshift[7], p->qshift[6]) > 0, p->hint());
+}
+// level 2 of the inverse alone as a march, where neither the one-wavefront launch nor the pair takes levels 2 + 1
+static bool plan_march_inv2(const dtcwt_hip_plan2d *p) {
+    return p->nlevels >= 2 && plan_march_geometry(p) && p->bp2[2].empty() && !plan_march_inv21(p) && !plan_march_inv21p(p) &&
+           dtcwt_march_inv2_ok(p->batch, p->lv[0].LR, p->lv[0].LC, p->qshift[2], dotd(p->qshift[3], p->qshift[2]) > 0,
+                               dotd(p->qshift[7], p->qshift[6]) > 0, p->hint());
 }
 
 // level 1 alone as a march (near_sym_b, antonini): no odd-size extension, columns in fours, no band-pass set
@@ -557,6 +567,15 @@ int dtcwt_hip_plan2d_inverse(dtcwt_hip_plan2d *p, const float *Yl, const void *c
             if (bp) {
                 put_taps(q.b_a, p->bp2[3]); put_taps(q.b_b, p->bp2[2]);
                 q.bp_pos = dotd(p->bp2[3], p->bp2[2]) > 0;
+            }
+            if (l == 1 && plan_march_inv2(p)) {          // level 2 alone as a march (k_inv2m): Z2 + Yh[1] -> the level-1 lowpass
+                rc = dtcwt_march_inv2(in, (const float *)Yh[1], out, p->batch, p->lv[0].LR, p->lv[0].LC, q.l_a, q.l_b, q.h_a, q.h_b,
+                                      (int)p->qshift[2].size(), g, p->hint(), s);
+                in = out;
+                if (rc) return dtcwt_set_error(rc, "no marching level-2 inverse kernel");
+                DT_CHECK_HIP(hipGetLastError());
+                if (p->profiling) DT_CHECK_HIP(hipEventRecord(p->ev[2 * (nl + l) + 1], s));
+                continue;
             }
             // the coarsest levels of a single image (fewer than two 16 x 56 tiles per CU): 8 x 64 tiles, twice the
             // workgroups of half the rows each (fused2d_table.hpp)

@@ -446,3 +446,38 @@ int dtcwt_march_inv21p(const float *Z2, const float *Yh1, const float *Yh0, floa
     if (m == 18) return launch_inv21p<18>(p, hint, s);
     return -3;
 }
+
+// ---- level 2 of the inverse alone as a march (march2d_ipair.hpp: k_inv2m) ------------------------------------------------------
+// For the 14- / 18-tap q-shift sets where no pair takes levels 2 + 1 (near_sym_b: its level 1 is k_inv1m): Z2 + Yh[1] -> Z1.
+// Standard phases, sizes in fours; chosen by the crossover of the level-1 marches.  DTCWT_HIP_MARCH_INV2=0: never.
+bool dtcwt_march_inv2_ok(int batch, int rows, int cols, const std::vector<double> &g0a, bool lo_pos, bool hi_pos, const DtMarchHint &hint) {
+    if (const char *e = getenv("DTCWT_HIP_MARCH_INV2")) { if (e[0] == '0') return false; }
+    const int m = (int)g0a.size();
+    if (!(m == 14 || m == 18) || !lo_pos || hi_pos) return false;
+    const int VL = m == 14 ? dtm::Inv2m<14>::VL : dtm::Inv2m<18>::VL;
+    if (!march_sizes_ok(batch, rows, cols, VL)) return false;
+    const int mm = march_mode(hint);
+    return mm > 0 || (mm < 0 && l1_pays(batch, rows, cols, VL, hint));
+}
+
+template <int M, int WPS>
+static int launch_inv2m(dtm::Inv21mParams &p, const DtMarchHint &hint, hipStream_t s) {
+    using G = dtm::Inv2m<M>;
+    const int nstrip = cdiv(p.C, 4 * G::VL);
+    const int cus = hint.cus * WPS / 2 > 0 ? hint.cus * WPS / 2 : 1;        // WPS wavefronts per SIMD where the band picker counts two
+    const unsigned jobs = dtm::dtm_set_jobs(p.jb, p.B, p.R, nstrip, pick_band_rows(p.B * hint.in_flight, p.R, nstrip, M, cus));
+    dtm::k_inv2m<M, WPS><<<jobs, 64, 0, s>>>(p);
+    return 0;
+}
+
+// Z2 [B][R/2][C/2], Yh1 [B][R/4][C/4][12] -> Z1 [B][R][C]; gain2: the level's six subband gains x sqrt(1/2)
+int dtcwt_march_inv2(const float *Z2, const float *Yh1, float *Z1, int B, int R, int C, const float *l_a, const float *l_b,
+                     const float *h_a, const float *h_b, int m, const float *gain2, const DtMarchHint &hint, hipStream_t s) {
+    dtm::Inv21mParams p{};
+    p.Z2 = Z2; p.Yh1 = Yh1; p.Yh0 = nullptr; p.X = Z1; p.B = B; p.R = R; p.C = C;
+    for (int k = 0; k < dtm::MAXT2; ++k) { p.l_a[k] = l_a[k]; p.l_b[k] = l_b[k]; p.h_a[k] = h_a[k]; p.h_b[k] = h_b[k]; }
+    for (int d = 0; d < 6; ++d) p.g2[d] = gain2[d];
+    if (m == 14) return launch_inv2m<14, 3>(p, hint, s);
+    if (m == 18) return launch_inv2m<18, 2>(p, hint, s);
+    return -3;
+}

@@ -55,6 +55,128 @@ __device__ __forceinline__ void ifilt_row_n(const pk2 (&W)[NW], const pk2 *ha2, 
 }
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// The level-2 wavefront: the first half of a k_inv21m macro-step for any M with (M - 2) % 4 == 0, on the strip whose lane 0 sits
+// HL lanes left of its first owned column; macro-steps nfirst .. nfirst + nms - 1 (one pair of Z2 rows + one Yh[1] record row each).
+// After macro-step ms (pair n) the group n - HL2 of four Z1 rows is complete: sink(ms, n, E, O) receives it -- rows (0, 2) of column c
+// in E[c], rows (1, 3) in O[c] -- and the groups move up by one at the first touch of the next macro-step.
+template <int M, int HL, class Sink>
+__device__ __forceinline__ void inv2_wave(const Inv21mParams &p, int lane, int strip, int b, int nfirst, int nms, Sink &&sink) {
+    constexpr int HL2 = (M - 2) / 4, NG = M / 2, VL = 64 - 2 * HL;
+    const int R = p.R, C = p.C;
+    const int cb = strip * (4 * VL) - 4 * HL;             // column of lane 0
+    const int c0 = cb + 4 * lane;
+    const bool mir = c0 < 0 || c0 >= C;
+    const bool edge_strip = cb < 0 || cb + 256 > C;      // uniform: some lane is mirrored
+    const int64_t img = (int64_t)b * R * C;
+    int zl = c0 < 0 ? -2 - c0 / 2 : (c0 >= C ? C - 2 - c0 / 2 : c0 / 2);
+    zl = zl < 0 ? 0 : (zl > C / 2 - 2 ? C / 2 - 2 : zl);
+    int ql = c0 < 0 ? -1 - c0 / 4 : (c0 >= C ? C / 2 - 1 - c0 / 4 : c0 / 4);
+    ql = ql < 0 ? 0 : (ql > C / 4 - 1 ? C / 4 - 1 : ql);
+    const DtBuf bz = dt_buf2g(p.Z2 + img / 4);
+    const DtBuf b2 = dt_buf2g(p.Yh1 + (img / 4) * 3);
+    const unsigned zpitch = (unsigned)C * 2u, r2pitch = (unsigned)C * 12u;          // bytes per Z2 row, per Yh1 record row
+    auto zrow = [&](int u) { u = u < 0 ? -1 - u : u; u = u >= R / 2 ? R - 1 - u : u; return u < 0 ? 0 : (u > R / 2 - 1 ? R / 2 - 1 : u); };
+    auto pair_row = [&](int n, bool &sw) { sw = n < 0 || n >= R / 4; n = n < 0 ? -1 - n : n; n = n >= R / 4 ? R / 2 - 1 - n : n; return n < 0 ? 0 : (n > R / 4 - 1 ? R / 4 - 1 : n); };
+    dt2d::f2 z2p[2];
+    f4 r2p[3];
+    auto request = [&](int n) {
+        bool sw;
+        z2p[0] = dt2d::dt_buf_ld2(bz, (unsigned)zl * 4u, (unsigned)zrow(2 * n) * zpitch);
+        z2p[1] = dt2d::dt_buf_ld2(bz, (unsigned)zl * 4u, (unsigned)zrow(2 * n + 1) * zpitch);
+        const unsigned ro2 = (unsigned)pair_row(n, sw) * r2pitch;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) r2p[m] = dt2d::dt_buf_ld4(b2, (unsigned)ql * 48u + 16u * m, ro2);
+    };
+    request(nfirst);
+    asm volatile("" : "+v"(z2p[0].x), "+v"(z2p[0].y), "+v"(z2p[1].x), "+v"(z2p[1].y) : : "memory");
+#pragma unroll
+    for (int m = 0; m < 3; ++m) asm volatile("" : "+v"(r2p[m].x), "+v"(r2p[m].y), "+v"(r2p[m].z), "+v"(r2p[m].w) : : "memory");
+
+    // pending Z1 groups: PzE[a][c] = rows (0, 2), PzO[a][c] = rows (1, 3) of group slot a, column c
+    pk2 PzE[NG][4], PzO[NG][4];
+#pragma unroll
+    for (int a = 0; a < NG; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { PzE[a][c] = pk2{0.f, 0.f}; PzO[a][c] = pk2{0.f, 0.f}; }
+    const pk2 *la2 = reinterpret_cast<const pk2 *>(p.l_a), *lb2 = reinterpret_cast<const pk2 *>(p.l_b);
+    const pk2 *ha2 = reinterpret_cast<const pk2 *>(p.h_a), *hb2 = reinterpret_cast<const pk2 *>(p.h_b);
+
+    for (int ms = 0; ms < nms; ++ms) {
+        const int n = nfirst + ms;
+        bool sw2;
+        (void)pair_row(n, sw2);
+        float z[2][2], p05[2][2], p23[2][2], p14[2][2];
+        {
+            const f4 ra = r2p[0], rc = r2p[1], re = r2p[2];
+            c2q_quad(ra.x, ra.y, re.z, re.w, p.g2[0], p.g2[5], p05);
+            c2q_quad(rc.x, rc.y, rc.z, rc.w, p.g2[2], p.g2[3], p23);
+            c2q_quad(ra.z, ra.w, re.x, re.y, p.g2[1], p.g2[4], p14);
+            z[0][0] = z2p[0].x; z[0][1] = z2p[0].y; z[1][0] = z2p[1].x; z[1][1] = z2p[1].y;
+            if (sw2) {              // a reflected record row: its quads upside down
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    float t_;
+                    t_ = p05[0][f]; p05[0][f] = p05[1][f]; p05[1][f] = t_;
+                    t_ = p23[0][f]; p23[0][f] = p23[1][f]; p23[1][f] = t_;
+                    t_ = p14[0][f]; p14[0][f] = p14[1][f]; p14[1][f] = t_;
+                }
+            }
+            if (edge_strip) {       // mirrored lanes: the mirror lane's two columns in reverse
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    float t_;
+                    t_ = z[e][0]; z[e][0] = mir ? z[e][1] : t_; z[e][1] = mir ? t_ : z[e][1];
+                    t_ = p05[e][0]; p05[e][0] = mir ? p05[e][1] : t_; p05[e][1] = mir ? t_ : p05[e][1];
+                    t_ = p23[e][0]; p23[e][0] = mir ? p23[e][1] : t_; p23[e][1] = mir ? t_ : p23[e][1];
+                    t_ = p14[e][0]; p14[e][0] = mir ? p14[e][1] : t_; p14[e][1] = mir ? t_ : p14[e][1];
+                }
+            }
+        }
+        request(n + 1);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            // u0 = R0 z + R1 p23, u1 = R0 p05 + R1 p14 as (u[0], u[2]) and (u[1], u[3])
+            pk2 U0E = {0.f, 0.f}, U0O = {0.f, 0.f}, U1E = {0.f, 0.f}, U1O = {0.f, 0.f}, W[NG];
+            win_pairs<HL2>(z[e][0], z[e][1], W);     ifilt_row_n<true, NG>(W, la2, lb2, U0E, U0O);
+            win_pairs<HL2>(p23[e][0], p23[e][1], W); ifilt_row_n<false, NG>(W, ha2, hb2, U0E, U0O);
+            win_pairs<HL2>(p05[e][0], p05[e][1], W); ifilt_row_n<true, NG>(W, la2, lb2, U1E, U1O);
+            win_pairs<HL2>(p14[e][0], p14[e][1], W); ifilt_row_n<false, NG>(W, ha2, hb2, U1E, U1O);
+#pragma unroll
+            for (int a = 0; a < NG; ++a) {          // slot a = group n - HL2 + a, tap pair k = a
+                if (e == 0) {       // the even row of the pair; the first touch of a slot also moves the groups up by one
+                    if (a + 1 < NG) {
+                        PzE[a][0] = la2[a] * DTM_BX(U0E) + PzE[a + 1][0]; PzE[a][2] = la2[a] * DTM_BY(U0E) + PzE[a + 1][2];
+                        PzE[a][1] = la2[a] * DTM_BX(U0O) + PzE[a + 1][1]; PzE[a][3] = la2[a] * DTM_BY(U0O) + PzE[a + 1][3];
+                        PzO[a][0] = hb2[a] * DTM_BX(U1E) + PzO[a + 1][0]; PzO[a][2] = hb2[a] * DTM_BY(U1E) + PzO[a + 1][2];
+                        PzO[a][1] = hb2[a] * DTM_BX(U1O) + PzO[a + 1][1]; PzO[a][3] = hb2[a] * DTM_BY(U1O) + PzO[a + 1][3];
+                    } else {
+                        PzE[a][0] = la2[a] * DTM_BX(U0E); PzE[a][2] = la2[a] * DTM_BY(U0E);
+                        PzE[a][1] = la2[a] * DTM_BX(U0O); PzE[a][3] = la2[a] * DTM_BY(U0O);
+                        PzO[a][0] = hb2[a] * DTM_BX(U1E); PzO[a][2] = hb2[a] * DTM_BY(U1E);
+                        PzO[a][1] = hb2[a] * DTM_BX(U1O); PzO[a][3] = hb2[a] * DTM_BY(U1O);
+                        // the last slot starts from a PRODUCT, and the odd row adds another product to it: pinned as a rounded product here, so that
+                        // the sum is fma(odd-row product's factors, this) in every kernel that inlines these lines (left alone, WHICH of the two
+                        // products is rounded first differed between k_inv21m and the marching pair: their outputs disagreed in the last bit)
+#ifndef DTM_NO_PIN      /* (A/B builds only: tools/build_variant.sh) */
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) { asm("" : "+v"(PzE[a][c])); asm("" : "+v"(PzO[a][c])); }
+#endif
+                    }
+                } else {
+                    PzO[a][0] += lb2[a] * DTM_BX(U0E); PzO[a][2] += lb2[a] * DTM_BY(U0E);
+                    PzO[a][1] += lb2[a] * DTM_BX(U0O); PzO[a][3] += lb2[a] * DTM_BY(U0O);
+                    PzE[a][0] += ha2[a] * DTM_BX(U1E); PzE[a][2] += ha2[a] * DTM_BY(U1E);
+                    PzE[a][1] += ha2[a] * DTM_BX(U1O); PzE[a][3] += ha2[a] * DTM_BY(U1O);
+                }
+            }
+        }
+        // group n - HL2 (Z1 rows 4j .. 4j + 3) is complete in slot 0
+        sink(ms, n, PzE[0], PzO[0]);
+    }
+}
+#endif
+
 // WPS: wavefronts per SIMD the registers are allocated for (162 VGPRs at M = 14: three fit, i.e. six pairs per CU)
 template <int M0, int M1, int M, int WPS = 2>
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, WPS))) k_inv21p(const Inv21mParams p) {
@@ -80,117 +202,15 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, WPS
     const int nfirst = j0 - HL2, nms = j1 - j0 + 2 * HL2 + 1;       // level-2 pairs j0 - HL2 .. j1 + HL2
 
     if (role == 0) {
-        // ------------------------------------------------------------------ level 2 (the first half of a k_inv21m macro-step)
-        int zl = c0 < 0 ? -2 - c0 / 2 : (c0 >= C ? C - 2 - c0 / 2 : c0 / 2);
-        zl = zl < 0 ? 0 : (zl > C / 2 - 2 ? C / 2 - 2 : zl);
-        int ql = c0 < 0 ? -1 - c0 / 4 : (c0 >= C ? C / 2 - 1 - c0 / 4 : c0 / 4);
-        ql = ql < 0 ? 0 : (ql > C / 4 - 1 ? C / 4 - 1 : ql);
-        const DtBuf bz = dt_buf2g(p.Z2 + img / 4);
-        const DtBuf b2 = dt_buf2g(p.Yh1 + (img / 4) * 3);
-        const unsigned zpitch = (unsigned)C * 2u, r2pitch = (unsigned)C * 12u;          // bytes per Z2 row, per Yh1 record row
-        auto zrow = [&](int u) { u = u < 0 ? -1 - u : u; u = u >= R / 2 ? R - 1 - u : u; return u < 0 ? 0 : (u > R / 2 - 1 ? R / 2 - 1 : u); };
-        auto pair_row = [&](int n, bool &sw) { sw = n < 0 || n >= R / 4; n = n < 0 ? -1 - n : n; n = n >= R / 4 ? R / 2 - 1 - n : n; return n < 0 ? 0 : (n > R / 4 - 1 ? R / 4 - 1 : n); };
-        dt2d::f2 z2p[2];
-        f4 r2p[3];
-        auto request = [&](int n) {
-            bool sw;
-            z2p[0] = dt2d::dt_buf_ld2(bz, (unsigned)zl * 4u, (unsigned)zrow(2 * n) * zpitch);
-            z2p[1] = dt2d::dt_buf_ld2(bz, (unsigned)zl * 4u, (unsigned)zrow(2 * n + 1) * zpitch);
-            const unsigned ro2 = (unsigned)pair_row(n, sw) * r2pitch;
-#pragma unroll
-            for (int m = 0; m < 3; ++m) r2p[m] = dt2d::dt_buf_ld4(b2, (unsigned)ql * 48u + 16u * m, ro2);
-        };
-        request(nfirst);
-        asm volatile("" : "+v"(z2p[0].x), "+v"(z2p[0].y), "+v"(z2p[1].x), "+v"(z2p[1].y) : : "memory");
-#pragma unroll
-        for (int m = 0; m < 3; ++m) asm volatile("" : "+v"(r2p[m].x), "+v"(r2p[m].y), "+v"(r2p[m].z), "+v"(r2p[m].w) : : "memory");
-
-        // pending Z1 groups: PzE[a][c] = rows (0, 2), PzO[a][c] = rows (1, 3) of group slot a, column c
-        pk2 PzE[NG][4], PzO[NG][4];
-#pragma unroll
-        for (int a = 0; a < NG; ++a)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { PzE[a][c] = pk2{0.f, 0.f}; PzO[a][c] = pk2{0.f, 0.f}; }
-        const pk2 *la2 = reinterpret_cast<const pk2 *>(p.l_a), *lb2 = reinterpret_cast<const pk2 *>(p.l_b);
-        const pk2 *ha2 = reinterpret_cast<const pk2 *>(p.h_a), *hb2 = reinterpret_cast<const pk2 *>(p.h_b);
-
-        for (int ms = 0; ms < nms; ++ms) {
-            const int n = nfirst + ms;
-            bool sw2;
-            (void)pair_row(n, sw2);
-            float z[2][2], p05[2][2], p23[2][2], p14[2][2];
-            {
-                const f4 ra = r2p[0], rc = r2p[1], re = r2p[2];
-                c2q_quad(ra.x, ra.y, re.z, re.w, p.g2[0], p.g2[5], p05);
-                c2q_quad(rc.x, rc.y, rc.z, rc.w, p.g2[2], p.g2[3], p23);
-                c2q_quad(ra.z, ra.w, re.x, re.y, p.g2[1], p.g2[4], p14);
-                z[0][0] = z2p[0].x; z[0][1] = z2p[0].y; z[1][0] = z2p[1].x; z[1][1] = z2p[1].y;
-                if (sw2) {              // a reflected record row: its quads upside down
-#pragma unroll
-                    for (int f = 0; f < 2; ++f) {
-                        float t_;
-                        t_ = p05[0][f]; p05[0][f] = p05[1][f]; p05[1][f] = t_;
-                        t_ = p23[0][f]; p23[0][f] = p23[1][f]; p23[1][f] = t_;
-                        t_ = p14[0][f]; p14[0][f] = p14[1][f]; p14[1][f] = t_;
-                    }
-                }
-                if (edge_strip) {       // mirrored lanes: the mirror lane's two columns in reverse
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        float t_;
-                        t_ = z[e][0]; z[e][0] = mir ? z[e][1] : t_; z[e][1] = mir ? t_ : z[e][1];
-                        t_ = p05[e][0]; p05[e][0] = mir ? p05[e][1] : t_; p05[e][1] = mir ? t_ : p05[e][1];
-                        t_ = p23[e][0]; p23[e][0] = mir ? p23[e][1] : t_; p23[e][1] = mir ? t_ : p23[e][1];
-                        t_ = p14[e][0]; p14[e][0] = mir ? p14[e][1] : t_; p14[e][1] = mir ? t_ : p14[e][1];
-                    }
-                }
-            }
-            request(n + 1);
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                // u0 = R0 z + R1 p23, u1 = R0 p05 + R1 p14 as (u[0], u[2]) and (u[1], u[3])
-                pk2 U0E = {0.f, 0.f}, U0O = {0.f, 0.f}, U1E = {0.f, 0.f}, U1O = {0.f, 0.f}, W[NG];
-                win_pairs<HL2>(z[e][0], z[e][1], W);     ifilt_row_n<true, NG>(W, la2, lb2, U0E, U0O);
-                win_pairs<HL2>(p23[e][0], p23[e][1], W); ifilt_row_n<false, NG>(W, ha2, hb2, U0E, U0O);
-                win_pairs<HL2>(p05[e][0], p05[e][1], W); ifilt_row_n<true, NG>(W, la2, lb2, U1E, U1O);
-                win_pairs<HL2>(p14[e][0], p14[e][1], W); ifilt_row_n<false, NG>(W, ha2, hb2, U1E, U1O);
-#pragma unroll
-                for (int a = 0; a < NG; ++a) {          // slot a = group n - HL2 + a, tap pair k = a
-                    if (e == 0) {       // the even row of the pair; the first touch of a slot also moves the groups up by one
-                        if (a + 1 < NG) {
-                            PzE[a][0] = la2[a] * DTM_BX(U0E) + PzE[a + 1][0]; PzE[a][2] = la2[a] * DTM_BY(U0E) + PzE[a + 1][2];
-                            PzE[a][1] = la2[a] * DTM_BX(U0O) + PzE[a + 1][1]; PzE[a][3] = la2[a] * DTM_BY(U0O) + PzE[a + 1][3];
-                            PzO[a][0] = hb2[a] * DTM_BX(U1E) + PzO[a + 1][0]; PzO[a][2] = hb2[a] * DTM_BY(U1E) + PzO[a + 1][2];
-                            PzO[a][1] = hb2[a] * DTM_BX(U1O) + PzO[a + 1][1]; PzO[a][3] = hb2[a] * DTM_BY(U1O) + PzO[a + 1][3];
-                        } else {
-                            PzE[a][0] = la2[a] * DTM_BX(U0E); PzE[a][2] = la2[a] * DTM_BY(U0E);
-                            PzE[a][1] = la2[a] * DTM_BX(U0O); PzE[a][3] = la2[a] * DTM_BY(U0O);
-                            PzO[a][0] = hb2[a] * DTM_BX(U1E); PzO[a][2] = hb2[a] * DTM_BY(U1E);
-                            PzO[a][1] = hb2[a] * DTM_BX(U1O); PzO[a][3] = hb2[a] * DTM_BY(U1O);
-                            // the last slot starts from a PRODUCT, and the odd row adds another product to it: pinned as a rounded product here, so that
-                            // the sum is fma(odd-row product's factors, this) in every kernel that inlines these lines (left alone, WHICH of the two
-                            // products is rounded first differed between k_inv21m and the marching pair: their outputs disagreed in the last bit)
-#ifndef DTM_NO_PIN      /* (A/B builds only: tools/build_variant.sh) */
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) { asm("" : "+v"(PzE[a][c])); asm("" : "+v"(PzO[a][c])); }
-#endif
-                        }
-                    } else {
-                        PzO[a][0] += lb2[a] * DTM_BX(U0E); PzO[a][2] += lb2[a] * DTM_BY(U0E);
-                        PzO[a][1] += lb2[a] * DTM_BX(U0O); PzO[a][3] += lb2[a] * DTM_BY(U0O);
-                        PzE[a][0] += ha2[a] * DTM_BX(U1E); PzE[a][2] += ha2[a] * DTM_BY(U1E);
-                        PzE[a][1] += ha2[a] * DTM_BX(U1O); PzE[a][3] += ha2[a] * DTM_BY(U1O);
-                    }
-                }
-            }
-            // group n - HL2 (Z1 rows 4j .. 4j + 3) is complete in slot 0: hand it over
+        // ------------------------------------------------------------------ level 2: the completed group goes into the exchange
+        inv2_wave<M, HL>(p, lane, strip, b, nfirst, nms, [&](int ms, int, const pk2 (&E)[4], const pk2 (&O)[4]) {
             f4 (*xo)[64] = xb[ms & 1];
-            xo[0][lane] = f4{PzE[0][0].x, PzE[0][1].x, PzE[0][2].x, PzE[0][3].x};
-            xo[1][lane] = f4{PzO[0][0].x, PzO[0][1].x, PzO[0][2].x, PzO[0][3].x};
-            xo[2][lane] = f4{PzE[0][0].y, PzE[0][1].y, PzE[0][2].y, PzE[0][3].y};
-            xo[3][lane] = f4{PzO[0][0].y, PzO[0][1].y, PzO[0][2].y, PzO[0][3].y};
+            xo[0][lane] = f4{E[0].x, E[1].x, E[2].x, E[3].x};
+            xo[1][lane] = f4{O[0].x, O[1].x, O[2].x, O[3].x};
+            xo[2][lane] = f4{E[0].y, E[1].y, E[2].y, E[3].y};
+            xo[3][lane] = f4{O[0].y, O[1].y, O[2].y, O[3].y};
             DTM_PAIR_BARRIER();                      // the group is wavefront 1's now
-        }
+        });
     } else {
         // ------------------------------------------------------------------ level 1 (the second half of a k_inv21m macro-step)
         int sl = c0 < 0 ? (-c0 - 4 - cb) / 4 : (c0 >= C ? (2 * C - 4 - c0 - cb) / 4 : lane);
@@ -361,6 +381,49 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, WPS
             DT_WAVE_LDS_SYNC();
         }
     }
+#endif
+}
+
+// ======================================================================================================================
+// Level 2 of the inverse ALONE as a march (transform2d.py:242-273 at the second level): the level-2 wavefront of k_inv21p with its
+// completed groups of four Z1 rows stored instead of handed over -- for the sets whose level 1 no pair takes (near_sym_b's 19 / 13-tap
+// synthesis filters run as k_inv1m, march2d_l1.hpp).  Z2 [B][R/2][C/2] + Yh[1] -> Z1 = p.X [B][R][C]; no level-1 halo lane: HL = HL2.
+// Per pixel of Z1: 1 B of Z2 + 3 B of records read, 4 B written -- the bytes of the tile program k_inv2, in one pass without barriers.
+// ======================================================================================================================
+template <int M>
+struct Inv2m {
+    static constexpr int HL2 = (M - 2) / 4, HL = HL2, VL = 64 - 2 * HL;
+    static_assert((M - 2) % 4 == 0 && M >= 10 && M <= MAXT2, "q-shift lengths the level-2 march is built for");
+};
+
+template <int M, int WPS>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, WPS))) k_inv2m(const Inv21mParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using G = Inv2m<M>;
+    constexpr int HL = G::HL, HL2 = G::HL2, VL = G::VL;
+    const int lane = threadIdx.x;
+    int strip, band, b;
+    if (!dtm_job(p.jb, blockIdx.x, strip, band, b)) return;
+    const int R = p.R, C = p.C;
+    const int nv = (C - strip * (4 * VL)) / 4 < VL ? (C - strip * (4 * VL)) / 4 : VL;
+    const int rb = band * p.jb.band_rows;
+    const int nrow = R - rb < p.jb.band_rows ? R - rb : p.jb.band_rows;
+    const int g0 = rb / 4, g1 = (rb + nrow) / 4 - 1;     // the band's groups of four Z1 rows
+    float *const Xb = p.X + (int64_t)b * R * C + strip * (4 * VL);
+    const unsigned xv = 16u * (unsigned)(lane - HL);
+    inv2_wave<M, HL>(p, lane, strip, b, g0 - HL2, g1 - g0 + 2 * HL2 + 1, [&](int, int n, const pk2 (&E)[4], const pk2 (&O)[4]) {
+        // plain stores: the level-1 launch reads these rows next
+        const int j = n - HL2;
+        const bool ok = j >= g0 && j <= g1;            // uniform; otherwise the stores are dropped
+        const int jo = ok ? j : g0;
+        const f4 rows4[4] = {f4{E[0].x, E[1].x, E[2].x, E[3].x}, f4{O[0].x, O[1].x, O[2].x, O[3].x},
+                             f4{E[0].y, E[1].y, E[2].y, E[3].y}, f4{O[0].y, O[1].y, O[2].y, O[3].y}};
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const DtBuf bo = dt_buf_n(Xb + (int64_t)(4 * jo + r4) * C, ok ? 16u * nv : 0u);
+            dt2d::dt_buf_st4<false>(bo, xv, 0u, rows4[r4]);
+        }
+    });
 #endif
 }
 

@@ -237,6 +237,31 @@ def test_inverse_pair_on_a_share_of_the_compute_units():
     assert_close(zq, to.inverse(to.forward(as_f64(X), nlevels=3), gm), INV_TOL, 'inverse on a share')
 
 
+@pytest.mark.parametrize('shape', [(64, 64), (256, 320), (96, 1036), (520, 236), (1024, 232), (200, 464), (48, 212)])
+@pytest.mark.parametrize('bn,qn', [('near_sym_b', 'qshift_b'), ('near_sym_b', 'qshift_d'), ('antonini', 'qshift_b')])
+@pytest.mark.parametrize('band', [None, 8, 24])
+def test_level2_inverse_march_matches_tile_program_and_oracle(shape, bn, qn, band, monkeypatch):
+    """Level 2 of the inverse alone as a march (march2d_ipair.hpp: k_inv2m, the level-2 wavefront of the inverse pair storing its
+    groups of Z1 rows) for the 14- / 18-tap q-shift sets whose level 1 no pair takes: against the tile program (DTCWT_HIP_MARCH_INV2=0)
+    and the oracle, with a gain mask."""
+    rs = np.random.RandomState(35)
+    X = rs.standard_normal(shape).astype(np.float32)
+    nl = 2 if min(shape) < 160 else 3
+    gm = rs.uniform(0.3, 1.4, size=(6, nl)) * (rs.uniform(size=(6, nl)) > 0.2)
+    tm = Transform2d(bn, qn, program='march')
+    if band:
+        monkeypatch.setenv('DTCWT_HIP_MARCH_BAND', str(band))
+    p = tm.forward(X, nlevels=nl)
+    pyr = Pyramid(np.array(p.lowpass), tuple(np.array(y) for y in p.highpasses))
+    z1 = np.array(tm.inverse(pyr, gm))
+    monkeypatch.setenv('DTCWT_HIP_MARCH_INV2', '0')
+    z0 = np.array(tm.inverse(pyr, gm))
+    assert not np.array_equal(z0, z1)            # two programs: they agree to rounding, not to the bit
+    assert_close(z1, z0, 1e-6, 'level-2 inverse march vs tile program')
+    to = o.Transform2d(biort(bn), qshift(qn))
+    assert_close(z1, to.inverse(to.forward(as_f64(X), nlevels=nl), gm), INV_TOL, 'inverse')
+
+
 def test_forward_pair_on_a_batch():
     rs = np.random.RandomState(26)
     X = rs.standard_normal((5, 128, 424)).astype(np.float32)
