@@ -53,6 +53,10 @@ int dtcwt_march_inv21p(const float *Z2, const float *Yh1, const float *Yh0, floa
                        const std::vector<double> &g0o, const std::vector<double> &g1o, const float *l_a, const float *l_b,
                        const float *h_a, const float *h_b, int m, const float *gain1, const float *gain2, const DtMarchHint &hint, hipStream_t s);
 
+// level 2 of the forward alone as a march (march2d_pair.hpp: k_fwd2m)
+bool dtcwt_march_fwd2_ok(int batch, int rows, int cols, const std::vector<double> &h0a, bool lo_a_first, bool hi_a_first, const DtMarchHint &hint);
+int dtcwt_march_fwd2(const float *LoLo1, float *Yh1, float *LoLo2, int B, int R, int C, const float *l_a, const float *l_b,
+                     const float *h_a, const float *h_b, int m, const DtMarchHint &hint, hipStream_t s);
 // level 2 of the inverse alone as a march (march2d_ipair.hpp: k_inv2m)
 bool dtcwt_march_inv2_ok(int batch, int rows, int cols, const std::vector<double> &g0a, bool lo_pos, bool hi_pos, const DtMarchHint &hint);
 int dtcwt_march_inv2(const float *Z2, const float *Yh1, float *Z1, int B, int R, int C, const float *l_a, const float *l_b,
@@ -231,6 +235,12 @@ static bool plan_march_inv21p(const dtcwt_hip_plan2d *p) {
     return plan_march_geometry(p) && p->bp1[1].empty() && p->bp2[2].empty() &&
            dtcwt_march_inv21p_ok(p->batch, p->lv[0].LR, p->lv[0].LC, p->biort[1], p->biort[3], p->qshift[2],
                                  dotd(p->qshift[3], p->qshift[2]) > 0, dotd(p->qshift[7], p->qshift[6]) > 0, p->hint());
+}
+// level 2 of the forward alone as a march, where neither the one-wavefront launch nor the pair takes levels 1 + 2
+static bool plan_march_fwd2(const dtcwt_hip_plan2d *p) {
+    return p->nlevels >= 2 && plan_march_geometry(p) && p->bp2[0].empty() && !plan_march_fwd12(p) && !plan_march_fwd12p(p) &&
+           dtcwt_march_fwd2_ok(p->batch, p->lv[0].LR, p->lv[0].LC, p->qshift[0], dotd(p->qshift[1], p->qshift[0]) > 0,
+                               dotd(p->qshift[5], p->qshift[4]) > 0, p->hint());
 }
 // level 2 of the inverse alone as a march, where neither the one-wavefront launch nor the pair takes levels 2 + 1
 static bool plan_march_inv2(const dtcwt_hip_plan2d *p) {
@@ -483,6 +493,15 @@ int dtcwt_hip_plan2d_forward(dtcwt_hip_plan2d *p, const float *X, float *Yl, voi
             if (bp) {
                 put_taps(q.b_a, p->bp2[1]); put_taps(q.b_b, p->bp2[0]);
                 q.bp_a_first = dotd(p->bp2[1], p->bp2[0]) > 0;
+            }
+            if (l == 1 && plan_march_fwd2(p)) {          // level 2 alone as a march (k_fwd2m): the level-1 lowpass -> Yh[1], LoLo2
+                rc = dtcwt_march_fwd2(in, (float *)Yh[1], lo, p->batch, p->lv[0].LR, p->lv[0].LC, q.l_a, q.l_b, q.h_a, q.h_b,
+                                      (int)p->qshift[0].size(), p->hint(), s);
+                if (rc) return dtcwt_set_error(rc, "no marching level-2 forward kernel");
+                DT_CHECK_HIP(hipGetLastError());
+                if (p->profiling) DT_CHECK_HIP(hipEventRecord(p->ev[2 * l + 1], s));
+                in = lo;
+                continue;
             }
             // default tile 16 x ~56: use the small shape when that gives too few workgroups
             bool small = p->small_tiles >= 0 ? p->small_tiles != 0

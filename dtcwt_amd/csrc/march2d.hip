@@ -481,3 +481,43 @@ int dtcwt_march_inv2(const float *Z2, const float *Yh1, float *Z1, int B, int R,
     if (m == 18) return launch_inv2m<18, 2>(p, hint, s);
     return -3;
 }
+
+// ---- level 2 of the forward alone as a march (march2d_pair.hpp: k_fwd2m) ------------------------------------------------------
+// The forward counterpart of k_inv2m: LoLo1 -> Yh[1], LoLo2 for the 14- / 18-tap q-shift sets where no pair takes levels 1 + 2.
+// DTCWT_HIP_MARCH_FWD2=0: never.
+bool dtcwt_march_fwd2_ok(int batch, int rows, int cols, const std::vector<double> &h0a, bool lo_a_first, bool hi_a_first, const DtMarchHint &hint) {
+    if (const char *e = getenv("DTCWT_HIP_MARCH_FWD2")) { if (e[0] == '0') return false; }
+    const int m = (int)h0a.size();
+    if (!(m == 14 || m == 18) || !lo_a_first || hi_a_first) return false;
+    const int VL = m == 14 ? dtm::Fwd2m<14>::VL : dtm::Fwd2m<18>::VL;
+    if (!march_sizes_ok(batch, rows, cols, VL)) return false;
+    const int mm = march_mode(hint);
+    if (mm >= 0) return mm > 0;
+    // like the pairs: wherever other work shares the device from the usual crossover, alone from 60 M useful pixels (one 4096^2 image at
+    // a time ran 2.6 % slower per step with it, four in flight 3.5 % faster, the batches 2-3 % faster: profiles/r05/fwd2m.txt)
+    const int nstrip = cdiv(cols, 4 * VL);
+    const double useful = (double)batch * rows * cols * ((double)cols / (nstrip * 4.0 * VL));
+    const bool shared = hint.nparts > 1 || hint.in_flight > 1;
+    return useful >= (shared ? kCrossover[hint.nparts > 1 ? 2 : 1].useful_pixels : 6.0e7);
+}
+
+template <int M, int WPS>
+static int launch_fwd2m(dtm::Fwd12pParams &p, const DtMarchHint &hint, hipStream_t s) {
+    using G = dtm::Fwd2m<M>;
+    const int nstrip = cdiv(p.C, 4 * G::VL);
+    const int cus = hint.cus * WPS / 2 > 0 ? hint.cus * WPS / 2 : 1;
+    const unsigned jobs = dtm::dtm_set_jobs(p.jb, p.B, p.R, nstrip, pick_band_rows(p.B * hint.in_flight, p.R, nstrip, M, cus));
+    dtm::k_fwd2m<M, WPS><<<jobs, 64, 0, s>>>(p);
+    return 0;
+}
+
+// LoLo1 [B][R][C] -> Yh1 [B][R/4][C/4][12], LoLo2 [B][R/2][C/2]
+int dtcwt_march_fwd2(const float *LoLo1, float *Yh1, float *LoLo2, int B, int R, int C, const float *l_a, const float *l_b,
+                     const float *h_a, const float *h_b, int m, const DtMarchHint &hint, hipStream_t s) {
+    dtm::Fwd12pParams p{};
+    p.X = LoLo1; p.Yh0 = nullptr; p.Yh1 = Yh1; p.LoLo2 = LoLo2; p.B = B; p.R = R; p.C = C;
+    dtm::dtm_pack_qshift(p, m, l_a, l_b, h_a, h_b);
+    if (m == 14) return launch_fwd2m<14, 2>(p, hint, s);
+    if (m == 18) return launch_fwd2m<18, 2>(p, hint, s);
+    return -3;
+}

@@ -75,6 +75,108 @@ __device__ __forceinline__ float sym_lo(const float *xc, const pk2 *hp) {
 }
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// The level-2 wavefront: the second half of k_fwd12m for any M with (M - 2) % 4 == 0 on the strip whose lane 0 sits HL lanes left of
+// its first owned column.  Step t brings the LoLo1 rows rbase + 2t, + 1 as xbuf[t & 1][0 / 1][HL2 + lane] (the lane's four columns;
+// the 2M-sample windows are read across the lanes from there); stepsync(t, k) returns when they are in place.
+template <int M, int HL, class Sync>
+__device__ __forceinline__ void fwd2_wave(const Fwd12pParams &p, int lane, int strip, int64_t img, int nv, int rb, int nrow, int rbase, int nst,
+                                          f4 (*xbuf)[2][64 + 2 * ((M - 2) / 4)], f4 *slab2, Sync &&stepsync) {
+    constexpr int HL2 = (M - 2) / 4, NP2 = M / 2, VL = 64 - 2 * HL;
+    const int C = p.C;
+    const unsigned yv = 16u * (unsigned)lane;
+    float *const Y1b = p.Yh1 + (img / 4) * 3 + (int64_t)strip * (VL * 12);
+    float *const L2b = p.LoLo2 + img / 4 + strip * (VL * 2);
+    const unsigned l2v = 8u * (unsigned)(lane - HL);
+    const float sq = 0.70710678118654752440f;
+    const pk2 *ta2 = reinterpret_cast<const pk2 *>(p.ta2), *tb2 = reinterpret_cast<const pk2 *>(p.tb2);
+    pk2 S2[NP2][2][4];
+#pragma unroll
+    for (int a = 0; a < NP2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) S2[a][c][v] = pk2{0.f, 0.f};
+    for (int t0 = 0; t0 < nst; t0 += 2) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int t = t0 + k, r = rbase + 2 * t;
+            stepsync(t, k);                          // the rows of step t are in xbuf[k] (t0 is even: k = t & 1)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                // the 2M-sample window as M pairs of neighbouring samples: lanes l - HL2 .. l + HL2
+                pk2 w2[M];
+                const f4 *src = &xbuf[k][q][lane];
+#pragma unroll
+                for (int d = 0; d < 2 * HL2 + 1; ++d) { const f4 x = src[d]; w2[2 * d] = pk2{x.x, x.y}; w2[2 * d + 1] = pk2{x.z, x.w}; }
+                pk2 rA = {0.f, 0.f}, rB = {0.f, 0.f};          // (L_A, H_A), (L_B, H_B)
+#pragma unroll
+                for (int tt = 0; tt < M; ++tt) { rA += ta2[tt] * DTM_BX(w2[tt]); rB += tb2[tt] * DTM_BY(w2[tt]); }
+                const int phi = 2 * k + q;                 // row 4n + phi of its group (rbase % 4 == 0, t0 even)
+#pragma unroll
+                for (int a = 0; a < NP2; ++a) {
+                    const int tt = (phi + 8 * HL2 - 4 * a) >> 1;
+                    const pk2 cc = (phi & 1) ? tb2[tt] : ta2[tt];
+                    if (phi < 2) {      // the first rows to touch the A / B halves after a pair left: slot a continues slot a + 1
+                        if (a + 1 < NP2) {
+                            S2[a][phi & 1][0] = cc * DTM_BX(rA) + S2[a + 1][phi & 1][0]; S2[a][phi & 1][1] = cc * DTM_BX(rB) + S2[a + 1][phi & 1][1];
+                            S2[a][phi & 1][2] = cc * DTM_BY(rA) + S2[a + 1][phi & 1][2]; S2[a][phi & 1][3] = cc * DTM_BY(rB) + S2[a + 1][phi & 1][3];
+                        } else {
+                            S2[a][phi & 1][0] = cc * DTM_BX(rA); S2[a][phi & 1][1] = cc * DTM_BX(rB);
+                            S2[a][phi & 1][2] = cc * DTM_BY(rA); S2[a][phi & 1][3] = cc * DTM_BY(rB);
+                        }
+                    } else {
+                        S2[a][phi & 1][0] += cc * DTM_BX(rA); S2[a][phi & 1][1] += cc * DTM_BX(rB);
+                        S2[a][phi & 1][2] += cc * DTM_BY(rA); S2[a][phi & 1][3] += cc * DTM_BY(rB);
+                    }
+                }
+            }
+            if (k & 1) {
+                // rows 4n + 2, 4n + 3 are in: pair i = n - HL2 is complete (sum(ha hb) > 0 for the lowpass pair, < 0 for the
+                // highpass pair: every shipped set; the launcher checks)
+                const int i2 = (r - 2) / 4 - HL2;
+                const bool pair_ok = 4 * i2 >= rb && 4 * i2 < rb + nrow;        // uniform; otherwise the stores are dropped
+                constexpr bool la = true, ha = false;
+                float pl[2][4], ph[2][4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    pl[0][v] = la ? S2[0][0][v].x : S2[0][1][v].x; pl[1][v] = la ? S2[0][1][v].x : S2[0][0][v].x;
+                    ph[0][v] = ha ? S2[0][0][v].y : S2[0][1][v].y; ph[1][v] = ha ? S2[0][1][v].y : S2[0][0][v].y;
+                }
+                float llo[2][2], lh2[2][2], hl2[2][2], hh2[2][2];
+#pragma unroll
+                for (int er = 0; er < 2; ++er) {
+                    llo[er][0] = la ? pl[er][0] : pl[er][1]; llo[er][1] = la ? pl[er][1] : pl[er][0];
+                    lh2[er][0] = ha ? pl[er][2] : pl[er][3]; lh2[er][1] = ha ? pl[er][3] : pl[er][2];
+                    hl2[er][0] = la ? ph[er][0] : ph[er][1]; hl2[er][1] = la ? ph[er][1] : ph[er][0];
+                    hh2[er][0] = ha ? ph[er][2] : ph[er][3]; hh2[er][1] = ha ? ph[er][3] : ph[er][2];
+                }
+                const int io = pair_ok ? i2 : 0;
+                const DtBuf bl0 = dt_buf_n(L2b + (int64_t)(2 * io) * (C / 2), pair_ok ? 8u * nv : 0u);
+                const DtBuf bl1 = dt_buf_n(L2b + (int64_t)(2 * io + 1) * (C / 2), pair_ok ? 8u * nv : 0u);
+                dt2d::dt_buf_st2<false>(bl0, l2v, 0u, dt2d::f2{llo[0][0], llo[0][1]});
+                dt2d::dt_buf_st2<false>(bl1, l2v, 0u, dt2d::f2{llo[1][0], llo[1][1]});
+                const Zq a = q2c_s(hl2[0][0], hl2[0][1], hl2[1][0], hl2[1][1]);
+                const Zq bq = q2c_s(hh2[0][0], hh2[0][1], hh2[1][0], hh2[1][1]);
+                const Zq c = q2c_s(lh2[0][0], lh2[0][1], lh2[1][0], lh2[1][1]);
+                f4 *o = slab2 + lane * 3;
+                o[0] = f4{sq * a.z0r, sq * a.z0i, sq * bq.z0r, sq * bq.z0i};
+                o[1] = f4{sq * c.z0r, sq * c.z0i, sq * c.z1r, sq * c.z1i};
+                o[2] = f4{sq * bq.z1r, sq * bq.z1i, sq * a.z1r, sq * a.z1i};
+                DT_WAVE_LDS_SYNC();
+                const DtBuf by1 = dt_buf_n(Y1b + (int64_t)io * (C / 4) * 12, pair_ok ? 48u * nv : 0u);
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    const f4 v = slab2[3 * HL + lane + 64 * m];
+                    dt2d::dt_buf_st4<false>(by1, yv + 1024u * m, 0u, v);
+                }
+                DT_WAVE_LDS_SYNC();
+            }
+        }
+    }
+}
+#endif
+
 template <int M0, int M1, int M, int P>
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) k_fwd12p(const Fwd12pParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -215,97 +317,69 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
         }
     } else {
-        // ------------------------------------------------------------------ level 2 (the second half of k_fwd12m)
-        float *const Y1b = p.Yh1 + (img / 4) * 3 + (int64_t)strip * (VL * 12);
-        float *const L2b = p.LoLo2 + img / 4 + strip * (VL * 2);
-        const unsigned l2v = 8u * (unsigned)(lane - HL);
-        const float sq = 0.70710678118654752440f;
-        const pk2 *ta2 = reinterpret_cast<const pk2 *>(p.ta2), *tb2 = reinterpret_cast<const pk2 *>(p.tb2);
-        pk2 S2[NP2][2][4];
-#pragma unroll
-        for (int a = 0; a < NP2; ++a)
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) S2[a][c][v] = pk2{0.f, 0.f};
-        for (int t0 = 0; t0 < nst; t0 += 2) {
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int t = t0 + k, r = rbase + 2 * t;
-                DTM_PAIR_BARRIER();                      // the rows of step t are in xbuf[t & 1]
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    // the 2M-sample window as M pairs of neighbouring samples: lanes l - HL2 .. l + HL2
-                    pk2 w2[M];
-                    const f4 *src = &xbuf[k][q][lane];
-#pragma unroll
-                    for (int d = 0; d < 2 * HL2 + 1; ++d) { const f4 x = src[d]; w2[2 * d] = pk2{x.x, x.y}; w2[2 * d + 1] = pk2{x.z, x.w}; }
-                    pk2 rA = {0.f, 0.f}, rB = {0.f, 0.f};          // (L_A, H_A), (L_B, H_B)
-#pragma unroll
-                    for (int tt = 0; tt < M; ++tt) { rA += ta2[tt] * DTM_BX(w2[tt]); rB += tb2[tt] * DTM_BY(w2[tt]); }
-                    const int phi = 2 * k + q;                 // row 4n + phi of its group (rbase % 4 == 0, t0 even)
-#pragma unroll
-                    for (int a = 0; a < NP2; ++a) {
-                        const int tt = (phi + 8 * HL2 - 4 * a) >> 1;
-                        const pk2 cc = (phi & 1) ? tb2[tt] : ta2[tt];
-                        if (phi < 2) {      // the first rows to touch the A / B halves after a pair left: slot a continues slot a + 1
-                            if (a + 1 < NP2) {
-                                S2[a][phi & 1][0] = cc * DTM_BX(rA) + S2[a + 1][phi & 1][0]; S2[a][phi & 1][1] = cc * DTM_BX(rB) + S2[a + 1][phi & 1][1];
-                                S2[a][phi & 1][2] = cc * DTM_BY(rA) + S2[a + 1][phi & 1][2]; S2[a][phi & 1][3] = cc * DTM_BY(rB) + S2[a + 1][phi & 1][3];
-                            } else {
-                                S2[a][phi & 1][0] = cc * DTM_BX(rA); S2[a][phi & 1][1] = cc * DTM_BX(rB);
-                                S2[a][phi & 1][2] = cc * DTM_BY(rA); S2[a][phi & 1][3] = cc * DTM_BY(rB);
-                            }
-                        } else {
-                            S2[a][phi & 1][0] += cc * DTM_BX(rA); S2[a][phi & 1][1] += cc * DTM_BX(rB);
-                            S2[a][phi & 1][2] += cc * DTM_BY(rA); S2[a][phi & 1][3] += cc * DTM_BY(rB);
-                        }
-                    }
-                }
-                if (k & 1) {
-                    // rows 4n + 2, 4n + 3 are in: pair i = n - HL2 is complete (sum(ha hb) > 0 for the lowpass pair, < 0 for the
-                    // highpass pair: every shipped set; the launcher checks)
-                    const int i2 = (r - 2) / 4 - HL2;
-                    const bool pair_ok = 4 * i2 >= rb && 4 * i2 < rb + nrow;        // uniform; otherwise the stores are dropped
-                    constexpr bool la = true, ha = false;
-                    float pl[2][4], ph[2][4];
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        pl[0][v] = la ? S2[0][0][v].x : S2[0][1][v].x; pl[1][v] = la ? S2[0][1][v].x : S2[0][0][v].x;
-                        ph[0][v] = ha ? S2[0][0][v].y : S2[0][1][v].y; ph[1][v] = ha ? S2[0][1][v].y : S2[0][0][v].y;
-                    }
-                    float llo[2][2], lh2[2][2], hl2[2][2], hh2[2][2];
-#pragma unroll
-                    for (int er = 0; er < 2; ++er) {
-                        llo[er][0] = la ? pl[er][0] : pl[er][1]; llo[er][1] = la ? pl[er][1] : pl[er][0];
-                        lh2[er][0] = ha ? pl[er][2] : pl[er][3]; lh2[er][1] = ha ? pl[er][3] : pl[er][2];
-                        hl2[er][0] = la ? ph[er][0] : ph[er][1]; hl2[er][1] = la ? ph[er][1] : ph[er][0];
-                        hh2[er][0] = ha ? ph[er][2] : ph[er][3]; hh2[er][1] = ha ? ph[er][3] : ph[er][2];
-                    }
-                    const int io = pair_ok ? i2 : 0;
-                    const DtBuf bl0 = dt_buf_n(L2b + (int64_t)(2 * io) * (C / 2), pair_ok ? 8u * nv : 0u);
-                    const DtBuf bl1 = dt_buf_n(L2b + (int64_t)(2 * io + 1) * (C / 2), pair_ok ? 8u * nv : 0u);
-                    dt2d::dt_buf_st2<false>(bl0, l2v, 0u, dt2d::f2{llo[0][0], llo[0][1]});
-                    dt2d::dt_buf_st2<false>(bl1, l2v, 0u, dt2d::f2{llo[1][0], llo[1][1]});
-                    const Zq a = q2c_s(hl2[0][0], hl2[0][1], hl2[1][0], hl2[1][1]);
-                    const Zq bq = q2c_s(hh2[0][0], hh2[0][1], hh2[1][0], hh2[1][1]);
-                    const Zq c = q2c_s(lh2[0][0], lh2[0][1], lh2[1][0], lh2[1][1]);
-                    f4 *o = slab2 + lane * 3;
-                    o[0] = f4{sq * a.z0r, sq * a.z0i, sq * bq.z0r, sq * bq.z0i};
-                    o[1] = f4{sq * c.z0r, sq * c.z0i, sq * c.z1r, sq * c.z1i};
-                    o[2] = f4{sq * bq.z1r, sq * bq.z1i, sq * a.z1r, sq * a.z1i};
-                    DT_WAVE_LDS_SYNC();
-                    const DtBuf by1 = dt_buf_n(Y1b + (int64_t)io * (C / 4) * 12, pair_ok ? 48u * nv : 0u);
-#pragma unroll
-                    for (int m = 0; m < 3; ++m) {
-                        const f4 v = slab2[3 * HL + lane + 64 * m];
-                        dt2d::dt_buf_st4<false>(by1, yv + 1024u * m, 0u, v);
-                    }
-                    DT_WAVE_LDS_SYNC();
-                }
-            }
-        }
+        // ------------------------------------------------------------------ level 2: its rows arrive through the exchange
+        fwd2_wave<M, HL>(p, lane, strip, img, nv, rb, nrow, rbase, nst, xbuf, slab2, [&](int, int) { DTM_PAIR_BARRIER(); });
     }
+#endif
+}
+
+// ======================================================================================================================
+// Level 2 of the forward ALONE as a march (transform2d.py:132-160 at the second level): the level-2 wavefront of k_fwd12p fed from
+// memory instead of the exchange -- for the sets whose level 1 no pair takes (near_sym_b: k_fwd1m, march2d_l1.hpp).  LoLo1 = p.X
+// [B][R][C] -> Yh[1], LoLo2; no level-1 halo lane: HL = HL2.  The wavefront puts the two rows of a step into its own (wave-private)
+// copy of the exchange, so the windows are read across the lanes exactly as in the pair; rows are requested two steps ahead.
+// ======================================================================================================================
+template <int M>
+struct Fwd2m {
+    static constexpr int HL2 = (M - 2) / 4, HL = HL2, VL = 64 - 2 * HL, PRE = M - 2;
+    static_assert((M - 2) % 4 == 0 && M >= 10 && M <= MAXT2, "q-shift lengths the level-2 march is built for");
+};
+
+template <int M, int WPS>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, WPS))) k_fwd2m(const Fwd12pParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using G = Fwd2m<M>;
+    constexpr int HL = G::HL, HL2 = G::HL2, VL = G::VL;
+    __shared__ __attribute__((aligned(16))) f4 slab2[64 * 3 + 3 * G::HL + 8];
+    __shared__ __attribute__((aligned(16))) f4 xbuf[2][2][64 + 2 * G::HL2];
+    const int lane = threadIdx.x;
+    int strip, band, b;
+    if (!dtm_job(p.jb, blockIdx.x, strip, band, b)) return;
+    const int R = p.R, C = p.C;
+    const int nv = (C - strip * (4 * VL)) / 4 < VL ? (C - strip * (4 * VL)) / 4 : VL;     // owning lanes
+    const int64_t img = (int64_t)b * R * C;
+    const int rb = band * p.jb.band_rows;
+    const int nrow = R - rb < p.jb.band_rows ? R - rb : p.jb.band_rows;
+    const int rbase = rb - G::PRE;                     // first LoLo1 row the band's windows want (% 4 == 0)
+    const int nst = (nrow / 2 + G::PRE + 1) / 2 * 2;   // an even count: the step loop runs in pairs
+    const int c0 = strip * (4 * VL) - 4 * HL + 4 * lane;
+    const bool rev = c0 < 0 || c0 >= C;
+    int lc = c0 < 0 ? -c0 - 4 : (c0 >= C ? 2 * C - 4 - c0 : c0);
+    lc = lc < 0 ? 0 : (lc > C - 4 ? C - 4 : lc);
+    const bool edge_strip = strip == 0 || (strip + 1) * (4 * VL) + 4 * HL >= C;
+    const DtBuf bx = dt_buf2g(p.X + img);
+    const unsigned pitch = (unsigned)C * 4u;
+    const int last_row = rbase + 2 * (nrow / 2 + G::PRE) - 1;
+    auto ldrow = [&](int u) -> f4 {
+        u = u > last_row ? last_row : u;
+        u = u < 0 ? -1 - u : u;
+        u = u >= R ? 2 * R - 1 - u : u;
+        return dt2d::dt_buf_ld4(bx, (unsigned)lc * 4u, (unsigned)u * pitch);
+    };
+    f4 pre[4];          // the rows of steps t and t + 1: [2 (t & 1) + q]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pre[i] = ldrow(rbase + i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(pre[i].x), "+v"(pre[i].y), "+v"(pre[i].z), "+v"(pre[i].w) : : "memory");
+    fwd2_wave<M, HL>(p, lane, strip, img, nv, rb, nrow, rbase, nst, xbuf, slab2, [&](int t, int k) {
+        f4 e0 = pre[2 * k], e1 = pre[2 * k + 1];
+        pre[2 * k] = ldrow(rbase + 2 * t + 4);
+        pre[2 * k + 1] = ldrow(rbase + 2 * t + 5);
+        if (edge_strip) { e0 = rev ? rev4(e0) : e0; e1 = rev ? rev4(e1) : e1; }       // mirrored lanes: the mirror block in reverse
+        xbuf[k][0][HL2 + lane] = e0;
+        xbuf[k][1][HL2 + lane] = e1;
+        DT_WAVE_LDS_SYNC();
+    });
 #endif
 }
 

@@ -262,6 +262,36 @@ def test_level2_inverse_march_matches_tile_program_and_oracle(shape, bn, qn, ban
     assert_close(z1, to.inverse(to.forward(as_f64(X), nlevels=nl), gm), INV_TOL, 'inverse')
 
 
+@pytest.mark.parametrize('shape', [(64, 64), (256, 320), (96, 1036), (520, 236), (1024, 232), (200, 464), (48, 212)])
+@pytest.mark.parametrize('bn,qn', [('near_sym_b', 'qshift_b'), ('near_sym_b', 'qshift_d'), ('antonini', 'qshift_b')])
+@pytest.mark.parametrize('band', [None, 8, 24])
+def test_level2_forward_march_matches_tile_program_and_oracle(shape, bn, qn, band, monkeypatch):
+    """Level 2 of the forward alone as a march (march2d_pair.hpp: k_fwd2m, the level-2 wavefront of the forward pair fed from memory)
+    for the 14- / 18-tap q-shift sets whose level 1 no pair takes: against the tile program (DTCWT_HIP_MARCH_FWD2=0) and the oracle."""
+    rs = np.random.RandomState(37)
+    X = rs.standard_normal(shape).astype(np.float32)
+    nl = 2 if min(shape) < 160 else 3
+    tm = Transform2d(bn, qn, program='march')
+    if band:
+        monkeypatch.setenv('DTCWT_HIP_MARCH_BAND', str(band))
+    p1 = tm.forward(X, nlevels=nl)
+    yl1, ys1 = np.array(p1.lowpass), [np.array(y) for y in p1.highpasses]
+    monkeypatch.setenv('DTCWT_HIP_MARCH_FWD2', '0')
+    p0 = tm.forward(X, nlevels=nl)
+    assert np.array_equal(ys1[0], np.array(p0.highpasses[0]))            # level 1 is the same launch either way
+    assert not np.array_equal(ys1[1], np.array(p0.highpasses[1]))        # two programs: they agree to rounding, not to the bit
+    assert_close(yl1, p0.lowpass, 1e-6, 'Yl level-2 march vs tile program')
+    for a, b in zip(ys1, p0.highpasses):
+        assert_close(a, b, 1e-6, 'Yh level-2 march vs tile program')
+    want = o.Transform2d(biort(bn), qshift(qn)).forward(as_f64(X), nlevels=nl)
+    assert_close(yl1, want.lowpass, XFM_TOL, 'Yl')
+    for l, (a, b) in enumerate(zip(ys1, want.highpasses)):
+        assert_close(a, b, XFM_TOL, 'Yh[%d]' % l)
+    monkeypatch.delenv('DTCWT_HIP_MARCH_FWD2')
+    ps = tm.forward(X, nlevels=nl, include_scale=True)                   # with `scales`: the same launches, LoLo2 into its scale buffer
+    assert np.array_equal(np.array(ps.highpasses[1]), ys1[1]) and np.array_equal(np.array(ps.lowpass), yl1)
+
+
 def test_forward_pair_on_a_batch():
     rs = np.random.RandomState(26)
     X = rs.standard_normal((5, 128, 424)).astype(np.float32)
