@@ -361,9 +361,13 @@ template <int M0, int M1, int M>
 static int launch_fwd12p(dtm::Fwd12pParams &p, const DtMarchHint &hint, hipStream_t s) {
     using G = dtm::Fwd12p<M0, M1, M>;
     const int nstrip = cdiv(p.C, 4 * G::VL);
-    // a job is a PAIR of wavefronts: half as many fit the chip as single-wavefront jobs
-    const int cus = hint.cus / 2 > 0 ? hint.cus / 2 : 1;
+    // a job is a PAIR of wavefronts: half as many fit the chip as single-wavefront jobs -- three quarters with the M = 14 build for three
+    // wavefronts per SIMD (DTCWT_HIP_FPAIR_WPS=2 / 3 forces; profiles/r05/ab_fpair_occ.txt)
+    static const int wps_env = [] { const char *e = getenv("DTCWT_HIP_FPAIR_WPS"); return e ? atoi(e) : 0; }();
+    const int wps = wps_env ? wps_env : ((M == 14 && hint.nparts > 1) ? 3 : 2);
+    const int cus = hint.cus * wps / 4 > 0 ? hint.cus * wps / 4 : 1;
     const unsigned jobs = dtm::dtm_set_jobs(p.jb, p.B, p.R, nstrip, pick_band_rows(p.B * hint.in_flight, p.R, nstrip, M, cus));
+    if constexpr (M == 14) { if (wps == 3) { dtm::k_fwd12p<M0, M1, M, 2, 3><<<jobs, 128, 0, s>>>(p); return 0; } }
     dtm::k_fwd12p<M0, M1, M, 2><<<jobs, 128, 0, s>>>(p);
     return 0;
 }

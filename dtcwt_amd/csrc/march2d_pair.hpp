@@ -177,8 +177,9 @@ __device__ __forceinline__ void fwd2_wave(const Fwd12pParams &p, int lane, int s
 }
 #endif
 
-template <int M0, int M1, int M, int P>
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) k_fwd12p(const Fwd12pParams p) {
+// WPS: wavefronts per SIMD the registers are allocated for (146 VGPRs at M = 14 when asked: three fit, i.e. six pairs per CU)
+template <int M0, int M1, int M, int P, int WPS = 2>
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, WPS))) k_fwd12p(const Fwd12pParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using G = Fwd12p<M0, M1, M>;
     constexpr int HH = G::HH, H0_ = G::H0, WR = G::WR, HL = G::HL, HL2 = G::HL2, VL = G::VL, PER = G::PER, NP2 = G::NP2;

@@ -219,8 +219,8 @@ def test_headline_inverse_as_a_pair_is_bit_identical(shape, bn, monkeypatch):
     assert_close(out['1'], to.inverse(to.forward(as_f64(X), nlevels=nl), gm), INV_TOL, 'inverse')
 
 
-def test_inverse_pair_on_a_share_of_the_compute_units():
-    """On a partition context k_inv21p<7, 5, 14> is the build for three wavefronts per SIMD: the same arithmetic as on the whole
+def test_pairs_on_a_share_of_the_compute_units():
+    """On a partition context k_fwd12p<5, 7, 14> and k_inv21p<7, 5, 14> are the builds for three wavefronts per SIMD: the same arithmetic as on the whole
     device, bit for bit, and right."""
     from dtcwt_amd.hip import Context
     rs = np.random.RandomState(33)
@@ -229,7 +229,9 @@ def test_inverse_pair_on_a_share_of_the_compute_units():
     tw = Transform2d('near_sym_a', 'qshift_b', program='march')
     tq = Transform2d('near_sym_a', 'qshift_b', program='march', ctx=Context(0, partition=(1, 4)))
     assert tq.plan(1, 520, 696, 3).launches() == (True, True)
-    p = tw.forward(X, nlevels=3)
+    p, pq = tw.forward(X, nlevels=3), tq.forward(X, nlevels=3)              # k_fwd12p<5, 7, 14> for two / three wavefronts per SIMD
+    assert np.array_equal(np.array(p.lowpass), np.array(pq.lowpass))
+    assert all(np.array_equal(np.array(a), np.array(b)) for a, b in zip(p.highpasses, pq.highpasses))
     pyr = Pyramid(np.array(p.lowpass), tuple(np.array(y) for y in p.highpasses))
     zw, zq = np.array(tw.inverse(pyr, gm)), np.array(tq.inverse(pyr, gm))
     assert np.array_equal(zw, zq)
