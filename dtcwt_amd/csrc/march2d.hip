@@ -521,7 +521,7 @@ int dtcwt_march_fwd2(const float *LoLo1, float *Yh1, float *LoLo2, int B, int R,
     dtm::Fwd12pParams p{};
     p.X = LoLo1; p.Yh0 = nullptr; p.Yh1 = Yh1; p.LoLo2 = LoLo2; p.B = B; p.R = R; p.C = C;
     dtm::dtm_pack_qshift(p, m, l_a, l_b, h_a, h_b);
-    if (m == 14) return launch_fwd2m<14, 2>(p, hint, s);
+    if (m == 14) return launch_fwd2m<14, 2>(p, hint, s);        // (188 VGPRs: a build forced to three wavefronts per SIMD spills 80 bytes per lane)
     if (m == 18) return launch_fwd2m<18, 2>(p, hint, s);
     return -3;
 }
