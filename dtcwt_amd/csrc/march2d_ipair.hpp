@@ -182,7 +182,7 @@ template <int M0, int M1, int M, int WPS = 2>
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, WPS))) k_inv21p(const Inv21mParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using G = Inv21p<M0, M1, M>;
-    constexpr int H0 = G::H0, H1 = G::H1, HL = G::HL, HL2 = G::HL2, VL = G::VL, NG = G::NG, NPX = G::NPX;
+    constexpr int H0 = G::H0, H1 = G::H1, HL = G::HL, HL2 = G::HL2, VL = G::VL, NPX = G::NPX;
     __shared__ __attribute__((aligned(16))) f4 slab[2][64 * 6 + 6 * G::HL + 8];
     __shared__ __attribute__((aligned(16))) f4 xb[2][4][64];          // [macro-step parity][row of the group][lane]
     const int lane = threadIdx.x & 63;

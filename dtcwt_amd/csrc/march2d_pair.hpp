@@ -182,7 +182,7 @@ template <int M0, int M1, int M, int P, int WPS = 2>
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, WPS))) k_fwd12p(const Fwd12pParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using G = Fwd12p<M0, M1, M>;
-    constexpr int HH = G::HH, H0_ = G::H0, WR = G::WR, HL = G::HL, HL2 = G::HL2, VL = G::VL, PER = G::PER, NP2 = G::NP2;
+    constexpr int HH = G::HH, H0_ = G::H0, WR = G::WR, HL = G::HL, HL2 = G::HL2, VL = G::VL, PER = G::PER;
     static_assert(PER % P == 0, "prefetch depth divides the ring period");
     __shared__ __attribute__((aligned(16))) f4 slab[64 * 6 + 6 * G::HL + 8];
     __shared__ __attribute__((aligned(16))) f4 slab2[64 * 3 + 3 * G::HL + 8];
