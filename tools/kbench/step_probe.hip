@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstring>
+#include <cstdlib>
 #include <unistd.h>
 #include <cstdio>
 #include <vector>
@@ -35,8 +36,8 @@ __global__ void __launch_bounds__(256) k_mix(const v4 *__restrict__ in, v4 *__re
 }
 
 struct Set { v4 *X, *rec, *l2, *l3, *y2, *l4, *y3, *Z; };      // X 67 MB, rec 268 MB (incl. LoLo2 as its last quarter plane), ...
-static const size_t PX = (size_t)4096 * 4096;
-static const size_t NP = PX / 4;          // float4 per 67 MB plane
+static size_t PX = (size_t)4096 * 4096;     // pixels per step: x K with --scale K (K = 16: a 64 x 2048^2 batch, K = 4: 64 x 1024^2)
+static size_t NP = PX / 4;                  // float4 per plane
 
 static hipEvent_t g_ev[7];
 static bool g_mark = false;       // record an event before every kernel of the step and after the last
@@ -80,6 +81,9 @@ static double run(const std::vector<Set> &sets, const std::vector<hipStream_t> &
 int main(int argc, char **argv) {
     setvbuf(stdout, nullptr, _IOLBF, 0);
     const bool quick = argc > 1 && !strcmp(argv[1], "--json");       // one JSON line for bench.py: fewer repetitions
+    for (int i = 1; i + 1 < argc; ++i)
+        if (!strcmp(argv[i], "--scale")) { PX *= (size_t)atoi(argv[i + 1]); NP = PX / 4; }
+    if (PX != (size_t)4096 * 4096) printf("%zu pixels per step (x %zu)\n", PX, PX / ((size_t)4096 * 4096));
     const int NSET = 8;
     std::vector<Set> sets(NSET);
     for (auto &s : sets) {
@@ -114,7 +118,7 @@ int main(int argc, char **argv) {
             const double a = run(sets, sts, 20), b = run(sets, sts, 200);
             b20 = a < b20 ? a : b20; b200 = b < b200 ? b : b200; s20 += a / nrep; s200 += b / nrep;
         }
-        const double bytes = 40.0 * PX, moved = bytes + 2 * 2 * (16.8e6 + 4.2e6);
+        const double bytes = 40.0 * PX, moved = bytes + 2 * 2 * (1.0 + 0.25) * PX;
         if (quick) {
             printf("%s\"%s\": {\"ms_per_step_20\": %.5f, \"ms_per_step_200\": %.5f}%s", proto == 0 ? "{" : " ", proto == 0 ? "one_stream" : (proto == 1 ? "four_plain_streams" : "four_streams_on_quarters"),
                    s20, s200, proto == 2 ? "}\n" : ",");
