@@ -23,8 +23,9 @@ marching kernels, which run one or two wavefronts to a SIMD, four images in flig
 against 0.187 ms per step, profiles/r04/ab_streams.txt) HIP streams of independent
 images (the coarse-level kernels of one image overlap the level-1 kernels of the next); it is not
 the latency of one forward + inverse: `one_stream_ms_per_step` in the same line is the same
-rotating-buffer protocol on ONE stream.  For c2 and c5 each of the streams belongs to a context on its own share of the
-compute units (`--cu-partition`, dtcwt_hip_ctx_create_partition: -5 to -7 % per step, profiles/r04/ab_partition.txt); the
+rotating-buffer protocol on ONE stream.  For c2, c3 and c5 each of the streams belongs to a context on its own share of the
+compute units (`--cu-partition`, dtcwt_hip_ctx_create_partition: -5 to -7 % per step, profiles/r04/ab_partition.txt; c3 since the
+round-5 kernels: -2.5 to -3 %, profiles/r05/batch_streams.txt); the
 one-at-a-time phases and the roofline object's kernel times use a context on the whole device.
 
 The roofline object is for the dominant kernel (the launch with the longest median duration: the
@@ -73,7 +74,7 @@ STEP_BYTES_PER_PX = 40.0      # forward + inverse
 CONFIGS = {
     'c2': dict(rows=4096, cols=4096, batch=1, nlevels=4, seed=lambda rank: 1000 * rank, cu_partition=True,
                name='2D forward+inverse 4096x4096 f32, nlevels=4'),
-    'c3': dict(rows=1024, cols=1024, batch=64, nlevels=5, seed=lambda rank: 2 + 1000 * rank,
+    'c3': dict(rows=1024, cols=1024, batch=64, nlevels=5, seed=lambda rank: 2 + 1000 * rank, cu_partition=True,
                name='batched 2D 64x1024x1024 f32, nlevels=5'),
     'c5': dict(rows=2048, cols=2048, batch=64, nlevels=4, seed=lambda rank: 3 + 1000 * rank, cu_partition=True,
                name='batched 2D 512x2048x2048 f32 nlevels=4 sharded over 8 GPUs: 64 images per GPU'),

@@ -212,12 +212,14 @@ extern "C" {
 
 // Does a lane's shard run on a share of its device?  Measured under the bench protocol with four in flight
 // (profiles/r04/ab_partition.txt): images of 2048^2 and more gain from contexts on quarters of the compute units
-// (4096^2 -5 .. -7 %, 64 x 2048^2 -2 %), 64 x 1024^2 with five levels loses 4 % (its coarse levels are too small for 64
-// CUs); two and four shares divide the XCDs evenly, three do not.
+// (4096^2 -5 .. -7 %, 64 x 2048^2 -2 %); 64 x 1024^2 with five levels lost 4 % in round 4 and gains 2.5-3 % on QUARTERS with the
+// round-5 kernels (0.604 against 0.623 ms per step, profiles/r05/batch_streams.txt), while on halves it still loses 5 %; two and
+// four shares divide the XCDs evenly, three do not.
 static bool lane_on_a_share(int flags, int nlanes, int rows, int cols) {
     if (nlanes < 2 || (flags & DTCWT_HIP_MGPU_NO_PARTITION)) return false;
     if (flags & DTCWT_HIP_MGPU_PARTITION) return nlanes <= 16;
-    return (nlanes == 2 || nlanes == 4) && (int64_t)rows * cols >= (int64_t)2048 * 2048;
+    const int64_t px = (int64_t)rows * cols;
+    return (nlanes == 4 && px >= (int64_t)1024 * 1024) || (nlanes == 2 && px >= (int64_t)2048 * 2048);
 }
 
 int dtcwt_hip_mgpu_create(int ndev, const int *devices, int batch, int rows, int cols, int nlevels,

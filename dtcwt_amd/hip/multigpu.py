@@ -16,7 +16,7 @@ is built from the copy that arrived on its device.
 
 ``lanes=K`` keeps K batches in flight per device -- the engine of the one-process-per-GPU path: K native objects on the
 same devices (``dtcwt_hip_mgpu_create_lane``), lane k's shard contexts on share k of K of their device's compute units
-where that measured faster (two or four lanes, images of 2048 x 2048 and more), plain contexts with the concurrency hint
+where that measured faster (four lanes: images of 1024 x 1024 and more; two lanes: 2048 x 2048 and more), plain contexts with the concurrency hint
 otherwise.  ``alloc()`` hands out buffer sets lane by lane; ``forward_into`` / ``inverse_into`` run on the lane their
 buffers belong to, so consecutive batches overlap:
 

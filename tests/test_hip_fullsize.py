@@ -176,7 +176,8 @@ def test_mgpu_lanes_in_flight(lanes, partition, shape):
     rs = np.random.RandomState(lanes)
     nb = 3
     m = MultiGPUTransform2d(B, Q, devices=[0, 0], batch=nb, rows=shape[0], cols=shape[1], nlevels=3, lanes=lanes, partition=partition)
-    want_shares = lanes if (partition or (partition is None and lanes in (2, 4) and shape[0] * shape[1] >= 2048 * 2048)) else 1
+    px = shape[0] * shape[1]
+    want_shares = lanes if (partition or (partition is None and ((lanes == 4 and px >= 1024 * 1024) or (lanes == 2 and px >= 2048 * 2048)))) else 1
     assert m.shares == want_shares and m.lanes == lanes
     sets = [m.alloc() for _ in range(2 * lanes)]
     assert [s.lane for s in sets] == [k % lanes for k in range(2 * lanes)]
