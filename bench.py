@@ -653,7 +653,9 @@ def main_c4(args):
     nsets = max(nstreams, args.sets)
     if nsets % nstreams:
         nsets = (nsets // nstreams + 1) * nstreams
-    partitioned = nstreams > 1 and args.cu_partition == 'on'        # each stream on its own share of the compute units: measured slower here
+    # each stream on its own share of the compute units: slower for the short filters (forward 0.200 -> 0.211 ms), 3.5 % faster per forward +
+    # inverse for near_sym_b / qshift_b (0.626 -> 0.604, all of it the inverse; the forward alone level): profiles/r05/ab_c4_partition.txt
+    partitioned = nstreams in (2, 4) and (args.cu_partition == 'on' or (args.cu_partition == 'auto' and BIORT == 'near_sym_b'))
     ctxs = [Context(0, partition=(s, nstreams)) for s in range(nstreams)] if partitioned else [ctx] + [Context(0) for _ in range(nstreams - 1)]
     t3s = [Transform3d(BIORT, QSHIFT, ctx=c) for c in ctxs]
     rs = np.random.RandomState(4)
