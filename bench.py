@@ -43,7 +43,8 @@ them under `other_configs` (`--no-other-configs` skips them).  It then runs tool
 streaming program that moves the algorithmic bytes of a step in the same six launches, in the same three protocols:
 one stream / four plain streams / four streams on quarters of the compute units) and reports its ms per step and the
 transform's figures over it as `streaming_probe` (`--no-probe` skips it): not a roofline -- `roofline` quotes the 8 TB/s
-the contract asks for -- but what this box gives a program WITHOUT arithmetic, halo or warm-up rows in this very run.
+the contract asks for -- but what this box gives a program WITHOUT arithmetic, halo or warm-up rows in this very run.  `device_under_load` is rocm-smi's sclk and
+socket power read while the configuration keeps running (`--no-clocks` skips it): boxes of one pool differed by +-10 % on one tree.
 
 `--config c4` (BASELINE configs[3], one volume: it does not shard, N = 1 only) times the 3-D transform the same way:
 a step = Transform3d forward + inverse of one 256^3 float32 volume, nlevels=3, rotating over `--sets` volumes on
@@ -121,6 +122,7 @@ def parse_args(argv=None):
     ap.add_argument('--mgpu', action='store_true', help='N > 1 from ONE process: dtcwt_hip_mgpu_* with a host '
                     'thread per device instead of one process per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-clocks', action='store_true', help='c2 at N = 1 only: do not read rocm-smi (sclk, socket power) under the load')
     ap.add_argument('--no-probe', action='store_true', help='c2 at N = 1 only: do not run tools/kbench/step_probe (a trivial float4 '
                     'streaming program moving the algorithmic bytes of a step in the same launch structure) beside the transform')
     ap.add_argument('--no-other-configs', action='store_true', help='c2 at N = 1 only: do not append short runs of '
@@ -381,6 +383,11 @@ def main():
             step()
         drain()
         sustained_ms = (time.perf_counter() - t1) / n_sus * 1e3
+    # the device's clock and socket power UNDER this load (boxes of one pool differed by +-10 % on the same tree: the line says what
+    # the box was doing): rocm-smi read while the same steps run for ~1.5 s more; None where there is no rocm-smi
+    under_load = None
+    if not use_dist and rank == 0 and args.config == 'c2' and not args.no_clocks:
+        under_load = clocks_under_load(step, drain, dt / args.steps)
     nccl_ranks = 1
     if use_dist:
         nccl_ranks = rccl_ranks
@@ -530,7 +537,7 @@ def main():
                    'ms_per_step_is': 'throughput over %d overlapped stream(s) of independent images' % nstreams},
         'sustained_ms_per_step': None if sustained_ms is None else round(sustained_ms, 5), 'sustained_steps': n_sus if sustained_ms is not None else None,
         'one_stream_ms_per_step': round(one_stream_ms, 5), 'resident_ms_per_step': round(resident_ms, 5),
-        'roofline': roofline, 'recon_max_abs_err': err,
+        'roofline': roofline, 'recon_max_abs_err': err, 'device_under_load': under_load,
     }
 
     out['nccl_ranks'] = nccl_ranks
@@ -568,6 +575,33 @@ def main():
         print(json.dumps(out), flush=True)
         if saved_stdout is not None:
             os.dup2(2, 1)           # what the collective library still has in its stdio buffer (its banner) goes to stderr
+
+
+def clocks_under_load(step, drain, s_per_step):
+    """rocm-smi --showclocks --showpower while the bench's own steps keep the device busy (it takes a few hundred ms to answer)."""
+    import re
+    import shutil
+    exe = shutil.which('rocm-smi') or ('/opt/rocm/bin/rocm-smi' if os.path.exists('/opt/rocm/bin/rocm-smi') else None)
+    if exe is None:
+        return None
+    try:
+        pr = subprocess.Popen([exe, '--showclocks', '--showpower'], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        t_end = time.perf_counter() + 4.0
+        burst = max(8, int(0.02 / max(s_per_step, 1e-6)))
+        while pr.poll() is None and time.perf_counter() < t_end:
+            for _ in range(burst):
+                step()
+            drain()
+        if pr.poll() is None:
+            pr.kill()
+            return None
+        txt = pr.stdout.read().decode(errors='replace')
+        sclk = re.search(r'sclk clock level:[^(]*\((\d+)Mhz\)', txt)
+        pw = re.search(r'Power \(W\):\s*([0-9.]+)', txt)
+        return {'sclk_mhz': int(sclk.group(1)) if sclk else None, 'socket_power_w': float(pw.group(1)) if pw else None,
+                'is': 'rocm-smi --showclocks --showpower of GPU 0 while this configuration keeps running'}
+    except Exception as exc:
+        return {'error': repr(exc)[:200]}
 
 
 def streaming_probe(ms20, ms_sus, ms_one, partitioned, nstreams):
