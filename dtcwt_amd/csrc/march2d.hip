@@ -344,7 +344,7 @@ bool dtcwt_march_fwd12p_ok(int batch, int rows, int cols, const std::vector<doub
                            const std::vector<double> &h0a, bool lo_a_first, bool hi_a_first, const DtMarchHint &hint) {
     if (const char *e = getenv("DTCWT_HIP_MARCH_PAIR")) { if (e[0] == '0') return false; }
     const int m0 = (int)h0o.size(), m1 = (int)h1o.size(), m = (int)h0a.size();
-    if (!(m0 == 5 && m1 == 7 && (m == 14 || m == 18))) return false;
+    if (!(m0 == 5 && (m1 == 7 || m1 == 3) && (m == 14 || m == 18))) return false;          // near_sym_a, legall
     if (!symmetric(h0o) || !symmetric(h1o) || !lo_a_first || hi_a_first) return false;
     const int VL = m == 14 ? dtm::Fwd12p<5, 7, 14>::VL : dtm::Fwd12p<5, 7, 18>::VL;
     if (!march_sizes_ok(batch, rows, cols, VL)) return false;
@@ -387,8 +387,10 @@ int dtcwt_march_fwd12p(const float *X, float *Yh0, float *Yh1, float *LoLo2, int
         p.hph[2 * d] = (float)(a * rs); p.hph[2 * d + 1] = (float)(b * rs);
     }
     dtm::dtm_pack_qshift(p, m, l_a, l_b, h_a, h_b);
-    if (m0 == 5 && m == 14) return launch_fwd12p<5, 7, 14>(p, hint, s);
-    if (m0 == 5 && m == 18) return launch_fwd12p<5, 7, 18>(p, hint, s);
+    if (m0 == 5 && m1 == 7 && m == 14) return launch_fwd12p<5, 7, 14>(p, hint, s);
+    if (m0 == 5 && m1 == 7 && m == 18) return launch_fwd12p<5, 7, 18>(p, hint, s);
+    if (m0 == 5 && m1 == 3 && m == 14) return launch_fwd12p<5, 3, 14>(p, hint, s);
+    if (m0 == 5 && m1 == 3 && m == 18) return launch_fwd12p<5, 3, 18>(p, hint, s);
     return -3;
 }
 

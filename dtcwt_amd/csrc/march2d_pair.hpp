@@ -22,7 +22,8 @@ namespace dtm {
 
 template <int M0, int M1, int M>
 struct Fwd12p {
-    static constexpr int H0 = M0 / 2, H1 = M1 / 2, HH = H0 > H1 ? H0 : H1;
+    // the ring period (HH + 1 steps) must be even: legall's window (HH = 2) is run as a seven-row one whose outer taps are zero
+    static constexpr int H0 = M0 / 2, H1 = M1 / 2, HHx = H0 > H1 ? H0 : H1, HH = HHx % 2 ? HHx : HHx + 1;
     static constexpr int HL1 = (HH + 3) / 4, HL2 = (M - 2) / 4, HL = HL1 + HL2;
     static constexpr int VL = 64 - 2 * HL;
     static constexpr int WR = 2 * HH + 2, PER = WR / 2;

@@ -142,7 +142,7 @@ def test_march_with_include_scale(shape):
 
 
 @pytest.mark.parametrize('shape', SHAPES + [(48, 212), (1024, 208)])
-@pytest.mark.parametrize('bn,qn', [('near_sym_a', 'qshift_b'), ('near_sym_a', 'qshift_d')])
+@pytest.mark.parametrize('bn,qn', [('near_sym_a', 'qshift_b'), ('near_sym_a', 'qshift_d'), ('legall', 'qshift_b'), ('legall', 'qshift_d')])
 @pytest.mark.parametrize('band', [None, 8, 24])
 def test_forward_pair_matches_tile_programs_and_oracle(shape, bn, qn, band, monkeypatch):
     """Levels 1 + 2 of the forward as a marching PAIR of wavefronts (march2d_pair.hpp: k_fwd12p; near_sym_a with the 14- / 18-tap

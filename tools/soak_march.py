@@ -20,10 +20,10 @@ def rel(a, b):
 
 WAVES = [('near_sym_a', 'qshift_a'), ('near_sym_a', 'qshift_a'), ('near_sym_b', 'qshift_b'), ('near_sym_b', 'qshift_d'),
          ('antonini', 'qshift_c'), ('legall', 'qshift_06'),
-         # the marching PAIRS (march2d_pair.hpp / march2d_ipair.hpp): both directions for near_sym_a, the inverse for legall
-         ('near_sym_a', 'qshift_b'), ('near_sym_a', 'qshift_d'), ('legall', 'qshift_b')]
+         # the marching PAIRS (march2d_pair.hpp / march2d_ipair.hpp): both directions for near_sym_a and legall
+         ('near_sym_a', 'qshift_b'), ('near_sym_a', 'qshift_d'), ('legall', 'qshift_b'), ('legall', 'qshift_d')]
 if os.environ.get('SOAK_PAIRS_ONLY'):
-    WAVES = WAVES[-3:]
+    WAVES = WAVES[-4:]
 
 
 def run(X, nl, gm, batch, wave=WAVES[0]):
