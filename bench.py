@@ -122,6 +122,11 @@ def parse_args(argv=None):
     ap.add_argument('--mgpu', action='store_true', help='N > 1 from ONE process: dtcwt_hip_mgpu_* with a host '
                     'thread per device instead of one process per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-s', type=float, default=0.0, help='the CPU sample repeats its image until this many seconds have '
+                    'passed (the sub-runs of the batch configurations)')
+    ap.add_argument('--ab-protocols', type=int, default=0, help='c3 / c5 at N = 1: after the timed region, time the same steps on four '
+                    'PLAIN streams and on four streams on QUARTERS of the compute units, alternating, this many times each '
+                    '(`ab_protocols` in the line; the sub-runs of the default line pass 3)')
     ap.add_argument('--no-clocks', action='store_true', help='c2 at N = 1 only: do not read rocm-smi (sclk, socket power) under the load')
     ap.add_argument('--no-probe', action='store_true', help='c2 at N = 1 only: do not run tools/kbench/step_probe (a trivial float4 '
                     'streaming program moving the algorithmic bytes of a step in the same launch structure) beside the transform')
@@ -174,19 +179,25 @@ def upload_random(ctx, rs, B, R, C, chunk=64):
     return X
 
 
-def cpu_baseline(cfg, Xh):
-    """The NumPy oracle (port of the reference's algorithm, one core) on a bounded sample: one image."""
+def cpu_baseline(cfg, Xh, min_s=0.0):
+    """The NumPy oracle (port of the reference's algorithm, one core) on a bounded sample: one image, repeated until
+    `min_s` seconds have passed (the sub-runs of the batch configurations: their images take 0.3 - 2 s each)."""
     from dtcwt_amd.coeffs import biort, qshift
     from oracle import dtcwt_oracle as o
     R, C = Xh.shape
     to = o.Transform2d(biort(BIORT), qshift(QSHIFT))
     c0 = time.perf_counter()
-    p = to.forward(Xh, nlevels=cfg['nlevels'])
-    zc = to.inverse(p)
-    cdt = time.perf_counter() - c0
-    return {'value': round(R * C / cdt / 1e6, 3), 'unit': 'Mpixels/s', 'cores': 1, 'kind': 'port',
+    n = 0
+    while True:
+        p = to.forward(Xh, nlevels=cfg['nlevels'])
+        zc = to.inverse(p)
+        n += 1
+        cdt = time.perf_counter() - c0
+        if cdt >= min_s:
+            break
+    return {'value': round(n * R * C / cdt / 1e6, 3), 'unit': 'Mpixels/s', 'cores': 1, 'kind': 'port',
             'host_cpus': os.cpu_count(), 'numpy': np.__version__,
-            'sample': '1 image %dx%d f32 fwd+inv nlevels=%d (%.1f s)' % (R, C, cfg['nlevels'], cdt)}, zc
+            'sample': '%d image%s %dx%d f32 fwd+inv nlevels=%d (%.1f s)' % (n, '' if n == 1 else 's', R, C, cfg['nlevels'], cdt)}, zc
 
 
 def main():
@@ -386,8 +397,55 @@ def main():
     # the device's clock and socket power UNDER this load (boxes of one pool differed by +-10 % on the same tree: the line says what
     # the box was doing): rocm-smi read while the same steps run for ~1.5 s more; None where there is no rocm-smi
     under_load = None
-    if not use_dist and rank == 0 and args.config == 'c2' and not args.no_clocks:
+    if not use_dist and rank == 0 and not args.no_clocks:
         under_load = clocks_under_load(step, drain, dt / args.steps)
+    # ---- the two launch protocols in ONE run: the same steps on four plain streams and on four streams on
+    # quarters of the compute units, alternating, the same buffer sets; min and median per protocol.  Box-to-box variance (+-8 %)
+    # is larger than the difference between them, so only an A/B inside one process on one box says which the box prefers.
+    ab = None
+    if args.ab_protocols > 0 and not use_dist and nstreams == 4 and graphs is None:
+        try:
+            fam = {'quarters' if partitioned else 'plain_streams': plans}
+            if partitioned:
+                octx = [Context(ctx.device) for _ in range(nstreams)]
+            else:
+                octx = [Context(ctx.device, partition=(q, nstreams)) for q in range(nstreams)]
+            ot2 = [dtcwt_amd.hip.Transform2d(tuple(bt), tuple(qt), ctx=c) for c in octx]
+            opl = [t.plan(B, R, C, NL) for t in ot2]
+            if partitioned:
+                for pl in opl:
+                    pl.set_concurrency(nstreams)
+            fam['plain_streams' if partitioned else 'quarters'] = opl
+            n_ab = max(args.steps, 8)
+            times = {k: [] for k in fam}
+
+            def drain_all():
+                for c in octx:
+                    c.sync()
+                drain()
+            for rep in range(args.ab_protocols + 1):        # the first round of each is warm-up
+                for key in ('plain_streams', 'quarters'):
+                    pls = fam[key]
+                    for k in range(nstreams):
+                        step_on(k, pls[k % nstreams])
+                    drain_all()
+                    ta = time.perf_counter()
+                    for i in range(n_ab):
+                        k = i % nsets
+                        step_on(k, pls[k % nstreams])
+                    drain_all()
+                    if rep:
+                        times[key].append((time.perf_counter() - ta) / n_ab * 1e3)
+            ab = {'steps': n_ab, 'reps': args.ab_protocols,
+                  'plain_streams_ms_per_step': round(float(np.median(times['plain_streams'])), 5),
+                  'quarters_ms_per_step': round(float(np.median(times['quarters'])), 5),
+                  'plain_streams_min': round(min(times['plain_streams']), 5), 'quarters_min': round(min(times['quarters']), 5),
+                  'timed_region_ran_on': 'quarters' if partitioned else 'plain_streams',
+                  'is': 'the timed steps again on four plain streams / four streams on quarters of the compute units, alternating in this '
+                        'process on the same buffer sets; median (and min) ms per step of `reps` regions of `steps` steps each'}
+            del opl, ot2, octx
+        except Exception as exc:
+            ab = {'error': repr(exc)[:300]}
     nccl_ranks = 1
     if use_dist:
         nccl_ranks = rccl_ranks
@@ -480,7 +538,19 @@ def main():
                   if alone_pair else 'k_inv21m (levels 2+1 inverse, one launch)')
     cand = [('k_fwd12m (levels 1+2 forward, one launch)', kf[0], 20.0) if fwd12 else ('k_fwd1 (level-1 forward)', kf[0], 20.0),
             (inv21_name, ki[1], 20.0) if inv21 else ('k_inv1 (level-1 inverse)', ki[0], 20.0)]
-    name, ms, bpp = max(cand, key=lambda c: c[1])
+    # The dominant kernel is the one that tops the COMMITTED rocprof trace of this command (profiles/traffic.json `dominant`: the
+    # levels-2+1 inverse launch, 39-43 % of the kernel time with one and with four streams); the two candidates are within
+    # 5 % of each other, and picking by this run's event pairs named the second kernel of the trace on some boxes.  The
+    # other one is in fwd_kernel_ms / inv_kernel_ms.  No side file: the slower of the two by this run's event pairs.
+    dom = None
+    try:
+        tj0 = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
+        tj0 = tj0 if args.config == 'c2' else (tj0.get(args.config) or {})
+        dom = tj0.get('dominant')
+    except Exception:
+        pass
+    pick = [c for c in cand if dom and c[0].startswith(dom)]
+    name, ms, bpp = pick[0] if pick else max(cand, key=lambda c: c[1])
     achieved = bpp * px / (ms * 1e-3) / 1e9       # GB/s
     roofline = {'bound': 'hbm', 'kernel': name, 'achieved': round(achieved, 1), 'peak': HBM_PEAK / 1e9,
                 'unit': 'GB/s', 'frac': round(achieved * 1e9 / HBM_PEAK, 4),
@@ -489,6 +559,7 @@ def main():
                 'rocprof_kernel_ms': None, 'algorithmic_bytes_per_launch': bpp * px,
                 'fwd_kernel_ms': [round(float(x), 5) for x in kf],
                 'inv_kernel_ms': [round(float(x), 5) for x in ki],
+                'kernel_chosen_by': ('profiles/traffic.json: top kernel of the committed trace' if pick else 'slowest launch of this run'),
                 'launches': {'fwd_levels_1_2_one_launch': bool(fwd12), 'inv_levels_2_1_one_launch': bool(inv21),
                              'note': 'a shared launch is timed under the level it starts with; the other level shows an empty event pair'},
                 'sum_kernel_ms': round(float(kf.sum() + ki.sum()), 5), 'event_pair_overhead_ms': round(null_ms, 5),
@@ -539,6 +610,8 @@ def main():
         'one_stream_ms_per_step': round(one_stream_ms, 5), 'resident_ms_per_step': round(resident_ms, 5),
         'roofline': roofline, 'recon_max_abs_err': err, 'device_under_load': under_load,
     }
+    if ab is not None:
+        out['ab_protocols'] = ab
 
     out['nccl_ranks'] = nccl_ranks
     out['rank_ms_per_step'] = {'min': round(min(rank_ms), 5), 'max': round(max(rank_ms), 5)}
@@ -563,7 +636,7 @@ def main():
 
     # ---- CPU baseline: the oracle (a NumPy port of the reference's algorithm), rank 0 ----
     if rank == 0 and not args.no_cpu_baseline:
-        out['cpu_baseline'], zc = cpu_baseline(cfg, Xh0)
+        out['cpu_baseline'], zc = cpu_baseline(cfg, Xh0, args.cpu_baseline_s)
         # the timed GPU output against the CPU port on the same input
         out['gpu_vs_cpu_recon_max_abs_diff'] = float(np.abs(Zh0 - zc).max())
     elif rank == 0:
@@ -639,14 +712,18 @@ def other_configs():
     res = {}
     # c4_qbgn: BASELINE configs[3] reads "qbgn-style" -- the reference's own 3-D vectors (tests/test_againstmatlab.py:115-124) use
     # near_sym_b / qshift_b: 13 / 19-tap level-1 filters, two launches per direction around four plane volumes (fused3d_long.hpp)
-    for name, extra in (('c3', ['--steps', '40']), ('c5_share', ['--config', 'c5', '--steps', '20']), ('c4', ['--steps', '40']),
-                        ('c4_qbgn', ['--steps', '40', '--biort', 'near_sym_b', '--qshift', 'qshift_b'])):
+    # SURVEY 8(d) asks for the CPU path beside C3 / C4 / C5 as well: a bounded sample each (the oracle on one image repeated for ~3 s;
+    # one 256^3 volume, ~15 s); c4_qbgn is the same volume with the long filters and carries none (it would add ~40 s)
+    for name, extra in (('c3', ['--steps', '40', '--ab-protocols', '3', '--cpu-baseline-s', '3']),
+                        ('c5_share', ['--config', 'c5', '--steps', '20', '--ab-protocols', '3', '--cpu-baseline-s', '3']),
+                        ('c4', ['--steps', '40']),
+                        ('c4_qbgn', ['--steps', '40', '--biort', 'near_sym_b', '--qshift', 'qshift_b', '--no-cpu-baseline'])):
         cfgname = 'c5' if name == 'c5_share' else ('c4' if name == 'c4_qbgn' else name)
-        cmd = [sys.executable, os.path.abspath(__file__), '--config', cfgname, '--no-cpu-baseline', '--no-other-configs',
+        cmd = [sys.executable, os.path.abspath(__file__), '--config', cfgname, '--no-other-configs',
                '--warmup', '5', '--settle-ms', '150'] + [e for e in extra if e not in ('--config', 'c5')]
         t0 = time.perf_counter()
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=180)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
             d = json.loads(line)
             keep = {'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'], 'steps': d['steps'],
@@ -661,6 +738,9 @@ def other_configs():
                 keep['one_stream_ms_per_step'] = d.get('one_stream_ms_per_step')
                 keep['sustained_ms_per_step'] = d.get('sustained_ms_per_step')
                 keep['launches'] = d['roofline'].get('launches')
+            for k in ('cpu_baseline', 'ab_protocols', 'device_under_load'):
+                if d.get(k) is not None:
+                    keep[k] = d[k]
             keep['roofline'] = {k: d['roofline'].get(k) for k in ('kernel', 'kernel_ms', 'rocprof_kernel_ms', 'frac', 'frac_of_copy_ceiling',
                                                                   'algorithmic_bytes_per_launch', 'traffic', 'traffic_source')}
             res[name] = keep

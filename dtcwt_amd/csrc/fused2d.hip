@@ -237,8 +237,10 @@ static bool plan_march_inv21p(const dtcwt_hip_plan2d *p) {
                                  dotd(p->qshift[3], p->qshift[2]) > 0, dotd(p->qshift[7], p->qshift[6]) > 0, p->hint());
 }
 // level 2 of the forward alone as a march, where neither the one-wavefront launch nor the pair takes levels 1 + 2
-static bool plan_march_fwd2(const dtcwt_hip_plan2d *p) {
-    return p->nlevels >= 2 && plan_march_geometry(p) && p->bp2[0].empty() && !plan_march_fwd12(p) && !plan_march_fwd12p(p) &&
+// (`scales`: a forward call with include_scale, which the pair does not serve -- its LoLo1 lives in the LDS exchange only --
+// so level 2 of such a call is a march of its own where the q-shift set has one, not a tile program)
+static bool plan_march_fwd2(const dtcwt_hip_plan2d *p, bool scales = false) {
+    return p->nlevels >= 2 && plan_march_geometry(p) && p->bp2[0].empty() && !plan_march_fwd12(p) && (scales || !plan_march_fwd12p(p)) &&
            dtcwt_march_fwd2_ok(p->batch, p->lv[0].LR, p->lv[0].LC, p->qshift[0], dotd(p->qshift[1], p->qshift[0]) > 0,
                                dotd(p->qshift[5], p->qshift[4]) > 0, p->hint());
 }
@@ -494,7 +496,7 @@ int dtcwt_hip_plan2d_forward(dtcwt_hip_plan2d *p, const float *X, float *Yl, voi
                 put_taps(q.b_a, p->bp2[1]); put_taps(q.b_b, p->bp2[0]);
                 q.bp_a_first = dotd(p->bp2[1], p->bp2[0]) > 0;
             }
-            if (l == 1 && plan_march_fwd2(p)) {          // level 2 alone as a march (k_fwd2m): the level-1 lowpass -> Yh[1], LoLo2
+            if (l == 1 && plan_march_fwd2(p, Ys != nullptr)) {          // level 2 alone as a march (k_fwd2m): the level-1 lowpass -> Yh[1], LoLo2
                 rc = dtcwt_march_fwd2(in, (float *)Yh[1], lo, p->batch, p->lv[0].LR, p->lv[0].LC, q.l_a, q.l_b, q.h_a, q.h_b,
                                       (int)p->qshift[0].size(), p->hint(), s);
                 if (rc) return dtcwt_set_error(rc, "no marching level-2 forward kernel");

@@ -238,9 +238,20 @@ void put_centred(float *dst, const double *src, int m, int to) {
 // Level 1 as a marching pair of wavefronts (fused3d_march.hpp): filters of at most 7 taps (near_sym_a, legall), rows of
 // axis 2 in fours and wide enough to fill most of a strip's lanes; DTCWT_HIP_FWD3_MARCH=0 / =1 forces the tile program / the
 // march wherever it applies.
-static bool fwd3m_ok(int64_t n0, int64_t n1, int64_t n2, int m0, int m1) {
+static bool symmetric_taps(const double *h, int m) {
+    double mx = 0;
+    for (int k = 0; k < m; ++k) mx = fmax(mx, fabs(h[k]));
+    for (int k = 0; k < m / 2; ++k) if (fabs(h[k] - h[m - 1 - k]) > 1e-12 * mx) return false;
+    return true;
+}
+// The march folds the mirror pairs of a filter (t[d] * (x[H - d] + x[H + d]), pack_fwd3m keeps one half of the taps): only
+// SYMMETRIC filters, and only the length pairs of the shipped sets it is tested on (near_sym_a 5 / 7, legall 5 / 3; the
+// synthesis pairs 7 / 5 and 3 / 5 handed in as analysis filters) -- anything else keeps the tile program's full tap vector.
+static bool fwd3m_ok(int64_t n0, int64_t n1, int64_t n2, const double *h0, int m0, const double *h1, int m1) {
     const int mode = [] { const char *e = getenv("DTCWT_HIP_FWD3_MARCH"); return e ? atoi(e) : -1; }();    // read per call: the tests switch it
-    if (mode == 0 || m0 > 7 || m1 > 7 || m0 % 2 == 0 || m1 % 2 == 0) return false;
+    if (mode == 0) return false;
+    if (!((m0 == 5 && m1 == 7) || (m0 == 7 && m1 == 5) || (m0 == 5 && m1 == 3) || (m0 == 3 && m1 == 5))) return false;
+    if (!symmetric_taps(h0, m0) || !symmetric_taps(h1, m1)) return false;
     if (n2 % 4 || n0 % 2 || n1 % 2 || n0 < 8 || n1 < 8 || n2 < 16) return false;
     if (n0 * n1 * n2 * 4 >= ((int64_t)1 << 31)) return false;          // 32-bit byte offsets inside the volume
     if (mode == 1) return true;
@@ -279,12 +290,6 @@ static bool long3_ok(int64_t n0, int64_t n1, int64_t n2, int ma, int mb) {
     if (n0 % 2 || n1 % 2 || n2 % 4 || n0 < 20 || n1 < 40 || n2 < 40) return false;
     return 4 * n0 * n1 * n2 * 4 < ((int64_t)1 << 40) && n0 * n1 * n2 * 4 < ((int64_t)1 << 31);      // 32-bit byte offsets inside a plane volume
 }
-static bool symmetric_taps(const double *h, int m) {
-    double mx = 0;
-    for (int k = 0; k < m; ++k) mx = fmax(mx, fabs(h[k]));
-    for (int k = 0; k < m / 2; ++k) if (fabs(h[k] - h[m - 1 - k]) > 1e-12 * mx) return false;
-    return true;
-}
 static int launch_fwd3l_axis0(const float *P, int64_t pstride, float *LLL, float *Yh, int n0, int n1, int n2, const double *h0,
                               int m0, const double *h1, int m1, int cus, hipStream_t s) {
     dt3l::Fwd3lParams p{};
@@ -319,7 +324,7 @@ extern "C" int dtcwt_hip_fwd3_level1(dtcwt_hip_ctx *ctx, const float *X, int64_t
     if (m0 == 5 && m1 == 3) { put_centred(p.h1, h1o, 3, 7); m1 = 7; }
     if (m0 == 3 && m1 == 5) { put_centred(p.h0, h0o, 3, 7); m0 = 7; }
     DT_CHECK_HIP(hipSetDevice(ctx->device));
-    if (fwd3m_ok(n0, n1, n2, m0_in, m1_in)) {
+    if (fwd3m_ok(n0, n1, n2, h0o, m0_in, h1o, m1_in)) {
         launch_fwd3m(X, LLL, Yh, (int)n0, (int)n1, (int)n2, h0o, m0_in, h1o, m1_in, ctx->cus, ctx->stream);
         DT_CHECK_HIP(hipGetLastError());
         return 0;

@@ -360,8 +360,10 @@ int dtcwt_hip_plan2d_kernel_ms(dtcwt_hip_plan2d *plan, float *fwd_ms, float *inv
  * the level it starts with (fwd_ms[0], inv_ms[1]) and an empty event pair under the other.  Either pointer may be NULL. */
 int dtcwt_hip_plan2d_launches(const dtcwt_hip_plan2d *plan, int *fwd12, int *inv21);
 /* (ABI 5) *fwd1 / *inv1 = 1 when level 1 of the forward / inverse runs as a marching launch of its own (near_sym_b's 13 / 19
- * taps and antonini's 9 / 7 need a window the fused launch above has no registers for; dtcwt_amd/csrc/march2d_l1.hpp); the
- * levels >= 2 then stay with the tile programs.  Same choice rules and pin as dtcwt_hip_plan2d_launches. */
+ * taps and antonini's 9 / 7 need a window the fused launch above has no registers for; dtcwt_amd/csrc/march2d_l1.hpp).
+ * Level 2 then runs as a marching launch of its own as well where the q-shift set has one (k_fwd2m / k_inv2m: the 14- and
+ * 18-tap sets, march2d_pair.hpp / march2d_ipair.hpp), levels >= 3 -- and level 2 of every other set -- on the tile programs.
+ * Same choice rules and pin as dtcwt_hip_plan2d_launches. */
 int dtcwt_hip_plan2d_level1_march(const dtcwt_hip_plan2d *plan, int *fwd1, int *inv1);
 /* How many independent transforms the caller keeps in flight on this device at a time (this plan's included; other
  * plans on other streams -- the images of a video, the members of a batch handed over one by one; default 1).  The
@@ -459,8 +461,10 @@ int dtcwt_hip_mgpu_create(int ndev, const int *devices, int batch, int rows, int
 /* (ABI 5) The same object as one of `nlanes` the caller keeps in flight on the same devices, each with batches of its own
  * (the frames of a video handed to the node group by group; bench.py --mgpu rotates its steps over four): lane `lane`'s
  * shard contexts are share `lane` of `nlanes` of their device's compute units (dtcwt_hip_ctx_create_partition) where that
- * measured faster -- two or four lanes, images of 2048 x 2048 and more (profiles/r04/ab_partition.txt) -- and plain
- * contexts whose plans carry the concurrency hint `nlanes` otherwise; DTCWT_HIP_MGPU_PARTITION / _NO_PARTITION in `flags`
+ * measured faster -- FOUR lanes from images of 1024 x 1024, TWO lanes from images of 2048 x 2048 (mgpu.hip: lane_on_a_share;
+ * profiles/r04/ab_partition.txt, profiles/r05/batch_streams.txt) -- and plain contexts whose plans carry the concurrency hint
+ * `nlanes` otherwise.  Partition contexts own BLOCKING streams (see dtcwt_hip_ctx_create_partition): a caller whose framework
+ * enqueues on the NULL stream of the same device serialises with them at every size the rule above partitions; DTCWT_HIP_MGPU_PARTITION / _NO_PARTITION in `flags`
  * force one or the other.  This gives the one-process path the engine of the one-process-per-GPU path: one 4096 x 4096
  * image per device per call runs at the four-in-flight rate (0.15-0.16 ms) instead of the one-at-a-time rate (0.19 ms).
  * dtcwt_hip_mgpu_create is lane 0 of 1.  dtcwt_hip_mgpu_shares: the number of shares a lane's contexts divide their

@@ -415,3 +415,49 @@ def test_c4_whole_pyramid_vs_oracle_256cubed():
     r = t.forward(1.5 * V - 0.25 * W, nlevels=3)
     for l in range(3):
         assert_close(r.highpasses[l], 1.5 * p.highpasses[l] - 0.25 * q.highpasses[l], 1e-6, 'linearity Yh[%d]' % l)
+
+
+def test_c4_qbgn_whole_pyramid_vs_oracle_256cubed():
+    """BASELINE config[3] as it is worded ("qbgn-style"): the wavelet set and flags of the reference's own 3-D vectors
+    (tests/test_againstmatlab.py:114-124: near_sym_b / qshift_b, nlevels=3, include_scale=True) at 256^3 float32 -- the
+    lowpass, every scale, every level and every octant against the oracle evaluated in float64 on the same samples, then the
+    inverse."""
+    rs = np.random.RandomState(257)
+    V = rs.standard_normal((256, 256, 256)).astype(np.float32)
+    t = Transform3d(biort='near_sym_b', qshift='qshift_b')
+    p = t.forward(V, nlevels=3, include_scale=True)
+    want = o.Transform3d(biort('near_sym_b'), qshift('qshift_b')).forward(V.astype(np.float64), nlevels=3, include_scale=True)
+    assert_close(p.lowpass, want.lowpass, XFM_TOL, 'Yl')
+    assert len(p.scales) == 3
+    for l in range(3):
+        assert p.scales[l].shape == want.scales[l].shape
+        assert_close(p.scales[l], want.scales[l], XFM_TOL, 'Yscale[%d]' % l)
+        assert p.highpasses[l].shape == want.highpasses[l].shape
+        assert_close(p.highpasses[l], want.highpasses[l], XFM_TOL, 'Yh[%d]' % l)
+        for oct_ in range(7):
+            a, b = p.highpasses[l][..., 4 * oct_:4 * oct_ + 4], want.highpasses[l][..., 4 * oct_:4 * oct_ + 4]
+            assert_close(a, b, 2 * XFM_TOL, 'Yh[%d] octant %d' % (l, oct_))
+    assert_close(t.inverse(p), V.astype(np.float64), INV_TOL, 'reconstruction')
+
+
+@pytest.mark.parametrize('lens', [(5, 7), (7, 5), (5, 3), (7, 7), (3, 3)])
+def test_3d_level1_asymmetric_user_taps_keep_the_full_tap_vector(lens, monkeypatch):
+    """User-supplied level-1 filters that are NOT symmetric (and length pairs outside the shipped sets): the marching pair
+    k_fwd3m_l1 folds mirror pairs and must not take them (fused3d.hip: fwd3m_ok) -- whatever kernel runs, the forward
+    level 1 equals the oracle's with the same taps (the reference filters with the vector as given, lowlevel.py:47-80)."""
+    rs = np.random.RandomState(41)
+    m0, m1 = lens
+    h0o, h1o = rs.standard_normal(m0), rs.standard_normal(m1)
+    h0o /= np.abs(h0o).sum(); h1o /= np.abs(h1o).sum()
+    g0o, g1o = rs.standard_normal(m1), rs.standard_normal(m0)          # never used by the forward
+    taps = (h0o, g0o, h1o, g1o)
+    X = rs.standard_normal((16, 24, 64)).astype(np.float32)
+    monkeypatch.setenv('DTCWT_HIP_FWD3_MARCH', '1')                     # "wherever it applies": it does not apply here
+    p = Transform3d(biort=taps).forward(X, nlevels=1)
+    want = o.Transform3d(taps, qshift('qshift_a')).forward(as_f64(X), nlevels=1)
+    assert_pyramids_close(p, want, XFM_TOL, same_dtype=False)
+    # ... and the symmetric part of the same taps does take the march where the lengths are the shipped ones, with the same answer
+    hs0, hs1 = (h0o + h0o[::-1]) / 2, (h1o + h1o[::-1]) / 2
+    ps = Transform3d(biort=(hs0, g0o, hs1, g1o)).forward(X, nlevels=1)
+    ws = o.Transform3d((hs0, g0o, hs1, g1o), qshift('qshift_a')).forward(as_f64(X), nlevels=1)
+    assert_pyramids_close(ps, ws, XFM_TOL, same_dtype=False)
