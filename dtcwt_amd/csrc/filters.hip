@@ -220,6 +220,141 @@ __global__ void __launch_bounds__(256) k_colifilt_march(const T *__restrict__ X,
     }
 }
 
+// ---- LDS-row variants: the filter axis IS the contiguous one --------------------------------------------------------
+// "Along the rows" (axis_colfilter(X, h, axis=1); the reference transposes, filters down the columns and transposes back:
+// dtcwt/numpy/transform2d.py:112-130).  With one output group per thread and every tap a load of its own the three filters
+// ran at 1.2-2.6 TB/s on a 4096^2 image against 3.8-4.4 down the columns (profiles/r01/lowlevel_d.txt): every input sample
+// was requested m times.  Here a workgroup stages the segment of the row its 256 threads need into LDS once -- coalesced
+// loads, the symmetric extension applied on the way in -- and a thread takes the window of its FOUR consecutive outputs
+// (eight for colifilt) from there as 16-byte LDS reads, the register indices compile-time exactly as in the marching
+// kernels above (same tap buckets, same padding rules), and writes them as one 16-byte store (VEC: rows and crops in
+// fours, no accumulation).  blockIdx = (row, segment of the row).
+template <typename T, bool VEC>
+__device__ inline void put4(const Geo &g, T *Yb, int lo, const T (&v)[4]) {
+    const int w = lo - g.crop_lo;
+    if (VEC) {
+        if (w >= 0 && w + 3 < g.nwrite) {
+            if (sizeof(T) == 4) {
+                *reinterpret_cast<float4 *>(Yb + w) = float4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+            } else {
+                *reinterpret_cast<double2 *>(Yb + w) = double2{(double)v[0], (double)v[1]};
+                *reinterpret_cast<double2 *>(Yb + w + 2) = double2{(double)v[2], (double)v[3]};
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) put(g, Yb, (int64_t)lo + q, v[q]);
+}
+
+template <typename T, int MB, bool VEC>
+__global__ void __launch_bounds__(256) k_colfilter_rows(const T *__restrict__ X, T *__restrict__ Y, Geo g,
+                                                        Taps<T> taps, int m, int nseg) {
+    constexpr int G = 4, SEG = 256 * G, W = SEG + MB - 1;
+    __shared__ __attribute__((aligned(16))) T s[(W + 3) & ~3];
+    const int seg = blockIdx.x % nseg;
+    const int64_t row = blockIdx.x / nseg;
+    const T *Xb = X + row * g.xso;
+    T *Yb = Y + row * g.yso;
+    const int lo0 = seg * SEG + g.crop_lo;
+    const int u0 = lo0 + (m - 1) - (m / 2) - (MB - 1);
+    for (int j = threadIdx.x; j < W; j += 256) s[j] = Xb[src_index1(g, u0 + j)];
+    __syncthreads();
+    T w[G + MB - 1];
+#pragma unroll
+    for (int j = 0; j < G + MB - 1; ++j) w[j] = s[G * threadIdx.x + j];
+    T v[G];
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+        T acc = 0;
+#pragma unroll
+        for (int k = 0; k < MB; ++k) acc += taps.a[k] * w[q + MB - 1 - k];
+        v[q] = acc;
+    }
+    put4<T, VEC>(g, Yb, lo0 + G * (int)threadIdx.x, v);
+}
+
+// taps front padded to MB (k_coldfilt_march); two (A, B) pairs = four outputs per thread
+template <typename T, int MB, bool VEC>
+__global__ void __launch_bounds__(256) k_coldfilt_rows(const T *__restrict__ X, T *__restrict__ Y, Geo g,
+                                                       Taps<T> taps, int m, int a_first, int nseg) {
+    constexpr int GP = 2, SEGP = 256 * GP, W = 4 * (SEGP - 1) + 2 * MB;
+    __shared__ __attribute__((aligned(16))) T s[(W + 3) & ~3];
+    const int seg = blockIdx.x % nseg;
+    const int64_t row = blockIdx.x / nseg;
+    const T *Xb = X + row * g.xso;
+    T *Yb = Y + row * g.yso;
+    const int i0w = seg * SEGP;
+    const int u0 = 4 * i0w - m + 2;
+    for (int j = threadIdx.x; j < W; j += 256) s[j] = Xb[src_index1(g, u0 + j)];
+    __syncthreads();
+    constexpr int WN = 4 * (GP - 1) + 2 * MB;
+    T w[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) w[j] = s[4 * GP * threadIdx.x + j];
+    T v[4];
+#pragma unroll
+    for (int q = 0; q < GP; ++q) {
+        T A = 0, B = 0;
+#pragma unroll
+        for (int k = 0; k < MB / 2; ++k) {
+            A += taps.a[2 * k] * w[4 * q + 2 * MB - 2 - 4 * k];
+            A += taps.a[2 * k + 1] * w[4 * q + 2 * MB - 4 - 4 * k];
+            B += taps.b[2 * k] * w[4 * q + 2 * MB - 1 - 4 * k];
+            B += taps.b[2 * k + 1] * w[4 * q + 2 * MB - 3 - 4 * k];
+        }
+        v[2 * q] = a_first ? A : B; v[2 * q + 1] = a_first ? B : A;
+    }
+    const int i0 = i0w + GP * (int)threadIdx.x;
+    if (2 * i0 < g.nout) put4<T, VEC>(g, Yb, 2 * i0, v);
+}
+
+// taps padded to the bucket of their m / 2 parity (k_colifilt_march); two input pairs = eight outputs per thread
+template <typename T, int MB, bool VEC>
+__global__ void __launch_bounds__(256) k_colifilt_rows(const T *__restrict__ X, T *__restrict__ Y, Geo g,
+                                                       Taps<T> taps, int pos, int nseg) {
+    constexpr int M2 = MB / 2;
+    constexpr bool ODD = (M2 % 2) == 1;
+    constexpr int WN = ODD ? MB : MB + 2;
+    constexpr int ORG = ODD ? 1 - M2 : -M2;
+    constexpr int GJ = 2, SEGJ = 256 * GJ, W = WN + 2 * (SEGJ - 1);
+    __shared__ __attribute__((aligned(16))) T s[(W + 3) & ~3];
+    const int seg = blockIdx.x % nseg;
+    const int64_t row = blockIdx.x / nseg;
+    const T *Xb = X + row * g.xso;
+    T *Yb = Y + row * g.yso;
+    const int j0w = seg * SEGJ;
+    for (int j = threadIdx.x; j < W; j += 256) s[j] = Xb[src_index1(g, 2 * j0w + ORG + j)];
+    __syncthreads();
+    T w[WN + 2 * (GJ - 1)];
+#pragma unroll
+    for (int j = 0; j < WN + 2 * (GJ - 1); ++j) w[j] = s[2 * GJ * threadIdx.x + j];
+    const int j0 = j0w + GJ * (int)threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < GJ; ++q) {
+        const T *v = w + 2 * q;
+        T y[4] = {0, 0, 0, 0};
+        if (ODD) {
+#pragma unroll
+            for (int k = 0; k < M2; ++k) {
+                const T hi = v[MB - 1 - 2 * k], lo = v[MB - 2 - 2 * k];
+                const T xa = pos ? hi : lo, xb = pos ? lo : hi;
+                y[0] += taps.a[2 * k] * xb; y[1] += taps.b[2 * k] * xa;
+                y[2] += taps.a[2 * k + 1] * xb; y[3] += taps.b[2 * k + 1] * xa;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < M2; ++k) {
+                const T t0 = v[MB + 1 - 2 * k], t1 = v[MB - 2 * k], t2 = v[MB - 1 - 2 * k], t3 = v[MB - 2 - 2 * k];
+                const T xa = pos ? t0 : t1, xb = pos ? t1 : t0, xa2 = pos ? t2 : t3, xb2 = pos ? t3 : t2;
+                y[0] += taps.a[2 * k + 1] * xb2; y[1] += taps.b[2 * k + 1] * xa2;
+                y[2] += taps.a[2 * k] * xb; y[3] += taps.b[2 * k] * xa;
+            }
+        }
+        if (4 * (j0 + q) < g.nout) put4<T, VEC>(g, Yb, 4 * (j0 + q), y);
+    }
+}
+
 // Two undecimated filters of the same length parity applied to the same input in one pass
 // (the 3-D level loops always filter a volume with the lo AND the hi filter,
 // dtcwt/numpy/transform3d.py:256-273): every input sample is loaded once and feeds both.
@@ -549,6 +684,15 @@ bool unrolled_ok(const Geo &g, int reach) {
     return !(g.inner_fast && g.inner > 1) && g.idx32 && g.L >= reach && g.nwrite >= 16;
 }
 
+// The LDS-row kernels: the filter axis is the contiguous one on both sides (so inner == 1: rows = outer), one-bounce reflection,
+// a row long enough to be worth a workgroup; `vec`: 16-byte stores (rows, crop and base address in fours / 16 bytes)
+bool rows_ok(const Geo &g, int reach) {
+    return g.inner == 1 && g.xsn == 1 && g.ysn == 1 && g.idx32 && g.L >= reach && g.nwrite >= 256 && g.outer < ((int64_t)1 << 22);
+}
+bool rows_vec(const Geo &g, const void *Y, size_t esz) {
+    return !g.accumulate && g.crop_lo % 4 == 0 && g.yso % 4 == 0 && ((uintptr_t)Y % 16) == 0 && (esz == 4 || esz == 8);
+}
+
 // taps FRONT padded to mb entries (k_coldfilt_march)
 template <typename T>
 void load_taps_front(Taps<T> &t, const double *a, const double *b, int m, int mb) {
@@ -621,6 +765,21 @@ int dtcwt_hip_colfilter(dtcwt_hip_ctx *ctx, int dtype, const void *X, void *Y,
         DT_LAUNCH_CHECK();
         return 0;
     }
+    if (rows_ok(g, 20) && m <= 20) {
+        const int nseg = (int)((g.nwrite + 1023) / 1024);
+        const unsigned nb = (unsigned)(nseg * g.outer);
+#define DT_ROWS(T_, MB_)                                                                                                        \
+        do {                                                                                                                    \
+            Taps<T_> t; load_taps(t, h, nullptr, m);                                                                            \
+            if (rows_vec(g, Y, sizeof(T_))) k_colfilter_rows<T_, MB_, true><<<nb, 256, 0, ctx->stream>>>((const T_ *)X, (T_ *)Y, g, t, m, nseg); \
+            else k_colfilter_rows<T_, MB_, false><<<nb, 256, 0, ctx->stream>>>((const T_ *)X, (T_ *)Y, g, t, m, nseg);          \
+        } while (0)
+        if (dtype == DTCWT_HIP_F32) { if (m <= 8) DT_ROWS(float, 8); else DT_ROWS(float, 20); }
+        else { if (m <= 8) DT_ROWS(double, 8); else DT_ROWS(double, 20); }
+#undef DT_ROWS
+        DT_LAUNCH_CHECK();
+        return 0;
+    }
     if (unrolled_ok(g, 20) && m <= 20) {
         if (dtype == DTCWT_HIP_F32) {
             Taps<float> t; load_taps(t, h, nullptr, m);
@@ -675,6 +834,22 @@ int dtcwt_hip_coldfilt(dtcwt_hip_ctx *ctx, int dtype, const void *X, void *Y,
             if (mb == 10) k_coldfilt_march<double, 4, 10><<<blocks_for(tot), 256, 0, ctx->stream>>>((const double *)X, (double *)Y, g, t, m, a_first);
             else k_coldfilt_march<double, 4, 20><<<blocks_for(tot), 256, 0, ctx->stream>>>((const double *)X, (double *)Y, g, t, m, a_first);
         }
+        DT_LAUNCH_CHECK();
+        return 0;
+    }
+    if (rows_ok(g, 40) && m <= 20) {
+        const int mb = m <= 10 ? 10 : 20;
+        const int nseg = (int)((g.ngroups + 511) / 512);
+        const unsigned nb = (unsigned)(nseg * g.outer);
+#define DT_ROWS(T_, MB_)                                                                                                        \
+        do {                                                                                                                    \
+            Taps<T_> t; load_taps_front(t, ha, hb, m, mb);                                                                      \
+            if (rows_vec(g, Y, sizeof(T_))) k_coldfilt_rows<T_, MB_, true><<<nb, 256, 0, ctx->stream>>>((const T_ *)X, (T_ *)Y, g, t, m, a_first, nseg); \
+            else k_coldfilt_rows<T_, MB_, false><<<nb, 256, 0, ctx->stream>>>((const T_ *)X, (T_ *)Y, g, t, m, a_first, nseg);  \
+        } while (0)
+        if (dtype == DTCWT_HIP_F32) { if (mb == 10) DT_ROWS(float, 10); else DT_ROWS(float, 20); }
+        else { if (mb == 10) DT_ROWS(double, 10); else DT_ROWS(double, 20); }
+#undef DT_ROWS
         DT_LAUNCH_CHECK();
         return 0;
     }
@@ -734,6 +909,22 @@ int dtcwt_hip_colifilt(dtcwt_hip_ctx *ctx, int dtype, const void *X, void *Y,
         } while (0)
         if (dtype == DTCWT_HIP_F32) DT_IFILT_MARCH(float); else DT_IFILT_MARCH(double);
 #undef DT_IFILT_MARCH
+        DT_LAUNCH_CHECK();
+        return 0;
+    }
+    if (mb && rows_ok(g, mb + 4)) {
+        const int nseg = (int)((g.ngroups + 511) / 512);
+        const unsigned nb = (unsigned)(nseg * g.outer);
+#define DT_ROWS(T_, MB_)                                                                                                        \
+        do {                                                                                                                    \
+            Taps<T_> t; load_taps_centred(t, ha, hb, m, mb);                                                                    \
+            if (rows_vec(g, Y, sizeof(T_))) k_colifilt_rows<T_, MB_, true><<<nb, 256, 0, ctx->stream>>>((const T_ *)X, (T_ *)Y, g, t, pos, nseg); \
+            else k_colifilt_rows<T_, MB_, false><<<nb, 256, 0, ctx->stream>>>((const T_ *)X, (T_ *)Y, g, t, pos, nseg);         \
+        } while (0)
+#define DT_ROWS_T(T_) do { if (mb == 10) DT_ROWS(T_, 10); else if (mb == 18) DT_ROWS(T_, 18); else if (mb == 8) DT_ROWS(T_, 8); else DT_ROWS(T_, 16); } while (0)
+        if (dtype == DTCWT_HIP_F32) DT_ROWS_T(float); else DT_ROWS_T(double);
+#undef DT_ROWS_T
+#undef DT_ROWS
         DT_LAUNCH_CHECK();
         return 0;
     }

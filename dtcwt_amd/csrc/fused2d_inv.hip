@@ -112,13 +112,16 @@ int launch_inv2(Inv2Params &p, hipStream_t s) {
     // every shipped q-shift set: sum(g0a g0b) > 0 > sum(g1a g1b) (and the band-pass pair like g1) -- compile-time
     // filter phases; anything else takes the run-time flags
     const bool std_set = p.lo_pos && !p.hi_pos && (!C::BP || !p.bp_pos);
-    // The column phase in two halves (k_inv2s: six workgroups per CU) where there are workgroups to overlap -- 2048 tiles
-    // and more: a 2048^2 lowpass 35.4 -> 33.4 us -- the one-piece k_inv2 for the small launches, which are latency
+    // The column phase in two halves (k_inv2s: six workgroups per CU) where there are workgroups to overlap -- 1000 tiles
+    // and more: a 2048^2 lowpass 35.4 -> 33.4 us; round 6: level 3 of a 4096^2 image (a 1024^2 lowpass, 1216 tiles: 4.75 per CU,
+    // i.e. TWO rounds of the one-piece kernel's four per CU) in flight on a quarter 41 -> 37.8 us, and one transform at a time
+    // 0.179 -> 0.173 ms per step, the levels-2+1 launch behind it starting 5 us earlier (profiles/r06/ab_inv2s_min.txt; the
+    // threshold was 2048) -- the one-piece k_inv2 for the small launches, which are latency
     // chains (a 512^2 lowpass: 8.2 us against 8.8), for the band-pass sets (a third plane) and for filters with
     // other phases than the shipped sets.  One sweep decided it (profiles/r03/inv2_phase_stamps.txt, README of
     // profiles/r04); the environment switch of round 3 is gone, and with it the k_inv2s instantiations nothing used.
     if constexpr (!C::BP && C::TR >= 16) {
-        if (std_set && p.tilesR * p.tilesC * p.B >= 2048) {
+        if (std_set && p.tilesR * p.tilesC * p.B >= 1000) {
             k_inv2s<C, true><<<grid_for(p.tilesR * p.tilesC * p.B, p.xcd_order), DT_NT, 0, s>>>(p);
             return 0;
         }

@@ -146,3 +146,44 @@ def test_marching_kernels_all_tap_buckets(rows):
                 assert_close(coldfilt(X, ha, -hb), o.coldfilt(X, ha, -hb), tol, 'coldfilt m=%d flipped' % m)
             assert_close(colifilt(X, ha, hb), o.colifilt(X, ha, hb), tol, 'colifilt m=%d' % m)
             assert_close(colifilt(X, ha, -hb), o.colifilt(X, ha, -hb), tol, 'colifilt m=%d flipped' % m)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n', [256, 260, 1000, 1024, 1028, 2052, 4096])
+def test_row_kernels_filter_axis_contiguous(n):
+    """The LDS-row kernels (filters.hip: k_colfilter_rows / k_coldfilt_rows / k_colifilt_rows): the filter axis is the
+    contiguous one -- what the transforms' row passes and axis_*(X, ..., axis=1) run.  Every tap bucket and lengths outside
+    them, float32 and float64, rows that are whole segments of 1024 outputs, partial ones and one sample over; edge padding
+    and crops (in fours: the 16-byte-store path; otherwise the scalar one) and accumulation into an existing array."""
+    from dtcwt_amd.hip import default_context
+    from dtcwt_amd.hip import lowlevel as ll
+    ctx = default_context()
+    rs = np.random.RandomState(n)
+
+    def ref(fn, X, pad, crop, *taps):
+        Xp = np.pad(X, ((0, 0), tuple(pad)), mode='edge')
+        Y = fn(np.ascontiguousarray(Xp.T), *taps).T
+        return Y[:, crop[0]:Y.shape[1] - crop[1]]
+    for dt, tol in ((np.float32, LOW_TOL), (np.float64, F64_TOL)):
+        X = rs.standard_normal((5, n)).astype(dt)
+        d = ctx.to_device(X)
+        for m in (1, 5, 7, 8, 13, 19, 20, 21):
+            h = rs.standard_normal(m)
+            assert_close(ll.axis_colfilter(d, h, axis=1).get(), ref(o.colfilter, X, (0, 0), (0, 0), h), tol, 'colfilter rows m=%d' % m)
+        h = rs.standard_normal(7)
+        for pad, crop in (((0, 0), (4, 8)), ((1, 1), (1, 1)), ((2, 2), (0, 4)), ((0, 0), (3, 0))):
+            got = ll.axis_colfilter(d, h, axis=1, pad=pad, crop=crop).get()
+            assert_close(got, ref(o.colfilter, X, pad, crop, h), tol, 'colfilter rows pad %r crop %r' % (pad, crop))
+        acc = ctx.to_device(np.ones((5, n), dt))
+        ll.axis_colfilter(d, h, axis=1, out=acc, accumulate=True)
+        assert_close(acc.get(), 1 + ref(o.colfilter, X, (0, 0), (0, 0), h), tol, 'colfilter rows accumulate')
+        for m in (2, 6, 10, 14, 18, 20, 22):
+            ha, hb = rs.standard_normal(m), rs.standard_normal(m)
+            for sgn in (1, -1):
+                assert_close(ll.axis_coldfilt(d, ha, sgn * hb, axis=1).get(), ref(o.coldfilt, X, (0, 0), (0, 0), ha, sgn * hb), tol, 'coldfilt rows m=%d' % m)
+                assert_close(ll.axis_colifilt(d, ha, sgn * hb, axis=1).get(), ref(o.colifilt, X, (0, 0), (0, 0), ha, sgn * hb), tol, 'colifilt rows m=%d' % m)
+        q = qshift('qshift_b')
+        for pad, crop in (((2, 2), (0, 0)), ((0, 0), (2, 2)), ((0, 0), (4, 4))):
+            if (n + pad[0] + pad[1]) % 4 == 0:
+                assert_close(ll.axis_coldfilt(d, q[1], q[0], axis=1, pad=pad, crop=crop).get(), ref(o.coldfilt, X, pad, crop, q[1], q[0]), tol, 'coldfilt rows pad/crop')
+            assert_close(ll.axis_colifilt(d, q[3], q[2], axis=1, pad=pad, crop=crop).get(), ref(o.colifilt, X, pad, crop, q[3], q[2]), tol, 'colifilt rows pad/crop')
