@@ -119,6 +119,9 @@ def parse_args(argv=None):
                     'share of the compute units (dtcwt_hip_ctx_create_partition) instead of plain streams whose kernels '
                     'share every CU.  auto: where it measured faster (profiles/r04/ab_partition.txt): c2 -5 %%, c5 -2 %%; '
                     'not c3 (+4 %%) and c4 (+4 %%)')
+    ap.add_argument('--per-share', type=int, default=1, help='with a CU partition: this many streams on EVERY share of the compute units '
+                    '(--streams 8 --per-share 2 = eight images in flight, two on each quarter: while one stream sits in the gap between two '
+                    'of its launches, the other one\'s kernel has the share)')
     ap.add_argument('--mgpu', action='store_true', help='N > 1 from ONE process: dtcwt_hip_mgpu_* with a host '
                     'thread per device instead of one process per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -296,10 +299,12 @@ def main():
     # XCD): 0.152-0.157 against 0.165-0.170 ms per step on plain streams (profiles/r04/ab_cu_mask_2.txt).  `ctx` keeps the
     # whole device for the uploads and the one-at-a-time phases below.
     # (two and four shares measured faster than plain streams, three slower: 85 CUs do not divide the XCDs evenly)
-    partitioned = nstreams > 1 and (args.cu_partition == 'on' or (args.cu_partition == 'auto' and cfg.get('cu_partition', False) and nstreams in (2, 4)))
+    per_share = max(1, args.per_share)
+    nshares = nstreams // per_share if nstreams % per_share == 0 else nstreams
+    partitioned = nstreams > 1 and (args.cu_partition == 'on' or (args.cu_partition == 'auto' and cfg.get('cu_partition', False) and nshares in (2, 4)))
     if partitioned:
         try:
-            ctxs = [Context(ctx.device, partition=(s, nstreams)) for s in range(nstreams)]
+            ctxs = [Context(ctx.device, partition=(s % nshares, nshares)) for s in range(nstreams)]
         except _lib.HipError as exc:        # a runtime that refuses CU masks: plain streams, and the line says so
             print('bench.py: no CU partition (%s); plain streams' % exc, file=sys.stderr)
             partitioned = False
@@ -566,7 +571,7 @@ def main():
                 'step_frac': round(STEP_BYTES_PER_PX * px / (dt / args.steps) / HBM_PEAK, 4),
                 'step_frac_of_copy_ceiling': round(STEP_BYTES_PER_PX * px / (dt / args.steps) / HBM_COPY, 4)}
     if in_flight is not None:
-        share = 1.0 / nstreams if partitioned else None
+        share = 1.0 / nshares if partitioned else None
         kms4 = float(in_flight[0][0] if name.startswith('k_fwd') else in_flight[1][1 if inv21 else 0])
         roofline['in_flight'] = {
             'streams': nstreams, 'cu_share': share, 'kernel_ms': round(kms4, 5),
@@ -604,7 +609,7 @@ def main():
         'config': {'workload': '%s, %s/%s, %d image(s) per GPU per step' % (cfg['name'], BIORT, QSHIFT, B),
                    'sharding': 'independent images per GPU, no data-path collective',
                    'buffer_sets': nsets, 'bytes_per_set': set_bytes, 'streams': nstreams,
-                   'cu_partition': ('%d contexts, each on 1/%d of the compute units' % (nstreams, nstreams)) if partitioned else None,
+                   'cu_partition': ('%d contexts, each on 1/%d of the compute units' % (nstreams, nshares)) if partitioned else None,
                    'ms_per_step_is': 'throughput over %d overlapped stream(s) of independent images' % nstreams},
         'sustained_ms_per_step': None if sustained_ms is None else round(sustained_ms, 5), 'sustained_steps': n_sus if sustained_ms is not None else None,
         'one_stream_ms_per_step': round(one_stream_ms, 5), 'resident_ms_per_step': round(resident_ms, 5),

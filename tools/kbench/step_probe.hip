@@ -42,6 +42,7 @@ static size_t NP = PX / 4;                  // float4 per plane
 static hipEvent_t g_ev[7];
 static bool g_mark = false;       // record an event before every kernel of the step and after the last
 #define MARK(i) do { if (g_mark) CK(hipEventRecord(g_ev[i], st)); } while (0)
+static bool g_fused_tail = false;   // --fused-tail: levels 3 + 4 as ONE launch per direction (see main)
 static void step(const Set &s, hipStream_t st, bool inv_first = false) {
     const unsigned g1 = (unsigned)((NP + 255) / 256), g3 = (unsigned)((NP / 4 + 255) / 256), g4 = (unsigned)((NP / 16 + 255) / 256);
     if (inv_first) {        // the same six kernels, the inverse half of the step first (it reads what the previous step on this set wrote)
@@ -58,9 +59,9 @@ static void step(const Set &s, hipStream_t st, bool inv_first = false) {
     MARK(1);
     k_mix<1, 1, false><<<g3, 256, 0, st>>>(s.l2, s.l3, NP / 4);            // level 3: LoLo2 -> LoLo3 + Yh[2] (16.8 MB each way)
     MARK(2);
-    k_mix<1, 1, false><<<g4, 256, 0, st>>>(s.l3, s.l4, NP / 16);           // level 4
+    if (!g_fused_tail) k_mix<1, 1, false><<<g4, 256, 0, st>>>(s.l3, s.l4, NP / 16);           // level 4
     MARK(3);
-    k_mix<1, 1, false><<<g4, 256, 0, st>>>(s.l4, s.l3, NP / 16);           // inverse level 4
+    if (!g_fused_tail) k_mix<1, 1, false><<<g4, 256, 0, st>>>(s.l4, s.l3, NP / 16);           // inverse level 4
     MARK(4);
     k_mix<1, 1, false><<<g3, 256, 0, st>>>(s.l3, s.l2, NP / 4);            // inverse level 3
     MARK(5);
@@ -83,6 +84,11 @@ int main(int argc, char **argv) {
     const bool quick = argc > 1 && !strcmp(argv[1], "--json");       // one JSON line for bench.py: fewer repetitions
     for (int i = 1; i + 1 < argc; ++i)
         if (!strcmp(argv[i], "--scale")) { PX *= (size_t)atoi(argv[i + 1]); NP = PX / 4; }
+    // --fused-tail (round 6): what would ONE launch per direction for levels >= 3 buy at best?  A fused launch reads
+    // LoLo2 (16.8 MB) and writes Yh[2] + Yh[3] + LoLo4 (12.6 + 3.1 + 1.0 = 16.8 MB): the bytes of the level-3 kernel above -- the LoLo3
+    // round trip (4.2 MB out, 4.2 MB back) is what it saves, exactly what the two level-4 kernels move.  So the step WITHOUT the two level-4
+    // launches is the trivial program of a fused tail with no halo, no recomputation and no longer dependency chain: an upper bound.
+    for (int i = 1; i < argc; ++i) if (!strcmp(argv[i], "--fused-tail")) { g_fused_tail = true; printf("fused tail: four launches per step (no level-4 launches)\n"); }
     if (PX != (size_t)4096 * 4096) printf("%zu pixels per step (x %zu)\n", PX, PX / ((size_t)4096 * 4096));
     const int NSET = 8;
     std::vector<Set> sets(NSET);

@@ -2,7 +2,10 @@
 """When does each of the four image streams finish its share of a K-step timed region?  (experiment: how much of the gap
 between 20-step and 200-step runs of bench.py is drain imbalance)  4096 x 4096 f32 nlevels=4, partitioned contexts.
 
-    python tools/stream_timeline.py [steps=20] [reps=6] [partition 1|0]
+    python tools/stream_timeline.py [steps=20] [reps=6] [partition 1|0] [mode]
+mode 1: the steps are issued to the streams in REVERSE order (stream 3 first); mode 2: stream s runs on share 3 - s
+mode 3: the host issues the forwards of four consecutive steps, then their inverses
+(round 6: is the stream that finishes first the one that starts first, or the one on share 0?)
 """
 import os
 import sys
@@ -21,8 +24,9 @@ def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
     part = (int(sys.argv[3]) if len(sys.argv) > 3 else 1) != 0
+    mode = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     S, R, NL = 4, 4096, 4
-    ctxs = [Context(0, partition=(s, S)) if part else Context(0) for s in range(S)]
+    ctxs = [Context(0, partition=((S - 1 - s) if mode == 2 else s, S)) if part else Context(0) for s in range(S)]
     t2s = [dtcwt_amd.hip.Transform2d(ctx=c) for c in ctxs]
     plans = [t.plan(1, R, R, NL) for t in t2s]
     if not part:
@@ -37,6 +41,8 @@ def main():
                      [DeviceArray(c, (1,) + pl.high[l] + (6,), np.complex64) for l in range(NL)], DeviceArray(c, (1,) + pl.ext, np.float32)))
 
     def step(k):
+        if mode == 1:
+            k = (k // S) * S + (S - 1 - k % S)
         X, Yl, Yh, Z = sets[k % 8]
         pl = plans[k % S]
         pl.forward_into(X, Yl, Yh)
@@ -49,6 +55,7 @@ def main():
     ctxs[0].device_sync()
     ev0 = [c.event() for c in ctxs]
     ev1 = [c.event() for c in ctxs]
+    print('mode %d;' % mode, end=' ')
     print('%d steps over %d streams (%s); per stream: ms from its first launch to its last kernel; wall = host clock' % (steps, S, 'CU partition' if part else 'plain streams'))
     for rep in range(reps):
         for i in range(5):
@@ -57,8 +64,17 @@ def main():
         t0 = time.perf_counter()
         for c, e in zip(ctxs, ev0):
             e.record()
-        for i in range(steps):
-            step(i)
+        if mode == 3:       # the forwards of S consecutive steps first, then their inverses: every stream has work after S calls
+            for i0 in range(0, steps, S):
+                for i in range(i0, min(i0 + S, steps)):
+                    X, Yl, Yh, Z = sets[i % 8]
+                    plans[i % S].forward_into(X, Yl, Yh)
+                for i in range(i0, min(i0 + S, steps)):
+                    X, Yl, Yh, Z = sets[i % 8]
+                    plans[i % S].inverse_into(Yl, Yh, None, Z)
+        else:
+            for i in range(steps):
+                step(i)
         t_issue = time.perf_counter() - t0
         for c, e in zip(ctxs, ev1):
             e.record()
