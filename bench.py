@@ -869,7 +869,7 @@ def main_c4(args):
         'fwd_ms_per_step': round(dt_f / args.steps * 1e3, 5), 'inv_ms_per_step': round(dt_i / args.steps * 1e3, 5),
         'step_frac': round(72.0 * vox / (ms * 1e-3) / HBM_PEAK, 4),
         'roofline': {'bound': 'hbm', 'kernel': ('k_fwd3m_l1 (level-1 forward, one launch: marching pairs of wavefronts; the tile program k_fwd3_l1 where it does not apply)' if BIORT != 'near_sym_b'
-                                                 else 'k_fwd1m<13,19,PLANES> + k_fwd3l_axis0 (level-1 forward for the 13 / 19-tap filters: two launches around four plane volumes, 68 B/voxel moved)') if fused_l1 else 'level-1 forward as Transform3d runs it for this wavelet set (several launches)',
+                                                 else 'colfilter2 along axis 0 (k_g2_fwd_p1) + k_fwd3l_slices (level-1 forward for the 13 / 19-tap filters: two launches around two axis-0 volumes, 52 B/voxel moved; until round 5 k_fwd1m<PLANES> + k_fwd3l_axis0 around four plane volumes, 68 B/voxel)') if fused_l1 else 'level-1 forward as Transform3d runs it for this wavelet set (several launches)',
                      'achieved': round(36.0 * vox / (kms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                      'frac': round(36.0 * vox / (kms * 1e-3) / HBM_PEAK, 4), 'traffic': None,
                      'kernel_ms': round(kms, 5), 'kernel_ms_is': 'median raw hipEvent pair around dtcwt_hip_fwd3_level1, 20 launches',

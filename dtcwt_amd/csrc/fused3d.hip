@@ -171,6 +171,11 @@ void launch_l2_planes_best(dt2d::Fwd2Params &p, float *planes, int64_t pstride, 
             return;
         }
     }
+    if constexpr (M == 14 || M == 16 || M == 18) {
+        // round 6: the same for the longer q-shift sets -- the 2-D table's 52- / 50- / 48-column tiles cut a 128-column lowpass into
+        // 52 + 52 + 24 (three tiles, 18 % of their lanes idle); 16 x 64 tiles are two whole ones (profiles/r06/c4_qbgn.txt)
+        if ((p.LC / 2) % 64 == 0) { launch_l2_planes<dt2d::Fwd2DCfg<16, 64, 4, M>>(p, planes, pstride, s); return; }
+    }
     launch_l2_planes<dt2d::Fwd2DCfg<TR, TC, PS, M>>(p, planes, pstride, s);
 }
 
@@ -282,6 +287,8 @@ static int launch_fwd3m(const float *X, float *LLL, float *Yh, int n0, int n1, i
 // DTCWT_HIP_LONG3D=0: never (the axis-by-axis generic kernels, as before round 5).
 int dtcwt_march_fwd1_planes(const float *X, float *P, int64_t pstride, int B, int R, int C, const double *h0o, int m0,
                             const double *h1o, int m1, int cus, hipStream_t s);
+int dtcwt_march_fwd3l_slices(const float *V, int64_t vstride, float *LLL, float *Yh, int n0, int n1, int n2, const double *h0o, int m0,
+                             const double *h1o, int m1, int cus, hipStream_t s);
 int dtcwt_march_inv1_planes(const float *P, int64_t pstride, float *X, int B, int R, int C, const double *g0o, int m0,
                             const double *g1o, int m1, int cus, hipStream_t s);
 static bool long3_ok(int64_t n0, int64_t n1, int64_t n2, int ma, int mb) {
@@ -337,6 +344,28 @@ extern "C" int dtcwt_hip_fwd3_level1(dtcwt_hip_ctx *ctx, const float *X, int64_t
     }
     DT_FWD3_L1_TABLE(X_)
 #undef X_
+    // round 6: axis 0 first (the generic marching pair filter: X -> lo0, hi0), then both in-slice axes + cube2c in one launch
+    // (k_fwd3l_slices): two intermediate volumes instead of four, 52 instead of 68 B/voxel.  DTCWT_HIP_LONG3D=2: the round-5 cut
+    // (in-slice first, four plane volumes, then axis 0) for A/B and as the cross-check of the tests.
+    const bool slices_first = [] { const char *e = getenv("DTCWT_HIP_LONG3D"); return !(e && e[0] == '2'); }();
+    if (slices_first && long3_ok(n0, n1, n2, m0, m1) && m0 == 13 && symmetric_taps(h0o, m0) && symmetric_taps(h1o, m1)) {
+        const int64_t ps = n0 * n1 * n2;
+        void *vol = nullptr;
+        if (int rc = dtcwt_hip_malloc(ctx, (size_t)(2 * ps) * sizeof(float), &vol)) return rc;
+        dtcwt_hip_view v{};
+        v.outer = 1; v.n = n0; v.inner = n1 * n2;
+        v.xso = ps; v.xsn = n1 * n2; v.xsi = 1; v.yso = ps; v.ysn = n1 * n2; v.ysi = 1;
+        int rc = dtcwt_hip_colfilter2(ctx, DTCWT_HIP_F32, X, vol, (float *)vol + ps, &v, h0o, m0, h1o, m1);
+        if (!rc) {
+            rc = dtcwt_march_fwd3l_slices((const float *)vol, ps, LLL, Yh, (int)n0, (int)n1, (int)n2, h0o, m0, h1o, m1, ctx->cus, ctx->stream);
+            if (rc) rc = dtcwt_set_error(-3, "the in-slice march does not take this volume");
+        }
+        hipError_t e = hipGetLastError();
+        dtcwt_hip_free(ctx, vol);          // stream-ordered reuse (common.hpp)
+        if (rc) return rc;
+        if (e != hipSuccess) return dtcwt_set_error(-2, "3-D level launch failed: %s", hipGetErrorString(e));
+        return 0;
+    }
     if (long3_ok(n0, n1, n2, m0, m1) && symmetric_taps(h0o, m0) && symmetric_taps(h1o, m1)) {
         const int64_t ps = n0 * n1 * n2;
         void *planes = nullptr;

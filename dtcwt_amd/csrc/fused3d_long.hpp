@@ -169,4 +169,203 @@ __global__ void __launch_bounds__(256) k_fwd3l_axis0(const Fwd3lParams p) {
 #endif
 }
 
+
+// ======================================================================================================================
+// Round 6: the level cut the OTHER way -- axis 0 first, then both in-slice axes + cube2c in one launch -- so that only TWO
+// intermediate volumes reach HBM instead of four:
+//
+//   forward   colfilter2 along axis 0 (generic2d.hip: the marching pair kernel)   X -> V[lo0], V[hi0]          4 -> 8 B/voxel
+//             k_fwd3l_slices (below)                                              V -> LLL, Yh                 8 -> 32 B/voxel
+//
+// 52 B/voxel instead of 68 (the three filters commute: the same sums in another order, agreeing with the axis-2-first order
+// of transform3d.py:256-273 to float32 rounding).  k_fwd3l_slices: a workgroup = FOUR wavefronts = (axis-0 band f0 = lo | hi)
+// x (slice parity a0) of one slice PAIR, one strip of columns and one band of rows: each wavefront runs the 2-D level-1 march
+// of march2d_l1.hpp on its own slice image (register ring of 20 rows down axis 1, DPP / in-lane mirror halo along axis 2) and
+// holds, per step of two rows, its four in-slice planes (f1, f2).  cube2c needs both slices of a cell: the two wavefronts of
+// a band exchange half of their planes through LDS -- a0 = 0 takes the f1 = lo octants of both slices, a0 = 1 the f1 = hi ones
+// -- run cube2c on the lane's two cells and put the results into the record row that all four wavefronts assemble in one slab
+// (7 octants x 8 floats per cell); the row leaves as one contiguous run of 16-byte pieces.  The f0 = lo wavefronts store their
+// (lo, lo) plane as the lowpass volume.  Two LDS-only barriers per step.  cube2c's 1/2 rides on the row taps.
+// Reference: dtcwt/numpy/transform3d.py:208-289, cube2c :532-579.
+// ======================================================================================================================
+struct Fwd3sParams {
+    const float *V;       // [2][n0][n1][n2]: axis 0 lowpass / highpass of X
+    int64_t vstride;      // n0 * n1 * n2
+    float *LLL;           // [n0][n1][n2]
+    float *Yh;            // [n0/2][n1/2][n2/2][56 floats]
+    int n0, n1, n2;       // n0, n1 even, n2 % 4 == 0
+    dtm::MarchJobs jb;    // strips along axis 2, bands of rows of axis 1, "images" = slice pairs (n0 / 2)
+    float hp[2 * (dtm::MAXH1 + 1)] __attribute__((aligned(8)));          // axis 1: (h0, h1) by distance from the centre
+    // axis 2 with cube2c's 1/2: (h0, h1) / 2 for every plane of every wavefront (one table, no indexing by f0: a run-time index
+    // into the parameter block put it on the stack); the (lo, lo, lo) plane is the lowpass volume and is doubled back on its
+    // way out -- exact, the halved taps are exact halves
+    float hq[2 * (dtm::MAXH1 + 1)] __attribute__((aligned(8)));
+};
+inline void pack_fwd3s(Fwd3sParams &p, const double *h0, int m0, const double *h1, int m1) {
+    for (int d = 0; d <= dtm::MAXH1; ++d) {
+        const double a = d <= m0 / 2 ? h0[m0 / 2 - d] : 0.0, b = d <= m1 / 2 ? h1[m1 / 2 - d] : 0.0;
+        p.hp[2 * d] = (float)a; p.hp[2 * d + 1] = (float)b;
+        p.hq[2 * d] = 0.5f * (float)a; p.hq[2 * d + 1] = 0.5f * (float)b;
+    }
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// c ? a : b by components (`c ? a : b` on two f4 LVALUES is a pointer select: both operands go to the stack)
+__device__ __forceinline__ f4 sel4(bool c, const f4 &a, const f4 &b) { return f4{c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w}; }
+#endif
+
+template <int M0, int M1, int P, bool EDGE>
+__global__ void __launch_bounds__(256, 2) k_fwd3l_slices(const Fwd3sParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using G = dtm::Fwd1m<M0, M1>;
+    using dtm::pk2; using dtm::dt_buf2g; using dtm::dt_buf_n;
+    constexpr int HH = G::HH, WR = G::WR, HL = EDGE ? 0 : G::HL, VL = EDGE ? 64 : G::VL, PER = G::PER;
+    static_assert(PER % P == 0, "prefetch depth divides the ring period");
+    __shared__ __attribute__((aligned(16))) f4 slab[128 * 15 + 8];           // a row of 128 cells, 14 pieces each, 15 apart
+    __shared__ __attribute__((aligned(16))) f4 xch[4][4 * 64];               // what a wavefront hands its partner: [plane][row][lane]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int v = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int f0 = v >> 1, a0 = v & 1;
+    int strip, band, b;
+    if (!dtm::dtm_job(p.jb, blockIdx.x, strip, band, b)) return;           // the whole workgroup
+    const int R = p.n1, C = p.n2;
+
+    const int c0 = strip * (4 * VL) - 4 * HL + 4 * lane;
+    const bool rev = c0 < 0 || c0 >= C;
+    int lc = c0 < 0 ? -c0 - 4 : (c0 >= C ? 2 * C - 4 - c0 : c0);
+    lc = lc < 0 ? 0 : (lc > C - 4 ? C - 4 : lc);
+    const bool edge_strip = !EDGE && (strip == 0 || (strip + 1) * (4 * VL) + 4 * HL >= C);
+    const int nv = (C - strip * (4 * VL)) / 4 < VL ? (C - strip * (4 * VL)) / 4 : VL;     // owning lanes
+    const bool owns = lane >= HL && lane < HL + nv;
+
+    const int64_t slice = (int64_t)R * C;
+    const int64_t img = (int64_t)(2 * b + a0) * slice;
+    const DtBuf bx = dt_buf2g(p.V + f0 * p.vstride + img);
+    float *const Lb = p.LLL + img + strip * (4 * VL);
+    const int64_t rec_row = (int64_t)(C / 2) * 56;                  // floats per row of cells
+    float *const Yb = p.Yh + (int64_t)b * (R / 2) * rec_row + (int64_t)strip * (2 * VL) * 56;
+    const unsigned pitch = (unsigned)C * 4u;
+
+    const int rb = band * p.jb.band_rows;
+    const int nrow = R - rb < p.jb.band_rows ? R - rb : p.jb.band_rows;
+    const int nst = (nrow / 2 + PER - 1) / PER * PER;
+    const int last_row = rb + nrow - 1 + HH;
+
+    auto ldrow = [&](int u) -> f4 {
+        u = u > last_row ? last_row : u;
+        u = u < 0 ? -1 - u : u;
+        u = u >= R ? 2 * R - 1 - u : u;
+        return dt2d::dt_buf_ld4(bx, (unsigned)lc * 4u, (unsigned)u * pitch);
+    };
+    auto fix = [&](f4 &x) { if (edge_strip) x = rev ? dtm::rev4(x) : x; };
+
+    f4 ring[WR], pre[2 * P];
+#pragma unroll
+    for (int i = 0; i < WR; ++i) ring[i] = ldrow(rb - HH + i);
+#pragma unroll
+    for (int i = 0; i < 2 * P; ++i) pre[i] = ldrow(rb - HH + WR + i);
+#pragma unroll
+    for (int i = 0; i < WR; ++i) asm volatile("" : "+v"(ring[i].x), "+v"(ring[i].y), "+v"(ring[i].z), "+v"(ring[i].w) : : "memory");
+#pragma unroll
+    for (int i = 0; i < 2 * P; ++i) asm volatile("" : "+v"(pre[i].x), "+v"(pre[i].y), "+v"(pre[i].z), "+v"(pre[i].w) : : "memory");
+#pragma unroll
+    for (int i = 0; i < WR; ++i) fix(ring[i]);
+
+    const unsigned lv = 16u * (unsigned)(lane - HL);        // halo lanes: out of range either side
+    const pk2 *hpp = reinterpret_cast<const pk2 *>(p.hp);
+    const pk2 *hq = reinterpret_cast<const pk2 *>(p.hq);
+    // record slots (oracle _OCTANTS order, (f0, f1, f2)): (0,1,0) (1,0,0) (1,1,0) (0,0,1) (0,1,1) (1,0,1) (1,1,1).  This
+    // wavefront runs cube2c on the planes f1 = a0: (f1, lo) -> slot_a, (f1, hi) -> slot_b; (0, 0, lo) is the lowpass volume
+    const int slot_a = a0 == 0 ? 1 : (f0 ? 2 : 0), slot_b = a0 == 0 ? (f0 ? 5 : 3) : (f0 ? 6 : 4);
+    const bool has_a = a0 == 1 || f0 == 1;
+    const int cell0 = 2 * (lane - HL);
+    const int npiece = 2 * nv * 14;
+    int pslab[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { const int piece = tid + 256 * i; pslab[i] = (piece / 14) * 15 + piece % 14; }
+    f4 *const xs = xch[v], *const xr = xch[v ^ 1];
+
+    for (int t0 = 0; t0 < nst; t0 += PER) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int r = rb + 2 * (t0 + k);
+            const f4 in0 = pre[(2 * k) % (2 * P)], in1 = pre[(2 * k + 1) % (2 * P)];
+            pre[(2 * k) % (2 * P)] = ldrow(r - HH + WR + 2 * P);
+            pre[(2 * k + 1) % (2 * P)] = ldrow(r - HH + WR + 2 * P + 1);
+            const bool in_band = r < rb + nrow;             // uniform
+            pk2 wp[2][WR];
+#pragma unroll
+            for (int j = 0; j < WR; ++j) {
+                const f4 &w = ring[(2 * k + j) % WR];
+                wp[0][j] = pk2{w.x, w.y}; wp[1][j] = pk2{w.z, w.w};
+            }
+            // pl[f1][f2][q]: the lane's four columns of row r + q of in-slice plane (f1, f2), cube2c's 1/2 included
+            f4 pl[2][2][2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                pk2 W[4 + 2 * HH];
+                dtm::col_lohi2<HH>(&wp[0][q + HH], hpp, W[HH], W[HH + 1]);
+                dtm::col_lohi2<HH>(&wp[1][q + HH], hpp, W[HH + 2], W[HH + 3]);
+                dtm::halo_pairs<HH>(W);
+                if constexpr (EDGE) dtm::edge_mirror<HH>(W, lane, nv);
+                pk2 ol[4], oh[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) dtm::row_lohi_s<HH>(&W[c + HH], hq, hq, ol[c], oh[c]);
+                pl[0][0][q] = f4{ol[0].x, ol[1].x, ol[2].x, ol[3].x}; pl[0][1][q] = f4{ol[0].y, ol[1].y, ol[2].y, ol[3].y};
+                pl[1][0][q] = f4{oh[0].x, oh[1].x, oh[2].x, oh[3].x}; pl[1][1][q] = f4{oh[0].y, oh[1].y, oh[2].y, oh[3].y};
+            }
+            // ---- hand the partner the planes it packs: f1 = 1 - a0 (the exchange area is free: the partner read it before the
+            // second barrier of the previous step)
+#pragma unroll
+            for (int f2 = 0; f2 < 2; ++f2)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) xs[(2 * f2 + q) * 64 + lane] = sel4(a0 == 0, pl[1][f2][q], pl[0][f2][q]);
+            // the lowpass volume: plane (lo, lo) of the f0 = lo wavefronts, rows r, r + 1 of slice 2 b + a0 (every wavefront
+            // issues the same stores, against zero bytes where they are not its business: march2d.hpp on vmcnt)
+            {
+                const int ro = in_band ? r : rb;
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    dt2d::dt_buf_st4<false>(dt_buf_n(Lb + (int64_t)(ro + q) * C, (in_band && f0 == 0) ? 16u * nv : 0u), lv, 0u,
+                                            f4{2.f * pl[0][0][q].x, 2.f * pl[0][0][q].y, 2.f * pl[0][0][q].z, 2.f * pl[0][0][q].w});
+            }
+            DT3M_LDS_BARRIER();            // the exchange is written; the slab is free (the flush of the previous step has read it)
+            {
+                f4 mine[2][2], other[2][2];         // [f2][row] of plane f1 = a0: this slice's, the partner slice's
+#pragma unroll
+                for (int f2 = 0; f2 < 2; ++f2)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) { mine[f2][q] = sel4(a0 == 0, pl[0][f2][q], pl[1][f2][q]); other[f2][q] = xr[(2 * f2 + q) * 64 + lane]; }
+#pragma unroll
+                for (int f2 = 0; f2 < 2; ++f2) {
+                    // S[slice parity][row parity]: the four columns
+                                        const f4 s00 = sel4(a0 == 0, mine[f2][0], other[f2][0]), s01 = sel4(a0 == 0, mine[f2][1], other[f2][1]);
+                    const f4 s10 = sel4(a0 == 0, other[f2][0], mine[f2][0]), s11 = sel4(a0 == 0, other[f2][1], mine[f2][1]);
+                    const int slot = f2 == 0 ? slot_a : slot_b;
+                    f4 o0, o1;
+                    dt3m::cube2c_cell(s00.x, s01.x, s10.x, s11.x, s00.y, s01.y, s10.y, s11.y, o0, o1);
+                    if (owns && (f2 == 1 || has_a)) { slab[cell0 * 15 + 2 * slot] = o0; slab[cell0 * 15 + 2 * slot + 1] = o1; }
+                    dt3m::cube2c_cell(s00.z, s01.z, s10.z, s11.z, s00.w, s01.w, s10.w, s11.w, o0, o1);
+                    if (owns && (f2 == 1 || has_a)) { slab[(cell0 + 1) * 15 + 2 * slot] = o0; slab[(cell0 + 1) * 15 + 2 * slot + 1] = o1; }
+                }
+            }
+            DT3M_LDS_BARRIER();            // the record row is complete
+            {
+                const int ro = in_band ? r : rb;
+                const DtBuf by = dt_buf_n(Yb + (int64_t)(ro >> 1) * rec_row, in_band ? 16u * npiece : 0u);
+#pragma unroll
+                for (int i = 0; i < 7; ++i) {
+                    const f4 val = slab[pslab[i]];
+                    dt2d::dt_buf_st4<true>(by, 16u * (unsigned)(tid + 256 * i), 0u, val);
+                }
+            }
+            f4 e0 = in0, e1 = in1;
+            fix(e0); fix(e1);
+            ring[(2 * k) % WR] = e0;
+            ring[(2 * k + 1) % WR] = e1;
+        }
+    }
+#endif
+}
+
 }  // namespace dt3l

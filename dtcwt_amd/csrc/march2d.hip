@@ -12,6 +12,7 @@
 #include "march2d_l1.hpp"
 #include "march2d_pair.hpp"
 #include "march2d_ipair.hpp"
+#include "fused3d_long.hpp"
 
 namespace {
 
@@ -327,6 +328,27 @@ int dtcwt_march_inv1_planes(const float *P, int64_t pstride, float *X, int B, in
     const unsigned jobs = dtm::dtm_set_jobs(p.jb, B, R, nstrip, pick_band_rows_l1(B, R, nstrip, 4, 2.0 * G::WARM, cus));
     if (edge) dtm::k_inv1m<19, 13, true, true><<<jobs, 64, 0, s>>>(p);
     else dtm::k_inv1m<19, 13, true><<<jobs, 64, 0, s>>>(p);
+    return 0;
+}
+
+// ---- round 6: both in-slice axes + cube2c of the 3-D level 1 for long filters in one launch (fused3d_long.hpp: k_fwd3l_slices),
+// after the axis-0 pair filter: V [2][n0][n1][n2] -> LLL, Yh.  A job = four wavefronts = a slice pair x (strip, band of rows).
+// DTCWT_HIP_LONG3D_BAND: rows per band (tests).
+int dtcwt_march_fwd3l_slices(const float *V, int64_t vstride, float *LLL, float *Yh, int n0, int n1, int n2, const double *h0o, int m0,
+                             const double *h1o, int m1, int cus, hipStream_t s) {
+    using G = dtm::Fwd1m<13, 19>;
+    if (!(m0 == 13 && m1 == 19) || n0 % 2 || !l1_sizes_ok(n0 / 2, n1, n2, G::VL)) return -3;
+    dt3l::Fwd3sParams p{};
+    p.V = V; p.vstride = vstride; p.LLL = LLL; p.Yh = Yh; p.n0 = n0; p.n1 = n1; p.n2 = n2;
+    dt3l::pack_fwd3s(p, h0o, m0, h1o, m1);
+    const bool edge = planes_one_strip(n2, G::VL);
+    const int nstrip = edge ? 1 : cdiv(n2, 4 * G::VL);
+    // two workgroups of four wavefronts per CU where the band picker counts eight one-wavefront jobs
+    int band = pick_band_rows_l1(n0 / 2, n1, nstrip, 2 * G::PER, 0.5 * G::HH, cus / 4 > 0 ? cus / 4 : 1);
+    if (const char *e = getenv("DTCWT_HIP_LONG3D_BAND")) { const int v = atoi(e) / (2 * G::PER) * (2 * G::PER); if (v >= 2 * G::PER) band = v; }
+    const unsigned jobs = dtm::dtm_set_jobs(p.jb, n0 / 2, n1, nstrip, band);
+    if (edge) dt3l::k_fwd3l_slices<13, 19, 2, true><<<jobs, 256, 0, s>>>(p);
+    else dt3l::k_fwd3l_slices<13, 19, 2, false><<<jobs, 256, 0, s>>>(p);
     return 0;
 }
 

@@ -266,6 +266,14 @@ def test_3d_level1_long_filters_match_generic_and_oracle(shape, chunks, monkeypa
     if X.size <= 900000:
         want = o.Transform3d(biort('near_sym_b'), qshift('qshift_b')).forward(as_f64(X), nlevels=1)
         assert_pyramids_close(p1, want, XFM_TOL, same_dtype=False)
+    # round 6: the default forward is axis 0 first, then k_fwd3l_slices (two intermediate volumes); '2' keeps the round-5 cut
+    # (four plane volumes, k_fwd1m<PLANES> + k_fwd3l_axis0) -- both against the generic path, and the new one with short bands
+    monkeypatch.setenv('DTCWT_HIP_LONG3D', '2')
+    assert_pyramids_close(t.forward(X, nlevels=1), p0, XFM_TOL)
+    monkeypatch.setenv('DTCWT_HIP_LONG3D', '1')
+    monkeypatch.setenv('DTCWT_HIP_LONG3D_BAND', '20')
+    assert_pyramids_close(t.forward(X, nlevels=1), p0, XFM_TOL)
+    monkeypatch.delenv('DTCWT_HIP_LONG3D_BAND')
     z1 = t.inverse(p1)
     assert_close(z1, X, INV_TOL, 'PR')
     assert_close(t.inverse(p0), z0, INV_TOL, 'long vs generic inverse')

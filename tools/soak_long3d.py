@@ -39,6 +39,13 @@ def main():
                 os.environ[k] = str(int(rs.randint(lo, hi)))
             else:
                 os.environ.pop(k, None)
+        # round 6: the forward's default cut is axis 0 first + k_fwd3l_slices; a quarter of the cases keep the round-5 cut ('2'),
+        # and the band height of the new launch is random in half of the others
+        os.environ['DTCWT_HIP_LONG3D'] = '2' if rs.rand() < 0.25 else '1'
+        if rs.rand() < 0.5:
+            os.environ['DTCWT_HIP_LONG3D_BAND'] = str(int(20 * rs.randint(1, 6)))
+        else:
+            os.environ.pop('DTCWT_HIP_LONG3D_BAND', None)
         if rs.rand() < 0.3:
             os.environ['DTCWT_HIP_LONG3D_EDGE'] = str(int(rs.randint(2)))
         else:
