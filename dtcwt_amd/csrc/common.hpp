@@ -47,9 +47,30 @@ struct dtcwt_hip_ctx {
 // is a share of the device, how many independent transforms the caller keeps in flight, and the program the caller
 // pinned (dtcwt_hip_plan2d_set_program: -1 = the library chooses, 0 = tile programs, 1 = marching launches wherever
 // the geometry and the filters allow).
+// ... and the three environment switches of the marching programs, read ONCE when a plan is created (dt_march_switches(),
+// march2d.hip) -- a plan runs the same programs for its whole life, and dtcwt_hip_plan2d_describe() reports them:
+//   DTCWT_HIP_MARCH        0 = never, 1 = wherever the geometry and the filters allow, unset = where it also pays (-1)
+//   DTCWT_HIP_MARCH_BAND   rows per band of every marching launch (0 / unset: chosen per launch from the job count)
+//   DTCWT_HIP_MARCH_PARTS  bit mask of the marching programs a plan may use (default: all but the last)
+enum {
+    DT_PART_FWD12 = 1,             // k_fwd12m   levels 1 + 2 forward, one wavefront per job
+    DT_PART_INV21 = 2,             // k_inv21m   levels 2 + 1 inverse
+    DT_PART_FPAIR = 4,             // k_fwd12p   levels 1 + 2 forward as a pair of wavefronts (14- / 18-tap q-shift sets)
+    DT_PART_IPAIR = 8,             // k_inv21p   levels 2 + 1 inverse as a pair (14- / 18-tap q-shift sets)
+    DT_PART_FWD2 = 16,             // k_fwd2m    level 2 forward alone
+    DT_PART_INV2 = 32,             // k_inv2m    level 2 inverse alone
+    DT_PART_L1 = 64,               // k_fwd1m / k_inv1m   level 1 alone (near_sym_b, antonini)
+    DT_PART_INV21_AS_PAIR = 128,   // the headline set's inverse as a pair where ONE transform has the device (bit-identical to k_inv21m)
+    DT_PART_INV21_ALWAYS_PAIR = 256,   // ... at every size and in flight too (tests: both forms of the same macro-steps)
+    DT_PART_DEFAULT = 255
+};
 struct DtMarchHint {
     int cus, nparts, in_flight, program;
+    int env_march = -1;
+    int band = 0;
+    unsigned parts = DT_PART_DEFAULT;
 };
+DtMarchHint dt_march_switches();
 
 struct dtcwt_hip_event {
     hipEvent_t ev;

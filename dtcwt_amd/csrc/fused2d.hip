@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <vector>
 
+#include <string>
+
 #include "common.hpp"
 #include "fused2d_tiles.hpp"
 #include "fused2d_tiles_v2.hpp"
@@ -63,11 +65,8 @@ int dtcwt_march_inv2(const float *Z2, const float *Yh1, float *Z1, int B, int R,
                      const float *h_a, const float *h_b, int m, const float *gain2, const DtMarchHint &hint, hipStream_t s);
 namespace {
 
-// record arrays at least this big leave with the non-temporal hint (DTCWT_HIP_STREAM_RECORDS_MB; default 32)
-inline int64_t stream_records_bytes() {
-    static const int64_t b = [] { const char *e = getenv("DTCWT_HIP_STREAM_RECORDS_MB"); return (int64_t)(e ? atoi(e) : 32) << 20; }();
-    return b;
-}
+// record arrays at least this big leave with the non-temporal hint (32 MiB: swept in round 2, profiles/r02; the switch is gone)
+inline int64_t stream_records_bytes() { return (int64_t)32 << 20; }
 
 // -------------------------------------------------------------------------- kernels
 // Level-1 forward: column pass straight from global memory into two LDS planes, one
@@ -149,9 +148,8 @@ int dispatch_fwd1(int m0, int m1, int m2, Fwd1Params &p, hipStream_t s) {
     if (m2) { DT_FWD1_BP_TABLE(DT_CASE_FWD1_BP) return -3; }
     DT_FWD1_TABLE(DT_CASE_FWD1) return -3;
 }
-int dispatch_fwd2(int m, bool bp, Fwd2Params &p, hipStream_t s, bool small) {
+int dispatch_fwd2(int m, bool bp, Fwd2Params &p, hipStream_t s) {
     if (bp) { DT_FWD2_BP_TABLE(DT_CASE_FWD2_BP) return -3; }
-    if (small) { DT_FWD2_SMALL_TABLE(DT_CASE_FWD2) }
     DT_FWD2_TABLE(DT_CASE_FWD2) return -3;
 }
 #define DT_HAS3(TR, TC, RS, A, B, C2) if (m0 == A && m1 == B && m2 == C2) return true;
@@ -198,8 +196,8 @@ struct dtcwt_hip_plan2d {
     std::vector<float *> work;        // LoLo / Z per level (level nlevels-1 unused on fwd)
     bool profiling = false;           // record an event pair around every level kernel
     std::vector<hipEvent_t> ev;       // [fwd: 2 per level][inv: 2 per level]
-    int xcd_order = -1;               // -1: per-kernel default, 0/1: forced (DTCWT_HIP_XCD_ORDER)
-    int small_tiles = -1;             // -1: by size, 0/1: forced (DTCWT_HIP_SMALL_TILES)
+    int xcd_order = -1;               // -1: per-kernel default, 0/1: forced (DTCWT_HIP_XCD_ORDER, read at plan creation)
+    DtMarchHint sw;                   // the marching programs' switches as the environment had them when the plan was made
     // tile order of the level-1 forward kernel (tile_of): 0 linear, 1 one contiguous run per XCD, g > 1 groups of g
     // neighbouring tiles per XCD.  Measured at 4096^2 (profiles/r02): g = 8 fetches 74.6 MB for the 67.1 MB image
     // (1.11 x; linear order: 133 MB, 1.99 x, every XCD's L2 fetching its own copy of the shared halo lines) in
@@ -207,7 +205,7 @@ struct dtcwt_hip_plan2d {
     int fwd1_order = 8;
     int concurrency = 1;              // independent transforms in flight on the device (dtcwt_hip_plan2d_set_concurrency)
     int program = -1;                 // -1: the library chooses per call, 0: tile programs, 1: marching launches (dtcwt_hip_plan2d_set_program)
-    DtMarchHint hint() const { return DtMarchHint{ctx->cus, ctx->nparts, concurrency, program}; }
+    DtMarchHint hint() const { DtMarchHint h = sw; h.cus = ctx->cus; h.nparts = ctx->nparts; h.in_flight = concurrency; h.program = program; return h; }
 };
 
 // levels 1 + 2 of the forward / 2 + 1 of the inverse in one marching launch (march2d.hpp): not for the band-pass sets,
@@ -284,6 +282,45 @@ int dtcwt_hip_plan2d_set_program(dtcwt_hip_plan2d *p, int program) {
     return 0;
 }
 
+// Which program runs every level of this plan, and the switches it was made under -- one line of text, e.g.
+//   fwd: L1+2 k_fwd12m | L3 k_fwd2 | L4 k_fwd2 ; inv: L4 k_inv2 | L3 k_inv2 | L2+1 k_inv21p ; march=auto band=auto parts=0xff xcd_order=-1 program=auto in_flight=1 cu_shares=1
+// `scales` != 0: as a forward with include_scale runs (the marching pair does not serve it).  The same predicates as
+// dtcwt_hip_plan2d_forward / _inverse consult: what this says is what runs.
+int dtcwt_hip_plan2d_describe(const dtcwt_hip_plan2d *p, int scales, char *buf, size_t len) {
+    DT_REQUIRE(p && buf && len >= 64, "NULL argument or a buffer shorter than 64 bytes");
+    std::string o = "fwd:";
+    const int nl = p->nlevels;
+    const bool f12 = plan_march_fwd12(p), f12p = !f12 && !scales && plan_march_fwd12p(p);
+    for (int l = 0; l < nl; ++l) {
+        char t[96];
+        if (l == 0 && (f12 || f12p)) { snprintf(t, sizeof t, " L1+2 %s", f12 ? (scales ? "k_fwd12m+LoLo1" : "k_fwd12m") : "k_fwd12p"); o += t; l = 1; }
+        else if (l == 0) { snprintf(t, sizeof t, " L1 %s", plan_march_fwd1(p) ? "k_fwd1m" : "k_fwd1"); o += t; }
+        else { snprintf(t, sizeof t, " L%d %s", l + 1, (l == 1 && plan_march_fwd2(p, scales != 0)) ? "k_fwd2m" : "k_fwd2"); o += t; }
+        if (l + 1 < nl) o += " |";
+    }
+    o += " ; inv:";
+    const bool i21 = plan_march_inv21(p), i21p = !i21 && plan_march_inv21p(p);
+    for (int l = nl - 1; l >= 0; --l) {
+        char t[96];
+        if (l == 1 && (i21 || i21p)) {
+            const DtMarchHint h = p->hint();
+            const int nstrip = (p->lv[0].LC + 4 * 58 - 1) / (4 * 58);
+            const double useful = (double)p->batch * p->lv[0].LR * p->lv[0].LC * ((double)p->lv[0].LC / (nstrip * 4.0 * 58));
+            const bool as_pair = i21 && ((h.parts & DT_PART_INV21_ALWAYS_PAIR) || ((h.parts & DT_PART_INV21_AS_PAIR) && h.in_flight <= 1 && h.nparts <= 1 && useful <= 1.8e7));
+            snprintf(t, sizeof t, " L2+1 %s", (i21p || as_pair) ? "k_inv21p" : "k_inv21m"); o += t; break;
+        }
+        if (l == 0) { snprintf(t, sizeof t, " L1 %s", plan_march_inv1(p) ? "k_inv1m" : "k_inv1"); o += t; }
+        else { snprintf(t, sizeof t, " L%d %s |", l + 1, (l == 1 && plan_march_inv2(p)) ? "k_inv2m" : "k_inv2"); o += t; }
+    }
+    char t[192];
+    snprintf(t, sizeof t, " ; march=%s band=%d parts=0x%x xcd_order=%d program=%s in_flight=%d cu_shares=%d",
+             p->sw.env_march < 0 ? "auto" : (p->sw.env_march ? "1" : "0"), p->sw.band, p->sw.parts, p->xcd_order,
+             p->program < 0 ? "auto" : (p->program ? "march" : "tiles"), p->concurrency, p->ctx->nparts);
+    o += t;
+    snprintf(buf, len, "%s", o.c_str());
+    return 0;
+}
+
 int dtcwt_hip_plan2d_launches(const dtcwt_hip_plan2d *p, int *fwd12, int *inv21) {
     DT_REQUIRE(p, "NULL plan");
     if (fwd12) *fwd12 = (plan_march_fwd12(p) || plan_march_fwd12p(p)) ? 1 : 0;
@@ -310,7 +347,7 @@ int dtcwt_hip_plan2d_create(dtcwt_hip_ctx *ctx, int batch, int rows, int cols, i
     for (int i = 0; i < 4; ++i) p->biort[i].assign(biort_host[i], biort_host[i] + biort_len[i]);
     for (int i = 0; i < 8; ++i) p->qshift[i].assign(qshift_host[i], qshift_host[i] + qshift_len[i]);
     { const char *e = getenv("DTCWT_HIP_XCD_ORDER"); p->xcd_order = e ? atoi(e) : -1; }
-    { const char *e = getenv("DTCWT_HIP_SMALL_TILES"); p->small_tiles = e ? (e[0] == '1' ? 1 : 0) : -1; }
+    p->sw = dt_march_switches();
     p->extR = rows + (rows & 1);
     p->extC = cols + (cols & 1);
     Level l0{rows, cols, 0, 0, p->extR, p->extC, p->extR, p->extC, p->extR / 2, p->extC / 2};
@@ -505,10 +542,9 @@ int dtcwt_hip_plan2d_forward(dtcwt_hip_plan2d *p, const float *X, float *Yl, voi
                 in = lo;
                 continue;
             }
-            // default tile 16 x ~56: use the small shape when that gives too few workgroups
-            bool small = p->small_tiles >= 0 ? p->small_tiles != 0
-                                             : (int64_t)cdiv(L.loR, 16) * cdiv(L.loC, 56) * p->batch < DT_SMALL_TILE_THRESHOLD;
-            rc = dispatch_fwd2((int)p->qshift[0].size(), bp, q, s, small);
+            // (8-row tiles for the coarsest levels measured no gain for the forward -- those launches sit at a 3-8 us floor
+            // either way: their builds and DTCWT_HIP_SMALL_TILES are gone; the inverse keeps its 8 x 64 tiles below)
+            rc = dispatch_fwd2((int)p->qshift[0].size(), bp, q, s);
         }
         if (rc) return dtcwt_set_error(rc, "no fused forward kernel at level %d", l);
         DT_CHECK_HIP(hipGetLastError());
@@ -600,8 +636,7 @@ int dtcwt_hip_plan2d_inverse(dtcwt_hip_plan2d *p, const float *Yl, const void *c
             }
             // the coarsest levels of a single image (fewer than two 16 x 56 tiles per CU): 8 x 64 tiles, twice the
             // workgroups of half the rows each (fused2d_table.hpp)
-            bool small = p->small_tiles >= 0 ? p->small_tiles != 0
-                                             : (int64_t)cdiv(L.loR, 16) * cdiv(L.loC, 56) * p->batch < DT_INV2_SMALL_BELOW;
+            const bool small = (int64_t)cdiv(L.loR, 16) * cdiv(L.loC, 56) * p->batch < DT_INV2_SMALL_BELOW;
             rc = dtcwt_dispatch_inv2((int)p->qshift[0].size(), bp, q, s, small);
             in = out;
         }

@@ -49,21 +49,13 @@
 #define DT_INV2_BP_TABLE(X) \
     X(16, 52, 2, 14)
 
-/* Smaller tiles for coarse levels (more workgroups).  Measured on MI355X (4096^2, levels 3-4):
- * no gain for the forward -- those launches sit at a ~3-8 us floor either way -- so its small tiles are only used
- * when forced with DTCWT_HIP_SMALL_TILES=1 (threshold 0 = never automatically). */
-#define DT_SMALL_TILE_THRESHOLD 0
-/* the inverse does gain at the very coarsest levels, with 8 x 64 tiles: below this many 16 x 56 tiles (two per CU;
- * measured: a 512^2 lowpass, 320 tiles: 4.7 -> 3.7 us; a 1024^2 one, 1216 tiles: 10.4 -> 11.7 us) */
+/* Smaller tiles for coarse levels (more workgroups).  Measured on MI355X (4096^2, levels 3-4): no gain for the forward --
+ * those launches sit at a ~3-8 us floor either way -- so the forward has none (its 8-row builds and DTCWT_HIP_SMALL_TILES
+ * went in round 6).  The inverse does gain at the very coarsest levels, with 8 x 64 tiles: below this many 16 x 56 tiles
+ * (two per CU; measured: a 512^2 lowpass, 320 tiles: 4.7 -> 3.7 us; a 1024^2 one, 1216 tiles: 10.4 -> 11.7 us) */
 #ifndef DT_INV2_SMALL_BELOW
 #define DT_INV2_SMALL_BELOW 512
 #endif
-#define DT_FWD2_SMALL_TABLE(X) \
-    X(8, 24, 2, 10) \
-    X(8, 20, 2, 14) \
-    X(8, 18, 2, 16) \
-    X(8, 16, 2, 18) \
-    X(16, 34, 2, 32)
 #define DT_INV2_SMALL_TABLE(X) \
     X(8, 64, 2, 10) \
     X(8, 20, 2, 14) \

@@ -28,13 +28,13 @@ __device__ __forceinline__ int xcd_tile3(int ntile_xcd) {
     const int t = (bid & 7) * per + (bid >> 3);
     return ((bid >> 3) < per && t < ntile_xcd) ? t : -1;
 }
-// bit mask of the kernels that take the XCD order (DTCWT_HIP_XCD3D): 1 k_fwd3_l1, 2 k_fwd3_l2_planes,
+// bit mask of the kernels that take the XCD order: 1 k_fwd3_l1, 2 k_fwd3_l2_planes,
 // 4 k_inv3_axis0 / k_inv3_l1_axis02, 8 (was k_inv3_l1_planes: unused), 16 k_inv3_l2_planes.  Measured at 256^3 (profiles/r02/xcd3d.txt): the
 // forward kernels gain (pass A of level 2: 46 -> 34 us; the transform 252 -> 240 us); so do the plane passes of
 // the inverse once its level 1 runs in slabs (345 -> 322 us); the inverse march (4) does not.
 enum { XCD3_FWD_L1 = 1, XCD3_FWD_PLANES = 2, XCD3_INV_AXIS0 = 4, XCD3_INV_L2_PLANES = 16 };
 inline bool xcd3_enabled(int bit) {
-    static const int mask = [] { const char *e = getenv("DTCWT_HIP_XCD3D"); return e ? atoi(e) : (XCD3_FWD_L1 | XCD3_FWD_PLANES | XCD3_INV_L2_PLANES); }();
+    constexpr int mask = XCD3_FWD_L1 | XCD3_FWD_PLANES | XCD3_INV_L2_PLANES;          // (the sweep's switch, DTCWT_HIP_XCD3D, is gone)
     return (mask & bit) != 0;
 }
 inline unsigned xcd3_grid(int ntile, int bit) { return xcd3_enabled(bit) ? (unsigned)(8 * ((ntile + 7) / 8)) : (unsigned)ntile; }
@@ -276,9 +276,9 @@ static int launch_fwd3m(const float *X, float *LLL, float *Yh, int n0, int n1, i
     p.chunk = chunk; p.nchunk = cdiv(n0, chunk);
     dt3m::pack_fwd3m(p, h0, m0, h1, m1);
     const int per = (p.nrp + 7) / 8;
-    const int occ = [] { const char *e = getenv("DTCWT_HIP_FWD3_OCC"); return e ? atoi(e) : 1; }();
-    if (occ == 2) dt3m::k_fwd3m_l1<5, 7, 2><<<(unsigned)(8 * per * p.nstrip * p.nchunk), 128, 0, s>>>(p);
-    else dt3m::k_fwd3m_l1<5, 7, 1><<<(unsigned)(8 * per * p.nstrip * p.nchunk), 128, 0, s>>>(p);
+    // one wavefront per SIMD (OCC = 1: 256 + 20 registers, no scratch; the two-per-SIMD build spilled 24 of them and measured
+    // equal, profiles/r05/ab_fwd3m.txt -- it and DTCWT_HIP_FWD3_OCC are gone)
+    dt3m::k_fwd3m_l1<5, 7, 1><<<(unsigned)(8 * per * p.nstrip * p.nchunk), 128, 0, s>>>(p);
     return 0;
 }
 

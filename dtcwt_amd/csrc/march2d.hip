@@ -32,8 +32,8 @@ bool symmetric(const std::vector<double> &h) {
 // the (cheaper) warm-up steps above and below the band that its level-2 windows reach into.  The kernel needs ~190
 // registers, i.e. two wavefronts per SIMD: `slots` wavefronts are resident at a time, and a grid of slots + 1 jobs
 // takes as long as one of 2 x slots -- so the band height is the one that minimises rounds x steps.
-int pick_band_rows(int B, int R, int nstrip, int M, int cus) {
-    if (const char *e = getenv("DTCWT_HIP_MARCH_BAND")) { const int v = atoi(e) & ~3; if (v >= 8) return v; }
+int pick_band_rows(int B, int R, int nstrip, int M, int cus, int forced) {
+    if ((forced & ~3) >= 8) return forced & ~3;          // DTCWT_HIP_MARCH_BAND as the plan read it
     const int64_t slots = (int64_t)cus * 8;
     int best = 64; double best_cost = 1e30;
     for (int br = 24; br <= 512; br += 4) {
@@ -46,8 +46,9 @@ int pick_band_rows(int B, int R, int nstrip, int M, int cus) {
 }
 // the level-1 marches (march2d_l1.hpp): bands in multiples of `quant` rows (the forward runs whole periods of its register
 // ring: 2 x (HH + 1) rows), `warm` extra steps per band (the inverse reads (HM + 1) / 2 record rows above and below)
-int pick_band_rows_l1(int B, int R, int nstrip, int quant, double warm, int cus) {
-    if (const char *e = getenv("DTCWT_HIP_MARCH_BAND")) { const int v = atoi(e) / quant * quant; if (v >= quant) return v; }
+int pick_band_rows_l1(int B, int R, int nstrip, int quant, double warm, int cus, int forced) {
+    if (forced / quant * quant >= quant) return forced / quant * quant;
+
     const int64_t slots = (int64_t)cus * 8;
     int best = quant; double best_cost = 1e30;
     for (int br = quant; br <= 640; br += quant) {
@@ -62,13 +63,23 @@ int pick_band_rows_l1(int B, int R, int nstrip, int quant, double warm, int cus)
 
 }  // namespace
 
-// DTCWT_HIP_MARCH: 0 = never, 1 = wherever the geometry and the filters allow, unset = where it also pays (below).
-// Read on every call, not cached: the tests switch it between two transforms of one process.  A program pinned on the
+// The three environment switches of the marching programs (common.hpp), read when a plan is created: a plan keeps its
+// programs for life and reports them (dtcwt_hip_plan2d_describe).  Every other decision below is a fixed rule with the
+// measurement that set it beside it; the switches that A/B experiments used until round 5 (DTCWT_HIP_MARCH_INV, _MARCH_PAIR,
+// _MARCH_IPAIR, _MARCH_FWD2, _MARCH_INV2, _INV21_PAIR -> bits of DTCWT_HIP_MARCH_PARTS; _INV21_PF, _FPAIR_WPS, _IPAIR_WPS ->
+// settled, gone with the kernel builds they selected) are in INTEGRATION.md.
+DtMarchHint dt_march_switches() {
+    DtMarchHint h{0, 1, 1, -1};
+    if (const char *e = getenv("DTCWT_HIP_MARCH")) h.env_march = e[0] == '0' ? 0 : 1;
+    if (const char *e = getenv("DTCWT_HIP_MARCH_BAND")) h.band = atoi(e) > 0 ? atoi(e) : 0;
+    if (const char *e = getenv("DTCWT_HIP_MARCH_PARTS")) h.parts = (unsigned)strtoul(e, nullptr, 0);
+    return h;
+}
+// 0 = never, 1 = wherever the geometry and the filters allow, -1 = where it also pays (below).  A program pinned on the
 // plan (dtcwt_hip_plan2d_set_program) wins over the environment.
 static int march_mode(const DtMarchHint &h) {
     if (h.program >= 0) return h.program ? 1 : 0;
-    const char *e = getenv("DTCWT_HIP_MARCH");
-    return e ? (e[0] == '0' ? 0 : 1) : -1;
+    return h.env_march;
 }
 
 // Does the one-launch form pay?  A marching job is one wavefront running 20-80 dependent steps: a launch takes ~30 us
@@ -107,7 +118,7 @@ static bool march_sizes_ok(int batch, int rows, int cols, int VL) {
 bool dtcwt_march_fwd12_ok(int batch, int rows, int cols, const std::vector<double> &h0o, const std::vector<double> &h1o,
                           const std::vector<double> &h0a, bool lo_a_first, bool hi_a_first, const DtMarchHint &hint) {
     const int mm = march_mode(hint);
-    if (mm == 0 || (mm < 0 && !march_pays(batch, rows, cols, hint))) return false;
+    if ((!(hint.parts & DT_PART_FWD12) && hint.program < 0) || mm == 0 || (mm < 0 && !march_pays(batch, rows, cols, hint))) return false;
     const int m0 = (int)h0o.size(), m1 = (int)h1o.size(), m = (int)h0a.size();
     if (!((m0 == 5 && m1 == 7) || (m0 == 5 && m1 == 3)) || m != 10) return false;       // near_sym_a, legall + qshift_a / _06
     if (!symmetric(h0o) || !symmetric(h1o)) return false;     // mirrored halo lanes: see march2d.hpp
@@ -119,15 +130,14 @@ bool dtcwt_march_fwd12_ok(int batch, int rows, int cols, const std::vector<doubl
 // (7, 5 taps), 10-tap q-shift filters with the standard phases
 bool dtcwt_march_inv21_ok(int batch, int rows, int cols, const std::vector<double> &g0o, const std::vector<double> &g1o,
                           const std::vector<double> &g0a, bool lo_pos, bool hi_pos, const DtMarchHint &hint) {
-    // DTCWT_HIP_MARCH_INV=0: never.  A band re-reads the rows its windows reach into above and below -- for the inverse
+    // (DTCWT_HIP_MARCH_PARTS without bit 2: never.)  A band re-reads the rows its windows reach into above and below -- for the inverse
     // those are level-1 RECORD rows, 12 of its 16 bytes per pixel -- so with the 40-row bands a single 4096^2 image has
     // to be cut into, the one launch alone is no faster than the two it replaces (97 against 94 us, 1.2 x the
     // records); it still wins where it counts: two images in flight 0.1821 against 0.1853 ms per step (A/B in one
     // call, profiles/r04/ab_inv_march.txt; fewer launches, 64 MB less traffic), and a batch affords tall bands
     // (64 x 2048^2: levels 2 + 1 in 1.27 ms against 1.08 + 0.44).
-    const int mode = [] { const char *e = getenv("DTCWT_HIP_MARCH_INV"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
     const int mm = march_mode(hint);
-    if ((mode == 0 && hint.program < 0) || mm == 0 || (mm < 0 && !march_pays(batch, rows, cols, hint))) return false;
+    if ((!(hint.parts & DT_PART_INV21) && hint.program < 0) || mm == 0 || (mm < 0 && !march_pays(batch, rows, cols, hint))) return false;
     // (7, 5): near_sym_a; (3, 5): legall, whose 3-tap g0o runs as a centred zero-padded 7-tap one
     if (!((g0o.size() == 7 || g0o.size() == 3) && g1o.size() == 5) || g0a.size() != 10 || !lo_pos || hi_pos) return false;
     if (!symmetric(g0o) || !symmetric(g1o)) return false;       // the row filters fold the mirror pairs
@@ -151,28 +161,22 @@ int dtcwt_march_inv21(const float *Z2, const float *Yh1, const float *Yh0, float
     dtm::dtm_pack_inv_biort(p, 7, 5);
     const int nstrip = cdiv(C, 4 * G::VL);
     if (!march_sizes_ok(B, R, C, G::VL)) return -3;         // (dtcwt_march_inv21_ok said so already)
-    // DTCWT_HIP_INV21_PF (experiment, profiles/r05/ab_inv21m_prefetch.txt): 2 = the requests two macro-steps ahead in a build for ONE
-    // wavefront per SIMD (its 512 registers hold the second set of rows; half the wave slots, so bands twice as tall),
-    // 1 = one wavefront per SIMD with the usual depth; unset = the default build (two per SIMD, one macro-step ahead)
-    const int pf = [] { const char *e = getenv("DTCWT_HIP_INV21_PF"); return e ? atoi(e) : 0; }();
+    // (round 5 also built this kernel for ONE wavefront per SIMD with its requests two macro-steps ahead -- 4 % faster alone, 1.9 x slower
+    // in flight, profiles/r05/ab_inv21m_prefetch.txt: not adopted, the builds and their switch are gone)
     // ONE transform at a time on the whole device, up to a 4096^2 image: the same macro-steps as a marching PAIR of wavefronts
     // (k_inv21p<7, 5, 10>, march2d_ipair.hpp; bit-identical output).  Such a launch does not fill the wave slots -- a pair puts two
     // wavefronts on every job and, where the slots are all taken (4096^2), affords bands twice as tall (72 rows instead of 40: 1.15 x
     // instead of 1.28 x the algorithmic bytes).  Inverse launch alone 2048^2 35.9 -> 29.6 us, 3072^2 55 -> 45.7, 4096^2 84 -> 80.6;
     // 5120^2 163 -> 172 (no longer chosen); with four in flight on quarters it loses outright (231 -> 338 us per image-share) and on
-    // batches it is level (profiles/r05/pair_headline_inverse.txt).  DTCWT_HIP_INV21_PAIR=0 / 1: never / always.
+    // batches it is level (profiles/r05/pair_headline_inverse.txt).  DTCWT_HIP_MARCH_PARTS bit 128 off / bit 256 on: never / always.
     {
-        const char *e = getenv("DTCWT_HIP_INV21_PAIR");
         const double useful = (double)B * R * C * ((double)C / (nstrip * 4.0 * G::VL));
         const bool alone = hint.in_flight <= 1 && hint.nparts <= 1;
-        if (!pf && (e ? e[0] == '1' : (alone && useful <= 1.8e7))) return launch_inv21p_m10(p, hint, s);
+        if ((hint.parts & DT_PART_INV21_ALWAYS_PAIR) || ((hint.parts & DT_PART_INV21_AS_PAIR) && alone && useful <= 1.8e7)) return launch_inv21p_m10(p, hint, s);
     }
-    const int cus_eff = pf ? hint.cus / 2 : hint.cus;
-    const unsigned jobs = dtm::dtm_set_jobs(p.jb, B, R, nstrip, pick_band_rows(B * hint.in_flight, R, nstrip, 10, cus_eff > 0 ? cus_eff : 1));
+    const unsigned jobs = dtm::dtm_set_jobs(p.jb, B, R, nstrip, pick_band_rows(B * hint.in_flight, R, nstrip, 10, hint.cus > 0 ? hint.cus : 1, hint.band));
     // (record rows loaded with the non-temporal hint: no difference, 0.1581 against 0.1586 ms per step)
-    if (pf == 2) dtm::k_inv21m<7, 5, 10, 0, 2, 1><<<jobs, 64, 0, s>>>(p);
-    else if (pf == 1) dtm::k_inv21m<7, 5, 10, 0, 1, 1><<<jobs, 64, 0, s>>>(p);
-    else dtm::k_inv21m<7, 5, 10, 0><<<jobs, 64, 0, s>>>(p);
+    dtm::k_inv21m<7, 5, 10, 0><<<jobs, 64, 0, s>>>(p);
     return 0;
 }
 
@@ -181,7 +185,7 @@ static int launch_fwd12(dtm::Fwd12mParams &p, const DtMarchHint &hint, hipStream
     using G = dtm::Fwd12m<M0, M1, M>;
     const int nstrip = cdiv(p.C, 4 * G::VL);
     if (!march_sizes_ok(p.B, p.R, p.C, G::VL)) return -3;   // (dtcwt_march_fwd12_ok said so already)
-    const unsigned jobs = dtm::dtm_set_jobs(p.jb, p.B, p.R, nstrip, pick_band_rows(p.B * hint.in_flight, p.R, nstrip, M, hint.cus));
+    const unsigned jobs = dtm::dtm_set_jobs(p.jb, p.B, p.R, nstrip, pick_band_rows(p.B * hint.in_flight, p.R, nstrip, M, hint.cus, hint.band));
     // (X rows loaded with the non-temporal hint: 81.4 against 85.4 us alone, no difference inside the transform -- not used)
     // rows requested FOUR steps ahead (P = 4: 249 VGPRs, no scratch) instead of two: k_fwd12m alone 71-74 against 74-77 us, one
     // transform at a time 0.181 against 0.184 ms per step, nothing with four in flight or on the batches; Yh[1] / LoLo2 written with
@@ -236,6 +240,7 @@ bool dtcwt_march_fwd1_ok(int batch, int rows, int cols, const std::vector<double
     if (!symmetric(h0o) || !symmetric(h1o)) return false;
     const int VL = m0 == 13 ? dtm::Fwd1m<13, 19>::VL : dtm::Fwd1m<9, 7>::VL;
     if (!l1_sizes_ok(batch, rows, cols, VL)) return false;
+    if (!(hint.parts & DT_PART_L1) && hint.program < 0) return false;
     const int mm = march_mode(hint);
     // antonini (9 / 7 taps): the tile programs re-filter 8 halo rows per 32-row tile only, and the march measured no faster
     // (4096^2 forward 67 against 63.5 us alone, the step 0.240 against 0.250 ms with four in flight: profiles/r05/level1_march.txt)
@@ -247,7 +252,7 @@ template <int M0, int M1, int P>
 static int launch_fwd1m(dtm::Fwd1mParams &p, const DtMarchHint &hint, hipStream_t s) {
     using G = dtm::Fwd1m<M0, M1>;
     const int nstrip = cdiv(p.C, 4 * G::VL);
-    const unsigned jobs = dtm::dtm_set_jobs(p.jb, p.B, p.R, nstrip, pick_band_rows_l1(p.B * hint.in_flight, p.R, nstrip, 2 * G::PER, 0.5 * G::HH, hint.cus));
+    const unsigned jobs = dtm::dtm_set_jobs(p.jb, p.B, p.R, nstrip, pick_band_rows_l1(p.B * hint.in_flight, p.R, nstrip, 2 * G::PER, 0.5 * G::HH, hint.cus, hint.band));
     dtm::k_fwd1m<M0, M1, P><<<jobs, 64, 0, s>>>(p);
     return 0;
 }
@@ -270,6 +275,7 @@ bool dtcwt_march_inv1_ok(int batch, int rows, int cols, const std::vector<double
     if (!symmetric(g0o) || !symmetric(g1o)) return false;
     const int VL = m0 == 19 ? dtm::Inv1m<19, 13>::VL : dtm::Inv1m<7, 9>::VL;
     if (!l1_sizes_ok(batch, rows, cols, VL)) return false;
+    if (!(hint.parts & DT_PART_L1) && hint.program < 0) return false;
     const int mm = march_mode(hint);
     return mm > 0 || (mm < 0 && m0 == 19 && l1_pays(batch, rows, cols, VL, hint));        // (antonini: see the forward)
 }
@@ -278,7 +284,7 @@ template <int M0, int M1>
 static int launch_inv1m(dtm::Inv1mParams &p, const DtMarchHint &hint, hipStream_t s) {
     using G = dtm::Inv1m<M0, M1>;
     const int nstrip = cdiv(p.C, 4 * G::VL);
-    const unsigned jobs = dtm::dtm_set_jobs(p.jb, p.B, p.R, nstrip, pick_band_rows_l1(p.B * hint.in_flight, p.R, nstrip, 4, 2.0 * G::WARM, hint.cus));
+    const unsigned jobs = dtm::dtm_set_jobs(p.jb, p.B, p.R, nstrip, pick_band_rows_l1(p.B * hint.in_flight, p.R, nstrip, 4, 2.0 * G::WARM, hint.cus, hint.band));
     dtm::k_inv1m<M0, M1><<<jobs, 64, 0, s>>>(p);
     return 0;
 }
@@ -297,6 +303,9 @@ int dtcwt_march_inv1(const float *Z, const float *Yh0, float *X, int B, int R, i
 
 // ---- the in-slice half of the 3-D level 1 for long filters (fused3d_long.hpp): the level-1 marches above with the four row-
 // filtered planes in place of the lowpass + records; every slice of the volume is an image of the batch.  Called by fused3d.hip.
+// DTCWT_HIP_LONG3D_BAND: rows per band of the in-slice launches of the 3-D level 1 (test hook, read per call like the other
+// DTCWT_HIP_LONG3D_* hooks: the 3-D level functions have no plan to carry them)
+static int long3d_band() { const char *e = getenv("DTCWT_HIP_LONG3D_BAND"); return e && atoi(e) > 0 ? atoi(e) : 0; }
 static bool planes_one_strip(int C, int VL) {
     if (const char *e = getenv("DTCWT_HIP_LONG3D_EDGE")) return e[0] != '0' && C <= 256 && C >= 48;       // tests: force / forbid
     return C > 4 * VL && C <= 256;
@@ -311,7 +320,7 @@ int dtcwt_march_fwd1_planes(const float *X, float *P, int64_t pstride, int B, in
     // a row of 236 .. 256 columns: one strip without halo lanes (EDGE build) instead of two strips with 58 owning lanes each
     const bool edge = planes_one_strip(C, G::VL);
     const int nstrip = edge ? 1 : cdiv(C, 4 * G::VL);
-    const unsigned jobs = dtm::dtm_set_jobs(p.jb, B, R, nstrip, pick_band_rows_l1(B, R, nstrip, 2 * G::PER, 0.5 * G::HH, cus));
+    const unsigned jobs = dtm::dtm_set_jobs(p.jb, B, R, nstrip, pick_band_rows_l1(B, R, nstrip, 2 * G::PER, 0.5 * G::HH, cus, long3d_band()));
     if (edge) dtm::k_fwd1m<13, 19, 2, true, true><<<jobs, 64, 0, s>>>(p);
     else dtm::k_fwd1m<13, 19, 2, true><<<jobs, 64, 0, s>>>(p);
     return 0;
@@ -325,7 +334,7 @@ int dtcwt_march_inv1_planes(const float *P, int64_t pstride, float *X, int B, in
     using G = dtm::Inv1m<19, 13>;
     const bool edge = planes_one_strip(C, G::VL);
     const int nstrip = edge ? 1 : cdiv(C, 4 * G::VL);
-    const unsigned jobs = dtm::dtm_set_jobs(p.jb, B, R, nstrip, pick_band_rows_l1(B, R, nstrip, 4, 2.0 * G::WARM, cus));
+    const unsigned jobs = dtm::dtm_set_jobs(p.jb, B, R, nstrip, pick_band_rows_l1(B, R, nstrip, 4, 2.0 * G::WARM, cus, long3d_band()));
     if (edge) dtm::k_inv1m<19, 13, true, true><<<jobs, 64, 0, s>>>(p);
     else dtm::k_inv1m<19, 13, true><<<jobs, 64, 0, s>>>(p);
     return 0;
@@ -333,7 +342,6 @@ int dtcwt_march_inv1_planes(const float *P, int64_t pstride, float *X, int B, in
 
 // ---- round 6: both in-slice axes + cube2c of the 3-D level 1 for long filters in one launch (fused3d_long.hpp: k_fwd3l_slices),
 // after the axis-0 pair filter: V [2][n0][n1][n2] -> LLL, Yh.  A job = four wavefronts = a slice pair x (strip, band of rows).
-// DTCWT_HIP_LONG3D_BAND: rows per band (tests).
 int dtcwt_march_fwd3l_slices(const float *V, int64_t vstride, float *LLL, float *Yh, int n0, int n1, int n2, const double *h0o, int m0,
                              const double *h1o, int m1, int cus, hipStream_t s) {
     using G = dtm::Fwd1m<13, 19>;
@@ -344,8 +352,7 @@ int dtcwt_march_fwd3l_slices(const float *V, int64_t vstride, float *LLL, float 
     const bool edge = planes_one_strip(n2, G::VL);
     const int nstrip = edge ? 1 : cdiv(n2, 4 * G::VL);
     // two workgroups of four wavefronts per CU where the band picker counts eight one-wavefront jobs
-    int band = pick_band_rows_l1(n0 / 2, n1, nstrip, 2 * G::PER, 0.5 * G::HH, cus / 4 > 0 ? cus / 4 : 1);
-    if (const char *e = getenv("DTCWT_HIP_LONG3D_BAND")) { const int v = atoi(e) / (2 * G::PER) * (2 * G::PER); if (v >= 2 * G::PER) band = v; }
+    const int band = pick_band_rows_l1(n0 / 2, n1, nstrip, 2 * G::PER, 0.5 * G::HH, cus / 4 > 0 ? cus / 4 : 1, long3d_band());
     const unsigned jobs = dtm::dtm_set_jobs(p.jb, n0 / 2, n1, nstrip, band);
     if (edge) dt3l::k_fwd3l_slices<13, 19, 2, true><<<jobs, 256, 0, s>>>(p);
     else dt3l::k_fwd3l_slices<13, 19, 2, false><<<jobs, 256, 0, s>>>(p);
@@ -361,10 +368,10 @@ int dtcwt_march_fwd3l_slices(const float *V, int64_t vstride, float *LLL, float 
 // other work shares the device (concurrency hint, partition context) from the usual crossover, alone from 60 M useful pixels.
 // near_sym_b was built too and lost everywhere (146 us against 72 + 28 alone, 451 against 245 + 157 in flight: its level-1
 // wavefront carries 573 instructions per step, the partner 130): its level 1 stays a march of its own (march2d_l1.hpp).
-// DTCWT_HIP_MARCH_PAIR=0: never.
+// DTCWT_HIP_MARCH_PARTS without bit 4: never.
 bool dtcwt_march_fwd12p_ok(int batch, int rows, int cols, const std::vector<double> &h0o, const std::vector<double> &h1o,
                            const std::vector<double> &h0a, bool lo_a_first, bool hi_a_first, const DtMarchHint &hint) {
-    if (const char *e = getenv("DTCWT_HIP_MARCH_PAIR")) { if (e[0] == '0') return false; }
+    if (!(hint.parts & DT_PART_FPAIR)) return false;
     const int m0 = (int)h0o.size(), m1 = (int)h1o.size(), m = (int)h0a.size();
     if (!(m0 == 5 && (m1 == 7 || m1 == 3) && (m == 14 || m == 18))) return false;          // near_sym_a, legall
     if (!symmetric(h0o) || !symmetric(h1o) || !lo_a_first || hi_a_first) return false;
@@ -384,11 +391,10 @@ static int launch_fwd12p(dtm::Fwd12pParams &p, const DtMarchHint &hint, hipStrea
     using G = dtm::Fwd12p<M0, M1, M>;
     const int nstrip = cdiv(p.C, 4 * G::VL);
     // a job is a PAIR of wavefronts: half as many fit the chip as single-wavefront jobs -- three quarters with the M = 14 build for three
-    // wavefronts per SIMD (DTCWT_HIP_FPAIR_WPS=2 / 3 forces; profiles/r05/ab_fpair_occ.txt)
-    static const int wps_env = [] { const char *e = getenv("DTCWT_HIP_FPAIR_WPS"); return e ? atoi(e) : 0; }();
-    const int wps = wps_env ? wps_env : ((M == 14 && hint.nparts > 1) ? 3 : 2);
+    // wavefronts per SIMD, taken on partition contexts (profiles/r05/ab_fpair_occ.txt)
+    const int wps = (M == 14 && hint.nparts > 1) ? 3 : 2;
     const int cus = hint.cus * wps / 4 > 0 ? hint.cus * wps / 4 : 1;
-    const unsigned jobs = dtm::dtm_set_jobs(p.jb, p.B, p.R, nstrip, pick_band_rows(p.B * hint.in_flight, p.R, nstrip, M, cus));
+    const unsigned jobs = dtm::dtm_set_jobs(p.jb, p.B, p.R, nstrip, pick_band_rows(p.B * hint.in_flight, p.R, nstrip, M, cus, hint.band));
     if constexpr (M == 14) { if (wps == 3) { dtm::k_fwd12p<M0, M1, M, 2, 3><<<jobs, 128, 0, s>>>(p); return 0; } }
     dtm::k_fwd12p<M0, M1, M, 2><<<jobs, 128, 0, s>>>(p);
     return 0;
@@ -419,11 +425,10 @@ int dtcwt_march_fwd12p(const float *X, float *Yh0, float *Yh1, float *LoLo2, int
 // ---- levels 2 + 1 of the inverse as a marching PAIR of wavefronts (march2d_ipair.hpp) -----------------------------------------
 // The synthesis filters of near_sym_a (7, 5) / legall (3, 5) with the 14- / 18-tap q-shift sets, standard phases; chosen like the
 // forward pair: wherever other work shares the device from the usual crossover, alone from 60 M useful pixels
-// (profiles/r05/pair_inverse.txt).  DTCWT_HIP_MARCH_PAIR=0: never (both directions); DTCWT_HIP_MARCH_IPAIR=0: not the inverse.
+// (profiles/r05/pair_inverse.txt).  DTCWT_HIP_MARCH_PARTS without bit 8: never.
 bool dtcwt_march_inv21p_ok(int batch, int rows, int cols, const std::vector<double> &g0o, const std::vector<double> &g1o,
                            const std::vector<double> &g0a, bool lo_pos, bool hi_pos, const DtMarchHint &hint) {
-    if (const char *e = getenv("DTCWT_HIP_MARCH_PAIR")) { if (e[0] == '0') return false; }
-    if (const char *e = getenv("DTCWT_HIP_MARCH_IPAIR")) { if (e[0] == '0') return false; }
+    if (!(hint.parts & DT_PART_IPAIR)) return false;
     const int m = (int)g0a.size();
     if (!((g0o.size() == 7 || g0o.size() == 3) && g1o.size() == 5) || !(m == 14 || m == 18) || !lo_pos || hi_pos) return false;
     if (!symmetric(g0o) || !symmetric(g1o)) return false;
@@ -446,10 +451,10 @@ static int launch_inv21p(dtm::Inv21mParams &p, const DtMarchHint &hint, hipStrea
     // A job is a PAIR of wavefronts: half as many are resident as single-wavefront jobs.  At M = 14 the registers (162) allow a third
     // wavefront per SIMD: on a partition context (a share of the CUs, the other shares busy) that measured -8 % per step (four 4096^2 in
     // flight 0.202 -> 0.186 ms, 64 x 2048^2 on quarters -2 %), on the whole device +3.5 % (64 x 1024^2): profiles/r05/ab_ipair_occ.txt
-    static const int wps_env = [] { const char *e = getenv("DTCWT_HIP_IPAIR_WPS"); return e ? atoi(e) : 0; }();       // 2 / 3: force (M = 14 only; at M = 10 three measured no faster alone: profiles/r05/ab_ipair_occ.txt)
-    const int wps = wps_env ? wps_env : ((M == 14 && hint.nparts > 1) ? 3 : 2);
+    // (at M = 10 three measured no faster alone)
+    const int wps = (M == 14 && hint.nparts > 1) ? 3 : 2;
     const int cus = hint.cus * wps / 4 > 0 ? hint.cus * wps / 4 : 1;
-    const unsigned jobs = dtm::dtm_set_jobs(p.jb, p.B, p.R, nstrip, pick_band_rows(p.B * hint.in_flight, p.R, nstrip, M, cus));
+    const unsigned jobs = dtm::dtm_set_jobs(p.jb, p.B, p.R, nstrip, pick_band_rows(p.B * hint.in_flight, p.R, nstrip, M, cus, hint.band));
     if constexpr (M == 14) { if (wps == 3) { dtm::k_inv21p<7, 5, M, 3><<<jobs, 128, 0, s>>>(p); return 0; } }
     dtm::k_inv21p<7, 5, M><<<jobs, 128, 0, s>>>(p);
     return 0;
@@ -477,9 +482,9 @@ int dtcwt_march_inv21p(const float *Z2, const float *Yh1, const float *Yh0, floa
 
 // ---- level 2 of the inverse alone as a march (march2d_ipair.hpp: k_inv2m) ------------------------------------------------------
 // For the 14- / 18-tap q-shift sets where no pair takes levels 2 + 1 (near_sym_b: its level 1 is k_inv1m): Z2 + Yh[1] -> Z1.
-// Standard phases, sizes in fours; chosen by the crossover of the level-1 marches.  DTCWT_HIP_MARCH_INV2=0: never.
+// Standard phases, sizes in fours; chosen by the crossover of the level-1 marches.  DTCWT_HIP_MARCH_PARTS without bit 32: never.
 bool dtcwt_march_inv2_ok(int batch, int rows, int cols, const std::vector<double> &g0a, bool lo_pos, bool hi_pos, const DtMarchHint &hint) {
-    if (const char *e = getenv("DTCWT_HIP_MARCH_INV2")) { if (e[0] == '0') return false; }
+    if (!(hint.parts & DT_PART_INV2)) return false;
     const int m = (int)g0a.size();
     if (!(m == 14 || m == 18) || !lo_pos || hi_pos) return false;
     const int VL = m == 14 ? dtm::Inv2m<14>::VL : dtm::Inv2m<18>::VL;
@@ -493,7 +498,7 @@ static int launch_inv2m(dtm::Inv21mParams &p, const DtMarchHint &hint, hipStream
     using G = dtm::Inv2m<M>;
     const int nstrip = cdiv(p.C, 4 * G::VL);
     const int cus = hint.cus * WPS / 2 > 0 ? hint.cus * WPS / 2 : 1;        // WPS wavefronts per SIMD where the band picker counts two
-    const unsigned jobs = dtm::dtm_set_jobs(p.jb, p.B, p.R, nstrip, pick_band_rows(p.B * hint.in_flight, p.R, nstrip, M, cus));
+    const unsigned jobs = dtm::dtm_set_jobs(p.jb, p.B, p.R, nstrip, pick_band_rows(p.B * hint.in_flight, p.R, nstrip, M, cus, hint.band));
     dtm::k_inv2m<M, WPS><<<jobs, 64, 0, s>>>(p);
     return 0;
 }
@@ -512,9 +517,9 @@ int dtcwt_march_inv2(const float *Z2, const float *Yh1, float *Z1, int B, int R,
 
 // ---- level 2 of the forward alone as a march (march2d_pair.hpp: k_fwd2m) ------------------------------------------------------
 // The forward counterpart of k_inv2m: LoLo1 -> Yh[1], LoLo2 for the 14- / 18-tap q-shift sets where no pair takes levels 1 + 2.
-// DTCWT_HIP_MARCH_FWD2=0: never.
+// DTCWT_HIP_MARCH_PARTS without bit 16: never.
 bool dtcwt_march_fwd2_ok(int batch, int rows, int cols, const std::vector<double> &h0a, bool lo_a_first, bool hi_a_first, const DtMarchHint &hint) {
-    if (const char *e = getenv("DTCWT_HIP_MARCH_FWD2")) { if (e[0] == '0') return false; }
+    if (!(hint.parts & DT_PART_FWD2)) return false;
     const int m = (int)h0a.size();
     if (!(m == 14 || m == 18) || !lo_a_first || hi_a_first) return false;
     const int VL = m == 14 ? dtm::Fwd2m<14>::VL : dtm::Fwd2m<18>::VL;
@@ -534,7 +539,7 @@ static int launch_fwd2m(dtm::Fwd12pParams &p, const DtMarchHint &hint, hipStream
     using G = dtm::Fwd2m<M>;
     const int nstrip = cdiv(p.C, 4 * G::VL);
     const int cus = hint.cus * WPS / 2 > 0 ? hint.cus * WPS / 2 : 1;
-    const unsigned jobs = dtm::dtm_set_jobs(p.jb, p.B, p.R, nstrip, pick_band_rows(p.B * hint.in_flight, p.R, nstrip, M, cus));
+    const unsigned jobs = dtm::dtm_set_jobs(p.jb, p.B, p.R, nstrip, pick_band_rows(p.B * hint.in_flight, p.R, nstrip, M, cus, hint.band));
     dtm::k_fwd2m<M, WPS><<<jobs, 64, 0, s>>>(p);
     return 0;
 }

@@ -54,7 +54,7 @@ _dbl = ctypes.c_double
 _pd = ctypes.POINTER(ctypes.c_double)
 
 # name -> (restype, argtypes); every symbol include/dtcwt_hip.h declares
-ABI_VERSION = 5          # == DTCWT_HIP_ABI_VERSION of include/dtcwt_hip.h (checked in load_library)
+ABI_VERSION = 6          # == DTCWT_HIP_ABI_VERSION of include/dtcwt_hip.h (checked in load_library)
 
 SIGNATURES = {
     'dtcwt_hip_abi_version': (_i, []),
@@ -142,6 +142,7 @@ SIGNATURES = {
     'dtcwt_hip_plan2d_set_concurrency': (_i, [_vp, _i]),
     'dtcwt_hip_plan2d_set_program': (_i, [_vp, _i]),
     'dtcwt_hip_plan2d_level1_march': (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    'dtcwt_hip_plan2d_describe': (_i, [_vp, _i, ctypes.c_char_p, ctypes.c_size_t]),
     'dtcwt_hip_plan3d_create': (_i, [_vp, _i64, _i64, _i64, _i, _i, ctypes.POINTER(_pd), ctypes.POINTER(_i),
                                      ctypes.POINTER(_pd), ctypes.POINTER(_i), ctypes.POINTER(_vp)]),
     'dtcwt_hip_plan3d_destroy': (_i, [_vp]),

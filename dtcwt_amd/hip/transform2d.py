@@ -159,6 +159,13 @@ class _Plan2d(object):
         check(self._lib.dtcwt_hip_plan2d_launches(self._h, ctypes.byref(a), ctypes.byref(b)))
         return bool(a.value), bool(b.value)
 
+    def describe(self, scales=False):
+        """One line of text: the kernel that runs every level of the forward and of the inverse of this plan (*scales*: a
+        forward with ``include_scale``) and the switches the plan was made under (``dtcwt_hip_plan2d_describe``)."""
+        buf = ctypes.create_string_buffer(1024)
+        check(self._lib.dtcwt_hip_plan2d_describe(self._h, 1 if scales else 0, buf, 1024))
+        return buf.value.decode()
+
     def level1_march(self):
         """(level 1 of the forward as a marching launch of its own?, of the inverse?) -- near_sym_b and antonini, whose
         filters are too long for the fused levels 1 + 2 (``dtcwt_hip_plan2d_level1_march``)."""
@@ -226,6 +233,7 @@ def _fused_levels(rows, cols, nlevels):
 
 
 _DEGENERATE_DIM = 8
+_PLAN_SWITCHES = ('DTCWT_HIP_MARCH', 'DTCWT_HIP_MARCH_BAND', 'DTCWT_HIP_MARCH_PARTS', 'DTCWT_HIP_XCD_ORDER')
 
 
 def _degenerate(rows, cols, nlevels):
@@ -296,7 +304,9 @@ class Transform2d(object):
         """Fused plan or None when the wavelets have no fused kernels."""
         if len(self.biort) not in (4, 6) or len(self.qshift) not in (8, 12):
             return None
-        key = (batch, rows, cols, nlevels)
+        # a native plan reads its environment switches once, when it is made (include/dtcwt_hip.h: dtcwt_hip_plan2d_describe):
+        # a process that changes them (the tests do) gets a new plan, not a stale one
+        key = (batch, rows, cols, nlevels) + tuple(os.environ.get(k) for k in _PLAN_SWITCHES)
         if key not in self._plans:
             try:
                 self._plans[key] = _Plan2d(self.ctx, batch, rows, cols, nlevels, self.biort, self.qshift)

@@ -31,8 +31,9 @@ extern "C" {
 
 /* 2: plan1d_*, plan3d_*, mgpu_* (round 2), mgpu_forward2d_scales, host_alloc / host_free / memcpy_*_async (round 3)
  * 3: plan2d_launches, plan2d_set_concurrency, mgpu_scatter_async / gather_async;  4: ctx_create_partition (round 4)
- * 5: plan2d_set_program, plan2d_level1_march, mgpu_create_lane, mgpu_shares, to_float kinds 9 / 10 (round 5) */
-#define DTCWT_HIP_ABI_VERSION 5
+ * 5: plan2d_set_program, plan2d_level1_march, mgpu_create_lane, mgpu_shares, to_float kinds 9 / 10 (round 5)
+ * 6: plan2d_describe; a plan reads its environment switches once, at creation (round 6) */
+#define DTCWT_HIP_ABI_VERSION 6
 
 #define DTCWT_HIP_F32 0
 #define DTCWT_HIP_F64 1
@@ -365,6 +366,14 @@ int dtcwt_hip_plan2d_launches(const dtcwt_hip_plan2d *plan, int *fwd12, int *inv
  * 18-tap sets, march2d_pair.hpp / march2d_ipair.hpp), levels >= 3 -- and level 2 of every other set -- on the tile programs.
  * Same choice rules and pin as dtcwt_hip_plan2d_launches. */
 int dtcwt_hip_plan2d_level1_march(const dtcwt_hip_plan2d *plan, int *fwd1, int *inv1);
+/* (ABI 6) Which kernel runs every level of this plan, as one line of text in `buf` (>= 64 bytes; 512 hold any plan):
+ *   fwd: L1+2 k_fwd12m | L3 k_fwd2 | L4 k_fwd2 ; inv: L4 k_inv2 | L3 k_inv2 | L2+1 k_inv21p ; march=auto band=0 parts=0xff xcd_order=-1 program=auto in_flight=1 cu_shares=1
+ * scales != 0: as dtcwt_hip_plan2d_forward runs it with Ys != NULL.  It consults the very predicates the forward and the inverse
+ * consult -- what it says is what runs -- and ends with the environment switches AS THE PLAN READ THEM WHEN IT WAS CREATED
+ * (DTCWT_HIP_MARCH, DTCWT_HIP_MARCH_BAND, DTCWT_HIP_MARCH_PARTS, DTCWT_HIP_XCD_ORDER: INTEGRATION.md section 5; a plan keeps
+ * them for life, later changes of the environment reach new plans only), the pinned program, the concurrency hint and the
+ * number of shares the context divides its device into. */
+int dtcwt_hip_plan2d_describe(const dtcwt_hip_plan2d *plan, int scales, char *buf, size_t len);
 /* How many independent transforms the caller keeps in flight on this device at a time (this plan's included; other
  * plans on other streams -- the images of a video, the members of a batch handed over one by one; default 1).  The
  * marching launches cut an image into bands of rows, each of which re-reads the rows its filters reach into above

@@ -349,13 +349,13 @@ def test_bench_config_c4_line():
     assert line['roofline']['kernel'].startswith('k_fwd3m_l1') and 0 < line['roofline']['frac'] < 1
     assert line['recon_max_abs_err'] < 1e-4 and line['gpu_vs_cpu_recon_max_abs_diff'] < 1e-4
     assert line['cpu_baseline']['kind'] == 'port'
-    # "qbgn-style" (near_sym_b / qshift_b: other_configs.c4_qbgn of the default run): level 1 as two launches (fused3d_long.hpp)
+    # "qbgn-style" (near_sym_b / qshift_b: other_configs.c4_qbgn of the default run): level 1 as two launches (fused3d_long.hpp: axis 0, then k_fwd3l_slices)
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--config', 'c4', '--rows', '64', '--steps', '3',
                         '--warmup', '1', '--settle-ms', '0', '--sets', '2', '--streams', '2', '--biort', 'near_sym_b',
                         '--qshift', 'qshift_b', '--no-cpu-baseline'], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert 'near_sym_b/qshift_b' in line['config']['workload'] and line['roofline']['kernel'].startswith('k_fwd1m<13,19,PLANES>')
+    assert 'near_sym_b/qshift_b' in line['config']['workload'] and 'k_fwd3l_slices' in line['roofline']['kernel']
     assert line['recon_max_abs_err'] < 1e-4 and line['roofline']['traffic'] is None
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--config', 'c4', '--gpus', '2', '--steps', '1'],
                        capture_output=True, text=True, env=env, timeout=300)

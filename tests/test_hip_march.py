@@ -39,7 +39,6 @@ def test_march_matches_tile_programs_and_oracle(shape, band, monkeypatch):
     monkeypatch.setenv('DTCWT_HIP_MARCH', '0')
     yl0, ys0, z0 = _fwd_inv(X, nl, gm)
     monkeypatch.setenv('DTCWT_HIP_MARCH', '1')
-    monkeypatch.setenv('DTCWT_HIP_MARCH_INV', '1')          # also where the bands would be short
     if band:
         monkeypatch.setenv('DTCWT_HIP_MARCH_BAND', str(band))
     t = Transform2d()
@@ -162,7 +161,7 @@ def test_forward_pair_matches_tile_programs_and_oracle(shape, bn, qn, band, monk
     want = o.Transform2d(biort(bn), qshift(qn)).forward(as_f64(X), nlevels=nl)
     assert_pyramids_close(p1, want, XFM_TOL, same_dtype=False)
     assert_close(tm.inverse(p1), X, INV_TOL, 'reconstruction')
-    monkeypatch.setenv('DTCWT_HIP_MARCH_PAIR', '0')              # the switch: back to level 1 alone + a level-2 tile launch
+    monkeypatch.setenv('DTCWT_HIP_MARCH_PARTS', str(255 & ~12))  # without the pairs (bits 4, 8): back to level 1 alone + a level-2 tile launch
     assert tm.plan(1, shape[0], shape[1], nl).launches()[0] is False
 
 
@@ -189,7 +188,7 @@ def test_inverse_pair_matches_tile_programs_and_oracle(shape, bn, qn, band, monk
     want = to.forward(as_f64(X), nlevels=nl)
     assert_close(z1, to.inverse(want, gm), INV_TOL, 'inverse')
     assert_close(tm.inverse(tm.forward(X, nlevels=nl)), X, INV_TOL, 'reconstruction')
-    monkeypatch.setenv('DTCWT_HIP_MARCH_PAIR', '0')              # the switch: back to a level-2 tile launch + a level-1 tile launch
+    monkeypatch.setenv('DTCWT_HIP_MARCH_PARTS', str(255 & ~12))  # without the pairs: back to a level-2 tile launch + a level-1 tile launch
     assert tm.plan(1, shape[0], shape[1], nl).launches()[1] is False
 
 
@@ -199,7 +198,6 @@ def test_headline_inverse_as_a_pair_is_bit_identical(shape, bn, monkeypatch):
     """One transform at a time on the whole device (up to 4096^2) runs levels 2 + 1 of the inverse as a marching pair of wavefronts
     (k_inv21p<7, 5, 10>) instead of k_inv21m: the same sums in the same order, whatever the band heights -- not a bit differs."""
     monkeypatch.setenv('DTCWT_HIP_MARCH', '1')
-    monkeypatch.setenv('DTCWT_HIP_MARCH_INV', '1')
     rs = np.random.RandomState(29)
     X = rs.standard_normal(shape).astype(np.float32)
     nl = 2 if min(shape) < 160 else 3
@@ -209,11 +207,12 @@ def test_headline_inverse_as_a_pair_is_bit_identical(shape, bn, monkeypatch):
     p = t.forward(X, nlevels=nl)
     pyr = Pyramid(np.array(p.lowpass), tuple(np.array(y) for y in p.highpasses))
     out = {}
-    for arm in ('0', '1'):
-        monkeypatch.setenv('DTCWT_HIP_INV21_PAIR', arm)
+    for arm, parts in (('0', 255 & ~128), ('1', 255 | 256)):        # DTCWT_HIP_MARCH_PARTS: never / always as a pair (bits 128, 256)
+        monkeypatch.setenv('DTCWT_HIP_MARCH_PARTS', str(parts))
+        assert ('k_inv21p' in t.plan(1, shape[0], shape[1], nl).describe()) == (arm == '1')
         out[arm] = np.array(t.inverse(pyr, gm))
     assert np.array_equal(out['0'], out['1'])
-    monkeypatch.delenv('DTCWT_HIP_INV21_PAIR')
+    monkeypatch.delenv('DTCWT_HIP_MARCH_PARTS')
     assert np.array_equal(np.array(t.inverse(pyr, gm)), out['0'])           # the library's own choice
     to = o.Transform2d(biort(bn), qshift('qshift_a' if bn == 'near_sym_a' else 'qshift_06'))
     assert_close(out['1'], to.inverse(to.forward(as_f64(X), nlevels=nl), gm), INV_TOL, 'inverse')
@@ -244,7 +243,7 @@ def test_pairs_on_a_share_of_the_compute_units():
 @pytest.mark.parametrize('band', [None, 8, 24])
 def test_level2_inverse_march_matches_tile_program_and_oracle(shape, bn, qn, band, monkeypatch):
     """Level 2 of the inverse alone as a march (march2d_ipair.hpp: k_inv2m, the level-2 wavefront of the inverse pair storing its
-    groups of Z1 rows) for the 14- / 18-tap q-shift sets whose level 1 no pair takes: against the tile program (DTCWT_HIP_MARCH_INV2=0)
+    groups of Z1 rows) for the 14- / 18-tap q-shift sets whose level 1 no pair takes: against the tile program (DTCWT_HIP_MARCH_PARTS without bit 32)
     and the oracle, with a gain mask."""
     rs = np.random.RandomState(35)
     X = rs.standard_normal(shape).astype(np.float32)
@@ -256,7 +255,7 @@ def test_level2_inverse_march_matches_tile_program_and_oracle(shape, bn, qn, ban
     p = tm.forward(X, nlevels=nl)
     pyr = Pyramid(np.array(p.lowpass), tuple(np.array(y) for y in p.highpasses))
     z1 = np.array(tm.inverse(pyr, gm))
-    monkeypatch.setenv('DTCWT_HIP_MARCH_INV2', '0')
+    monkeypatch.setenv('DTCWT_HIP_MARCH_PARTS', str(255 & ~32))
     z0 = np.array(tm.inverse(pyr, gm))
     assert not np.array_equal(z0, z1)            # two programs: they agree to rounding, not to the bit
     assert_close(z1, z0, 1e-6, 'level-2 inverse march vs tile program')
@@ -269,7 +268,7 @@ def test_level2_inverse_march_matches_tile_program_and_oracle(shape, bn, qn, ban
 @pytest.mark.parametrize('band', [None, 8, 24])
 def test_level2_forward_march_matches_tile_program_and_oracle(shape, bn, qn, band, monkeypatch):
     """Level 2 of the forward alone as a march (march2d_pair.hpp: k_fwd2m, the level-2 wavefront of the forward pair fed from memory)
-    for the 14- / 18-tap q-shift sets whose level 1 no pair takes: against the tile program (DTCWT_HIP_MARCH_FWD2=0) and the oracle."""
+    for the 14- / 18-tap q-shift sets whose level 1 no pair takes: against the tile program (DTCWT_HIP_MARCH_PARTS without bit 16) and the oracle."""
     rs = np.random.RandomState(37)
     X = rs.standard_normal(shape).astype(np.float32)
     nl = 2 if min(shape) < 160 else 3
@@ -278,7 +277,7 @@ def test_level2_forward_march_matches_tile_program_and_oracle(shape, bn, qn, ban
         monkeypatch.setenv('DTCWT_HIP_MARCH_BAND', str(band))
     p1 = tm.forward(X, nlevels=nl)
     yl1, ys1 = np.array(p1.lowpass), [np.array(y) for y in p1.highpasses]
-    monkeypatch.setenv('DTCWT_HIP_MARCH_FWD2', '0')
+    monkeypatch.setenv('DTCWT_HIP_MARCH_PARTS', str(255 & ~16))
     p0 = tm.forward(X, nlevels=nl)
     assert np.array_equal(ys1[0], np.array(p0.highpasses[0]))            # level 1 is the same launch either way
     assert not np.array_equal(ys1[1], np.array(p0.highpasses[1]))        # two programs: they agree to rounding, not to the bit
@@ -289,7 +288,7 @@ def test_level2_forward_march_matches_tile_program_and_oracle(shape, bn, qn, ban
     assert_close(yl1, want.lowpass, XFM_TOL, 'Yl')
     for l, (a, b) in enumerate(zip(ys1, want.highpasses)):
         assert_close(a, b, XFM_TOL, 'Yh[%d]' % l)
-    monkeypatch.delenv('DTCWT_HIP_MARCH_FWD2')
+    monkeypatch.delenv('DTCWT_HIP_MARCH_PARTS')
     ps = tm.forward(X, nlevels=nl, include_scale=True)                   # with `scales`: the same launches, LoLo2 into its scale buffer
     assert np.array_equal(np.array(ps.highpasses[1]), ys1[1]) and np.array_equal(np.array(ps.lowpass), yl1)
 
@@ -317,7 +316,6 @@ def test_forward_pair_on_a_batch():
 
 def test_march_on_a_batch_and_other_level1_filters(monkeypatch):
     monkeypatch.setenv('DTCWT_HIP_MARCH', '1')              # wherever it applies, not only where it pays
-    monkeypatch.setenv('DTCWT_HIP_MARCH_INV', '1')
     rs = np.random.RandomState(6)
     X = rs.standard_normal((3, 128, 248)).astype(np.float32)
     for bn in ('near_sym_a', 'legall', 'antonini'):       # up to 7 taps (legall's 3-tap g0o as a centred zero-padded 7-tap one)

@@ -225,14 +225,13 @@ def test_3d_level1_march_matches_tile_program_and_oracle(shape, bname, monkeypat
     """k_fwd3m_l1 (fused3d_march.hpp: level 1 as a marching pair of wavefronts) against the tile program k_fwd3_l1 and the
     oracle: one strip with and without idle lanes (16 .. 256 columns), two and three strips (260, 520: halo lanes at the
     interior boundaries, the mirror columns taken in-lane at the faces), slice counts that are not whole chunks or ring
-    periods, both wavefront occupancies."""
+    periods, whole-volume and 8-slice chunks."""
     X = np.random.RandomState(31).standard_normal(shape).astype(np.float32)
     t = Transform3d(biort=bname)
     monkeypatch.setenv('DTCWT_HIP_FWD3_MARCH', '0')
     p0 = t.forward(X, nlevels=1)
     monkeypatch.setenv('DTCWT_HIP_FWD3_MARCH', '1')
-    for occ, chunk in (('1', None), ('2', '8')):
-        monkeypatch.setenv('DTCWT_HIP_FWD3_OCC', occ)
+    for chunk in (None, '8'):
         if chunk:
             monkeypatch.setenv('DTCWT_HIP_FWD3_CHUNK', chunk)
         p1 = t.forward(X, nlevels=1)

@@ -64,9 +64,9 @@ def main():
             os.environ['DTCWT_HIP_MARCH_BAND'] = str(band)
         else:
             os.environ.pop('DTCWT_HIP_MARCH_BAND', None)
-        os.environ['DTCWT_HIP_INV21_PAIR'] = str(rs.choice(['0', '1']))       # k_inv21m or the same macro-steps as a pair (bit-identical)
+        os.environ['DTCWT_HIP_MARCH_PARTS'] = str(rs.choice([255 & ~128, 255 | 256]))       # k_inv21m or the same macro-steps as a pair (bit-identical)
         b = run(X, nl, gm, B, wave)
-        os.environ.pop('DTCWT_HIP_INV21_PAIR')
+        os.environ.pop('DTCWT_HIP_MARCH_PARTS')
         errs = [rel(b[0], a[0])] + [rel(y, w) for y, w in zip(b[1], a[1])] + [rel(b[2], a[2])]
         worst = max(worst, max(errs))
         assert max(errs) < 2e-6, (wave, R, C, B, nl, band, errs)
@@ -84,7 +84,6 @@ def main():
         os.environ['DTCWT_HIP_FWD3_MARCH'] = '0'
         a = t.forward(V, nlevels=1)
         os.environ['DTCWT_HIP_FWD3_MARCH'] = '1'
-        os.environ['DTCWT_HIP_FWD3_OCC'] = str(rs.choice([1, 2]))
         os.environ['DTCWT_HIP_FWD3_CHUNK'] = str(rs.choice([8, 16, 64]))
         b = t.forward(V, nlevels=1)
         e = max(rel(np.asarray(b.lowpass), np.asarray(a.lowpass)), rel(np.asarray(b.highpasses[0]), np.asarray(a.highpasses[0])))
