@@ -528,3 +528,38 @@ def test_pageable_host_buffers(monkeypatch):
     want = o.Transform2d(biort('near_sym_a'), qshift('qshift_a')).forward(as_f64(X), nlevels=2)
     assert_pyramids_close(p, want, XFM_TOL, same_dtype=False)
     _lib.host_pool.trim()
+
+
+_PAIRS = [('near_sym_a', 'qshift_a'), ('near_sym_a', 'qshift_b'), ('near_sym_a', 'qshift_c'), ('near_sym_a', 'qshift_d'),
+          ('near_sym_a', 'qshift_06'), ('near_sym_b', 'qshift_a'), ('near_sym_b', 'qshift_b'), ('near_sym_b', 'qshift_d'),
+          ('antonini', 'qshift_a'), ('antonini', 'qshift_b'), ('legall', 'qshift_06'), ('legall', 'qshift_b'),
+          ('legall', 'qshift_c'), ('near_sym_b_bp', 'qshift_b_bp')]
+
+
+@pytest.mark.parametrize('bn,qn', _PAIRS)
+@pytest.mark.parametrize('prog', ['march', 'tiles'])
+def test_batch_and_its_images_agree_bit_for_bit_for_every_shipped_pair(bn, qn, prog, monkeypatch):
+    """with a program pinned, a batch and each of its images transformed alone give the same bits --
+    forward (every level, the lowpass) and inverse (with a gain mask) -- for EVERY shipped wavelet pair, whichever kernels
+    the pair runs on (fused marches, marching pairs, level-1 / level-2 marches, tile programs, band-pass tiles): band
+    heights and job layouts differ between the two calls, the sums and their order do not.  Under 'auto' the library may
+    pick different programs for the two call shapes (documented: 2e-7, not bit-identical)."""
+    monkeypatch.delenv('DTCWT_HIP_MARCH', raising=False)
+    rs = np.random.RandomState(len(bn) * 31 + len(qn))
+    Xb = rs.standard_normal((6, 256, 320)).astype(np.float32)
+    nl = 3
+    gm = rs.uniform(0.3, 1.4, size=(6, nl)) * (rs.uniform(size=(6, nl)) > 0.2)
+    t = Transform2d(bn, qn, program=prog)
+    pb = t.forward_channels(Xb, 'nhw', nlevels=nl)
+    assert t.plan(6, 256, 320, nl).describe() != ''
+    for i in (0, 3, 5):
+        single = t.forward(Xb[i], nlevels=nl)
+        assert np.array_equal(pb.lowpass[i], single.lowpass), (bn, qn, prog, i)
+        for l in range(nl):
+            assert np.array_equal(pb.highpasses[l][i], single.highpasses[l]), (bn, qn, prog, i, l)
+        zs = np.array(t.inverse(single, gm))
+        zb = np.array(t.inverse(Pyramid(np.array(pb.lowpass[i]), tuple(np.array(y[i]) for y in pb.highpasses)), gm))
+        assert np.array_equal(zs, zb), (bn, qn, prog, i)
+    want = o.Transform2d(biort(bn), qshift(qn)).forward(as_f64(Xb[3]), nlevels=nl)
+    got = t.forward(Xb[3], nlevels=nl)
+    assert_pyramids_close(got, want, XFM_TOL, same_dtype=False)
