@@ -240,7 +240,8 @@ def _degenerate(rows, cols, nlevels):
     """A float32 image some level of which is `_DEGENERATE_DIM` samples or fewer along an axis: its filters reflect
     several times and sum the same few samples over and over, and float32 arithmetic leaves up to 1e-6 of a subband's own
     maximum against the float64 oracle (profiles/r04/parity_worst.json: 9.9e-7 for a 2 x 2 image through four levels).
-    Such transforms run in float64 on the device and are rounded to float32 once, at the end."""
+    The coarse tail of such a transform (every level the fused float32 plan does not take) runs in float64 on the device and is
+    rounded to float32 once; images too small for any fused level run in float64 whole."""
     if nlevels < 1:
         return False
     _, lv = _level_geometry(rows, cols, nlevels)
@@ -334,7 +335,20 @@ class Transform2d(object):
         a leading batch axis."""
         B, r, c = Xd.shape
         if Xd.dtype == np.float32 and _degenerate(r, c, nlevels):
+            # Only the coarse TAIL runs in float64 (ADVICE r05): the leading levels that are large enough for the fused float32
+            # plan keep it -- a 4096^2 image with ten levels is a fused four... seven-level transform plus a tiny float64 tail,
+            # not a float64 transform of the whole image (three convert passes and no fused kernel at all until round 5)
             ctx = Xd.ctx
+            k = _fused_levels(r, c, nlevels)
+            plan = self._plan(B, r, c, k) if k > 0 else None
+            if plan is not None:
+                Yl, Yh, Ys = plan.forward(Xd, include_scale)
+                Yl, Yh2, Ys2 = self._forward_generic(None, nlevels, include_scale, start_level=k,
+                                                     LoLo=ctx.convert(Yl, np.float64), shape=(B, r, c))
+                Yh = Yh + [ctx.convert(y, np.complex64) for y in Yh2]
+                if include_scale:
+                    Ys = Ys + [ctx.convert(y, np.float32) for y in Ys2]
+                return ctx.convert(Yl, np.float32), Yh, (Ys if include_scale else None)
             Yl, Yh, Ys = self._forward_generic(ctx.convert(Xd, np.float64), nlevels, include_scale)
             return (ctx.convert(Yl, np.float32), [ctx.convert(y, np.complex64) for y in Yh],
                     [ctx.convert(y, np.float32) for y in Ys] if include_scale else None)
@@ -521,6 +535,16 @@ class Transform2d(object):
         R, C = 2 * Yh[0].shape[1], 2 * Yh[0].shape[2]
         if Yl.dtype == np.float32 and _degenerate(R, C, nl):
             ctx = Yl.ctx
+            k = _fused_levels(R, C, nl)
+            plan = self._plan(B, R, C, k) if k > 0 else None
+            if plan is not None and all(plan.high[l] == tuple(Yh[l].shape[1:3]) for l in range(k)):
+                # the coarse tail in float64, then the fused float32 plan for the leading levels (see _forward_device)
+                Yh64 = [None] * k + [ctx.convert(y, np.complex128) for y in Yh[k:]]
+                Z = ctx.convert(self._inverse_generic(ctx.convert(Yl, np.float64), Yh64, gain_mask, crops, stop_level=k), np.float32)
+                if plan.low != tuple(Z.shape[1:]):
+                    raise ValueError('Sizes of highpasses are not valid for DTWAVEIFM2')
+                gm = None if gain_mask is None else np.asarray(gain_mask, dtype=np.float64)[:, :k]
+                return plan.inverse(Z, list(Yh[:k]), gm)
             Z = self._inverse_generic(ctx.convert(Yl, np.float64), [ctx.convert(y, np.complex128) for y in Yh], gain_mask, crops)
             return ctx.convert(Z, np.float32)
         if Yl.dtype == np.float32:

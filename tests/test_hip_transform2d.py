@@ -593,3 +593,27 @@ def test_user_taps_with_other_filter_phases(flip):
     want = to.forward(as_f64(X), nlevels=3)
     assert_pyramids_close(t.forward(X, nlevels=3), want, XFM_TOL, same_dtype=False)
     assert_close(t.inverse(cast_pyramid(want, np.float32)), to.inverse(want), INV_TOL, 'inverse, user taps ' + flip)
+
+
+@pytest.mark.parametrize('shape,nl', [((256, 256), 7), ((1024, 512), 8), ((200, 328), 7), ((64, 48), 5), ((6, 10), 3)])
+def test_deep_pyramids_keep_the_fused_plan_for_their_leading_levels(shape, nl):
+    """A float32 pyramid deep enough that some level is <= 8 samples wide: the coarse tail runs in float64 (its filters
+    reflect several times over the same few samples), the leading levels keep the fused float32 plan (until
+    round 5 the WHOLE transform went to the generic float64 path).  Every level against the oracle, include_scale, the
+    inverse with a gain mask, and the fused plan really is the one that ran."""
+    from dtcwt_amd.hip import transform2d as T
+    rs = np.random.RandomState(nl * 7 + shape[0])
+    X = rs.standard_normal(shape).astype(np.float32)
+    assert T._degenerate(shape[0], shape[1], nl)
+    t = Transform2d()
+    p = t.forward(X, nlevels=nl, include_scale=True)
+    k = T._fused_levels(shape[0], shape[1], nl)
+    assert (k > 0) == (min(shape) >= 40)
+    if k > 0:
+        assert any(key[:4] == (1, shape[0], shape[1], k) for key in t._plans)          # the fused plan of the leading levels
+    to = o.Transform2d(biort('near_sym_a'), qshift('qshift_a'))
+    want = to.forward(as_f64(X), nlevels=nl, include_scale=True)
+    assert_pyramids_close(p, want, XFM_TOL, same_dtype=False)
+    gm = rs.uniform(0.3, 1.4, size=(6, nl))
+    assert_close(t.inverse(p, gm), to.inverse(want, gm), INV_TOL, 'inverse with gains')
+    assert_close(t.inverse(p), X, INV_TOL, 'PR')
