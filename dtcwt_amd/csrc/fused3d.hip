@@ -289,6 +289,8 @@ int dtcwt_march_fwd1_planes(const float *X, float *P, int64_t pstride, int B, in
                             const double *h1o, int m1, int cus, hipStream_t s);
 int dtcwt_march_fwd3l_slices(const float *V, int64_t vstride, float *LLL, float *Yh, int n0, int n1, int n2, const double *h0o, int m0,
                              const double *h1o, int m1, int cus, hipStream_t s);
+int dtcwt_march_inv3l_slices(const float *LLL, const float *Yh, float *V, int64_t vstride, int n0, int n1, int n2, const double *g0o, int m0,
+                             const double *g1o, int m1, int cus, hipStream_t s);
 int dtcwt_march_inv1_planes(const float *P, int64_t pstride, float *X, int B, int R, int C, const double *g0o, int m0,
                             const double *g1o, int m1, int cus, hipStream_t s);
 static bool long3_ok(int64_t n0, int64_t n1, int64_t n2, int ma, int mb) {
@@ -679,6 +681,28 @@ extern "C" int dtcwt_hip_inv3_level1(dtcwt_hip_ctx *ctx, const float *LLL, const
 #define X_(A, B) if (m0 == A && m1 == B) have = true;
     DT_INV3_L1_TABLE(X_)
 #undef X_
+    // round 6: c2cube + both in-slice axes in one launch (k_inv3l_slices: LLL, Yh -> the two volumes the axis-0 synthesis filters take),
+    // then the generic marching sum filter along axis 0: 52 instead of 68 B/voxel.  DTCWT_HIP_LONG3D=2: the round-5 cut.
+    const bool slices_first = [] { const char *e = getenv("DTCWT_HIP_LONG3D"); return !(e && e[0] == '2'); }();
+    if (!have && slices_first && long3_ok(n0, n1, n2, m0, m1) && m0 == 19 && symmetric_taps(g0o, m0) && symmetric_taps(g1o, m1)) {
+        const int64_t ps = n0 * n1 * n2;
+        void *vol = nullptr;
+        if (int rc = dtcwt_hip_malloc(ctx, (size_t)(2 * ps) * sizeof(float), &vol)) return rc;
+        DT_CHECK_HIP(hipSetDevice(ctx->device));
+        int rc = dtcwt_march_inv3l_slices(LLL, Yh, (float *)vol, ps, (int)n0, (int)n1, (int)n2, g0o, m0, g1o, m1, ctx->cus, ctx->stream);
+        if (rc) rc = dtcwt_set_error(-3, "the in-slice inverse march does not take this volume");
+        if (!rc) {
+            dtcwt_hip_view v{};
+            v.outer = 1; v.n = n0; v.inner = n1 * n2;
+            v.xso = ps; v.xsn = n1 * n2; v.xsi = 1; v.yso = ps; v.ysn = n1 * n2; v.ysi = 1;
+            rc = dtcwt_hip_colfilter_sum2(ctx, DTCWT_HIP_F32, vol, (const float *)vol + ps, Z, &v, g0o, m0, g1o, m1);
+        }
+        hipError_t er = hipGetLastError();
+        dtcwt_hip_free(ctx, vol);
+        if (rc) return rc;
+        if (er != hipSuccess) return dtcwt_set_error(-2, "3-D inverse launch failed: %s", hipGetErrorString(er));
+        return 0;
+    }
     if (!have && long3_ok(n0, n1, n2, m0, m1) && m0 == 19 && symmetric_taps(g0o, m0) && symmetric_taps(g1o, m1)) {
         // long filters (fused3d_long.hpp): c2cube + axis 0 into four plane volumes, then the 2-D level-1 march slice by slice
         Inv3AParams a{};

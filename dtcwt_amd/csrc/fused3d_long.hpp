@@ -368,4 +368,214 @@ __global__ void __launch_bounds__(256, 2) k_fwd3l_slices(const Fwd3sParams p) {
 #endif
 }
 
+
+// ======================================================================================================================
+// The inverse the same way round (round 6): c2cube + both in-slice axes in one launch, then axis 0 --
+//
+//   inverse   k_inv3l_slices (below)                                               LLL, Yh -> V[lo0], V[hi0]     32 + 4 -> 8 B/voxel
+//             colfilter_sum2 along axis 0 (generic2d.hip: the marching sum kernel)  V -> X                        8 -> 4 B/voxel
+//
+// 52 B/voxel instead of 68 (k_inv3l_axis0 + k_inv1m<PLANES> around four plane volumes).  k_inv3l_slices: a workgroup = FOUR
+// wavefronts = (axis-0 band f0) x (slice parity a0) of one slice pair, one strip, one band of rows; per step the 256 threads
+// bring ONE row of cells (one record row of the slice pair: 224 bytes per cell) into a shared slab, requested a step ahead;
+// every wavefront takes from it the c2cube samples of ITS slice (a0) of ITS four octants (f0, f1, f2) -- the (lo, lo, lo)
+// plane of the f0 = lo wavefronts is the lowpass volume instead -- and runs the level-1 inverse march of march2d_l1.hpp on
+// them (row filters through DPP / in-lane mirrors, transposed column filters into 20 pending rows), storing its slice of
+// V[f0].  Two LDS-only barriers per step, no exchange between the wavefronts.
+// Reference: dtcwt/numpy/transform3d.py:385-440, c2cube :581-619.
+// ======================================================================================================================
+struct Inv3sParams {
+    const float *LLL;     // [n0][n1][n2]
+    const float *Yh;      // [n0/2][n1/2][n2/2][56 floats]
+    float *V;             // [2][n0][n1][n2]: what the axis-0 synthesis filters g0o / g1o take
+    int64_t vstride;
+    int n0, n1, n2;
+    dtm::MarchJobs jb;    // strips along axis 2, bands of rows of axis 1, "images" = slice pairs
+    float gd0[2 * (dtm::MAXH1 + 1)] __attribute__((aligned(8))), gd1[2 * (dtm::MAXH1 + 1)] __attribute__((aligned(8)));
+};
+inline void pack_inv3s(Inv3sParams &p, int m0, int m1, const double *g0, const double *g1) {
+    for (int d = 0; d <= dtm::MAXH1; ++d) {
+        p.gd0[2 * d] = p.gd0[2 * d + 1] = d <= m0 / 2 ? (float)g0[m0 / 2 - d] : 0.f;
+        p.gd1[2 * d] = p.gd1[2 * d + 1] = d <= m1 / 2 ? (float)g1[m1 / 2 - d] : 0.f;
+    }
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// c2cube of one octant piece (two f4 = four complex numbers of a cell, transform3d.py:581-619), the half a wavefront needs: the
+// four samples v[dj][dk] of slice parity a0 (uniform)
+__device__ __forceinline__ void c2cube_half(const f4 &a, const f4 &b, bool odd, float (&v)[2][2]) {
+    const float pr = a.x, pi = a.y, qr = a.z, qi = a.w, rr = b.x, ri = b.y, sr = b.z, si = b.w, h = 0.5f;
+    if (!odd) {
+        v[0][0] = (pr + qr + rr + sr) * h; v[0][1] = (pi + qi + ri + si) * h;
+        v[1][0] = (pi - qi + ri - si) * h; v[1][1] = (-pr + qr - rr + sr) * h;
+    } else {
+        v[0][0] = (pi + qi - ri - si) * h; v[0][1] = (-pr - qr + rr + sr) * h;
+        v[1][0] = (-pr + qr + rr - sr) * h; v[1][1] = (-pi + qi + ri - si) * h;
+    }
+}
+#endif
+
+template <int M0, int M1, bool EDGE>
+__global__ void __launch_bounds__(256, 2) k_inv3l_slices(const Inv3sParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using G = dtm::Inv1m<M0, M1>;
+    using dtm::pk2; using dtm::dt_buf2g; using dtm::dt_buf_n;
+    constexpr int H0 = G::H0, H1 = G::H1, HM = G::HM, HL = EDGE ? 0 : G::HL, VL = EDGE ? 64 : G::VL, NPX = G::NPX, WARM = G::WARM;
+    __shared__ __attribute__((aligned(16))) f4 slab[128 * 15 + 8];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int v = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int f0 = v >> 1, a0 = v & 1;
+    int strip, band, b;
+    if (!dtm::dtm_job(p.jb, blockIdx.x, strip, band, b)) return;           // the whole workgroup
+    const int R = p.n1, C = p.n2;
+    const int cb = strip * (4 * VL) - 4 * HL;             // column of lane 0
+    const int c0 = cb + 4 * lane;
+    const bool mir = c0 < 0 || c0 >= C;
+    const bool edge_strip = !EDGE && (cb < 0 || cb + 256 > C);      // uniform: some lane is mirrored
+    const int nv = (C - strip * (4 * VL)) / 4 < VL ? (C - strip * (4 * VL)) / 4 : VL;
+    int lc = c0 < 0 ? -c0 - 4 : (c0 >= C ? 2 * C - 4 - c0 : c0);
+    lc = lc < 0 ? 0 : (lc > C - 4 ? C - 4 : lc);
+    int sl = c0 < 0 ? (-c0 - 4 - cb) / 4 : (c0 >= C ? (2 * C - 4 - c0 - cb) / 4 : lane);      // the slab lane that holds this lane's cells
+    sl = sl < 0 ? 0 : (sl > 63 ? 63 : sl);
+    const int lmin = cb < 0 ? -cb / 4 : 0, lmax = (C - cb) / 4 - 1 < 63 ? (C - cb) / 4 - 1 : 63;     // lanes inside the volume
+
+    const int64_t slice = (int64_t)R * C;
+    const int64_t img = (int64_t)(2 * b + a0) * slice;
+    // the lowpass volume feeds plane (lo, lo) of the f0 = lo wavefronts only: the others load against zero bytes
+    const DtBuf bz = dt_buf_n(p.LLL + img, f0 == 0 ? (unsigned)slice * 4u : 0u);
+    const int64_t rec_row_f = (int64_t)(C / 2) * 56;                 // floats per row of cells
+    const float *const Yb = p.Yh + (int64_t)b * (R / 2) * rec_row_f + (int64_t)((cb + 4 * lmin) / 2) * 56;    // first cell inside, row 0
+    float *const Xb = p.V + f0 * p.vstride + img + strip * (4 * VL);
+    const unsigned pitch = (unsigned)C * 4u;
+    const unsigned npiece = (unsigned)(2 * (lmax - lmin + 1)) * 14u;
+
+    const int rb = band * p.jb.band_rows;
+    const int nrow = R - rb < p.jb.band_rows ? R - rb : p.jb.band_rows;
+    const int rr0 = rb / 2 - WARM, nst = nrow / 2 + 2 * WARM;      // record rows rr0 .. rr0 + nst - 1
+
+    auto zrow = [&](int u) { u = u < 0 ? -1 - u : u; u = u >= R ? 2 * R - 1 - u : u; return u < 0 ? 0 : (u > R - 1 ? R - 1 : u); };
+    auto rec_row = [&](int rr, bool &sw) { sw = rr < 0 || rr >= R / 2; rr = rr < 0 ? -1 - rr : rr; rr = rr >= R / 2 ? R - 1 - rr : rr; return rr < 0 ? 0 : (rr > R / 2 - 1 ? R / 2 - 1 : rr); };
+
+    int pdst[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { const int piece = tid + 256 * i; pdst[i] = (2 * lmin + piece / 14) * 15 + piece % 14; }
+    f4 zp[2], rp[7];
+    auto request = [&](int rr) {
+        bool sw;
+        zp[0] = dt2d::dt_buf_ld4(bz, (unsigned)lc * 4u + (unsigned)zrow(2 * rr) * pitch, 0u);
+        zp[1] = dt2d::dt_buf_ld4(bz, (unsigned)lc * 4u + (unsigned)zrow(2 * rr + 1) * pitch, 0u);
+        const DtBuf br = dt_buf_n(Yb + (int64_t)rec_row(rr, sw) * rec_row_f, 16u * npiece);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) rp[i] = dt2d::dt_buf_ld4(br, 16u * (unsigned)(tid + 256 * i), 0u);
+    };
+    request(rr0);
+    asm volatile("" : "+v"(zp[0].x), "+v"(zp[0].y), "+v"(zp[0].z), "+v"(zp[0].w), "+v"(zp[1].x), "+v"(zp[1].y), "+v"(zp[1].z), "+v"(zp[1].w) : : "memory");
+#pragma unroll
+    for (int i = 0; i < 7; ++i) asm volatile("" : "+v"(rp[i].x), "+v"(rp[i].y), "+v"(rp[i].z), "+v"(rp[i].w) : : "memory");
+
+    pk2 PX[NPX][2];
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) { PX[i][0] = pk2{0.f, 0.f}; PX[i][1] = pk2{0.f, 0.f}; }
+    const unsigned xv = 16u * (unsigned)(lane - HL);
+    const pk2 *gd0 = reinterpret_cast<const pk2 *>(p.gd0), *gd1 = reinterpret_cast<const pk2 *>(p.gd1);
+    // record slots of this wavefront's octants (f0, f1, f2): idx = 4 f0 + 2 f1 + f2, slot = idx odd ? 3 + idx / 2 : idx / 2 - 1
+    const int s00 = f0 ? 1 : 0 /* unused for f0 = lo */, s01 = f0 ? 5 : 3, s10 = f0 ? 2 : 0, s11 = f0 ? 6 : 4;
+
+    for (int st = 0; st < nst; ++st) {
+        const int rr = rr0 + st, rho = 2 * rr;
+        bool sw;
+        (void)rec_row(rr, sw);
+        // ---- what was requested a step ago: the record row to the slab, the lowpass rows in place
+#pragma unroll
+        for (int i = 0; i < 7; ++i) if ((unsigned)(tid + 256 * i) < npiece) slab[pdst[i]] = rp[i];
+        f4 zz[2] = {zp[0], zp[1]};
+        if (edge_strip) { zz[0] = mir ? dtm::rev4(zz[0]) : zz[0]; zz[1] = mir ? dtm::rev4(zz[1]) : zz[1]; }
+        request(rr + 1);
+        DT3M_LDS_BARRIER();
+        float qz[2][4], q05[2][4], q23[2][4], q14[2][4];
+        {
+            const f4 *ca = slab + (2 * sl) * 15, *cbp = ca + 15;        // the lane's two cells
+            float t[2][2];
+#define DT3L_OCT(dst_, slot_)                                                                   \
+            c2cube_half(ca[2 * (slot_)], ca[2 * (slot_) + 1], a0 != 0, t);                       \
+            dst_[0][0] = t[0][0]; dst_[0][1] = t[0][1]; dst_[1][0] = t[1][0]; dst_[1][1] = t[1][1]; \
+            c2cube_half(cbp[2 * (slot_)], cbp[2 * (slot_) + 1], a0 != 0, t);                     \
+            dst_[0][2] = t[0][0]; dst_[0][3] = t[0][1]; dst_[1][2] = t[1][0]; dst_[1][3] = t[1][1];
+            DT3L_OCT(q23, s01) DT3L_OCT(q05, s10) DT3L_OCT(q14, s11)
+            if (f0) { DT3L_OCT(qz, s00) }
+            else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { qz[0][c] = 0.f; qz[1][c] = 0.f; }
+            }
+#undef DT3L_OCT
+            if (sw) {               // a reflected record row (top / bottom of the slices): its cells upside down
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float t_;
+                    t_ = q05[0][c]; q05[0][c] = q05[1][c]; q05[1][c] = t_;
+                    t_ = q23[0][c]; q23[0][c] = q23[1][c]; q23[1][c] = t_;
+                    t_ = q14[0][c]; q14[0][c] = q14[1][c]; q14[1][c] = t_;
+                    t_ = qz[0][c]; qz[0][c] = qz[1][c]; qz[1][c] = t_;
+                }
+            }
+            if (edge_strip) {       // mirrored lanes: the mirror lane's four columns in reverse
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    float t_;
+#define DTM_REV4(x_) t_ = x_[e][0]; x_[e][0] = mir ? x_[e][3] : t_; x_[e][3] = mir ? t_ : x_[e][3]; \
+                     t_ = x_[e][1]; x_[e][1] = mir ? x_[e][2] : t_; x_[e][2] = mir ? t_ : x_[e][2];
+                    DTM_REV4(q05) DTM_REV4(q23) DTM_REV4(q14) DTM_REV4(qz)
+#undef DTM_REV4
+                }
+            }
+        }
+        DT3M_LDS_BARRIER();            // every wavefront has read the row: the slab may take the next one
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float zl[4] = {zz[e].x, zz[e].y, zz[e].z, zz[e].w};
+            pk2 Wa[4 + 2 * H0], Wb[4 + 2 * H1], Vv[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                Wa[H0 + c] = pk2{f0 ? qz[e][c] : zl[c], q05[e][c]};
+                Wb[H1 + c] = pk2{q23[e][c], q14[e][c]};
+            }
+            dtm::halo_pairs<H0>(Wa);
+            dtm::halo_pairs<H1>(Wb);
+            if constexpr (EDGE) { dtm::edge_mirror<H0>(Wa, lane, nv); dtm::edge_mirror<H1>(Wb, lane, nv); }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) Vv[c] = dtm::sym_gg<H0>(&Wa[H0 + c], gd0) + dtm::sym_gg<H1>(&Wb[H1 + c], gd1);
+            const pk2 v0p[2] = {pk2{Vv[0].x, Vv[1].x}, pk2{Vv[2].x, Vv[3].x}}, v1p[2] = {pk2{Vv[0].y, Vv[1].y}, pk2{Vv[2].y, Vv[3].y}};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int i = 0; i < NPX; ++i) {
+                    constexpr int o0 = HM - H0, o1 = HM - H1;
+                    const int k0 = i - e - o0, k1 = i - e - o1;            // tap indices that reach row i
+                    const bool t0 = k0 >= 0 && k0 < M0, t1 = k1 >= 0 && k1 < M1;
+                    const int d0 = t0 ? (k0 < H0 ? H0 - k0 : k0 - H0) : 0, d1 = t1 ? (k1 < H1 ? H1 - k1 : k1 - H1) : 0;
+                    if (e == 0) {
+                        pk2 acc = i + 2 < NPX ? PX[i + 2][h] : pk2{0.f, 0.f};
+                        if (t0) acc = gd0[d0] * v0p[h] + acc;
+                        if (t1) acc = gd1[d1] * v1p[h] + acc;
+                        PX[i][h] = acc;
+                    } else {
+                        if (t0) PX[i][h] += gd0[d0] * v0p[h];
+                        if (t1) PX[i][h] += gd1[d1] * v1p[h];
+                    }
+                }
+            }
+        }
+        // rows rho - HM, rho - HM + 1 of this wavefront's slice of V[f0] are complete
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int x = rho - HM + e;
+            const bool ok = x >= rb && x < rb + nrow;
+            const int xo = ok ? x : 0;
+            const DtBuf bo = dt_buf_n(Xb + (int64_t)xo * C, ok ? 16u * nv : 0u);
+            dt2d::dt_buf_st4<false>(bo, xv, 0u, f4{PX[e][0].x, PX[e][0].y, PX[e][1].x, PX[e][1].y});
+        }
+    }
+#endif
+}
+
 }  // namespace dt3l

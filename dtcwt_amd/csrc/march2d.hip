@@ -359,6 +359,23 @@ int dtcwt_march_fwd3l_slices(const float *V, int64_t vstride, float *LLL, float 
     return 0;
 }
 
+// ... and the inverse the same way round (k_inv3l_slices): LLL, Yh -> V [2][n0][n1][n2], which the axis-0 sum filter then merges
+int dtcwt_march_inv3l_slices(const float *LLL, const float *Yh, float *V, int64_t vstride, int n0, int n1, int n2, const double *g0o, int m0,
+                             const double *g1o, int m1, int cus, hipStream_t s) {
+    using G = dtm::Inv1m<19, 13>;
+    if (!(m0 == 19 && m1 == 13) || n0 % 2 || !l1_sizes_ok(n0 / 2, n1, n2, G::VL)) return -3;
+    dt3l::Inv3sParams p{};
+    p.LLL = LLL; p.Yh = Yh; p.V = V; p.vstride = vstride; p.n0 = n0; p.n1 = n1; p.n2 = n2;
+    dt3l::pack_inv3s(p, m0, m1, g0o, g1o);
+    const bool edge = planes_one_strip(n2, G::VL);
+    const int nstrip = edge ? 1 : cdiv(n2, 4 * G::VL);
+    const int band = pick_band_rows_l1(n0 / 2, n1, nstrip, 4, 2.0 * G::WARM, cus / 4 > 0 ? cus / 4 : 1, long3d_band());
+    const unsigned jobs = dtm::dtm_set_jobs(p.jb, n0 / 2, n1, nstrip, band);
+    if (edge) dt3l::k_inv3l_slices<19, 13, true><<<jobs, 256, 0, s>>>(p);
+    else dt3l::k_inv3l_slices<19, 13, false><<<jobs, 256, 0, s>>>(p);
+    return 0;
+}
+
 // ---- levels 1 + 2 of the forward as a marching PAIR of wavefronts (march2d_pair.hpp) ------------------------------------------
 // near_sym_a / legall-length level-1 filters (5, 7) with the 14- / 18-tap q-shift sets (qshift_b, qshift_d): 112 / 144 registers
 // of pending sums that one wavefront cannot hold beside level 1.  Measured (profiles/r05/pair_forward.txt, pair / level-1 tile

@@ -276,6 +276,13 @@ def test_3d_level1_long_filters_match_generic_and_oracle(shape, chunks, monkeypa
     z1 = t.inverse(p1)
     assert_close(z1, X, INV_TOL, 'PR')
     assert_close(t.inverse(p0), z0, INV_TOL, 'long vs generic inverse')
+    # the inverse likewise: k_inv3l_slices + the axis-0 sum filter (default), the round-5 cut ('2'), short bands of the new launch
+    monkeypatch.setenv('DTCWT_HIP_LONG3D', '2')
+    assert_close(t.inverse(p0), z0, INV_TOL, 'round-5 cut vs generic inverse')
+    monkeypatch.setenv('DTCWT_HIP_LONG3D', '1')
+    monkeypatch.setenv('DTCWT_HIP_LONG3D_BAND', '8')
+    assert_close(t.inverse(p0), z0, INV_TOL, 'long (8-row bands) vs generic inverse')
+    monkeypatch.delenv('DTCWT_HIP_LONG3D_BAND')
     # the whole transform as one native plan: levels >= 2 on the q-shift tile programs
     p2 = t.forward(X, nlevels=2)
     assert_close(t.inverse(p2), X, INV_TOL, 'PR, two levels')
