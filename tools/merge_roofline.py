@@ -1,6 +1,7 @@
-"""profiles/rNN/roofline.json + profiles/traffic.json from the per-config outputs of tools/profile_r05.sh.
+"""profiles/rNN/roofline.json + profiles/traffic.json from the per-config outputs of tools/profile_round.sh (written to <src>/c2) and
+tools/profile_configs.sh (<src>/c3, c5, c4, c4q).
 
-    python tools/merge_roofline_r05.py gpurun_out/r05prof profiles/r05
+    python tools/merge_roofline.py gpurun_out/r06prof profiles/r06
 
 Per config (c2, c3, c5, c4) and kernel: rocprofv3 median durations (alone = one transform in flight on the whole device;
 in flight = the config's default streams), fabric bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) KiB, the algorithmic
@@ -10,14 +11,14 @@ import os
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
-PX = {'c2': 4096 * 4096, 'c3': 64 * 1024 * 1024, 'c5': 64 * 2048 * 2048, 'c4': 256 ** 3}
+PX = {'c2': 4096 * 4096, 'c3': 64 * 1024 * 1024, 'c5': 64 * 2048 * 2048, 'c4': 256 ** 3, 'c4q': 256 ** 3}
 ALG = {  # algorithmic bytes per unit of the launches DESIGN section 3 prices
-    'k_fwd12m#0': 20.0, 'k_inv21m#0': 20.0, 'k_fwd1#0': 20.0, 'k_inv1#0': 20.0,
+    'k_fwd12m#0': 20.0, 'k_inv21m#0': 20.0, 'k_inv21p#0': 20.0, 'k_fwd1#0': 20.0, 'k_inv1#0': 20.0,
     'k_fwd3m_l1#0': 36.0, 'k_fwd3_l1#0': 36.0,
 }
 out = {}
 side = json.load(open('profiles/traffic.json')) if os.path.exists('profiles/traffic.json') else {}
-for cfg in ('c2', 'c3', 'c5', 'c4'):
+for cfg in ('c2', 'c3', 'c5', 'c4', 'c4q'):
     f = os.path.join(src, cfg, 'roofline.json')
     if not os.path.exists(f):
         continue
@@ -63,7 +64,7 @@ for cfg in ('c2', 'c3', 'c5', 'c4'):
             v['alone_frac_of_8TBs'] = round(alg / (us * 1e-6) / 8e12, 4)
             v['alone_frac_of_copy_ceiling'] = round(alg / (us * 1e-6) / 6.29e12, 4)
     out[cfg] = t
-    sec = {'source': os.path.join(dst, 'roofline.json') + ' [%s]' % cfg, 'rocprof_median_us': {}, 'rocprof_median_us_one_stream': {}}
+    sec = {'source': os.path.join(dst, 'roofline.json').replace(os.sep, '/') + ' [%s]' % cfg, 'dominant': 'k_inv21', 'rocprof_median_us': {}, 'rocprof_median_us_one_stream': {}}
     for k, v in t.items():
         if not k.endswith('#0'):
             continue
@@ -75,17 +76,26 @@ for cfg in ('c2', 'c3', 'c5', 'c4'):
             sec[fam] = int(v['traffic_bytes'])
     if cfg == 'c2':
         keep = {k: side[k] for k in ('_method',) if k in side}
-        side = dict(keep, **{k: v for k, v in side.items() if k in ('c3', 'c5', 'c4')})
+        side = dict(keep, **{k: v for k, v in side.items() if k in ('c3', 'c5', 'c4', 'c4_qbgn')})
         side.update(sec)
         side['_algorithmic_bytes_per_launch'] = 20 * PX['c2']
     else:
+        if cfg == 'c4q':
+            # the level-1 forward of the long filters is two launches: the axis-0 pair filter + k_fwd3l_slices (bench.py prices them together)
+            pair = [t.get('k_g2_fwd_p1#0'), t.get('k_fwd3l_slices#0')]
+            if all(pair):
+                if all('traffic_bytes' in v for v in pair):
+                    sec['level1_forward'] = int(sum(v['traffic_bytes'] for v in pair))
+                sec['rocprof_median_us_one_stream']['level1_forward'] = round(sum(v.get('one_stream_median_us', v['median_us']) for v in pair), 2)
+            side['c4_qbgn'] = sec
+            continue
         if cfg == 'c4' and 'k_fwd3m_l1' in sec:
             sec['k_fwd3_l1'] = sec['k_fwd3m_l1']          # the name bench.py's c4 roofline object was written for
             sec['rocprof_median_us_one_stream']['k_fwd3_l1'] = sec['rocprof_median_us_one_stream'].get('k_fwd3m_l1', sec['rocprof_median_us'].get('k_fwd3m_l1'))
         side[cfg] = sec
 os.makedirs(dst, exist_ok=True)
 json.dump(out, open(os.path.join(dst, 'roofline.json'), 'w'), indent=1, sort_keys=True)
-side['_method'] = ('tools/profile_r05.sh + tools/merge_roofline_r05.py: rocprofv3 --kernel-trace --stats and separate --pmc FETCH_SIZE / --pmc WRITE_SIZE '
+side['_method'] = ('tools/profile_round.sh + tools/profile_configs.sh + tools/merge_roofline.py: rocprofv3 --kernel-trace --stats and separate --pmc FETCH_SIZE / --pmc WRITE_SIZE '
                    'passes per config; bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md); '
                    'c2: the driver\'s command, statistics over the last 60 dispatches (one-stream phases); c3 / c5 / c4: counters and the alone medians '
                    'from --streams 1 --cu-partition off runs.  Counts fabric requests, Infinity-Cache hits included.')
