@@ -687,7 +687,9 @@ bool unrolled_ok(const Geo &g, int reach) {
 // The LDS-row kernels: the filter axis is the contiguous one on both sides (so inner == 1: rows = outer), one-bounce reflection,
 // a row long enough to be worth a workgroup; `vec`: 16-byte stores (rows, crop and base address in fours / 16 bytes)
 bool rows_ok(const Geo &g, int reach) {
-    return g.inner == 1 && g.xsn == 1 && g.ysn == 1 && g.idx32 && g.L >= reach && g.nwrite >= 256 && g.outer < ((int64_t)1 << 22);
+    // (one workgroup per (row, segment of >= 512 outputs): the grid must fit 31 bits)
+    return g.inner == 1 && g.xsn == 1 && g.ysn == 1 && g.idx32 && g.L >= reach && g.nwrite >= 256 &&
+           (g.nout / 512 + 2) * g.outer < ((int64_t)1 << 31);
 }
 bool rows_vec(const Geo &g, const void *Y, size_t esz) {
     return !g.accumulate && g.crop_lo % 4 == 0 && g.yso % 4 == 0 && ((uintptr_t)Y % 16) == 0 && (esz == 4 || esz == 8);
