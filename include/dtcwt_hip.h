@@ -256,8 +256,11 @@ int dtcwt_hip_inv3_axis1_c2cube(dtcwt_hip_ctx *ctx, int dtype, const void *plain
  * (dtcwt/numpy/transform3d.py:208-289) for odd-length biort filters -- the three axis
  * passes (h0o/h1o along axes 2, 1, 0) and the seven cube2c packings in ONE launch.
  * X, LLL: [n0][n1][n2] contiguous float32 (n* even); Yh: [n0/2][n1/2][n2/2][28] complex64,
- * octants in the reference's order (:278-289).  Returns -3 (use the generic colfilter2 +
- * cube2c path) when no fused kernel exists for the tap lengths or the volume is tiny. */
+ * octants in the reference's order (:278-289).  Filters of at most 7 taps: ONE launch (a marching pair of wavefronts for the
+ * symmetric 5 / 7, 7 / 5, 5 / 3, 3 / 5 pairs where rows of axis 2 come in fours, the tile program otherwise); the 13 / 19-tap
+ * filters of near_sym_b: TWO launches around two pooled axis-0 volumes (the marching pair filter along axis 0, then both
+ * in-slice axes + cube2c: fused3d_long.hpp).  Returns -3 (use the generic colfilter2 + cube2c path) when no fused kernel
+ * exists for the tap lengths or the volume is tiny. */
 int dtcwt_hip_fwd3_level1(dtcwt_hip_ctx *ctx, const float *X, int64_t n0, int64_t n1, int64_t n2,
                           const double *h0o, int m0, const double *h1o, int m1, float *LLL,
                           float *Yh);
@@ -277,8 +280,9 @@ int dtcwt_hip_fwd3_level2(dtcwt_hip_ctx *ctx, const float *X, int64_t n0, int64_
  * octants and the three merges colfilter(lo, g0o) + colfilter(hi, g1o) -- in two launches
  * (unpack + axis-0 merge marching along axis 0 into four pooled planes, then the 2-D
  * column/row passes per slice).  LLL, Z: [n0][n1][n2] float32; Yh: [n0/2][n1/2][n2/2][28]
- * complex64.  Returns -3 when no fused kernel exists for the tap lengths or the volume is
- * small (n0 < 12 or n1/n2 under twice the tap count). */
+ * complex64.  The 19 / 13-tap synthesis filters of near_sym_b: c2cube + both in-slice axes in one launch into two pooled
+ * volumes, then the marching sum filter along axis 0.  Returns -3 when no fused kernel exists for the tap lengths or the
+ * volume is small (n0 < 12 or n1/n2 under twice the tap count). */
 int dtcwt_hip_inv3_level1(dtcwt_hip_ctx *ctx, const float *LLL, const float *Yh, int64_t n0, int64_t n1,
                           int64_t n2, const double *g0o, int m0, const double *g1o, int m1, float *Z);
 /* Fused float32 level >= 2 of the 3-D inverse transform: replaces `_level2_ifm`
