@@ -125,6 +125,8 @@ def parse_args(argv=None):
     ap.add_argument('--mgpu', action='store_true', help='N > 1 from ONE process: dtcwt_hip_mgpu_* with a host '
                     'thread per device instead of one process per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample-n', type=int, default=0, help='--config c4: the CPU sample is the leading n^3 corner of the first volume '
+                    '(default: the whole volume; the c4_qbgn sub-run of the default line passes 192: the long filters take ~40 s at 256^3)')
     ap.add_argument('--cpu-baseline-s', type=float, default=0.0, help='the CPU sample repeats its image until this many seconds have '
                     'passed (the sub-runs of the batch configurations)')
     ap.add_argument('--ab-protocols', type=int, default=0, help='c3 / c5 at N = 1: after the timed region, time the same steps on four '
@@ -718,11 +720,11 @@ def other_configs():
     # c4_qbgn: BASELINE configs[3] reads "qbgn-style" -- the reference's own 3-D vectors (tests/test_againstmatlab.py:115-124) use
     # near_sym_b / qshift_b: 13 / 19-tap level-1 filters, two launches per direction around four plane volumes (fused3d_long.hpp)
     # SURVEY 8(d) asks for the CPU path beside C3 / C4 / C5 as well: a bounded sample each (the oracle on one image repeated for ~3 s;
-    # one 256^3 volume, ~15 s); c4_qbgn is the same volume with the long filters and carries none (it would add ~40 s)
+    # one 256^3 volume, ~15 s; c4_qbgn: the leading 192^3 corner of its volume, ~3-20 s by host -- the long filters take ~40 s at 256^3)
     for name, extra in (('c3', ['--steps', '40', '--ab-protocols', '3', '--cpu-baseline-s', '3']),
                         ('c5_share', ['--config', 'c5', '--steps', '20', '--ab-protocols', '3', '--cpu-baseline-s', '3']),
                         ('c4', ['--steps', '40']),
-                        ('c4_qbgn', ['--steps', '40', '--biort', 'near_sym_b', '--qshift', 'qshift_b', '--no-cpu-baseline'])):
+                        ('c4_qbgn', ['--steps', '40', '--biort', 'near_sym_b', '--qshift', 'qshift_b', '--cpu-sample-n', '192'])):
         cfgname = 'c5' if name == 'c5_share' else ('c4' if name == 'c4_qbgn' else name)
         cmd = [sys.executable, os.path.abspath(__file__), '--config', cfgname, '--no-other-configs',
                '--warmup', '5', '--settle-ms', '150'] + [e for e in extra if e not in ('--config', 'c5')]
@@ -900,8 +902,8 @@ def main_c4(args):
     if not args.no_cpu_baseline:
         # the NumPy oracle (one core) on the first volume: ~15 s at 256^3
         from oracle import dtcwt_oracle as o
-        m = n
-        Xh = vols[0].get()[:m, :m, :m].astype(np.float32)
+        m = min(n, args.cpu_sample_n) if args.cpu_sample_n > 0 else n
+        Xh = np.ascontiguousarray(vols[0].get()[:m, :m, :m].astype(np.float32))
         to = o.Transform3d(biort(BIORT), qshift(QSHIFT))
         c0 = time.perf_counter()
         po = to.forward(Xh, nlevels=nl)
@@ -909,7 +911,7 @@ def main_c4(args):
         cdt = time.perf_counter() - c0
         out['cpu_baseline'] = {'value': round(m ** 3 / cdt / 1e6, 3), 'unit': 'Mvoxels/s', 'cores': 1, 'kind': 'port',
                                'host_cpus': os.cpu_count(), 'numpy': np.__version__,
-                               'sample': 'one %d^3 f32 volume fwd+inv nlevels=%d (%.1f s)' % (m, nl, cdt)}
+                               'sample': 'one %d^3 f32 volume%s fwd+inv nlevels=%d (%.1f s)' % (m, '' if m == n else ' (the leading corner of the %d^3 one)' % n, nl, cdt)}
         zg = np.asarray(t3.inverse(t3.forward(Xh, nlevels=nl)))
         out['gpu_vs_cpu_recon_max_abs_diff'] = float(np.abs(zg - zo).max())
     print(json.dumps(out))
